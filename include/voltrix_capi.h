@@ -1,0 +1,130 @@
+/*
+ * Voltrix-SpMM for MI355X (gfx950) -- C-ABI of libvoltrix_hip.so (the drop-in boundary).
+ *
+ * The reference (YaqiXia/Voltrix-SpMM) has exactly one process-internal FFI: each kernel module is
+ * JIT-compiled into its own kernel.so exporting
+ *
+ *     extern "C" void launch(<args...>, int& __return_code);
+ *
+ * (voltrix/jit/template.py:104-123) which voltrix/jit/runtime.py:38-52 calls through ctypes with tensors
+ * as data_ptr() -> void*, Python int -> C int, bool -> bool, torch.cuda.Stream -> void* (stream handle)
+ * and `int&` passed as ctypes.byref(c_int), i.e. a pointer at ABI level.
+ *
+ * This header declares the same four argument lists as named symbols of ONE ahead-of-time library
+ * (voltrix_launch_*), plus the gfx950 extensions (fp16 operand, tile selection, fused GPU preprocess).
+ * The JIT layer of the Python package (voltrix/jit) still generates per-kernel `launch` wrappers with
+ * these exact argument lists; both routes call the same voltrix:: host launchers
+ * (the .hpp headers under voltrix-spmm_amd/voltrix/include/voltrix).
+ *
+ * Contract shared by every entry point
+ *   - plain C types only; every buffer is owned by the caller (the reference allocates everything in
+ *     Python, voltrix/spmm/spmm.py:28-57,101); the library never allocates or frees device memory and keeps
+ *     no state between calls;
+ *   - device work is enqueued asynchronously on `stream` (a hipStream_t; NULL = the null stream, which is
+ *     where the reference runs its preprocess kernels, bmat_kernels.cuh:204,234); no host synchronisation;
+ *   - *return_code is ALWAYS written: 0 on success, a voltrix_rc value otherwise (the reference plumbs
+ *     __return_code but never sets it; on errors it throws through ctypes or exit(1)s,
+ *     spmm_kernels.cuh:28-45);
+ *   - nothing is printed (the reference's preprocess printf's, bmat_kernels.cuh:309-310).
+ */
+#ifndef VOLTRIX_CAPI_H_
+#define VOLTRIX_CAPI_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VOLTRIX_ABI_VERSION 1
+
+#define VOLTRIX_BLK_H 16 /* rows per row window           (voltrix/spmm/spmm.py:12) */
+#define VOLTRIX_BLK_W 8  /* condensed columns per TC block (voltrix/spmm/spmm.py:13) */
+
+enum voltrix_rc {
+  VOLTRIX_OK = 0,
+  VOLTRIX_ERR_BAD_SHAPE = 1,  /* negative sizes, embedding_dim % 8 != 0 (fp16) / % 4 (fp32), misaligned pointer */
+  VOLTRIX_ERR_LAUNCH = 2,     /* hipGetLastError() after the launch */
+  VOLTRIX_ERR_BAD_CONFIG = 3, /* tile (fs, depth, waves) not instantiated */
+  VOLTRIX_ERR_OVERFLOW = 4,   /* total TC blocks exceed int32 (the handle stores int32 offsets) */
+  VOLTRIX_ERR_DUPLICATE = 5
+};
+
+int voltrix_abi_version(void);
+
+/* ---- the reference's four launch() argument lists ------------------------------------------------------- */
+
+/* Replaces launch() of kernel.preprocess_kernel.* -- voltrix/jit_kernels/preprocess.py:57-65 ->
+ * voltrix::preprocess, bmat_kernels.cuh:264-320.  ALL pointers are HOST int32 arrays:
+ * edge_list[E], node_pointer[num_nodes+1], block_partition[W], edge_to_column[E], edge_to_row[E],
+ * pointer1[W+1], W = ceil(num_nodes/16). */
+void voltrix_launch_preprocess(void* edge_list, void* node_pointer, int num_nodes, void* block_partition,
+                               void* edge_to_column, void* edge_to_row, void* pointer1, int* return_code);
+
+/* Replaces launch() of kernel.hmat_gen_kernel.* -- voltrix/jit_kernels/hmat_gem.py:56-68 -> voltrix::hmat_cuda,
+ * bmat_kernels.cuh:195-212 (kernel :21-111).  DEVICE pointers; hspa float[T*128] and hind int[T*8] are fully
+ * written (zero-filled then scattered), T = pointer1[num_row_windows].  Runs on the null stream like the
+ * reference (:204). */
+void voltrix_launch_hmat_gen(void* node_pointer, void* edge_list, void* block_partition, void* edge_to_column,
+                             void* edge_to_row, void* pointer1, int num_row_windows, int num_nodes, int num_edges,
+                             void* hspa, void* hind, int* return_code);
+
+/* Replaces launch() of kernel.hmat_packed_swizzle_kernel.* -- voltrix/jit_kernels/bmat_swizzle.py:38-43 ->
+ * voltrix::hmat_packed_swizzle_cuda, bmat_kernels.cuh:228-242 (kernel :151-193).  hspa_packed uint32[T*4]. */
+void voltrix_launch_hmat_packed_swizzle(int num_row_windows, void* pointer1, void* hspa, void* hspa_packed,
+                                        int* return_code);
+
+/* Replaces launch() of kernel.spmm_kernel.* -- voltrix/jit_kernels/spmm.py:78-88 ->
+ * voltrix::voltrix_spmm_forward_cuda, spmm_kernels.cuh:2003-2113.  input float32 [*, embedding_dim], output
+ * float32 [num_nodes, embedding_dim], both row-major contiguous DEVICE buffers; every row of output
+ * (including the num_nodes % 16 tail the reference leaves unwritten) is stored.  Exact fp32 products on
+ * v_mfma_f32_16x16x4_f32 (the reference rounds `input` to TF32).  embedding_dim % 4 == 0.  num_edges is unused,
+ * as in the reference.  The tile is chosen by voltrix_spmm_default_tile(). */
+void voltrix_launch_spmm(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
+                         int embedding_dim, void* input, void* output, void* stream, int* return_code);
+
+/* ---- gfx950 extensions ------------------------------------------------------------------------------------ */
+
+/* Same as voltrix_launch_spmm with an explicit tile: fs = feature slab per wave (32/64/128), depth = LDS ring
+ * depth (2..4), waves = waves per workgroup (1/2/4).  VOLTRIX_ERR_BAD_CONFIG if not instantiated. */
+void voltrix_launch_spmm_f32_tile(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
+                                  int embedding_dim, void* input, void* output, int fs, int depth, int waves,
+                                  void* stream, int* return_code);
+
+/* fp16 dense operand (BASELINE.json's headline configuration): input _Float16 [*, embedding_dim], output float32.
+ * v_mfma_f32_16x16x32_f16, fp32 accumulate.  embedding_dim % 8 == 0, input 16-byte aligned. */
+void voltrix_launch_spmm_f16(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
+                             int embedding_dim, void* input, void* output, void* stream, int* return_code);
+void voltrix_launch_spmm_f16_tile(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
+                                  int embedding_dim, void* input, void* output, int fs, int depth, int waves,
+                                  void* stream, int* return_code);
+
+/* Default tile for a feature width; is_f16 selects the operand type.  Always succeeds. */
+void voltrix_spmm_default_tile(int embedding_dim, int is_f16, int* fs, int* depth, int* waves);
+
+/* Number of instantiated tiles and the i-th one (for autotuners that enumerate the ahead-of-time space). */
+int voltrix_spmm_num_tiles(int is_f16);
+void voltrix_spmm_tile_at(int is_f16, int index, int* fs, int* depth, int* waves);
+
+/* fp32 -> fp16 cast of the dense operand into a caller-provided buffer (count % 8 == 0). */
+void voltrix_launch_cast_f32_f16(void* src, void* dst, int64_t count, void* stream, int* return_code);
+
+/* Fused GPU preprocess: CSR on the DEVICE -> (pointer1, hspa_packed, hind) without the reference's host
+ * preprocess, the O(TCb*E) rescan or the 512-byte/TC-block fp32 `hspa` intermediate.  Two phases because the
+ * caller owns every buffer and T is data dependent:
+ *   phase 1  voltrix_launch_csr_window_count: block_partition[W], pointer1[W+1] (device int32)
+ *            workspace: voltrix_csr_preprocess_workspace_bytes(num_nodes, num_edges) bytes, device, 16-B aligned
+ *   (caller reads T = pointer1[W], allocates hspa_packed uint32[4T] and hind int32[8T])
+ *   phase 2  voltrix_launch_csr_fill: writes hspa_packed and hind (every word), same workspace.
+ * Output is bit-identical to preprocess + hmat_gen + hmat_packed_swizzle. */
+int64_t voltrix_csr_preprocess_workspace_bytes(int num_nodes, int64_t num_edges);
+void voltrix_launch_csr_window_count(void* node_pointer, void* edge_list, int num_nodes, int64_t num_edges,
+                                     void* workspace, void* block_partition, void* pointer1, void* stream,
+                                     int* return_code);
+void voltrix_launch_csr_fill(void* node_pointer, void* edge_list, int num_nodes, int64_t num_edges, void* workspace,
+                             void* pointer1, void* hspa_packed, void* hind, void* stream, int* return_code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOLTRIX_CAPI_H_ */

@@ -1,0 +1,240 @@
+"""TEST INFRASTRUCTURE ONLY -- numpy restatement of the reference's hot path.
+
+This module is the *checker*: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.  The product package
+(``voltrix-spmm_amd/voltrix``) never imports anything from ``oracle/``.
+
+Every function restates one reference function and cites the lines it follows
+(paths relative to the reference checkout):
+
+=====================  ==========================================================
+``preprocess``         voltrix/include/voltrix/bmat_kernels.cuh:264-320 (+248-262)
+``hmat_gen``           voltrix/include/voltrix/bmat_kernels.cuh:21-111
+``hmat_packed_swizzle``  voltrix/include/voltrix/bmat_kernels.cuh:151-193
+``spmm_blocked``       voltrix/include/voltrix/spmm_kernels.cuh:1632-1716
+``calc_diff``          voltrix/utils.py:38-42
+``relative_error``     voltrix/utils.py:21-35
+=====================  ==========================================================
+
+Pinning (see DESIGN.md "Oracle"): the reference's native code cannot be built in
+this image (nvcc / CUDA runtime headers / PTX), so the restatement is pinned by
+(i) the reference's own test criterion -- ``calc_diff`` against
+``torch.sparse_csr_tensor(indptr, indices, ones) @ feat`` on the inputs of
+tests/test_spmm.py and tests/test_spmm_kernel.py, (ii) the known answers the
+survey recorded from the reference's ``preprocess``,
+(iii) golden vectors produced by importing the reference's pure-Python modules
+(tests/golden/make_goldens.py) and (iv) an independent unpack -> CSR round trip.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+BLK_H = 16  # voltrix/spmm/spmm.py:12, traits.h:6
+BLK_W = 8   # voltrix/spmm/spmm.py:13, traits.h:7
+
+
+# --------------------------------------------------------------------------- a2
+def preprocess(indptr, indices, num_nodes, blk_h=BLK_H, blk_w=BLK_W):
+    """CPU row-window condensing -- bmat_kernels.cuh:264-320.
+
+    Returns ``(block_partition[W], edge_to_column[E], edge_to_row[E], pointer1[W+1])``,
+    all int32.  Quirk kept: a window without edges still owns one (all-zero) TC
+    block because ``inplace_deduplication`` unconditionally inserts ``array[0]``
+    (bmat_kernels.cuh:252) so the map has size 1 (-> ``:298-299``).
+    """
+    indptr = np.asarray(indptr, dtype=np.int64)
+    indices = np.asarray(indices, dtype=np.int64)
+    num_edges = int(indices.shape[0])
+    num_windows = (num_nodes + blk_h - 1) // blk_h
+    edge_to_row = np.zeros(num_edges, dtype=np.int32)
+    edge_to_column = np.zeros(num_edges, dtype=np.int32)
+    block_partition = np.zeros(num_windows, dtype=np.int32)
+
+    # :273-276  edgeToRow[eid] = nid
+    deg = np.diff(indptr[: num_nodes + 1])
+    edge_to_row[:] = np.repeat(np.arange(num_nodes, dtype=np.int32), deg)
+
+    for w in range(num_windows):
+        lo = int(indptr[w * blk_h])
+        hi = int(indptr[min((w + 1) * blk_h, num_nodes)])
+        if hi == lo:
+            block_partition[w] = 1  # quirk, see docstring
+            continue
+        # :288-293 sort + de-duplicate the window's neighbour ids (as unsigned)
+        uniq = np.unique(indices[lo:hi].astype(np.uint32))
+        block_partition[w] = (uniq.size + blk_w - 1) // blk_w  # :298-299
+        # :304-307 edge -> rank of its column among the window's distinct columns
+        edge_to_column[lo:hi] = np.searchsorted(uniq, indices[lo:hi].astype(np.uint32))
+
+    pointer1 = np.zeros(num_windows + 1, dtype=np.int32)  # :312-319
+    pointer1[1:] = np.cumsum(block_partition, dtype=np.int64).astype(np.int32)
+    return block_partition, edge_to_column, edge_to_row, pointer1
+
+
+# --------------------------------------------------------------------------- a3
+def hmat_gen(indptr, indices, block_partition, edge_to_column, edge_to_row, pointer1,
+             num_nodes, blk_h=BLK_H, blk_w=BLK_W):
+    """Dense 0/1 fp32 tiles + per-tile column map -- bmat_kernels.cuh:21-111.
+
+    ``hspa`` f32 [T*128] row-major ``[r*8+c]`` (``:100-103``); ``hind`` i32 [T*8],
+    unused slots 0 (``:71-73``).
+    """
+    indices = np.asarray(indices)
+    total = int(pointer1[-1])
+    hspa = np.zeros(total * blk_h * blk_w, dtype=np.float32)
+    hind = np.zeros(total * blk_w, dtype=np.int32)
+    num_windows = block_partition.shape[0]
+    for w in range(num_windows):
+        lo = int(indptr[w * blk_h])
+        hi = int(indptr[min((w + 1) * blk_h, num_nodes)])
+        if hi == lo:
+            continue
+        e = np.arange(lo, hi)
+        col = edge_to_column[e].astype(np.int64)
+        blk = int(pointer1[w]) + col // blk_w                       # :94-96
+        row_local = edge_to_row[e].astype(np.int64) % blk_h          # :98
+        col_local = col % blk_w                                      # :99
+        hspa[blk * (blk_h * blk_w) + row_local * blk_w + col_local] = 1.0   # :100-102
+        hind[blk * blk_w + col_local] = indices[e]                   # :103-105
+    return hspa, hind
+
+
+# --------------------------------------------------------------------------- a4
+def hmat_packed_swizzle(pointer1, hspa, blk_h=BLK_H, blk_w=BLK_W):
+    """128 floats -> 4 x uint32 in mma.m16n8k8 A-fragment order -- bmat_kernels.cuh:151-193.
+
+    word ``t`` bit ``b`` <= ``hspa[(b>>2) + 8*(t&1)][(b&3) + 4*(t>>1)] != 0`` (``:180-188``).
+    """
+    total = int(pointer1[-1])
+    tiles = np.asarray(hspa, dtype=np.float32).reshape(total, blk_h, blk_w)
+    nz = np.abs(tiles) > 1e-5                                        # :186
+    packed = np.zeros((total, 4), dtype=np.uint32)
+    for t in range(4):
+        for bit in range(32):
+            row = (bit >> 2) + 8 * (t % 2)                           # :180-183
+            col = (bit % 4) + 4 * (t // 2)
+            packed[:, t] |= nz[:, row, col].astype(np.uint32) << np.uint32(bit)
+    return packed.reshape(-1)
+
+
+def unpack_swizzled(hspa_packed, blk_h=BLK_H, blk_w=BLK_W):
+    """Inverse of :func:`hmat_packed_swizzle` -> bool [T,16,8] (independent decode
+    written from the consumer side, spmm_kernels.cuh:1632-1644: lane ``l`` tests
+    ``word_t & (1<<l)`` and owns A[row=l>>2 (+8 for odd t)][col=l&3 (+4 for t>=2)])."""
+    words = np.asarray(hspa_packed, dtype=np.uint32).reshape(-1, 4)
+    total = words.shape[0]
+    tiles = np.zeros((total, blk_h, blk_w), dtype=bool)
+    for lane in range(32):
+        for t in range(4):
+            r = (lane >> 2) + (8 if (t & 1) else 0)
+            c = (lane & 3) + (4 if t >= 2 else 0)
+            tiles[:, r, c] = (words[:, t] >> np.uint32(lane)) & np.uint32(1)
+    return tiles
+
+
+def blocked_to_csr(pointer1, hspa_packed, hind, num_nodes, blk_h=BLK_H, blk_w=BLK_W):
+    """Round trip: (pointer1, hspa_packed, hind) -> de-duplicated, column-sorted CSR."""
+    tiles = unpack_swizzled(hspa_packed, blk_h, blk_w)
+    hind = np.asarray(hind, dtype=np.int64).reshape(-1, blk_w)
+    rows_out = [[] for _ in range(num_nodes)]
+    num_windows = len(pointer1) - 1
+    for w in range(num_windows):
+        for b in range(int(pointer1[w]), int(pointer1[w + 1])):
+            rr, cc = np.nonzero(tiles[b])
+            for r, c in zip(rr, cc):
+                row = w * blk_h + int(r)
+                assert row < num_nodes, "bit set in a row beyond num_nodes"
+                rows_out[row].append(int(hind[b, c]))
+    indptr = np.zeros(num_nodes + 1, dtype=np.int64)
+    out = []
+    for i, r in enumerate(rows_out):
+        r.sort()
+        out.extend(r)
+        indptr[i + 1] = len(out)
+    return indptr, np.asarray(out, dtype=np.int64)
+
+
+# ------------------------------------------------------------------- a8 numerics
+def round_tf32_rna(x):
+    """``cvt.rna.tf32.f32`` (spmm_kernels.cuh:1642,1671): round-to-nearest, ties away
+    from zero, to a 10-bit mantissa, result kept in an fp32 container."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).copy()
+    finite = (u & np.uint32(0x7F800000)) != np.uint32(0x7F800000)
+    u[finite] = (u[finite] + np.uint32(0x1000)) & np.uint32(0xFFFFE000)
+    return u.view(np.float32)
+
+
+def round_operand(x, mode):
+    x = np.asarray(x, dtype=np.float32)
+    if mode in (None, "none", "fp32"):
+        return x
+    if mode == "tf32":
+        return round_tf32_rna(x)
+    if mode == "fp16":
+        return x.astype(np.float16).astype(np.float32)
+    if mode == "bf16":
+        import torch
+        return torch.from_numpy(x.copy()).to(torch.bfloat16).to(torch.float32).numpy()
+    raise ValueError(mode)
+
+
+def spmm_blocked(pointer1, hspa_packed, hind, num_nodes, feat, rounding="tf32",
+                 blk_h=BLK_H, blk_w=BLK_W):
+    """Reference SpMM semantics on the block format -- spmm_kernels.cuh:1632-1716:
+
+    ``out[16w+r, f] = sum_{TCb i of w} sum_{c<8} bit(i,r,c) * round(feat[hind[8b+c], f])``
+    with fp32 accumulation in TC-block order.  ``rounding`` is ``"tf32"`` for the
+    reference's ``cvt.rna`` (``:1642,1671``), ``"fp16"`` for the gfx950 build.
+    Rows >= ``num_nodes`` of the last window are dropped (the reference leaves the
+    N%16 tail uncomputed, ``:1514``; the oracle -- like torch.sparse.mm -- computes it).
+    """
+    feat_r = round_operand(feat, rounding)
+    num_feats = feat_r.shape[1]
+    tiles = unpack_swizzled(hspa_packed, blk_h, blk_w).astype(np.float32)
+    hind = np.asarray(hind, dtype=np.int64).reshape(-1, blk_w)
+    num_windows = len(pointer1) - 1
+    out = np.zeros((num_windows * blk_h, num_feats), dtype=np.float32)
+    for w in range(num_windows):
+        acc = np.zeros((blk_h, num_feats), dtype=np.float32)
+        for b in range(int(pointer1[w]), int(pointer1[w + 1])):
+            acc += tiles[b] @ feat_r[hind[b]]  # fp32, one TC block (k=8) at a time
+        out[w * blk_h:(w + 1) * blk_h] = acc
+    return out[:num_nodes]
+
+
+def spmm_csr(indptr, indices, feat, num_nodes, dtype=np.float64):
+    """Plain ``csr(ones) @ feat`` (duplicates summed, like torch.sparse.mm) in ``dtype``."""
+    import scipy.sparse as sp
+    indptr = np.asarray(indptr, dtype=np.int64)
+    indices = np.asarray(indices, dtype=np.int64)
+    a = sp.csr_matrix((np.ones(indices.shape[0], dtype=dtype), indices, indptr),
+                      shape=(num_nodes, int(feat.shape[0])))
+    return np.asarray(a @ np.asarray(feat, dtype=dtype))
+
+
+# ----------------------------------------------------------------------- metrics
+def calc_diff(x, y):
+    """``1 - 2<x,y>/(<x,x>+<y,y>)`` -- voltrix/utils.py:38-42 (fp32 there; fp64 here
+    when the inputs are fp64)."""
+    x = np.asarray(x)
+    y = np.asarray(y)
+    den = (x * x + y * y).sum()
+    return 1 - 2 * (x * y).sum() / den
+
+
+def relative_error(value, real):
+    """Mean |value-real|/|real| over entries with real != 0 -- voltrix/utils.py:21-35."""
+    value = np.asarray(value, dtype=np.float64).ravel()
+    real = np.asarray(real, dtype=np.float64).ravel()
+    mask = (np.abs(real) == 0) | np.isinf(real) | np.isinf(value)
+    return float((np.abs(value - real)[~mask] / np.abs(real[~mask])).mean())
+
+
+def forward_error_bound(indptr, indices, feat, num_nodes, rounding="fp16"):
+    """Element-wise bound of SURVEY.md section 8c (iii):
+    ``|out-ref|_ij <= (u + deg_i * 2^-24) * (A |B|)_ij`` with u the unit round-off of
+    the operand rounding (2^-11 for fp16 and tf32-rna)."""
+    u = {"fp16": 2.0 ** -11, "tf32": 2.0 ** -11, "bf16": 2.0 ** -8, "none": 0.0}[rounding]
+    deg = np.diff(np.asarray(indptr, dtype=np.int64))[:num_nodes].astype(np.float64)
+    aabs = spmm_csr(indptr, indices, np.abs(np.asarray(feat, dtype=np.float64)), num_nodes)
+    return (u + deg[:, None] * 2.0 ** -24) * aabs + 1e-30

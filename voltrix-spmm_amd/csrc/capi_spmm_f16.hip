@@ -1,0 +1,35 @@
+// libvoltrix_hip.so -- fp16-operand SpMM entry points (include/voltrix_capi.h).
+#include "capi_common.hpp"
+
+using namespace voltrix_capi;
+
+extern "C" {
+
+void voltrix_launch_spmm_f16_tile(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
+                                  int embedding_dim, void* input, void* output, int fs, int depth, int waves,
+                                  void* stream, int* return_code) {
+  (void)num_edges;  // unused by the reference's live kernels as well
+  *return_code = dispatch_spmm<2, _Float16>(fs, depth, waves, static_cast<const int*>(blk_offsets),
+                                            static_cast<const uint32_t*>(hspa_packed), static_cast<const int*>(hind),
+                                            num_nodes, embedding_dim, static_cast<const _Float16*>(input),
+                                            static_cast<float*>(output), static_cast<hipStream_t>(stream));
+}
+
+void voltrix_launch_spmm_f16(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
+                             int embedding_dim, void* input, void* output, void* stream, int* return_code) {
+  const TileId t = default_tile(embedding_dim, true);
+  voltrix_launch_spmm_f16_tile(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, output, t.fs,
+                               t.depth, t.waves, stream, return_code);
+}
+
+void voltrix_launch_cast_f32_f16(void* src, void* dst, int64_t count, void* stream, int* return_code) {
+  *return_code = voltrix::cast_f32_to_f16(static_cast<const float*>(src), static_cast<_Float16*>(dst), count,
+                                          static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"
+
+namespace voltrix_capi {
+int num_tiles_f16() { return num_tiles<2>(); }
+bool tile_at_f16(int i, TileId* t) { return tile_at<2>(i, t); }
+}  // namespace voltrix_capi

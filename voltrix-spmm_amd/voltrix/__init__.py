@@ -1,0 +1,14 @@
+"""voltrix -- MI355X-native (gfx950 / CDNA4) drop-in for the Voltrix-SpMM operator surface.
+
+Same public names as the reference package (voltrix/__init__.py:1-3): ``BLK_H``, ``BLK_W``,
+``csr_preprocess``, ``spmm``, the four ``*_kernel`` wrappers, ``jit`` and the ``VOLTRIX_*`` flag names.
+"""
+from .project import *  # noqa: F401,F403
+from .jit_kernels import *  # noqa: F401,F403
+from .jit_kernels import (csr_fused_preprocess_kernel, hmat_gen_kernel, hmat_packed_swizzle_kernel, jit_tuner,
+                          preprocess_kernel, spmm_kernel)
+from .spmm import *  # noqa: F401,F403
+from .spmm import BLK_H, BLK_W, csr_preprocess, spmm
+from . import jit, utils
+
+__version__ = "0.1.0"

@@ -1,0 +1,133 @@
+"""ctypes binding of the ahead-of-time C-ABI library ``lib/libvoltrix_hip.so`` (include/voltrix_capi.h).
+
+The library is the drop-in boundary for non-Python hosts and the home of the gfx950 extensions that have no
+reference counterpart (fused GPU preprocess, fp16 operand, tile enumeration).  There is NO fallback: if the
+library is missing it is built with hipcc (csrc/Makefile); if that fails the import error is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_ROOT, "lib", "libvoltrix_hip.so")
+CSRC_DIR = os.path.join(_ROOT, "csrc")
+
+_lib = None
+
+# every symbol include/voltrix_capi.h declares (tests/test_capi_symbols.py cross-checks this list with the header)
+SYMBOLS = (
+    "voltrix_abi_version",
+    "voltrix_launch_preprocess",
+    "voltrix_launch_hmat_gen",
+    "voltrix_launch_hmat_packed_swizzle",
+    "voltrix_launch_spmm",
+    "voltrix_launch_spmm_f32_tile",
+    "voltrix_launch_spmm_f16",
+    "voltrix_launch_spmm_f16_tile",
+    "voltrix_spmm_default_tile",
+    "voltrix_spmm_num_tiles",
+    "voltrix_spmm_tile_at",
+    "voltrix_launch_cast_f32_f16",
+    "voltrix_csr_preprocess_workspace_bytes",
+    "voltrix_launch_csr_window_count",
+    "voltrix_launch_csr_fill",
+)
+
+
+def build(force: bool = False) -> str:
+    """Compile the library for gfx950 (works without a GPU)."""
+    cmd = ["make", "-s", "-C", CSRC_DIR, "-j4"]
+    if force:
+        subprocess.check_call(["make", "-s", "-C", CSRC_DIR, "clean"])
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.voltrix_abi_version.restype = ctypes.c_int
+        _lib.voltrix_spmm_num_tiles.restype = ctypes.c_int
+        _lib.voltrix_csr_preprocess_workspace_bytes.restype = ctypes.c_int64
+        for name in SYMBOLS:
+            if name.startswith("voltrix_launch_") or name in ("voltrix_spmm_default_tile", "voltrix_spmm_tile_at"):
+                getattr(_lib, name).restype = None
+    return _lib
+
+
+class VoltrixError(RuntimeError):
+    pass
+
+
+_RC = {1: "bad shape / alignment", 2: "HIP launch error", 3: "tile configuration not instantiated",
+       4: "int32 overflow of the block format", 5: "duplicate CSR entries"}
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise VoltrixError(f"{what}: return code {rc} ({_RC.get(rc, 'unknown')})")
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def default_tile(embedding_dim: int, is_f16: bool):
+    fs, d, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    lib().voltrix_spmm_default_tile(ctypes.c_int(embedding_dim), ctypes.c_int(int(is_f16)), ctypes.byref(fs),
+                                    ctypes.byref(d), ctypes.byref(w))
+    return fs.value, d.value, w.value
+
+
+def tiles(is_f16: bool):
+    out = []
+    for i in range(lib().voltrix_spmm_num_tiles(ctypes.c_int(int(is_f16)))):
+        fs, d, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        lib().voltrix_spmm_tile_at(ctypes.c_int(int(is_f16)), ctypes.c_int(i), ctypes.byref(fs), ctypes.byref(d),
+                                   ctypes.byref(w))
+        out.append((fs.value, d.value, w.value))
+    return out
+
+
+def csr_preprocess_workspace_bytes(num_nodes: int, num_edges: int) -> int:
+    return int(lib().voltrix_csr_preprocess_workspace_bytes(ctypes.c_int(num_nodes), ctypes.c_int64(num_edges)))
+
+
+def launch_csr_window_count(indptr, indices, num_nodes, workspace, block_partition, pointer1, stream) -> None:
+    rc = ctypes.c_int(-1)
+    lib().voltrix_launch_csr_window_count(_ptr(indptr), _ptr(indices), ctypes.c_int(num_nodes),
+                                          ctypes.c_int64(indices.numel()), _ptr(workspace), _ptr(block_partition),
+                                          _ptr(pointer1), ctypes.c_void_p(stream), ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_csr_window_count")
+
+
+def launch_csr_fill(indptr, indices, num_nodes, workspace, pointer1, hspa_packed, hind, stream) -> None:
+    rc = ctypes.c_int(-1)
+    lib().voltrix_launch_csr_fill(_ptr(indptr), _ptr(indices), ctypes.c_int(num_nodes), ctypes.c_int64(indices.numel()),
+                                  _ptr(workspace), _ptr(pointer1), _ptr(hspa_packed), _ptr(hind),
+                                  ctypes.c_void_p(stream), ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_csr_fill")
+
+
+def launch_spmm(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input_ptr, output_ptr, is_f16,
+                tile, stream) -> int:
+    """Raw-pointer launch (used by bench.py and the no-JIT mode); returns the return code."""
+    rc = ctypes.c_int(-1)
+    fn = lib().voltrix_launch_spmm_f16_tile if is_f16 else lib().voltrix_launch_spmm_f32_tile
+    fn(ctypes.c_void_p(blk_offsets), ctypes.c_void_p(hspa_packed), ctypes.c_void_p(hind), ctypes.c_int(num_nodes),
+       ctypes.c_int(num_edges), ctypes.c_int(embedding_dim), ctypes.c_void_p(input_ptr), ctypes.c_void_p(output_ptr),
+       ctypes.c_int(tile[0]), ctypes.c_int(tile[1]), ctypes.c_int(tile[2]), ctypes.c_void_p(stream), ctypes.byref(rc))
+    return rc.value
+
+
+def launch_cast_f32_f16(src, dst, stream) -> None:
+    rc = ctypes.c_int(-1)
+    lib().voltrix_launch_cast_f32_f16(_ptr(src), _ptr(dst), ctypes.c_int64(src.numel()), ctypes.c_void_p(stream),
+                                      ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_cast_f32_f16")

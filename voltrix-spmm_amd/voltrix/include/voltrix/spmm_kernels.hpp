@@ -1,0 +1,415 @@
+// Voltrix-SpMM for MI355X (gfx950 / CDNA4) -- the tiled SpMM accumulate.
+//
+//   C[16w + r, :] = sum_{TC block b of window w} sum_{c < 8} bit(b, r, c) * B[hind[8b + c], :]
+//
+// Same math and the same (blk_offsets, hspa_packed, hind) handle as the reference's live kernels
+// spmm_mma161616_spa_swizzle_d/_dd (voltrix/include/voltrix/spmm_kernels.cuh:1458-1727, :1729-2001)
+// and host dispatcher voltrix_spmm_forward_cuda (:2003-2113).  The design is gfx950-native, not a
+// translation of that Hopper code:
+//
+//   reference (sm_90a)                            here (gfx950)
+//   ------------------------------------------   -----------------------------------------------------
+//   CTA = 1 producer + 4 consumer warps,          work unit = ONE wave64 owning (row window, FS-column
+//   mbarrier full/empty ring (:1496-1505)         slab); wave-private LDS ring; NO workgroup barrier at
+//                                                 all -- the only ordering an LDS-DMA has is the issuing
+//                                                 wave's vmcnt, so a wave-private pipeline needs nothing else
+//   cp.async.bulk row gathers + cp.async          global_load_lds_dwordx4 (1 KiB / instruction, per-lane source
+//   bitmaps (:1548-1570)                          = row gather) for B rows, global_load_lds_dword for the
+//                                                 stage's hind + bitmap words; counted s_waitcnt vmcnt(N)
+//   2 x mma.m16n8k8.tf32 per 16 columns per       1 x v_mfma_f32_16x16x32_f16 per 16 columns per FOUR TC blocks
+//   TC block, B via 4 scalar LDS loads (:1654)    (K = 32); B operand via ds_read_b64_tr_b16 (hardware transpose)
+//   +8 float row padding against bank conflicts   XOR slot swizzle applied on the DMA *source* address and on the
+//   (traits.h:116-118)                            transposed read (LDS-DMA writes are lane-linear)
+//   bit(lane) of 4 words -> tf32 1.0 (:1632-1644) 8 bits (two nibbles of two words) -> four packed fp16 {1,0} regs
+//   hind padding (=0) gathers B[0] (quirk)        padded / out-of-window columns gather the window's first real
+//                                                 column instead (A bits are 0), so B[0,:] = NaN cannot leak
+//   grid = floor(N/16) (tail rows never written)  ceil(N/16) windows, tail rows masked at the store
+//   int32 offsets (:1568,:1688)                   64-bit row offsets
+//
+// Bound: the kernel is gather-bound (B rows from L2 / Infinity Cache / HBM); MFMA utilisation is a few percent
+// by construction (DESIGN.md "Roofline").
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <type_traits>
+
+#include "voltrix/traits.hpp"
+
+namespace voltrix {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
+typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+
+using gas_ptr = const void __attribute__((address_space(1)))*;
+using lds_ptr = void __attribute__((address_space(3)))*;
+
+// ---- LDS / wait helpers.  All LDS *reads* of DMA-written data go through inline asm so that hipcc does not
+// ---- serialise them behind in-flight LDS-DMAs with a vmcnt(0) (cdna_hip_programming.md section 5, "Pipelining").
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_lgkmcnt0() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);  // keep MFMAs / users below the wait (guide rule 18)
+}
+__device__ __forceinline__ unsigned lds_read_b32(unsigned addr) {
+  unsigned v;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+__device__ __forceinline__ uint2_t lds_read_b64(unsigned addr) {
+  uint2_t v;
+  asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ uint2_t lds_read_tr16_b64(unsigned addr) {
+  uint2_t v;  // EXEC must be all ones here (T10): every caller is wave-uniform control flow
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+__device__ __forceinline__ void dma_b128(const void* src, unsigned lds_byte_addr) {
+  __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(uintptr_t)lds_byte_addr, 16, 0, 0);
+}
+__device__ __forceinline__ void dma_b32(const void* src, unsigned lds_byte_addr) {
+  __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(uintptr_t)lds_byte_addr, 4, 0, 0);
+}
+
+// Slot swizzle: LDS row r keeps logical 32-byte slot s at physical slot s ^ slot_swizzle(r).  One transposed read
+// touches, per 32-lane half, rows {8g+q, 8g'+q : q<4} (+4 for the second read); this makes their 8 x 32 B land on
+// 8 distinct slots of the 256-B bank row for every FS (derivation in DESIGN.md "LDS image").
+template <int SLOTS>
+__device__ __forceinline__ constexpr int slot_swizzle(int r) {
+  const int ident = (r & 3) | (((r >> 3) & 1) << 2);
+  return SLOTS >= 8 ? ident : (SLOTS == 4 ? (ident >> 1) : (ident >> 2));
+}
+
+// 8 adjacency bits -> four packed fp16x2 registers holding 1.0 / 0.0
+__device__ __forceinline__ half8_t bits_to_half8(unsigned bits8) {
+  uint4_t r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned pair = ((bits8 >> (2 * i)) & 1u) | (((bits8 >> (2 * i + 1)) & 1u) << 16);
+    r[i] = pair * 0x3C00u;  // 0x3C00 = fp16 1.0
+  }
+  return __builtin_bit_cast(half8_t, r);
+}
+
+__device__ __forceinline__ float lds_read_f32(unsigned addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
+template <class T>
+struct SpmmArgs {
+  using in_t = typename std::conditional<T::EB == 2, _Float16, float>::type;
+  const int* blk_offsets;        // [W+1]  (reference Pointer1)
+  const uint32_t* hspa_packed;   // [4T]   swizzled bitmaps
+  const int* hind;               // [8T]   condensed column -> row of B
+  const in_t* input;             // [num_input_rows, F] row-major
+  float* output;                 // [N, F] fp32 row-major
+  int num_nodes;
+  int num_windows;
+  int F;
+  int num_slabs;
+  long long num_units;           // num_windows * num_slabs
+  long long blocks_per_xcd;
+};
+
+// One wave64 = one (row window, FS-column slab) unit.  EB == 2: fp16 operand, v_mfma_f32_16x16x32_f16.
+// EB == 4: fp32 operand, exact products on v_mfma_f32_16x16x4_f32 (k-step m of a stage uses LDS rows 4m + lane/16).
+template <class T>
+static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const SpmmArgs<T> a) {
+  constexpr int FS = T::FS, D = T::DEPTH, MS = T::META_SLOTS, EB = T::EB;
+  constexpr int ROW_BYTES = T::ROW_BYTES, STAGE_BYTES = T::STAGE_BYTES, NDMA = T::DMA_PER_STAGE;
+  constexpr int RPD = T::ROWS_PER_DMA, LPR = T::LANES_PER_ROW, SLOTS = T::SLOTS;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+
+  // XCD-aware unit id: blocks b, b+8, b+16 ... share an XCD (speed only; any placement is correct).  XCD x walks a
+  // contiguous range of units, so co-resident waves of one L2 gather from overlapping row neighbourhoods.
+  const long long blin = (long long)(blockIdx.x % kNumXcd) * a.blocks_per_xcd + blockIdx.x / kNumXcd;
+  const long long unit = blin * T::WAVES + wave;
+  if (unit >= a.num_units) return;  // wave-uniform; the kernel has no barriers
+  const int w = (int)(unit / a.num_slabs);
+  const int fs0 = (int)(unit % a.num_slabs) * FS;
+
+  const int kb0 = a.blk_offsets[w];
+  const int kb1 = a.blk_offsets[w + 1];
+  const int nblk = kb1 - kb0;
+  const int nst = (nblk + kTcbPerStage - 1) / kTcbPerStage;
+  const int F = a.F;
+
+  float4_t acc[SLOTS];
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) acc[s] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem + (unsigned)wave * T::WAVE_LDS;
+  const unsigned meta0 = lds0 + D * STAGE_BYTES;
+
+  // a window without edges owns one all-zero TC block (reference quirk, bmat_kernels.cuh:252): nothing to gather
+  bool empty = false;
+  if (nblk == 1) {
+    const uint4 w4 = *reinterpret_cast<const uint4*>(a.hspa_packed + 4ll * kb0);
+    empty = (w4.x | w4.y | w4.z | w4.w) == 0u;
+  }
+
+  if (nblk > 0 && !empty) {
+    const int h_safe = a.hind[8ll * kb0];  // first real column of the window: finite data, gathered anyway
+
+    // ---- lane constants -------------------------------------------------------------------------------------
+    const int k32 = lane & 31;             // condensed column of the stage this lane holds metadata for
+    const int kblk = k32 >> 3, kcol = k32 & 7;
+    const unsigned colmask = 0x11111111u << (kcol & 3);
+    const unsigned vword_off = 128 + 4 * (4 * kblk + 2 * (kcol >> 2));  // words t = 2(c>>2), +1 of block kblk
+    const int g = lane >> 4, R = lane & 15;  // MFMA lane group / row (A) or column (B, D)
+    const unsigned a_shift = 4 * (R & 7);
+    const int mj = (lane - 32) & 15;         // metadata DMA: lanes 32-63 fetch bitmap words (48-63 duplicate)
+
+    auto issue_meta = [&](int tau, int mslot) {
+      const void* src;
+      if (lane < 32) {
+        int blk = kb0 + 4 * tau + kblk;
+        blk = blk < kb1 ? blk : kb1 - 1;  // stay inside the window: stages past its end re-read its last block
+        src = a.hind + (8ll * blk + kcol);
+      } else {
+        int blk = kb0 + 4 * tau + (mj >> 2);
+        blk = blk < kb1 ? blk : kb1 - 1;
+        src = a.hspa_packed + (4ll * blk + (mj & 3));
+      }
+      dma_b32(src, meta0 + mslot * T::META_BYTES);
+    };
+
+    // hv: lane L holds the (sanitised) row of B for condensed column L & 31 of the stage
+    auto issue_data = [&](int dslot, int hv) {
+      const unsigned dst = lds0 + dslot * STAGE_BYTES;
+#pragma unroll
+      for (int i = 0; i < NDMA; ++i) {
+        const int r = i * RPD + lane / LPR;           // LDS row written by this lane
+        const int c = lane % LPR;                     // 16-byte chunk inside the row
+        int col;                                      // logical column of that chunk (swizzle on the SOURCE)
+        if constexpr (EB == 2)
+          col = fs0 + (((c >> 1) ^ slot_swizzle<SLOTS>(r)) * 16) + (c & 1) * 8;
+        else
+          col = fs0 + (((c >> 2) ^ (r & 1)) * 16) + (c & 3) * 4;
+        col = col < F ? col : fs0;                    // F % FS tail: stay in bounds, results are not stored
+        const int hrow = __shfl(hv, r, kWave);
+        dma_b128(a.input + ((long long)hrow * F + col), dst + i * 1024);
+      }
+    };
+
+    auto sanitise = [&](int tau, unsigned hraw, uint2_t vw) -> int {
+      const bool inwin = (kb0 + 4 * tau + kblk) < kb1;
+      const bool valid = inwin && (((vw[0] | vw[1]) & colmask) != 0u);
+      return valid ? (int)hraw : h_safe;  // padded hind slots are 0 in the format: never gather B[0] for them
+    };
+
+    // ---- prologue: metadata of stages 0..D-1, then (metadata D+j, rows of stage j) for j < D -------------------
+#pragma unroll
+    for (int j = 0; j < D; ++j) issue_meta(j, j);
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      issue_meta(D + j, (D + j) % MS);
+      if (j < nst) {
+        const unsigned m = meta0 + j * T::META_BYTES;
+        const unsigned hraw = lds_read_b32(m + 4 * k32);
+        const uint2_t vw = lds_read_b64(m + vword_off);
+        wait_lgkmcnt0();
+        issue_data(j, sanitise(j, hraw, vw));
+      }
+    }
+
+    // ---- main loop -----------------------------------------------------------------------------------------
+    int dslot = 0;                  // t % D
+    int mslot = 0;                  // t % MS
+    int mslot_d = D;                // (t + D) % MS
+    int mslot_2d = (2 * D) % MS;    // (t + 2D) % MS
+    for (int t = 0; t < nst; ++t) {
+      // stage t's rows and stage t+D's metadata were issued D steps ago; everything younger may stay in flight:
+      // (D-1) metadata DMAs + NDMA per younger row stage (at most D-1 of them)
+      const int rem = nst - 1 - t;
+      if (rem >= D - 1) {
+        wait_vmcnt<T::vm_behind(D - 1)>();
+      } else {
+        switch (rem) {  // rem <= D-2
+          case 0: wait_vmcnt<T::vm_behind(0)>(); break;
+          case 1: wait_vmcnt<T::vm_behind(1)>(); break;
+          case 2: wait_vmcnt<T::vm_behind(2)>(); break;
+          case 3: wait_vmcnt<T::vm_behind(3)>(); break;
+          default: wait_vmcnt<T::vm_behind(4)>(); break;
+        }
+      }
+
+      const unsigned mt = meta0 + mslot * T::META_BYTES;
+      const bool more = (t + D) < nst;  // wave-uniform
+      unsigned hraw = 0;
+      uint2_t vw = {0u, 0u};
+      if (more) {
+        const unsigned md = meta0 + mslot_d * T::META_BYTES;
+        hraw = lds_read_b32(md + 4 * k32);
+        vw = lds_read_b64(md + vword_off);
+      }
+
+      if constexpr (EB == 2) {
+        // A: lane -> row R of TC block g; its 8 bits are nibble R&7 of words t = R>>3 (cols 0-3), 2 + R>>3 (cols 4-7)
+        const unsigned wlo = lds_read_b32(mt + 128 + 4 * (4 * g + (R >> 3)));
+        const unsigned whi = lds_read_b32(mt + 128 + 4 * (4 * g + 2 + (R >> 3)));
+        // B: lane 16g+4q+p supplies LDS row 8g+q (+4), bytes 8p.. of logical slot s; receives column R
+        const int q = (lane >> 2) & 3, p = lane & 3;
+        const int trow = 8 * g + q;
+        const unsigned dbase = lds0 + dslot * STAGE_BYTES + trow * ROW_BYTES + 8 * p;
+        const int tr_z = slot_swizzle<SLOTS>(trow);
+        uint2_t blo[SLOTS], bhi[SLOTS];
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+          const unsigned addr = dbase + ((s ^ tr_z) << 5);
+          blo[s] = lds_read_tr16_b64<0>(addr);
+          bhi[s] = lds_read_tr16_b64<4 * ROW_BYTES>(addr);
+        }
+        wait_lgkmcnt0();
+
+        // refill: metadata for stage t+2D (always: keeps the vmcnt arithmetic static), rows for stage t+D
+        issue_meta(t + 2 * D, mslot_2d);
+        if (more) issue_data(dslot, sanitise(t + D, hraw, vw));
+
+        unsigned bits8 = ((wlo >> a_shift) & 0xFu) | (((whi >> a_shift) & 0xFu) << 4);
+        if (kb0 + 4 * t + g >= kb1) bits8 = 0u;  // TC blocks past the window's end contribute zero
+        const half8_t afrag = bits_to_half8(bits8);
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+          const uint4_t bq = {blo[s][0], blo[s][1], bhi[s][0], bhi[s][1]};
+          acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, __builtin_bit_cast(half8_t, bq), acc[s], 0, 0, 0);
+        }
+      } else {
+        // A: k-step m covers condensed columns 4m+g: TC block m>>1, column 4(m&1)+g -> word 2(m&1) + R>>3, bit
+        // 4(R&7) + g.  Per lane: words R>>3 and 2 + R>>3 of each of the stage's 4 blocks.
+        unsigned wlo[4], whi[4];
+#pragma unroll
+        for (int bm = 0; bm < 4; ++bm) {
+          wlo[bm] = lds_read_b32(mt + 128 + 4 * (4 * bm + (R >> 3)));
+          whi[bm] = lds_read_b32(mt + 128 + 4 * (4 * bm + 2 + (R >> 3)));
+        }
+        // B: lane reads LDS row 4m+g, column 16s+R; 64-byte slots are XORed with (row & 1) = g & 1, which turns into
+        // two lane bases (even / odd s) plus compile-time offsets
+        const int z = g & 1;
+        const unsigned lbase = lds0 + dslot * STAGE_BYTES + g * ROW_BYTES + 4 * R;
+        const unsigned base_e = lbase + 64 * z, base_o = lbase - 64 * z;
+        float bv[8][SLOTS];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+#pragma unroll
+          for (int s = 0; s < SLOTS; ++s) {
+            bv[m][s] = lds_read_f32(((s & 1) ? base_o : base_e) + (4 * m * ROW_BYTES + 64 * s));
+          }
+        }
+        wait_lgkmcnt0();
+
+        issue_meta(t + 2 * D, mslot_2d);
+        if (more) issue_data(dslot, sanitise(t + D, hraw, vw));
+
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const int bm = m >> 1;
+          unsigned word = (m & 1) ? whi[bm] : wlo[bm];
+          if (kb0 + 4 * t + bm >= kb1) word = 0u;
+          const float av = ((word >> (a_shift + g)) & 1u) ? 1.0f : 0.0f;
+#pragma unroll
+          for (int s = 0; s < SLOTS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[m][s], acc[s], 0, 0, 0);
+        }
+      }
+
+      dslot = dslot + 1 == D ? 0 : dslot + 1;
+      mslot = mslot + 1 == MS ? 0 : mslot + 1;
+      mslot_d = mslot_d + 1 == MS ? 0 : mslot_d + 1;
+      mslot_2d = mslot_2d + 1 == MS ? 0 : mslot_2d + 1;
+    }
+    wait_vmcnt<0>();  // the trailing metadata DMAs must have landed before the wave's LDS is released
+  }
+
+  // ---- epilogue: D[row = 4*(lane>>4) + j][col = lane & 15] per 16-column slot ----------------------------------
+  const int orow0 = w * kBlkH + 4 * (lane >> 4);
+  const int ocol0 = fs0 + (lane & 15);
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    const int col = ocol0 + 16 * s;
+    if (col < F) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = orow0 + j;
+        if (row < a.num_nodes) a.output[(long long)row * F + col] = acc[s][j];
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Host launcher for one tile configuration.
+template <class T>
+inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed, const int* hind, int num_nodes,
+                            int embedding_dim, const typename SpmmArgs<T>::in_t* input, float* output,
+                            hipStream_t stream) {
+  if (num_nodes < 0 || embedding_dim < 0) return kErrBadShape;
+  if (num_nodes == 0 || embedding_dim == 0) return kOk;
+  if (embedding_dim % (16 / T::EB) != 0) return kErrBadShape;  // 16-byte row chunks
+  if (((uintptr_t)input & 15) || ((uintptr_t)hspa_packed & 15)) return kErrBadShape;
+  SpmmArgs<T> a;
+  a.blk_offsets = blk_offsets;
+  a.hspa_packed = hspa_packed;
+  a.hind = hind;
+  a.input = input;
+  a.output = output;
+  a.num_nodes = num_nodes;
+  a.num_windows = (num_nodes + kBlkH - 1) / kBlkH;
+  a.F = embedding_dim;
+  a.num_slabs = (embedding_dim + T::FS - 1) / T::FS;
+  a.num_units = (long long)a.num_windows * a.num_slabs;
+  const long long blocks = (a.num_units + T::WAVES - 1) / T::WAVES;
+  a.blocks_per_xcd = (blocks + kNumXcd - 1) / kNumXcd;
+  const long long grid = a.blocks_per_xcd * kNumXcd;
+  if (grid > 0x7FFFFFFFll) return kErrBadShape;
+  static bool attr_done = false;  // per instantiation
+  if (!attr_done) {
+    if (T::BLOCK_LDS > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_tc16_kernel<T>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, T::BLOCK_LDS) != hipSuccess)
+      return kErrBadConfig;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(spmm_tc16_kernel<T>, dim3((unsigned)grid), dim3(T::THREADS), T::BLOCK_LDS, stream, a);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+// fp32 -> fp16 cast of the dense operand (the reference rounds B to TF32 in-kernel, spmm_kernels.cuh:1671; gfx950
+// has no TF32, fp16 keeps the same 10-bit mantissa -- SURVEY.md section 8c "tolerance evidence").
+static __global__ __launch_bounds__(256) void cast_f32_to_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst,
+                                                              const long long n8) {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    const float4 x = reinterpret_cast<const float4*>(src)[2 * i];
+    const float4 y = reinterpret_cast<const float4*>(src)[2 * i + 1];
+    h8 o = {(_Float16)x.x, (_Float16)x.y, (_Float16)x.z, (_Float16)x.w,
+            (_Float16)y.x, (_Float16)y.y, (_Float16)y.z, (_Float16)y.w};
+    reinterpret_cast<h8*>(dst)[i] = o;
+  }
+}
+
+inline int cast_f32_to_f16(const float* src, _Float16* dst, long long n, hipStream_t stream) {
+  if (n < 0 || (n % 8) != 0 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return kErrBadShape;
+  if (n == 0) return kOk;
+  const long long n8 = n / 8;
+  const int blocks = (int)(n8 / 256 + 1 < 256 * 16 ? n8 / 256 + 1 : 256 * 16);
+  hipLaunchKernelGGL(cast_f32_to_f16_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, n8);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+}  // namespace voltrix

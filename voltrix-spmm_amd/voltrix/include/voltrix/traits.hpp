@@ -1,0 +1,70 @@
+// Voltrix-SpMM for MI355X (gfx950 / CDNA4) -- compile-time tile geometry.
+//
+// Counterpart of the reference's voltrix/include/voltrix/traits.h:6-11,13-60 (BLK_H/BLK_W
+// macros, PersistenKernelTraits).  Nothing is shared with it beyond the 16x8 "TC block"
+// format constants: the gfx950 kernels are wave64, wave-private LDS rings, no thread-block
+// wide barriers, and one v_mfma_f32_16x16x32_f16 consumes four 16x8 TC blocks (K = 32).
+#pragma once
+
+#include <cstdint>
+
+#define VOLTRIX_BLK_H 16  // rows per row window          (reference traits.h:6)
+#define VOLTRIX_BLK_W 8   // condensed columns per TC block (reference traits.h:7)
+
+namespace voltrix {
+
+constexpr int kBlkH = VOLTRIX_BLK_H;
+constexpr int kBlkW = VOLTRIX_BLK_W;
+constexpr int kWave = 64;                 // gfx950 wavefront
+constexpr int kTcbPerStage = 4;           // 4 TC blocks = 32 condensed columns = one MFMA K step
+constexpr int kStageK = kTcbPerStage * kBlkW;
+constexpr int kNumXcd = 8;                // MI355X: 8 XCDs, blocks b and b+8 share an L2
+
+// Error codes written to `__return_code` by every C-ABI entry point (the reference plumbs the
+// variable but never sets it: template.py:114, runtime.py:50-52).
+enum ReturnCode : int {
+  kOk = 0,
+  kErrBadShape = 1,       // unsupported num_nodes / embedding_dim / alignment
+  kErrLaunch = 2,         // hipGetLastError() != hipSuccess after the launch
+  kErrBadConfig = 3,      // tile configuration not instantiated / LDS budget exceeded
+  kErrOverflow = 4,       // a 32-bit quantity of the reference format would overflow
+  kErrDuplicate = 5,      // duplicate (row, col) entries where the contract forbids them
+};
+
+// Tile parameters of the SpMM kernel template (the autotune space; replaces the reference's
+// `model` 0/1/2 switch, spmm_kernels.cuh:2014-2108).
+//   FS     feature slab handled by one wave (columns of B / C): 32, 64, 128 or 256
+//   DEPTH  stages of 32 gathered rows kept in flight per wave (LDS ring slots)
+//   WAVES  waves per workgroup (each wave owns its (row window, slab) unit; no barriers)
+//   EB     bytes per element of the dense operand in LDS: 2 (fp16, v_mfma_f32_16x16x32_f16) or
+//          4 (fp32, exact v_mfma_f32_16x16x4_f32)
+template <int FS_, int DEPTH_, int WAVES_, int EB_ = 2>
+struct SpmmTile {
+  static constexpr int FS = FS_;
+  static constexpr int DEPTH = DEPTH_;
+  static constexpr int WAVES = WAVES_;
+  static constexpr int EB = EB_;
+  static_assert(FS == 32 || FS == 64 || FS == 128 || FS == 256, "feature slab");
+  static_assert(EB == 2 || EB == 4, "element bytes");
+  static_assert(DEPTH >= 2 && DEPTH <= 6, "ring depth");
+  static constexpr int ROW_BYTES = FS * EB;                      // slab of one gathered row
+  static constexpr int STAGE_BYTES = kStageK * ROW_BYTES;         // 32 rows
+  static constexpr int DMA_PER_STAGE = STAGE_BYTES / 1024;        // 1 KiB per global_load_lds_dwordx4
+  static constexpr int ROWS_PER_DMA = 1024 / ROW_BYTES;
+  static constexpr int LANES_PER_ROW = ROW_BYTES / 16;
+  static constexpr int SLOTS = FS / 16;                           // 16-column slots (one MFMA N) per row
+  static constexpr int META_SLOTS = 2 * DEPTH + 1;                // metadata ring (hind + bitmaps)
+  static constexpr int META_BYTES = 256;                          // 32 hind + 16 bitmap words + pad
+  static constexpr int WAVE_LDS = DEPTH * STAGE_BYTES + META_SLOTS * META_BYTES;
+  static constexpr int BLOCK_LDS = WAVES * WAVE_LDS;
+  static constexpr int THREADS = WAVES * kWave;
+  // ops a wave issues per pipeline step: 1 metadata DMA + DMA_PER_STAGE row-gather DMAs
+  static constexpr int VM_PER_STEP = 1 + DMA_PER_STAGE;
+  static_assert(VM_PER_STEP * (DEPTH - 1) <= 63, "vmcnt is a 6-bit counter on gfx9");
+  // s_waitcnt vmcnt immediate that retires the row stage being consumed while `k` younger row stages (k <= DEPTH-1)
+  // and the DEPTH-1 metadata DMAs issued between them stay in flight
+  static constexpr int vm_behind(int k) { return (DEPTH - 1) + (k < DEPTH - 1 ? k : DEPTH - 1) * DMA_PER_STAGE; }
+  static_assert(BLOCK_LDS <= 160 * 1024, "LDS per CU");
+};
+
+}  // namespace voltrix

@@ -1,0 +1,162 @@
+"""hipcc driver + on-disk kernel cache.
+
+Counterpart of the reference's voltrix/jit/compiler.py (nvcc, sm_90a): same cache layout
+``$VOLTRIX_CACHE_DIR | ~/.voltrix-spmm`` ``/cache/kernel.<name>.<md5[:12]>/`` + ``/tmp``, same atomic
+``os.replace`` publication (compiler.py:109-114,185), same kind of signature (kernel name, hash of the device
+headers, generated code, compiler identity, flags -- compiler.py:140-142).  The compiler is hipcc for
+``--offload-arch=gfx950``; it cross-compiles without a GPU, so ``__graft_entry__.build()`` can pre-populate
+an in-tree cache that travels to the GPU box.
+"""
+from __future__ import annotations
+
+import functools
+import hashlib
+import os
+import re
+import subprocess
+import uuid
+from typing import Tuple
+
+from ..project import (
+    CACHE_DIR_FLAG,
+    DEBUG_FLAG,
+    HIPCC_COMPILER_FLAG,
+    JIT_PRINT_NVCC_COMMAND_FLAG,
+    NVCC_COMPILER_FLAG,
+    OFFLOAD_ARCH_FLAG,
+    PROJECT_NAME_ABBR_LOWER,
+    PROJECT_NAME_FULL_LOWER,
+    PTXAS_VERBOSE_FLAG,
+)
+from .runtime import Runtime, RuntimeCache
+from .template import args_to_text
+
+runtime_cache = RuntimeCache()
+
+
+def hash_to_hex(s: str) -> str:
+    """First 12 hex digits of md5 (reference compiler.py:25-28; golden-tested)."""
+    return hashlib.md5(s.encode("utf-8")).hexdigest()[0:12]
+
+
+@functools.lru_cache(maxsize=None)
+def get_jit_include_dir() -> str:
+    return os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include"))
+
+
+@functools.lru_cache(maxsize=None)
+def get_repo_version() -> str:
+    """md5 over every device header: editing a kernel invalidates the cache (reference compiler.py:45-59)."""
+    root = os.path.join(get_jit_include_dir(), PROJECT_NAME_ABBR_LOWER)
+    assert os.path.isdir(root), f"Cannot find include directory {root}"
+    md5 = hashlib.md5()
+    for dirpath, _, filenames in sorted(os.walk(root, followlinks=True)):
+        for fn in sorted(filenames):
+            if fn.endswith((".hpp", ".h")):
+                with open(os.path.join(dirpath, fn), "rb") as f:
+                    md5.update(f.read())
+    return md5.hexdigest()[0:12]
+
+
+@functools.lru_cache(maxsize=None)
+def get_hipcc_compiler() -> Tuple[str, str]:
+    """(path, version) of the first usable hipcc: $VOLTRIX_HIPCC_COMPILER, $VOLTRIX_NVCC_COMPILER (legacy name),
+    $ROCM_PATH/bin/hipcc, /opt/rocm/bin/hipcc (reference get_nvcc_compiler, compiler.py:62-81)."""
+    candidates = [os.getenv(HIPCC_COMPILER_FLAG), os.getenv(NVCC_COMPILER_FLAG)]
+    if os.getenv("ROCM_PATH"):
+        candidates.append(os.path.join(os.environ["ROCM_PATH"], "bin", "hipcc"))
+    candidates.append("/opt/rocm/bin/hipcc")
+    pattern = re.compile(r"HIP version:\s*([\d.]+)")
+    for path in candidates:
+        if path and os.path.exists(path):
+            out = subprocess.run([path, "--version"], capture_output=True, text=True).stdout
+            match = pattern.search(out)
+            assert match, f"Cannot get the version of HIP compiler {path}"
+            return path, match.group(1)
+    raise RuntimeError("Cannot find any available hipcc compiler")
+
+
+get_nvcc_compiler = get_hipcc_compiler  # drop-in alias (reference name)
+
+
+def get_offload_arch() -> str:
+    return os.getenv(OFFLOAD_ARCH_FLAG, "gfx950")
+
+
+def get_default_user_dir() -> str:
+    if CACHE_DIR_FLAG in os.environ:
+        path = os.environ[CACHE_DIR_FLAG]
+        os.makedirs(path, exist_ok=True)
+        return path
+    return os.path.join(os.path.expanduser("~"), f".{PROJECT_NAME_FULL_LOWER}")
+
+
+def get_tmp_dir() -> str:
+    return os.path.join(get_default_user_dir(), "tmp")
+
+
+def get_cache_dir() -> str:
+    return os.path.join(get_default_user_dir(), "cache")
+
+
+def make_tmp_dir() -> str:
+    os.makedirs(get_tmp_dir(), exist_ok=True)
+    return get_tmp_dir()
+
+
+def put(path: str, data, is_binary: bool = False) -> None:
+    """Write then POSIX-atomic replace, so concurrent builders never expose a torn file."""
+    tmp = os.path.join(make_tmp_dir(), f"file.tmp.{uuid.uuid4()}.{hash_to_hex(path)}")
+    with open(tmp, "wb" if is_binary else "w") as f:
+        f.write(data)
+    os.replace(tmp, path)
+
+
+def compile_flags() -> list:
+    flags = [
+        "-std=c++17",
+        "-shared",
+        "-fPIC",
+        "-O3",
+        f"--offload-arch={get_offload_arch()}",
+        "-Wno-unused-function",
+        "-Wno-deprecated-declarations",
+    ]
+    if PTXAS_VERBOSE_FLAG in os.environ:
+        flags.append("-Rpass-analysis=kernel-resource-usage")
+    return flags
+
+
+def kernel_dir(name: str, code: str) -> str:
+    flags = compile_flags()
+    signature = f"{name}$${get_repo_version()}$${code}$${get_hipcc_compiler()}$${flags}"
+    return os.path.join(get_cache_dir(), f"kernel.{name}.{hash_to_hex(signature)}")
+
+
+def build(name: str, arg_defs: tuple, code: str) -> Runtime:
+    path = kernel_dir(name, code)
+    cached = runtime_cache[path]
+    if cached is not None:
+        if os.getenv(DEBUG_FLAG, None):
+            print(f"Using cached JIT runtime {os.path.basename(path)} during build")
+        return cached
+
+    os.makedirs(path, exist_ok=True)
+    src_path = os.path.join(path, "kernel.hip")
+    put(os.path.join(path, "kernel.args"), args_to_text(arg_defs))
+    put(src_path, code)
+
+    so_path = os.path.join(path, "kernel.so")
+    tmp_so = os.path.join(make_tmp_dir(), f"hipcc.tmp.{uuid.uuid4()}.{hash_to_hex(so_path)}.so")
+    command = [get_hipcc_compiler()[0], src_path, "-o", tmp_so, *compile_flags(), f"-I{get_jit_include_dir()}"]
+    if os.getenv(DEBUG_FLAG, None) or os.getenv(JIT_PRINT_NVCC_COMMAND_FLAG, False):
+        print(f"Compiling JIT runtime {os.path.basename(path)} with command {command}")
+    proc = subprocess.run(command, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"Failed to compile {src_path}:\n{proc.stderr[-4000:]}")
+    if PTXAS_VERBOSE_FLAG in os.environ:
+        print(proc.stderr)
+    os.replace(tmp_so, so_path)
+
+    runtime_cache[path] = Runtime(path)
+    return runtime_cache[path]

@@ -1,0 +1,70 @@
+"""ctypes runtime of one JIT-built kernel directory (kernel.hip, kernel.args, kernel.so).
+
+Counterpart of the reference's voltrix/jit/runtime.py:9-72: same call contract -- positional args checked
+against kernel.args (count, tensor dtype / python type), marshalled with ``map_ctype``, ``launch`` called
+with a trailing ``byref(c_int)`` and the integer return code handed back (0 = success).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+from .template import args_from_text, map_ctype
+
+KERNEL_FILES = ("kernel.hip", "kernel.args", "kernel.so")
+
+
+class Runtime:
+    def __init__(self, path: str) -> None:
+        self.path = path
+        self.lib = None
+        self.args = None
+        self._launch = None
+        assert self.is_path_valid(self.path), f"not a built kernel directory: {path}"
+
+    @staticmethod
+    def is_path_valid(path: str) -> bool:
+        return os.path.isdir(path) and all(os.path.exists(os.path.join(path, f)) for f in KERNEL_FILES)
+
+    def _load(self) -> None:
+        self.lib = ctypes.CDLL(os.path.join(self.path, "kernel.so"))
+        self._launch = self.lib.launch
+        self._launch.restype = None
+        with open(os.path.join(self.path, "kernel.args"), "r") as f:
+            self.args = args_from_text(f.read())
+
+    def __call__(self, *args) -> int:
+        if self.lib is None:
+            self._load()
+        assert len(args) == len(self.args), f"Expected {len(self.args)} arguments, got {len(args)}"
+        cargs = []
+        for arg, (name, dtype) in zip(args, self.args):
+            if isinstance(arg, torch.Tensor):
+                assert arg.dtype == dtype, f"Expected tensor dtype `{dtype}` for `{name}`, got `{arg.dtype}`"
+            else:
+                assert isinstance(arg, dtype), f"Expected built-in type `{dtype}` for `{name}`, got `{type(arg)}`"
+            cargs.append(map_ctype(arg))
+        return_code = ctypes.c_int(-1)
+        self._launch(*cargs, ctypes.byref(return_code))
+        return return_code.value
+
+
+class RuntimeCache:
+    """path -> Runtime; falls back to the file system (reference runtime.py:55-72)."""
+
+    def __init__(self) -> None:
+        self.cache = {}
+
+    def __getitem__(self, path: str) -> Optional[Runtime]:
+        if path in self.cache:
+            return self.cache[path]
+        if Runtime.is_path_valid(path):
+            self.cache[path] = Runtime(path)
+            return self.cache[path]
+        return None
+
+    def __setitem__(self, path: str, runtime: Runtime) -> None:
+        self.cache[path] = runtime

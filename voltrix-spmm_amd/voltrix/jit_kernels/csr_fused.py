@@ -1,0 +1,27 @@
+"""Fused GPU preprocess (no reference counterpart): CSR on the device ->
+``(pointer1, hspa_packed, hind)`` bit-identical to preprocess + hmat_gen + hmat_packed_swizzle.
+Goes through the ahead-of-time C-ABI (include/voltrix_capi.h: voltrix_launch_csr_window_count / _csr_fill)."""
+import torch
+
+from .. import capi
+
+
+def csr_fused_preprocess_kernel(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int):
+    assert indptr.is_cuda and indptr.dtype == torch.int32 and indptr.is_contiguous()
+    assert indices.is_cuda and indices.dtype == torch.int32 and indices.is_contiguous()
+    assert indptr.numel() == num_nodes + 1
+    device = indptr.device
+    num_edges = indices.numel()
+    num_row_windows = (num_nodes + 15) // 16
+    stream = torch.cuda.current_stream().cuda_stream
+
+    workspace = torch.empty(capi.csr_preprocess_workspace_bytes(num_nodes, num_edges), dtype=torch.uint8, device=device)
+    block_partition = torch.empty(num_row_windows, dtype=torch.int32, device=device)
+    pointer1 = torch.empty(num_row_windows + 1, dtype=torch.int32, device=device)
+    capi.launch_csr_window_count(indptr, indices, num_nodes, workspace, block_partition, pointer1, stream)
+
+    total_blocks = int(pointer1[-1].item())  # host sync point, as in the reference (spmm.py:44)
+    hspa_packed = torch.empty(total_blocks * 4, dtype=torch.uint32, device=device)
+    hind = torch.empty(total_blocks * 8, dtype=torch.int32, device=device)
+    capi.launch_csr_fill(indptr, indices, num_nodes, workspace, pointer1, hspa_packed, hind, stream)
+    return pointer1, hspa_packed, hind, block_partition

@@ -1,0 +1,105 @@
+"""``spmm_kernel``: the tiled SpMM accumulate (reference voltrix/jit_kernels/spmm.py:39-94).
+
+The tuning space is the gfx950 tile template ``SpmmTile<FS, DEPTH, WAVES, EB>`` (traits.hpp) instead of the
+reference's ``model`` 0/1/2; the tuner key adds the feature width, operand dtype and device to the matrix tag
+(the reference keys on the tag alone, so the model picked at the first F is reused for every F -- SURVEY.md
+section 8a quirk 9).
+"""
+import os
+import warnings
+
+import torch
+
+from ..jit.compiler import hash_to_hex
+from ..project import TUNE_SPACE_FLAG
+from .tuner import jit_tuner
+
+includes = ('"voltrix/spmm_kernels.hpp"',)
+template = """
+__return_code = voltrix::launch_spmm_tc16<voltrix::SpmmTile<{FS}, {DEPTH}, {WAVES}, {EB}>>(
+    blk_offsets, hspa_packed, hind,
+    num_nodes, embedding_dim, input, output, stream);
+"""
+
+
+def feature_hash(feature: torch.Tensor) -> str:
+    """Tag of the sparse matrix the handle belongs to (reference spmm.py:17-36): the caller-set
+    ``hspa_packed.hash_tag`` string, else the buffer address (with the reference's warning)."""
+    if hasattr(feature, "hash_tag") and isinstance(feature.hash_tag, str):
+        return hash_to_hex(feature.hash_tag)
+    warnings.warn(
+        "The feature tensor(i.e. `hspa_packed`)'s hash_tag attr is not set. "
+        "Voltrix will use the memory address as the key value for profiling, "
+        "which may lead to performance degradation of different cases."
+    )
+    return hash_to_hex(str(feature.data_ptr()))
+
+
+def _lds_bytes(fs, depth, waves, eb):
+    return waves * (depth * 32 * fs * eb + (2 * depth + 1) * 256)
+
+
+def tile_space(embedding_dim: int, elem_bytes: int):
+    """Points of the tile space worth trying for this feature width."""
+    mode = os.getenv(TUNE_SPACE_FLAG, "default")
+    fs_max = 128
+    fs_fit = 32 if embedding_dim <= 32 else (64 if embedding_dim <= 64 else fs_max)
+    if mode == "none":
+        depth = 4 if elem_bytes == 2 else (2 if fs_fit == 128 else 4)
+        return ({"FS": fs_fit, "DEPTH": depth, "WAVES": 1, "EB": elem_bytes},)
+    if mode == "full":
+        fs_list = sorted({fs_fit, max(32, fs_fit // 2), min(256, fs_fit * 2) if embedding_dim > 128 else fs_fit})
+        depths, waves = (2, 3, 4), (1, 2, 4)
+    else:
+        fs_list = sorted({fs_fit, max(32, fs_fit // 2)})
+        depths, waves = (3, 4), (1, 4)
+    space = []
+    for fs in fs_list:
+        for d in depths:
+            for w in waves:
+                ndma = 32 * fs * elem_bytes // 1024
+                if _lds_bytes(fs, d, w, elem_bytes) <= 160 * 1024 and (1 + ndma) * (d - 1) <= 63:
+                    space.append({"FS": fs, "DEPTH": d, "WAVES": w, "EB": elem_bytes})
+    return tuple(space)
+
+
+def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, output):
+    assert blk_offsets.is_cuda and blk_offsets.dtype == torch.int32
+    assert hspa_packed.is_cuda and hspa_packed.dtype == torch.uint32
+    assert hind.is_cuda and hind.dtype == torch.int32
+    assert input.is_cuda and input.dtype in (torch.float, torch.float16) and input.is_contiguous()
+    assert output.is_cuda and output.dtype == torch.float and output.is_contiguous()
+    assert input.dim() == 2 and input.shape[1] == embedding_dim
+    assert output.shape[0] == num_nodes and output.shape[1] == embedding_dim
+    elem_bytes = input.element_size()
+    assert embedding_dim % (16 // elem_bytes) == 0, "embedding_dim must keep rows 16-byte aligned (voltrix.spmm pads)"
+
+    args = (blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, output,
+            torch.cuda.current_stream())
+    runtime = jit_tuner.compile_and_tune(
+        name="spmm_kernel",
+        keys={
+            "feature_hash": feature_hash(hspa_packed),
+            "embedding_dim": embedding_dim,
+            "dtype": str(input.dtype),
+            "device": torch.cuda.get_device_name(input.device),
+        },
+        space=tile_space(embedding_dim, elem_bytes),
+        includes=includes,
+        arg_defs=(
+            ("blk_offsets", blk_offsets.dtype),
+            ("hspa_packed", hspa_packed.dtype),
+            ("hind", hind.dtype),
+            ("num_nodes", int),
+            ("num_edges", int),
+            ("embedding_dim", int),
+            ("input", input.dtype),
+            ("output", output.dtype),
+            ("stream", torch.cuda.Stream),
+        ),
+        template=template,
+        args=args,
+        kernel_tag="spmm",
+    )
+    rc = runtime(*args)
+    assert rc == 0, f"spmm_kernel failed with return code {rc}"

@@ -1,0 +1,130 @@
+"""Build-and-pick autotuner for JIT kernels.
+
+Counterpart of the reference's voltrix/jit_kernels/tuner.py:42-168: every point of ``space`` is rendered
+(``cpp_format`` -> ``generate``), built in parallel, run once for validity (non-zero return code = skipped;
+here the kernels really set it), timed, and the fastest ``Runtime`` is memoised per ``(name, keys)``.
+Differences, all deliberate:
+  * builds run in a thread pool of hipcc subprocesses, not a forked ``mp.Pool`` (forking a process that has
+    initialised HIP is not safe);
+  * timing is HIP events on the launch stream (utils.GPU_bench), not kineto text scraping;
+  * the winning point is also persisted in ``<cache dir>/tuned.json`` so that a later process builds/loads only
+    that variant (the reference forgets it at exit, tuner.py:44,164).
+"""
+from __future__ import annotations
+
+import copy
+import json
+import os
+from concurrent.futures import ThreadPoolExecutor
+from typing import Any, Callable, Dict, Optional
+
+from ..jit import build, cpp_format, generate
+from ..jit.compiler import get_default_user_dir, put
+from ..project import DEBUG_FLAG, PRINT_AUTOTUNE_FLAG
+
+
+def _debug() -> bool:
+    return bool(os.getenv(DEBUG_FLAG, None))
+
+
+def _build_one(name, arg_defs, code, tuned_keys):
+    try:
+        return build(name, arg_defs, code), tuned_keys
+    except Exception as exc:  # an illegal point of the space must not kill tuning (reference tuner.py:35-39)
+        if _debug():
+            print(f"JIT build of {name} {tuned_keys} failed: {exc}")
+        return None, tuned_keys
+
+
+class JITTuner:
+    def __init__(self) -> None:
+        self.tuned: Dict[Any, Any] = {}
+        self.tuned_keys: Dict[Any, Dict] = {}
+
+    # ---- persistent choices ------------------------------------------------------------------------------
+    @staticmethod
+    def _store_path() -> str:
+        return os.path.join(get_default_user_dir(), "tuned.json")
+
+    def _load_store(self) -> Dict[str, Dict]:
+        try:
+            with open(self._store_path(), "r") as f:
+                return json.load(f)
+        except (OSError, ValueError):
+            return {}
+
+    def _save_choice(self, signature, tuned_keys) -> None:
+        store = self._load_store()
+        store[f"{signature[0]}|{signature[1]}"] = tuned_keys
+        try:
+            os.makedirs(get_default_user_dir(), exist_ok=True)
+            put(self._store_path(), json.dumps(store, indent=1, sort_keys=True))
+        except OSError:
+            pass
+
+    # ---- main entry --------------------------------------------------------------------------------------
+    def compile_and_tune(self, name: str, keys: Dict[str, Any], space: tuple, includes: tuple, arg_defs: tuple,
+                         template: str, args: tuple, kernel_tag: Optional[str] = None,
+                         bench: Optional[Callable] = None):
+        keys = {k: keys[k] for k in sorted(keys.keys())}
+        signature = (name, f"{keys}")
+        if signature in self.tuned:
+            if _debug():
+                print(f"Using cached JIT kernel {name} with keys {keys}")
+            return self.tuned[signature]
+        if _debug():
+            print(f"Auto-tuning JIT kernel {name} with keys {keys}")
+        assert args is not None
+        space = (dict(),) if len(space) == 0 else tuple(space)
+
+        def render(tuned_keys):
+            full = copy.deepcopy(keys)
+            full.update(tuned_keys)
+            return generate(includes, arg_defs, cpp_format(template, full))
+
+        # a choice persisted by an earlier process short-circuits the sweep
+        if len(space) > 1:
+            stored = self._load_store().get(f"{signature[0]}|{signature[1]}")
+            if stored is not None and stored in list(space):
+                runtime, _ = _build_one(name, arg_defs, render(stored), stored)
+                if runtime is not None:
+                    self.tuned[signature], self.tuned_keys[signature] = runtime, stored
+                    return runtime
+
+        workers = max(1, min(len(space), os.cpu_count() or 1))
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            futures = [pool.submit(_build_one, name, arg_defs, render(tk), tk) for tk in space]
+            kernels = [f.result() for f in futures]
+        kernels = [(rt, tk) for rt, tk in kernels if rt is not None]
+
+        best_runtime, best_time, best_keys = None, None, None
+        for runtime, tuned_keys in kernels:
+            if len(space) > 1:
+                if runtime(*args) != 0:  # illegal kernel for these arguments (e.g. LDS budget, alignment)
+                    if _debug():
+                        print(f"Illegal JIT kernel {name} with keys {keys} and tuned keys {tuned_keys}")
+                    continue
+                if bench is not None:
+                    elapsed = bench(lambda: runtime(*args))
+                else:
+                    from ..utils import GPU_bench
+
+                    elapsed = GPU_bench(lambda: runtime(*args), iters=8, warmup=2, kernel_name=kernel_tag)
+            else:
+                elapsed = 0.0
+            if best_time is None or elapsed < best_time:
+                best_runtime, best_time, best_keys = runtime, elapsed, tuned_keys
+            if _debug():
+                print(f"Tuned JIT kernel {name} with keys {keys} and tuned keys {tuned_keys} has time {elapsed}")
+        assert best_runtime is not None, f"Failed to tune JIT kernel {name} with keys {keys}"
+
+        if _debug() or os.getenv(PRINT_AUTOTUNE_FLAG, None):
+            print(f"JIT kernel {name}[in {len(kernels)}/{len(space)}] with keys {keys} has tuned keys {best_keys} "
+                  f"and time {best_time:.4f}ms")
+        self.tuned[signature], self.tuned_keys[signature] = best_runtime, best_keys
+        if len(space) > 1:
+            self._save_choice(signature, best_keys)
+        return best_runtime
+
+
+jit_tuner = JITTuner()

@@ -1,0 +1,5 @@
+from .spmm import BLK_H, BLK_W
+from .spmm import (
+    csr_preprocess,
+    spmm,
+)

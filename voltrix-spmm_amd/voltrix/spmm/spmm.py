@@ -1,0 +1,93 @@
+"""Public operator API: ``csr_preprocess`` and ``spmm`` (reference voltrix/spmm/spmm.py:16-114).
+
+Drop-in contract: same names, argument meaning, assertion behaviour and return types;
+the returned handle ``(blk_offsets, hspa_packed, hind)`` has the reference's exact byte layout.
+"""
+import math
+import os
+
+import torch
+
+from ..jit_kernels import (
+    csr_fused_preprocess_kernel,
+    hmat_gen_kernel,
+    hmat_packed_swizzle_kernel,
+    preprocess_kernel,
+    spmm_kernel,
+)
+from ..project import FP32_MODE_FLAG, PREPROCESS_FLAG
+
+BLK_H = 16
+BLK_W = 8
+
+
+def csr_preprocess(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int):
+    """CSR (CPU int32, as in the reference :21-22) -> ``(blk_offsets int32 [W+1], hspa_packed uint32 [4T],
+    hind int32 [8T])`` on the current CUDA device.
+
+    Default: one H2D copy of the CSR and the fused GPU preprocess.  ``VOLTRIX_PREPROCESS=reference`` runs the
+    reference's own three-stage pipeline (host ``preprocess_kernel``, ``hmat_gen_kernel``,
+    ``hmat_packed_swizzle_kernel``, with the transient fp32 ``hspa``); both give identical bytes.
+    Duplicate (row, col) entries count once (bitmap), whereas ``torch.sparse.mm`` sums them (quirk 5).
+    """
+    assert indptr.is_cpu and indptr.dtype == torch.int32
+    assert indices.is_cpu and indices.dtype == torch.int32
+    assert indptr.numel() == num_nodes + 1
+
+    if os.getenv(PREPROCESS_FLAG, "fused") != "reference":
+        pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(
+            indptr.contiguous().cuda(), indices.contiguous().cuda(), num_nodes)
+        return pointer1, hspa_packed, hind
+
+    num_edges = indices.numel()
+    num_row_windows = math.ceil(num_nodes / BLK_H)
+    edge_to_column = torch.zeros(num_edges, dtype=torch.int32)
+    edge_to_row = torch.zeros(num_edges, dtype=torch.int32)
+    block_partition = torch.zeros(num_row_windows, dtype=torch.int32)
+    pointer1 = torch.zeros(block_partition.numel() + 1, dtype=torch.int32)
+    preprocess_kernel(edge_list=indices.contiguous(), node_pointer=indptr.contiguous(),
+                      block_partition=block_partition, edge_to_column=edge_to_column, edge_to_row=edge_to_row,
+                      pointer1=pointer1)
+
+    total_blocks = int(pointer1[-1].item())
+    hspa = torch.empty(total_blocks * BLK_H * BLK_W, dtype=torch.float32, device="cuda")
+    hind = torch.empty(total_blocks * BLK_W, dtype=torch.int32, device="cuda")
+    hspa_packed = torch.empty(hspa.numel() // 32, dtype=torch.uint32, device="cuda")
+
+    indptr_d, indices_d = indptr.cuda(), indices.cuda()
+    edge_to_column, edge_to_row = edge_to_column.cuda(), edge_to_row.cuda()
+    block_partition, pointer1 = block_partition.cuda(), pointer1.cuda()
+    hmat_gen_kernel(node_pointer=indptr_d, edge_list=indices_d, block_partition=block_partition,
+                    edge_to_column=edge_to_column, edge_to_row=edge_to_row, pointer1=pointer1, hspa=hspa, hind=hind)
+    hmat_packed_swizzle_kernel(block_partition=block_partition, pointer1=pointer1, hspa=hspa, hspa_packed=hspa_packed)
+    return pointer1, hspa_packed, hind
+
+
+def spmm(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tensor, num_nodes: int, num_edges: int,
+         feat: torch.Tensor):
+    """``csr(ones) @ feat`` -> new float32 ``[num_nodes, F]`` on ``feat.device``, on the current stream.
+
+    ``feat``: CUDA, 2-D, contiguous; float32 (the reference's only dtype, jit_kernels/spmm.py:53) or float16
+    (BASELINE.json's headline).  float32 is rounded to fp16 for the MFMA -- the same 10-bit mantissa as the
+    reference's TF32 rounding (spmm_kernels.cuh:1671) -- unless ``VOLTRIX_FP32_MODE=exact``, which keeps exact
+    fp32 products.  Every output row is written, including the ``num_nodes % 16`` tail the reference skips.
+    """
+    assert feat.is_cuda and feat.dim() == 2
+    feat = feat.contiguous()
+    num_feats = feat.shape[1]
+    assert feat.dtype in (torch.float32, torch.float16), f"unsupported feature dtype {feat.dtype}"
+    tag = getattr(hspa_packed, "hash_tag", None)
+
+    exact = feat.dtype == torch.float32 and os.getenv(FP32_MODE_FLAG, "fp16") == "exact"
+    operand = feat if (exact or feat.dtype == torch.float16) else feat.to(torch.float16)
+    align = 16 // operand.element_size()
+    padded = (num_feats + align - 1) // align * align
+    if padded != num_feats:  # keep gathered rows 16-byte aligned
+        operand = torch.nn.functional.pad(operand, (0, padded - num_feats))
+    output = torch.empty((num_nodes, padded), dtype=torch.float32, device=feat.device)
+
+    if tag is not None and not hasattr(hspa_packed, "hash_tag"):
+        hspa_packed.hash_tag = tag
+    spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes=num_nodes, num_edges=num_edges, embedding_dim=padded,
+                input=operand, output=output)
+    return output if padded == num_feats else output[:, :num_feats].contiguous()
