@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SpMM GFLOP/s + achieved HBM GB/s, reddit-like CSR x dense feat=128 fp16 (BASELINE.json).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over the whole synthetic graph: (N > 1: RCCL all-gather of the dense operand B,
+then) the tiled SpMM accumulate on every rank's row-window shard.  Inputs are resident in HBM before the timed region;
+preprocessing (CSR -> block format) is done once, outside it, as in the reference's protocol (bench/bm_voltrix.py:17,36).
+Rank 0 prints ONE JSON line.  N > 1 shards the SAME matrix by row windows (strong scaling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.join(REPO, "voltrix-spmm_amd")
+for _p in (REPO, PKG_ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+os.environ.setdefault("VOLTRIX_CACHE_DIR", os.path.join(PKG_ROOT, ".jit_cache"))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import synth_graphs  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured-achievable)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="reddit_like", choices=sorted(synth_graphs.CONFIGS))
+    ap.add_argument("--feat", type=int, default=None, help="feature width (default: the workload's)")
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the node count (debug only)")
+    ap.add_argument("--tile", default=None, help="fs,depth,waves (default: quick sweep over the tile space)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(indptr, indices, num_nodes, num_feats, seed=0):
+    """torch.sparse.mm (the reference's own oracle call, tests/test_spmm.py:24-29) on the host cores, fp32 -- CPU fp16
+    CSR mm is not implemented in torch.  Bounded sample: the whole matrix up to 150 M edges, else a contiguous 1/16 row
+    sample."""
+    from oracle import torch_ref  # checker / baseline leg only
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ip, ix = indptr.cpu(), indices.cpu()
+    rows, sample = num_nodes, "all rows"
+    if ix.numel() > 150_000_000:
+        rows = (num_nodes // 16) // 16 * 16
+        sample = f"contiguous 1/16 row sample (rows 0..{rows})"
+        ip = ip[: rows + 1].clone()
+        ix = ix[: int(ip[-1])].clone()
+    a = torch_ref.csr_ones(ip, ix, rows, num_nodes)
+    gen = torch.Generator().manual_seed(seed)
+    feat = torch.randn(num_nodes, num_feats, generator=gen)
+    for _ in range(2):
+        a @ feat
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        a @ feat
+        times.append(time.perf_counter() - t0)
+    t = sorted(times)[len(times) // 2]
+    nnz = int(ix.numel())
+    return {
+        "value": 2.0 * nnz * num_feats / t / 1e9,
+        "unit": "GFLOP/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"torch.sparse.mm(csr(ones fp32), feat fp32) on CPU, {sample}, nnz={nnz}, F={num_feats}, "
+                  f"median of 5 after 2 warm-ups ({t * 1e3:.1f} ms); the reference's own CPU oracle call",
+        "ms": t * 1e3,
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    import voltrix
+    from voltrix import capi
+    from voltrix import dist as vdist
+
+    cfg = synth_graphs.CONFIGS[args.workload]
+    num_feats = args.feat or cfg["feat"]
+    is_f16 = args.dtype == "f16"
+    in_bytes = 2 if is_f16 else 4
+
+    # ---- synthetic graph (same seed on every rank), row-window shard, block-format handle ------------------------
+    indptr, indices, _ = synth_graphs.generate(args.workload, device=device, scale=args.scale)
+    num_nodes, nnz = indptr.numel() - 1, indices.numel()
+    parts = vdist.partition_rows(indptr, num_nodes, world)
+    r0, r1 = parts[rank]
+    rows_padded = max(1, max(p[1] - p[0] for p in parts))
+    local_indptr, local_indices = vdist.shard_csr(indptr, indices, num_nodes, parts, rank)
+    if world > 1:
+        local_indices = vdist.remap_columns(local_indices, parts, rows_padded)
+    local_rows, local_nnz = r1 - r0, local_indices.numel()
+    t0 = time.perf_counter()
+    blk_offsets, hspa_packed, hind, _ = voltrix.csr_fused_preprocess_kernel(local_indptr, local_indices, local_rows)
+    torch.cuda.synchronize()
+    preprocess_ms = (time.perf_counter() - t0) * 1e3
+    total_blocks = int(blk_offsets[-1])
+
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    feat_local = torch.randn(local_rows, num_feats, generator=gen, device=device,
+                             dtype=torch.float32).to(torch.float16 if is_f16 else torch.float32)
+    if world > 1:
+        gathered = torch.zeros(world * rows_padded, num_feats, dtype=feat_local.dtype, device=device)
+        send = gathered[rank * rows_padded:(rank + 1) * rows_padded]
+        send[:local_rows].copy_(feat_local)
+    else:
+        gathered, send = feat_local, None
+    out = torch.empty(local_rows, num_feats, dtype=torch.float32, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    ptrs = (blk_offsets.data_ptr(), hspa_packed.data_ptr(), hind.data_ptr())
+
+    def spmm(tile):
+        rc = capi.launch_spmm(ptrs[0], ptrs[1], ptrs[2], local_rows, local_nnz, num_feats, gathered.data_ptr(),
+                              out.data_ptr(), is_f16, tile, stream)
+        assert rc == 0, f"voltrix_launch_spmm rc={rc}"
+
+    # ---- tile: explicit, or a quick sweep over the instantiated space (what the autotuner does on first call) ----
+    if args.tile:
+        tile = tuple(int(x) for x in args.tile.split(","))
+    else:
+        from voltrix.jit_kernels.spmm import tile_space
+
+        cands = sorted({(p["FS"], p["DEPTH"], p["WAVES"]) for p in tile_space(num_feats, in_bytes)}
+                       & set(capi.tiles(is_f16)))
+        best = None
+        for cand in cands:
+            spmm(cand)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(3):
+                spmm(cand)
+            e.record()
+            e.synchronize()
+            ms = s.elapsed_time(e) / 3
+            if world > 1:
+                t = torch.tensor([ms], device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ms = float(t)
+            if best is None or ms < best[0]:
+                best = (ms, cand)
+        tile = best[1]
+
+    def step():
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, send)  # RCCL, in-place form (send == recv + rank * count)
+        spmm(tile)
+
+    for _ in range(args.warmup):
+        step()
+
+    # ---- timed region: exactly K steps between barrier + synchronize, MAX over ranks ------------------------------
+    kernel_events = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, send)
+        ks, ke = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ks.record()  # HIP events on the launch stream, live inside the timed region
+        spmm(tile)
+        ke.record()
+        kernel_events.append((ks, ke))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    kernel_ms = sum(s.elapsed_time(e) for s, e in kernel_events) / len(kernel_events)
+    if world > 1:
+        t = torch.tensor([kernel_ms], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        kernel_ms = float(t)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        flop = synth_graphs.flops(nnz, num_feats)
+        # roofline of the dominant kernel (spmm_tc16_kernel), per launch on THIS rank's shard:
+        # algorithmic bytes = int32 CSR once + B once + C once
+        alg_bytes = 4 * (local_nnz + local_rows + 1) + gathered.shape[0] * num_feats * in_bytes + local_rows * num_feats * 4
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        gather_bytes = 8 * total_blocks * num_feats * in_bytes  # rows actually gathered from L2 / Infinity Cache / HBM
+        line = {
+            "metric": "spmm_gflops",
+            "value": flop / (ms_per_step * 1e-3) / 1e9,
+            "unit": "GFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f16" if is_f16 else "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: N={num_nodes} nnz={nnz} (BASELINE.json configs[1] stand-in, "
+                            f"SURVEY.md 8d generator, seed {cfg['seed']}) x dense F={num_feats} "
+                            f"{'fp16' if is_f16 else 'fp32'} -> fp32",
+                "num_nodes": num_nodes, "nnz": nnz, "feat": num_feats, "tc_blocks_rank0": total_blocks,
+                "tile": {"fs": tile[0], "depth": tile[1], "waves": tile[2]},
+                "parallelism": f"row-window shards x{world}" + (" + RCCL all-gather(B) per step" if world > 1 else ""),
+                "preprocess_ms": preprocess_ms,
+                "hbm_gbs_algorithmic": synth_graphs.algorithmic_bytes(num_nodes, nnz, num_feats, in_bytes)
+                / (ms_per_step * 1e-3) / 1e9,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "spmm_tc16_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
+                "gather_bytes": gather_bytes, "gather_gbs": gather_bytes / (kernel_ms * 1e-3) / 1e9,
+                "note": "gather-bound: B rows are served by L2 / Infinity Cache (~8.6-19 TB/s row-gather ceilings), "
+                        "see DESIGN.md Roofline",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(indptr, indices, num_nodes, num_feats)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,98 @@
+"""CPU, world_size 2, gloo: the multi-GPU path (voltrix.dist.RowShardedSpMM) -- row-window partition, column remap,
+padded all-gather of B, per-rank SpMM on the shard -- reproduces the single-process result.  The local compute is
+injected from here (the oracle's CPU block-format SpMM); on the GPU box the same class runs the HIP path
+(tests/test_gpu_dist.py, bench.py --gpus N)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO, PKG_ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, num_feats, scale, out_dir):
+    for p in (REPO, PKG_ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import synth_graphs
+        from oracle import oracle_c
+        from voltrix.dist import RowShardedSpMM
+
+        indptr, indices, _ = synth_graphs.generate("reddit_like", scale=scale)
+        n = indptr.numel() - 1
+        gen = torch.Generator().manual_seed(5)
+        feat = torch.randn(n, num_feats, generator=gen)
+
+        def local_preprocess(ip, ix, rows):
+            return oracle_c.csr_preprocess(ip.numpy(), ix.numpy(), rows)
+
+        def local_spmm(handle, rows, edges, b):
+            return torch.from_numpy(oracle_c.spmm_blocked(handle[0], handle[1], handle[2], rows, b.numpy(), "none"))
+
+        op = RowShardedSpMM(indptr, indices, n, local_preprocess=local_preprocess, local_spmm=local_spmm)
+        assert op.world_size == world and op.rank == rank
+        out = op(feat[op.row_start:op.row_end].contiguous())
+        assert out.shape == (op.local_rows, num_feats)
+        out2 = op(feat[op.row_start:op.row_end].contiguous())  # gather buffer reuse
+        assert torch.equal(out, out2)
+        np.save(os.path.join(out_dir, f"out_{rank}.npy"), out.numpy())
+        np.save(os.path.join(out_dir, f"rows_{rank}.npy"), np.array([op.row_start, op.row_end]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_row_sharded_spmm_world2(tmp_path, world):
+    import synth_graphs
+    from oracle import oracle_c
+
+    num_feats, scale = 24, 0.004
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, num_feats, scale, str(tmp_path)), nprocs=world, join=True)
+
+    indptr, indices, _ = synth_graphs.generate("reddit_like", scale=scale)
+    n = indptr.numel() - 1
+    gen = torch.Generator().manual_seed(5)
+    feat = torch.randn(n, num_feats, generator=gen)
+    ref = oracle_c.spmm_csr(indptr.numpy(), indices.numpy(), feat.numpy(), n)
+    got = np.zeros_like(ref)
+    covered = 0
+    for r in range(world):
+        r0, r1 = np.load(tmp_path / f"rows_{r}.npy")
+        got[r0:r1] = np.load(tmp_path / f"out_{r}.npy")
+        covered += r1 - r0
+        assert r0 % 16 == 0
+    assert covered == n
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-6
+
+
+def test_single_process_path_is_identity_remap():
+    import synth_graphs
+    from oracle import oracle_c
+    from voltrix.dist import RowShardedSpMM
+
+    indptr, indices, _ = synth_graphs.generate("cora_like")
+    n = indptr.numel() - 1
+    feat = torch.randn(n, 8)
+    op = RowShardedSpMM(indptr, indices, n,
+                        local_preprocess=lambda ip, ix, rows: oracle_c.csr_preprocess(ip.numpy(), ix.numpy(), rows),
+                        local_spmm=lambda h, rows, e, b: torch.from_numpy(
+                            oracle_c.spmm_blocked(h[0], h[1], h[2], rows, b.numpy(), "none")))
+    assert op.parts == [(0, n)] and op.rows_padded == n
+    ref = oracle_c.spmm_csr(indptr.numpy(), indices.numpy(), feat.numpy(), n)
+    assert np.allclose(op(feat).numpy(), ref, rtol=1e-5, atol=1e-5)

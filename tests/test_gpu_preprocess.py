@@ -1,0 +1,109 @@
+"""GPU: CSR -> (pointer1, hspa_packed, hind) is BIT-EXACT against the oracle for both preprocess routes
+(fused GPU kernels through the C-ABI; the reference's three-stage pipeline through the JIT launch wrappers)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import synth_graphs
+import voltrix
+from oracle import oracle_c
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    rng = np.random.default_rng(11)
+    out = {}
+    out["single_row"] = (np.array([0, 1]), np.array([0]), 1)
+    out["no_edges"] = (np.zeros(50, dtype=np.int64), np.array([], dtype=np.int64), 49)
+    out["fifteen"] = (np.arange(16), rng.integers(0, 15, 15), 15)
+    out["sixteen"] = (np.arange(17), rng.integers(0, 16, 16), 16)
+    out["seventeen"] = (np.arange(18), rng.integers(0, 17, 17), 17)
+    # duplicates + unsorted rows: a (row, col) pair counts once (bitmap), order inside a row is irrelevant
+    out["dups_unsorted"] = (np.array([0, 4, 4, 9, 9] + [9] * 30), np.array([5, 1, 5, 1, 33, 2, 2, 0, 33]), 34)
+    a = sp.random(700, 700, density=0.05, format="csr", random_state=7)
+    out["sp700"] = (a.indptr, a.indices, 700)
+    # one window with more than 8192 edges (LDS sort capacity) next to tiny ones -> global-memory sort path
+    deg = np.zeros(96, dtype=np.int64)
+    deg[16:32] = 700
+    deg[40] = 3
+    deg[95] = 9000
+    n = 12000
+    indptr = np.concatenate([[0], np.cumsum(deg)])
+    indices = np.concatenate([np.sort(rng.choice(n, d, replace=False)) for d in deg if d > 0])
+    out["huge_window"] = (indptr, indices, 96)
+    return out
+
+
+CASES = _cases()
+
+
+def _check(handle, indptr, indices, n):
+    p1, packed, hind = handle
+    torch.cuda.synchronize()
+    op1, opacked, ohind = oracle_c.csr_preprocess(np.asarray(indptr, np.int32), np.asarray(indices, np.int32), n)
+    assert p1.dtype == torch.int32 and packed.dtype == torch.uint32 and hind.dtype == torch.int32
+    assert p1.is_cuda and packed.is_cuda and hind.is_cuda
+    assert np.array_equal(p1.cpu().numpy(), op1)
+    assert np.array_equal(hind.cpu().numpy(), ohind)
+    assert np.array_equal(packed.cpu().numpy(), opacked)
+
+
+@pytest.mark.parametrize("route", ["fused", "reference"])
+def test_fixtures_bit_exact(cuda_device, csr_fixture, route, monkeypatch):
+    monkeypatch.setenv("VOLTRIX_PREPROCESS", route)
+    g = csr_fixture
+    n = int(g["num_nodes"])
+    handle = voltrix.csr_preprocess(torch.from_numpy(g["indptr"]), torch.from_numpy(g["indices"]), n)
+    _check(handle, g["indptr"], g["indices"], n)
+    for got, want in zip(handle, (g["pointer1"], g["hspa_packed"], g["hind"])):
+        assert np.array_equal(got.cpu().numpy(), want)  # the committed golden handle itself
+
+
+@pytest.mark.parametrize("route", ["fused", "reference"])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_edge_cases_bit_exact(cuda_device, name, route, monkeypatch):
+    monkeypatch.setenv("VOLTRIX_PREPROCESS", route)
+    indptr, indices, n = CASES[name]
+    handle = voltrix.csr_preprocess(torch.as_tensor(np.asarray(indptr), dtype=torch.int32),
+                                    torch.as_tensor(np.asarray(indices), dtype=torch.int32), n)
+    _check(handle, indptr, indices, n)
+
+
+def test_low_level_kernel_wrappers_like_reference_test(cuda_device):
+    """tests/test_spmm_kernel.py:45-113 flow with the four public *_kernel wrappers and caller-allocated buffers
+    (hspa / hind pre-filled with garbage: the kernels must write every element)."""
+    np.random.seed(20)
+    n = 2048
+    a = sp.random(n, n, density=0.01, format="csr")
+    indptr = torch.tensor(a.indptr, dtype=torch.int32)
+    indices = torch.tensor(a.indices, dtype=torch.int32)
+    e, w = indices.numel(), (n + 15) // 16
+    e2c, e2r = torch.zeros(e, dtype=torch.int32), torch.zeros(e, dtype=torch.int32)
+    bp, p1 = torch.zeros(w, dtype=torch.int32), torch.zeros(w + 1, dtype=torch.int32)
+    voltrix.preprocess_kernel(edge_list=indices, node_pointer=indptr, block_partition=bp, edge_to_column=e2c,
+                              edge_to_row=e2r, pointer1=p1)
+    obp, oe2c, oe2r, op1 = oracle_c.preprocess(a.indptr, a.indices, n)
+    assert np.array_equal(bp.numpy(), obp) and np.array_equal(p1.numpy(), op1)
+    assert np.array_equal(e2c.numpy(), oe2c) and np.array_equal(e2r.numpy(), oe2r)
+    t = int(p1[-1])
+    hspa = torch.full((t * 128,), float("nan"), device="cuda")
+    hind = torch.full((t * 8,), -7, dtype=torch.int32, device="cuda")
+    packed = torch.full((t * 4,), 0x7FFFFFFF, dtype=torch.int32, device="cuda").view(torch.uint32)
+    voltrix.hmat_gen_kernel(node_pointer=indptr.cuda(), edge_list=indices.cuda(), block_partition=bp.cuda(),
+                            edge_to_column=e2c.cuda(), edge_to_row=e2r.cuda(), pointer1=p1.cuda(), hspa=hspa, hind=hind)
+    voltrix.hmat_packed_swizzle_kernel(block_partition=bp.cuda(), pointer1=p1.cuda(), hspa=hspa, hspa_packed=packed)
+    torch.cuda.synchronize()
+    ohspa, ohind = oracle_c.hmat_gen(a.indptr, a.indices, obp, oe2c, oe2r, op1, n)
+    assert np.array_equal(hspa.cpu().numpy(), ohspa) and np.array_equal(hind.cpu().numpy(), ohind)
+    assert np.array_equal(packed.cpu().numpy(), oracle_c.hmat_packed_swizzle(op1, ohspa))
+
+
+def test_fused_preprocess_mid_size_with_large_windows(cuda_device):
+    indptr, indices, _ = synth_graphs.generate("reddit_like", device="cuda", scale=0.02)
+    n = indptr.numel() - 1
+    assert int((indptr[16::16] - indptr[:-16:16]).max()) > 8192  # exercises the global-memory sort
+    p1, packed, hind, bp = voltrix.csr_fused_preprocess_kernel(indptr, indices, n)
+    _check((p1, packed, hind), indptr.cpu().numpy(), indices.cpu().numpy(), n)
+    assert np.array_equal(bp.cpu().numpy(), np.diff(p1.cpu().numpy()))

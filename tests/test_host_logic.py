@@ -1,0 +1,90 @@
+"""CPU: host-side logic of the product package -- operator-API assertions, tile space, tuner key, synthetic graph
+generators, roofline accounting, row-window sharding."""
+import numpy as np
+import pytest
+import torch
+
+import synth_graphs
+import voltrix
+from voltrix import dist as vdist
+from voltrix.jit_kernels import spmm as spmm_mod
+
+
+def test_csr_preprocess_asserts_like_reference():
+    indptr = torch.tensor([0, 1, 2], dtype=torch.int32)
+    with pytest.raises(AssertionError):  # reference spmm.py:21-22: CPU int32 only
+        voltrix.csr_preprocess(indptr.long(), torch.tensor([0, 1], dtype=torch.int32), 2)
+    with pytest.raises(AssertionError):
+        voltrix.csr_preprocess(indptr, torch.tensor([0, 1], dtype=torch.int64), 2)
+
+
+def test_spmm_kernel_asserts_like_reference():
+    t = torch.zeros(4, dtype=torch.int32)
+    with pytest.raises(AssertionError):  # reference jit_kernels/spmm.py:50-54: CUDA tensors required
+        voltrix.spmm_kernel(t, t, t, num_nodes=1, num_edges=0, embedding_dim=8, input=torch.zeros(1, 8),
+                            output=torch.zeros(1, 8))
+    with pytest.raises(AssertionError):
+        voltrix.spmm(t, t, t, 1, 0, torch.zeros(1, 8))
+
+
+def test_tile_space_is_valid_and_bounded(monkeypatch):
+    for mode, lo, hi in (("default", 4, 12), ("full", 9, 40), ("none", 1, 1)):
+        monkeypatch.setenv("VOLTRIX_TUNE_SPACE", mode)
+        for f in (16, 32, 64, 128, 512):
+            for eb in (2, 4):
+                space = spmm_mod.tile_space(f, eb)
+                assert lo <= len(space) <= hi, (mode, f, eb, len(space))
+                for p in space:
+                    assert spmm_mod._lds_bytes(p["FS"], p["DEPTH"], p["WAVES"], p["EB"]) <= 160 * 1024
+                    assert p["EB"] == eb and p["FS"] in (32, 64, 128, 256)
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    assert spmm_mod.tile_space(128, 2) == ({"FS": 128, "DEPTH": 4, "WAVES": 1, "EB": 2},)
+
+
+def test_feature_hash_uses_tag_then_address():
+    t = torch.zeros(4, dtype=torch.int32)
+    with pytest.warns(UserWarning, match="hash_tag"):
+        h_addr = spmm_mod.feature_hash(t)
+    t.hash_tag = "test_20_8192_0.1"
+    assert spmm_mod.feature_hash(t) == voltrix.jit.hash_to_hex("test_20_8192_0.1") != h_addr
+
+
+def test_synthetic_graphs_are_canonical_and_seeded():
+    a = synth_graphs.generate("reddit_like", scale=0.004)
+    b = synth_graphs.generate("reddit_like", scale=0.004)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    indptr, indices, cfg = a
+    n = indptr.numel() - 1
+    assert indptr.dtype == torch.int32 and indices.dtype == torch.int32 and int(indptr[-1]) == indices.numel()
+    ip, ix = indptr.numpy(), indices.numpy()
+    for r in np.random.default_rng(0).choice(n, 50, replace=False):
+        row = ix[ip[r]:ip[r + 1]]
+        assert (np.diff(row) > 0).all() and row.min(initial=0) >= 0 and row.max(initial=0) < n
+    assert (np.diff(ip) >= 1).all()
+    # the published shapes of the BASELINE configs
+    assert synth_graphs.CONFIGS["reddit_like"]["num_nodes"] == 232965
+    assert synth_graphs.algorithmic_bytes(232965, 114615892, 128, 2) == 4 * (114615892 + 232966) + 232965 * 128 * 6
+    assert synth_graphs.flops(114615892, 128) == 2 * 114615892 * 128
+
+
+def test_partition_rows_balances_edges_on_window_boundaries():
+    indptr, indices, _ = synth_graphs.generate("reddit_like", scale=0.01)
+    n = indptr.numel() - 1
+    for world in (1, 2, 3, 8):
+        parts = vdist.partition_rows(indptr, n, world)
+        assert parts[0][0] == 0 and parts[-1][1] == n and len(parts) == world
+        edges = []
+        for (r0, r1), nxt in zip(parts, parts[1:] + [(n, n)]):
+            assert r1 == nxt[0] and r0 % 16 == 0 and r0 <= r1
+            edges.append(int(indptr[r1]) - int(indptr[r0]))
+        assert sum(edges) == indices.numel()
+        if world > 1:
+            assert max(edges) <= 1.25 * (indices.numel() / world) + 16 * 3000
+
+
+def test_remap_columns_addresses_the_padded_gather_buffer():
+    parts = [(0, 32), (32, 48), (48, 100)]
+    rows_padded = 52
+    cols = torch.tensor([0, 31, 32, 47, 48, 99], dtype=torch.int32)
+    got = vdist.remap_columns(cols, parts, rows_padded).tolist()
+    assert got == [0, 31, 52, 52 + 15, 104, 104 + 51]

@@ -1,0 +1,48 @@
+"""Ahead-of-time population of the JIT cache (hipcc cross-compiles gfx950 without a GPU).
+
+``__graft_entry__.build()`` calls this in the build container with ``VOLTRIX_CACHE_DIR`` pointing in-tree, so the
+kernel directories travel to the GPU box and the first ``voltrix.spmm`` there is a cache hit, not a compile.
+"""
+from __future__ import annotations
+
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import torch
+
+from ..jit import build, cpp_format, generate
+from . import bmat_swizzle, hmat_gem, preprocess, spmm
+
+
+def _spmm_arg_defs(dtype):
+    return (("blk_offsets", torch.int32), ("hspa_packed", torch.uint32), ("hind", torch.int32), ("num_nodes", int),
+            ("num_edges", int), ("embedding_dim", int), ("input", dtype), ("output", torch.float),
+            ("stream", torch.cuda.Stream))
+
+
+def jobs(feature_widths=(32, 64, 128)):
+    """(name, arg_defs, code) of every kernel the operator API can ask for with the current VOLTRIX_TUNE_SPACE."""
+    out = []
+    for mod in (preprocess, hmat_gem, bmat_swizzle):
+        name = {preprocess: "preprocess_kernel", hmat_gem: "hmat_gen_kernel",
+                bmat_swizzle: "hmat_packed_swizzle_kernel"}[mod]
+        out.append((name, mod.arg_defs, generate(mod.includes, mod.arg_defs, mod.template)))
+    seen = set()
+    for dtype, eb in ((torch.float16, 2), (torch.float32, 4)):
+        for width in feature_widths:
+            for point in spmm.tile_space(width, eb):
+                key = (eb, point["FS"], point["DEPTH"], point["WAVES"])
+                if key in seen:
+                    continue
+                seen.add(key)
+                arg_defs = _spmm_arg_defs(dtype)
+                out.append(("spmm_kernel", arg_defs, generate(spmm.includes, arg_defs, cpp_format(spmm.template, point))))
+    return out
+
+
+def prebuild(feature_widths=(32, 64, 128), workers=None) -> int:
+    todo = jobs(feature_widths)
+    workers = workers or max(1, min(len(todo), os.cpu_count() or 1))
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        list(pool.map(lambda j: build(*j), todo))
+    return len(todo)

@@ -76,7 +76,6 @@ def spmm(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tenso
     feat = feat.contiguous()
     num_feats = feat.shape[1]
     assert feat.dtype in (torch.float32, torch.float16), f"unsupported feature dtype {feat.dtype}"
-    tag = getattr(hspa_packed, "hash_tag", None)
 
     exact = feat.dtype == torch.float32 and os.getenv(FP32_MODE_FLAG, "fp16") == "exact"
     operand = feat if (exact or feat.dtype == torch.float16) else feat.to(torch.float16)
@@ -86,8 +85,6 @@ def spmm(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tenso
         operand = torch.nn.functional.pad(operand, (0, padded - num_feats))
     output = torch.empty((num_nodes, padded), dtype=torch.float32, device=feat.device)
 
-    if tag is not None and not hasattr(hspa_packed, "hash_tag"):
-        hspa_packed.hash_tag = tag
     spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes=num_nodes, num_edges=num_edges, embedding_dim=padded,
                 input=operand, output=output)
     return output if padded == num_feats else output[:, :num_feats].contiguous()
