@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the node count (debug only)")
     ap.add_argument("--tile", default=None, help="fs,depth,waves (default: quick sweep over the tile space)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for debugging)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="debug: every rank uses cuda:0 (exercises the sharded path on a 1-GPU box, with --backend gloo)")
     return ap.parse_args()
 
 
@@ -84,6 +87,17 @@ def cpu_baseline(indptr, indices, num_nodes, num_feats, seed=0):
     }
 
 
+def measured_traffic(workload, num_feats, dtype):
+    """Per-launch fabric-side bytes of the dominant kernel from the committed rocprofv3 PMC summary (profiles/), or
+    None: the counters need their own profiling passes and cannot be read live in this process."""
+    try:
+        with open(os.path.join(REPO, "profiles", "traffic.json")) as f:
+            entry = json.load(f).get(f"{workload}|{num_feats}|{dtype}")
+        return None if entry is None else entry["traffic_bytes"]
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,10 +105,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     import voltrix
     from voltrix import capi
@@ -165,9 +184,14 @@ def main():
                 best = (ms, cand)
         tile = best[1]
 
+    in_place = args.backend == "nccl"  # only NCCL/RCCL defines the in-place (send == recv + rank * count) form
+
+    def exchange():
+        dist.all_gather_into_tensor(gathered, send if in_place else send.clone())
+
     def step():
         if world > 1:
-            dist.all_gather_into_tensor(gathered, send)  # RCCL, in-place form (send == recv + rank * count)
+            exchange()
         spmm(tile)
 
     for _ in range(args.warmup):
@@ -181,7 +205,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if world > 1:
-            dist.all_gather_into_tensor(gathered, send)
+            exchange()
         ks, ke = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ks.record()  # HIP events on the launch stream, live inside the timed region
         spmm(tile)
@@ -235,7 +259,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": measured_traffic(args.workload, num_feats, "f16" if is_f16 else "f32")
+                if (world == 1 and args.scale == 1.0) else None,
                 "kernel": "spmm_tc16_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
                 "gather_bytes": gather_bytes, "gather_gbs": gather_bytes / (kernel_ms * 1e-3) / 1e9,
                 "note": "gather-bound: B rows are served by L2 / Infinity Cache (~8.6-19 TB/s row-gather ceilings), "

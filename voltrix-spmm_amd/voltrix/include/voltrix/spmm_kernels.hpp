@@ -33,9 +33,16 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <type_traits>
 
 #include "voltrix/traits.hpp"
+
+// Diagnostic builds only (scratch/diag.py): bit 0 skips the consume side (LDS reads + MFMA), bit 1 folds every gathered
+// row into the first 1024 rows of B (all L2 hits).  Results are wrong by design; the shipped kernels use 0.
+#ifndef VOLTRIX_DIAG
+#define VOLTRIX_DIAG 0
+#endif
 
 namespace voltrix {
 
@@ -118,8 +125,7 @@ struct SpmmArgs {
   int num_windows;
   int F;
   int num_slabs;
-  long long num_units;           // num_windows * num_slabs
-  long long blocks_per_xcd;
+  int windows_per_xcd;           // ceil(num_windows / 8)
 };
 
 // One wave64 = one (row window, FS-column slab) unit.  EB == 2: fp16 operand, v_mfma_f32_16x16x32_f16.
@@ -136,11 +142,17 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
 
   // XCD-aware unit id: blocks b, b+8, b+16 ... share an XCD (speed only; any placement is correct).  XCD x walks a
   // contiguous range of units, so co-resident waves of one L2 gather from overlapping row neighbourhoods.
-  const long long blin = (long long)(blockIdx.x % kNumXcd) * a.blocks_per_xcd + blockIdx.x / kNumXcd;
-  const long long unit = blin * T::WAVES + wave;
-  if (unit >= a.num_units) return;  // wave-uniform; the kernel has no barriers
-  const int w = (int)(unit / a.num_slabs);
-  const int fs0 = (int)(unit % a.num_slabs) * FS;
+  // XCD x = blockIdx.x % 8 owns the contiguous window range [x * windows_per_xcd, ...) (blocks b, b+8, ... share an
+  // XCD: speed only, any placement is correct); its workgroups walk that range window by window, the slabs of a window
+  // side by side, so co-resident waves of one L2 gather overlapping row neighbourhoods and share the metadata.
+  // (Measured alternatives that lost: slab-major order, non-temporal loads for far rows -- DESIGN.md section 5.)
+  const int xcd = blockIdx.x % kNumXcd;
+  const int w_begin = xcd * a.windows_per_xcd;
+  const int w_count = (a.num_windows - w_begin) < a.windows_per_xcd ? (a.num_windows - w_begin) : a.windows_per_xcd;
+  const long long lu = (long long)(blockIdx.x / kNumXcd) * T::WAVES + wave;
+  if (w_count <= 0 || lu >= (long long)w_count * a.num_slabs) return;  // wave-uniform; the kernel has no barriers
+  const int w = w_begin + (int)(lu / a.num_slabs);
+  const int fs0 = (int)(lu % a.num_slabs) * FS;
 
   const int kb0 = a.blk_offsets[w];
   const int kb1 = a.blk_offsets[w + 1];
@@ -201,7 +213,8 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
         else
           col = fs0 + (((c >> 2) ^ (r & 1)) * 16) + (c & 3) * 4;
         col = col < F ? col : fs0;                    // F % FS tail: stay in bounds, results are not stored
-        const int hrow = __shfl(hv, r, kWave);
+        int hrow = __shfl(hv, r, kWave);
+        if (VOLTRIX_DIAG & 2) hrow &= 1023;
         dma_b128(a.input + ((long long)hrow * F + col), dst + i * 1024);
       }
     };
@@ -259,7 +272,11 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
         vw = lds_read_b64(md + vword_off);
       }
 
-      if constexpr (EB == 2) {
+      if (VOLTRIX_DIAG & 1) {
+        wait_lgkmcnt0();  // hraw / vw are inline-asm LDS reads: they must have landed before they become addresses
+        issue_meta(t + 2 * D, mslot_2d);
+        if (more) issue_data(dslot, sanitise(t + D, hraw, vw));
+      } else if constexpr (EB == 2) {
         // A: lane -> row R of TC block g; its 8 bits are nibble R&7 of words t = R>>3 (cols 0-3), 2 + R>>3 (cols 4-7)
         const unsigned wlo = lds_read_b32(mt + 128 + 4 * (4 * g + (R >> 3)));
         const unsigned whi = lds_read_b32(mt + 128 + 4 * (4 * g + 2 + (R >> 3)));
@@ -371,10 +388,9 @@ inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed,
   a.num_windows = (num_nodes + kBlkH - 1) / kBlkH;
   a.F = embedding_dim;
   a.num_slabs = (embedding_dim + T::FS - 1) / T::FS;
-  a.num_units = (long long)a.num_windows * a.num_slabs;
-  const long long blocks = (a.num_units + T::WAVES - 1) / T::WAVES;
-  a.blocks_per_xcd = (blocks + kNumXcd - 1) / kNumXcd;
-  const long long grid = a.blocks_per_xcd * kNumXcd;
+  a.windows_per_xcd = (a.num_windows + kNumXcd - 1) / kNumXcd;
+  const long long blocks_per_xcd = ((long long)a.windows_per_xcd * a.num_slabs + T::WAVES - 1) / T::WAVES;
+  const long long grid = blocks_per_xcd * kNumXcd;
   if (grid > 0x7FFFFFFFll) return kErrBadShape;
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
