@@ -41,7 +41,7 @@ def parse_args():
     ap.add_argument("--feat", type=int, default=None, help="feature width (default: the workload's)")
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the node count (debug only)")
-    ap.add_argument("--tile", default=None, help="fs,depth,waves (default: quick sweep over the tile space)")
+    ap.add_argument("--tile", default=None, help="fs,depth,waves[,sched] (default: quick sweep over the tile space)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for debugging)")
     ap.add_argument("--one-device", action="store_true",
@@ -153,19 +153,25 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     ptrs = (blk_offsets.data_ptr(), hspa_packed.data_ptr(), hind.data_ptr())
 
+    # "balance" schedule of this rank's handle (length-sorted windows inside 256-window chunks), computed on the GPU
+    order = torch.empty((local_rows + 15) // 16, dtype=torch.int32, device=device)
+    capi.launch_window_order(blk_offsets, local_rows, order, stream)
+
     def spmm(tile):
         rc = capi.launch_spmm(ptrs[0], ptrs[1], ptrs[2], local_rows, local_nnz, num_feats, gathered.data_ptr(),
-                              out.data_ptr(), is_f16, tile, stream)
+                              out.data_ptr(), is_f16, tile[:3], stream, order.data_ptr() if tile[3] else 0)
         assert rc == 0, f"voltrix_launch_spmm rc={rc}"
 
     # ---- tile: explicit, or a quick sweep over the instantiated space (what the autotuner does on first call) ----
     if args.tile:
         tile = tuple(int(x) for x in args.tile.split(","))
+        tile = tile if len(tile) == 4 else tile + (1,)
     else:
         from voltrix.jit_kernels.spmm import tile_space
 
-        cands = sorted({(p["FS"], p["DEPTH"], p["WAVES"]) for p in tile_space(num_feats, in_bytes)}
-                       & set(capi.tiles(is_f16)))
+        aot = set(capi.tiles(is_f16))
+        cands = sorted({(p["FS"], p["DEPTH"], p["WAVES"], p["SCHED"]) for p in tile_space(num_feats, in_bytes)
+                        if (p["FS"], p["DEPTH"], p["WAVES"]) in aot})
         best = None
         for cand in cands:
             spmm(cand)
@@ -251,7 +257,7 @@ def main():
                             f"SURVEY.md 8d generator, seed {cfg['seed']}) x dense F={num_feats} "
                             f"{'fp16' if is_f16 else 'fp32'} -> fp32",
                 "num_nodes": num_nodes, "nnz": nnz, "feat": num_feats, "tc_blocks_rank0": total_blocks,
-                "tile": {"fs": tile[0], "depth": tile[1], "waves": tile[2]},
+                "tile": {"fs": tile[0], "depth": tile[1], "waves": tile[2], "balanced_schedule": bool(tile[3])},
                 "parallelism": f"row-window shards x{world}" + (" + RCCL all-gather(B) per step" if world > 1 else ""),
                 "preprocess_ms": preprocess_ms,
                 "hbm_gbs_algorithmic": synth_graphs.algorithmic_bytes(num_nodes, nnz, num_feats, in_bytes)

@@ -86,10 +86,11 @@ void voltrix_launch_spmm(void* blk_offsets, void* hspa_packed, void* hind, int n
 /* ---- gfx950 extensions ------------------------------------------------------------------------------------ */
 
 /* Same as voltrix_launch_spmm with an explicit tile: fs = feature slab per wave (32/64/128), depth = LDS ring
- * depth (2..4), waves = waves per workgroup (1/2/4).  VOLTRIX_ERR_BAD_CONFIG if not instantiated. */
+ * depth (2..4), waves = waves per workgroup (1/2/4); VOLTRIX_ERR_BAD_CONFIG if not instantiated.
+ * window_order: NULL, or the int32[W] schedule written by voltrix_launch_window_order (changes speed only). */
 void voltrix_launch_spmm_f32_tile(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
                                   int embedding_dim, void* input, void* output, int fs, int depth, int waves,
-                                  void* stream, int* return_code);
+                                  void* window_order, void* stream, int* return_code);
 
 /* fp16 dense operand (BASELINE.json's headline configuration): input _Float16 [*, embedding_dim], output float32.
  * v_mfma_f32_16x16x32_f16, fp32 accumulate.  embedding_dim % 8 == 0, input 16-byte aligned. */
@@ -97,7 +98,14 @@ void voltrix_launch_spmm_f16(void* blk_offsets, void* hspa_packed, void* hind, i
                              int embedding_dim, void* input, void* output, void* stream, int* return_code);
 void voltrix_launch_spmm_f16_tile(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
                                   int embedding_dim, void* input, void* output, int fs, int depth, int waves,
-                                  void* stream, int* return_code);
+                                  void* window_order, void* stream, int* return_code);
+
+/* "Balance" schedule for a handle: order_out int32[W] (device) lists the windows of every XCD range, inside chunks of
+ * `chunk` (1..1024) consecutive windows, by descending TC-block count, so that co-resident waves sweep their sorted
+ * columns at a similar pace and share gathered rows through L2.  Depends on blk_offsets only; results of the SpMM are
+ * bit-identical with or without it. */
+void voltrix_launch_window_order(void* blk_offsets, int num_nodes, int chunk, void* order_out, void* stream,
+                                 int* return_code);
 
 /* Default tile for a feature width; is_f16 selects the operand type.  Always succeeds. */
 void voltrix_spmm_default_tile(int embedding_dim, int is_f16, int* fs, int* depth, int* waves);

@@ -176,6 +176,42 @@ def test_runs_on_the_callers_stream(cuda_device):
     _assert_close(out, g["indptr"], g["indices"], feat.float().cpu(), n, "fp16")
 
 
+def _reference_window_order(p1, num_windows, chunk):
+    nblk = np.diff(p1)
+    wpx = (num_windows + 7) // 8
+    order = np.arange(num_windows)
+    for x in range(8):
+        for b in range(x * wpx, min((x + 1) * wpx, num_windows), chunk):
+            e = min(b + chunk, (x + 1) * wpx, num_windows)
+            idx = np.arange(b, e)
+            order[b:e] = idx[np.lexsort((idx, -nblk[b:e]))]  # descending block count, ties by index
+    return order
+
+
+@pytest.mark.parametrize("chunk", [256, 1000, 7])
+def test_window_order_schedule_is_a_sorted_permutation_and_changes_no_bit(cuda_device, chunk):
+    indptr, indices, _ = synth_graphs.generate("reddit_like", device="cuda", scale=0.15)
+    n, e = indptr.numel() - 1, indices.numel()
+    handle = voltrix.csr_fused_preprocess_kernel(indptr, indices, n)[:3]
+    w = (n + 15) // 16
+    order = torch.full((w,), -1, dtype=torch.int32, device="cuda")
+    capi.launch_window_order(handle[0], n, order, torch.cuda.current_stream().cuda_stream, chunk)
+    torch.cuda.synchronize()
+    got = order.cpu().numpy()
+    assert np.array_equal(np.sort(got), np.arange(w))
+    assert np.array_equal(got, _reference_window_order(handle[0].cpu().numpy(), w, chunk))
+    feat = torch.randn(n, 128, device="cuda").half()
+    out0 = torch.full((n, 128), float("nan"), device="cuda")
+    out1 = torch.full((n, 128), float("nan"), device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    for out, ordptr in ((out0, 0), (out1, order.data_ptr())):
+        rc = capi.launch_spmm(handle[0].data_ptr(), handle[1].data_ptr(), handle[2].data_ptr(), n, e, 128,
+                              feat.data_ptr(), out.data_ptr(), True, (64, 4, 4), s, ordptr)
+        assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out0, out1) and not torch.isnan(out0).any()
+
+
 def test_cast_entry_point(cuda_device):
     x = torch.randn(1000, 64, device="cuda") * 300
     y = torch.empty(1000, 64, dtype=torch.float16, device="cuda")

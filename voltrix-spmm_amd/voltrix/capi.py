@@ -30,6 +30,7 @@ SYMBOLS = (
     "voltrix_spmm_default_tile",
     "voltrix_spmm_num_tiles",
     "voltrix_spmm_tile_at",
+    "voltrix_launch_window_order",
     "voltrix_launch_cast_f32_f16",
     "voltrix_csr_preprocess_workspace_bytes",
     "voltrix_launch_csr_window_count",
@@ -116,14 +117,23 @@ def launch_csr_fill(indptr, indices, num_nodes, workspace, pointer1, hspa_packed
 
 
 def launch_spmm(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input_ptr, output_ptr, is_f16,
-                tile, stream) -> int:
-    """Raw-pointer launch (used by bench.py and the no-JIT mode); returns the return code."""
+                tile, stream, window_order=0) -> int:
+    """Raw-pointer launch (used by bench.py and the tests); ``window_order`` is 0 (natural) or the device pointer of
+    the schedule written by :func:`launch_window_order`.  Returns the return code."""
     rc = ctypes.c_int(-1)
     fn = lib().voltrix_launch_spmm_f16_tile if is_f16 else lib().voltrix_launch_spmm_f32_tile
     fn(ctypes.c_void_p(blk_offsets), ctypes.c_void_p(hspa_packed), ctypes.c_void_p(hind), ctypes.c_int(num_nodes),
        ctypes.c_int(num_edges), ctypes.c_int(embedding_dim), ctypes.c_void_p(input_ptr), ctypes.c_void_p(output_ptr),
-       ctypes.c_int(tile[0]), ctypes.c_int(tile[1]), ctypes.c_int(tile[2]), ctypes.c_void_p(stream), ctypes.byref(rc))
+       ctypes.c_int(tile[0]), ctypes.c_int(tile[1]), ctypes.c_int(tile[2]), ctypes.c_void_p(window_order),
+       ctypes.c_void_p(stream), ctypes.byref(rc))
     return rc.value
+
+
+def launch_window_order(blk_offsets, num_nodes, order_out, stream, chunk: int = 256) -> None:
+    rc = ctypes.c_int(-1)
+    lib().voltrix_launch_window_order(_ptr(blk_offsets), ctypes.c_int(num_nodes), ctypes.c_int(chunk), _ptr(order_out),
+                                      ctypes.c_void_p(stream), ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_window_order")
 
 
 def launch_cast_f32_f16(src, dst, stream) -> None:

@@ -17,7 +17,7 @@ from . import bmat_swizzle, hmat_gem, preprocess, spmm
 def _spmm_arg_defs(dtype):
     return (("blk_offsets", torch.int32), ("hspa_packed", torch.uint32), ("hind", torch.int32), ("num_nodes", int),
             ("num_edges", int), ("embedding_dim", int), ("input", dtype), ("output", torch.float),
-            ("stream", torch.cuda.Stream))
+            ("win_order", torch.int32), ("stream", torch.cuda.Stream))
 
 
 def jobs(feature_widths=(32, 64, 128)):
@@ -31,7 +31,7 @@ def jobs(feature_widths=(32, 64, 128)):
     for dtype, eb in ((torch.float16, 2), (torch.float32, 4)):
         for width in feature_widths:
             for point in spmm.tile_space(width, eb):
-                key = (eb, point["FS"], point["DEPTH"], point["WAVES"])
+                key = (eb, point["FS"], point["DEPTH"], point["WAVES"], point["SCHED"])
                 if key in seen:
                     continue
                 seen.add(key)

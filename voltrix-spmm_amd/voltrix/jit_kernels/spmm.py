@@ -18,8 +18,10 @@ includes = ('"voltrix/spmm_kernels.hpp"',)
 template = """
 __return_code = voltrix::launch_spmm_tc16<voltrix::SpmmTile<{FS}, {DEPTH}, {WAVES}, {EB}>>(
     blk_offsets, hspa_packed, hind,
-    num_nodes, embedding_dim, input, output, stream);
+    num_nodes, embedding_dim, input, output, stream, {SCHED} ? win_order : nullptr);
 """
+
+ORDER_CHUNK = 256  # windows per length-sorted chunk of the "balance" schedule (spmm_kernels.hpp::launch_window_order)
 
 
 def feature_hash(feature: torch.Tensor) -> str:
@@ -46,7 +48,7 @@ def tile_space(embedding_dim: int, elem_bytes: int):
     fs_fit = 32 if embedding_dim <= 32 else (64 if embedding_dim <= 64 else fs_max)
     if mode == "none":
         depth = 4 if elem_bytes == 2 else (2 if fs_fit == 128 else 4)
-        return ({"FS": fs_fit, "DEPTH": depth, "WAVES": 1, "EB": elem_bytes},)
+        return ({"FS": fs_fit, "DEPTH": depth, "WAVES": 1, "EB": elem_bytes, "SCHED": 1},)
     if mode == "full":
         fs_list = sorted({fs_fit, max(32, fs_fit // 2), min(256, fs_fit * 2) if embedding_dim > 128 else fs_fit})
         depths, waves = (2, 3, 4), (1, 2, 4)
@@ -59,8 +61,25 @@ def tile_space(embedding_dim: int, elem_bytes: int):
             for w in waves:
                 ndma = 32 * fs * elem_bytes // 1024
                 if _lds_bytes(fs, d, w, elem_bytes) <= 160 * 1024 and (1 + ndma) * (d - 1) <= 63:
-                    space.append({"FS": fs, "DEPTH": d, "WAVES": w, "EB": elem_bytes})
+                    for sched in (0, 1):  # natural window order / length-balanced schedule
+                        space.append({"FS": fs, "DEPTH": d, "WAVES": w, "EB": elem_bytes, "SCHED": sched})
     return tuple(space)
+
+
+def window_order(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    """The handle's "balance" schedule, computed once on the GPU and cached on the ``hspa_packed`` tensor object."""
+    cached = getattr(hspa_packed, "_voltrix_window_order", None)
+    if cached is not None and cached[0] == blk_offsets.data_ptr() and cached[1] == num_nodes:
+        return cached[2]
+    from .. import capi
+
+    order = torch.empty((num_nodes + 15) // 16, dtype=torch.int32, device=blk_offsets.device)
+    capi.launch_window_order(blk_offsets, num_nodes, order, torch.cuda.current_stream().cuda_stream, ORDER_CHUNK)
+    try:
+        hspa_packed._voltrix_window_order = (blk_offsets.data_ptr(), num_nodes, order)
+    except AttributeError:
+        pass
+    return order
 
 
 def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, output):
@@ -75,7 +94,7 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
     assert embedding_dim % (16 // elem_bytes) == 0, "embedding_dim must keep rows 16-byte aligned (voltrix.spmm pads)"
 
     args = (blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, output,
-            torch.cuda.current_stream())
+            window_order(blk_offsets, hspa_packed, num_nodes), torch.cuda.current_stream())
     runtime = jit_tuner.compile_and_tune(
         name="spmm_kernel",
         keys={
@@ -95,6 +114,7 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
             ("embedding_dim", int),
             ("input", input.dtype),
             ("output", output.dtype),
+            ("win_order", torch.int32),
             ("stream", torch.cuda.Stream),
         ),
         template=template,
