@@ -19,6 +19,8 @@ CONFIGS = {
                            band=0, feat=128, seed=1),
     "products_like": dict(num_nodes=2449029, mean_deg=123718280 / 2449029, sigma=1.4, max_deg=17481, band_frac=0.5,
                           band=8192, feat=512, seed=2),
+    "papers_like": dict(num_nodes=111059956, mean_deg=1615685872 / 111059956, sigma=1.0, max_deg=20000, band_frac=0.5,
+                        band=32768, feat=128, seed=4),
     "powerlaw_4m": dict(num_nodes=4000000, mean_deg=400.0, sigma=2.0, max_deg=400000, band_frac=0.0, band=0,
                         feat=256, seed=3),
 }

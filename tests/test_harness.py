@@ -1,0 +1,57 @@
+"""The reference's benchmark file formats (bench/graph_gen.py, bench/bm_voltrix.py): CPU round trip of the files, GPU
+run of the timing script on them."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import REPO, load_csr_fixture
+
+sys.path.insert(0, os.path.join(REPO, "harness"))
+
+
+def _make(tmp_path, feats=24):
+    import graph_gen
+
+    g = load_csr_fixture("skewed_1005")
+    n = int(g["num_nodes"])
+    a = sp.csr_matrix((np.ones(len(g["indices"]), np.float32), g["indices"], g["indptr"]), shape=(n, n))
+    sp.save_npz(tmp_path / "g.npz", a)
+    graph_gen.main(["--npz", str(tmp_path / "g.npz"), "--num_feats", str(feats), "--out_dir", str(tmp_path), "--mtx"])
+    return g, n
+
+
+def test_graph_gen_file_formats(tmp_path):
+    g, n = _make(tmp_path)
+    assert np.array_equal(np.loadtxt(tmp_path / "indptr.csv", delimiter=",", dtype=np.int32), g["indptr"])
+    assert np.array_equal(np.loadtxt(tmp_path / "indices.csv", delimiter=",", dtype=np.int32), g["indices"])
+    feat = np.fromfile(tmp_path / "feat.csv", dtype=np.float32).reshape(n, 24)
+    base = np.fromfile(tmp_path / "output_base.csv", dtype=np.float32).reshape(n, 24)
+    a = sp.csr_matrix((np.ones(len(g["indices"])), g["indices"], g["indptr"]), shape=(n, n))
+    assert np.allclose(base, a @ feat, rtol=1e-5, atol=1e-5)
+    from scipy.io import mmread
+
+    assert (mmread(tmp_path / "data.mtx").tocsr() != a).nnz == 0
+    # TC-GNN style archive (src_li / dst_li / num_nodes) loads to the same CSR
+    import graph_gen
+
+    coo = a.tocoo()
+    np.savez(tmp_path / "tc.npz", src_li=coo.row, dst_li=coo.col, num_nodes=n)
+    ip, ix = graph_gen.load_npz(str(tmp_path / "tc.npz"))
+    assert np.array_equal(ip, g["indptr"]) and np.array_equal(ix, g["indices"])
+
+
+@pytest.mark.gpu
+def test_bm_voltrix_on_generated_files(tmp_path, cuda_device):
+    _make(tmp_path, feats=64)
+    env = dict(os.environ, VOLTRIX_TUNE_SPACE="none")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "harness", "bm_voltrix.py"), "--dir", str(tmp_path),
+                          "--dataset", "skewed", "--csv", str(tmp_path / "results.csv"), "--iters", "3"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "difference rate: 0.000%" in out.stdout and "[Voltrix] time:" in out.stdout
+    rows = open(tmp_path / "results.csv").read().strip().split("\n")
+    assert rows[0] == "Method,Dataset,FeatDim,Reorder,Time (ms)" and rows[1].startswith("voltrix,skewed,64,False,")

@@ -39,7 +39,8 @@
 #include "voltrix/traits.hpp"
 
 // Diagnostic builds only (scratch/diag.py): bit 0 skips the consume side (LDS reads + MFMA), bit 1 folds every gathered
-// row into the first 1024 rows of B (all L2 hits).  Results are wrong by design; the shipped kernels use 0.
+// row into the first 1024 rows of B (all L2 hits), bit 2 skips the output stores.  Results are wrong by design; the
+// shipped kernels use 0.
 #ifndef VOLTRIX_DIAG
 #define VOLTRIX_DIAG 0
 #endif
@@ -141,8 +142,6 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
 
-  // XCD-aware unit id: blocks b, b+8, b+16 ... share an XCD (speed only; any placement is correct).  XCD x walks a
-  // contiguous range of units, so co-resident waves of one L2 gather from overlapping row neighbourhoods.
   // XCD x = blockIdx.x % 8 owns the contiguous window range [x * windows_per_xcd, ...) (blocks b, b+8, ... share an
   // XCD: speed only, any placement is correct); its workgroups walk that range window by window, the slabs of a window
   // side by side, so co-resident waves of one L2 gather overlapping row neighbourhoods and share the metadata.
@@ -161,6 +160,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
   const int nblk = kb1 - kb0;
   const int nst = (nblk + kTcbPerStage - 1) / kTcbPerStage;
   const int F = a.F;
+  auto stage_block = [&](int tau) -> int { return kb0 + kTcbPerStage * tau; };  // first TC block of stage tau
 
   float4_t acc[SLOTS];
 #pragma unroll
@@ -190,12 +190,13 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
 
     auto issue_meta = [&](int tau, int mslot) {
       const void* src;
+      const int sb = stage_block(tau);
       if (lane < 32) {
-        int blk = kb0 + 4 * tau + kblk;
+        int blk = sb + kblk;
         blk = blk < kb1 ? blk : kb1 - 1;  // stay inside the window: stages past its end re-read its last block
         src = a.hind + (8ll * blk + kcol);
       } else {
-        int blk = kb0 + 4 * tau + (mj >> 2);
+        int blk = sb + (mj >> 2);
         blk = blk < kb1 ? blk : kb1 - 1;
         src = a.hspa_packed + (4ll * blk + (mj & 3));
       }
@@ -222,7 +223,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
     };
 
     auto sanitise = [&](int tau, unsigned hraw, uint2_t vw) -> int {
-      const bool inwin = (kb0 + 4 * tau + kblk) < kb1;
+      const bool inwin = (stage_block(tau) + kblk) < kb1;
       const bool valid = inwin && (((vw[0] | vw[1]) & colmask) != 0u);
       return valid ? (int)hraw : h_safe;  // padded hind slots are 0 in the format: never gather B[0] for them
     };
@@ -301,7 +302,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
         if (more) issue_data(dslot, sanitise(t + D, hraw, vw));
 
         unsigned bits8 = ((wlo >> a_shift) & 0xFu) | (((whi >> a_shift) & 0xFu) << 4);
-        if (kb0 + 4 * t + g >= kb1) bits8 = 0u;  // TC blocks past the window's end contribute zero
+        if (stage_block(t) + g >= kb1) bits8 = 0u;  // TC blocks past the window's end contribute zero
         const half8_t afrag = bits_to_half8(bits8);
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
@@ -339,7 +340,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
         for (int m = 0; m < 8; ++m) {
           const int bm = m >> 1;
           unsigned word = (m & 1) ? whi[bm] : wlo[bm];
-          if (kb0 + 4 * t + bm >= kb1) word = 0u;
+          if (stage_block(t) + bm >= kb1) word = 0u;
           const float av = ((word >> (a_shift + g)) & 1u) ? 1.0f : 0.0f;
 #pragma unroll
           for (int s = 0; s < SLOTS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[m][s], acc[s], 0, 0, 0);
@@ -355,6 +356,10 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
   }
 
   // ---- epilogue: D[row = 4*(lane>>4) + j][col = lane & 15] per 16-column slot ----------------------------------
+  if (VOLTRIX_DIAG & 4) {
+    if (acc[0][0] == 12345.678f) a.output[0] = acc[0][0];  // keep the accumulators live
+    return;
+  }
   const int orow0 = w * kBlkH + 4 * (lane >> 4);
   const int ocol0 = fs0 + (lane & 15);
 #pragma unroll
