@@ -4,7 +4,7 @@ Tolerances (fp32 output; stated per BASELINE.md section 2 / SURVEY.md section 8c
   fp16 operand (or fp32 operand rounded to fp16 -- the gfx950 stand-in for the reference's TF32 rounding):
       norm-wise  ||out - ref||_2 / ||ref||_2 <= 1e-3   (BASELINE.json asks <= 1e-2)
       calc_diff(out, ref) <= 1e-5                      (the reference's "difference rate 0.00 %")
-      element-wise |out - ref|_ij <= (2^-11 + deg_i 2^-24) (A |B|)_ij
+      element-wise |out - ref|_ij <= (2^-11 + deg_i 2^-23) (A |B|)_ij + deg_i 2^-25   (last term: fp16 subnormals)
   against the oracle evaluated on the SAME rounded operand, and for the exact-fp32 kernel against the fp32 oracle:
       element-wise |out - ref|_ij <= deg_i 2^-23 (A |B|)_ij  (accumulation order only)
 """
@@ -28,7 +28,8 @@ def _bounds(indptr, indices, feat, n, operand_rounded):
     deg = np.diff(np.asarray(indptr, np.int64))[:n].astype(np.float64)
     aabs = oracle_np.spmm_csr(indptr, indices, np.abs(np.asarray(feat, np.float64)), n)
     u = 0.0 if operand_rounded else 2.0 ** -11
-    return (u + deg[:, None] * 2.0 ** -23) * aabs + 1e-30
+    sub = 0.0 if operand_rounded else deg[:, None] * 2.0 ** -25  # fp16 subnormals round with an absolute 2^-25 error
+    return (u + deg[:, None] * 2.0 ** -23) * aabs + sub + 1e-30
 
 
 def _assert_close(out, indptr, indices, feat32, n, mode):
