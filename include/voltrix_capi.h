@@ -107,6 +107,14 @@ void voltrix_launch_spmm_f16_tile(void* blk_offsets, void* hspa_packed, void* hi
 void voltrix_launch_window_order(void* blk_offsets, int num_nodes, int chunk, void* order_out, void* stream,
                                  int* return_code);
 
+/* Stage-list executor (C-stationary schedule; spmm_list_kernels.hpp).  entries: int32[n][4] = {first TC block,
+ * count | g << 8 | flush << 16, window, 0}; wave_ptr: int32[num_waves + 1] offsets into entries, each wave's list ending
+ * with 2*depth+1 padding entries (count 0, a valid block).  Built by voltrix/schedule.py; the math and the handle are
+ * those of voltrix_launch_spmm_f16.  fs in {64,128}, depth in {3,4}, groups (windows resident per wave) in {1,2,4,8}. */
+void voltrix_launch_spmm_f16_list(void* hspa_packed, void* hind, int num_nodes, int embedding_dim, void* input,
+                                  void* output, void* entries, void* wave_ptr, int num_waves, int fs, int depth,
+                                  int groups, void* stream, int* return_code);
+
 /* Default tile for a feature width; is_f16 selects the operand type.  Always succeeds. */
 void voltrix_spmm_default_tile(int embedding_dim, int is_f16, int* fs, int* depth, int* waves);
 

@@ -27,6 +27,7 @@ SYMBOLS = (
     "voltrix_launch_spmm_f32_tile",
     "voltrix_launch_spmm_f16",
     "voltrix_launch_spmm_f16_tile",
+    "voltrix_launch_spmm_f16_list",
     "voltrix_spmm_default_tile",
     "voltrix_spmm_num_tiles",
     "voltrix_spmm_tile_at",
@@ -126,6 +127,18 @@ def launch_spmm(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
        ctypes.c_int(num_edges), ctypes.c_int(embedding_dim), ctypes.c_void_p(input_ptr), ctypes.c_void_p(output_ptr),
        ctypes.c_int(tile[0]), ctypes.c_int(tile[1]), ctypes.c_int(tile[2]), ctypes.c_void_p(window_order),
        ctypes.c_void_p(stream), ctypes.byref(rc))
+    return rc.value
+
+
+def launch_spmm_list(hspa_packed, hind, num_nodes, embedding_dim, input_ptr, output_ptr, entries, wave_ptr, num_waves,
+                     tile, stream) -> int:
+    """Stage-list executor; ``tile`` = (fs, depth, groups).  Returns the return code."""
+    rc = ctypes.c_int(-1)
+    lib().voltrix_launch_spmm_f16_list(ctypes.c_void_p(hspa_packed), ctypes.c_void_p(hind), ctypes.c_int(num_nodes),
+                                       ctypes.c_int(embedding_dim), ctypes.c_void_p(input_ptr),
+                                       ctypes.c_void_p(output_ptr), _ptr(entries), _ptr(wave_ptr),
+                                       ctypes.c_int(num_waves), ctypes.c_int(tile[0]), ctypes.c_int(tile[1]),
+                                       ctypes.c_int(tile[2]), ctypes.c_void_p(stream), ctypes.byref(rc))
     return rc.value
 
 
