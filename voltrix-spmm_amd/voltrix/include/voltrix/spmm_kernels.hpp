@@ -97,15 +97,26 @@ __device__ __forceinline__ constexpr int slot_swizzle(int r) {
   return SLOTS >= 8 ? ident : (SLOTS == 4 ? (ident >> 1) : (ident >> 2));
 }
 
-// 8 adjacency bits -> four packed fp16x2 registers holding 1.0 / 0.0
-__device__ __forceinline__ half8_t bits_to_half8(unsigned bits8) {
+// Two adjacency nibbles (columns 0-3 and 4-7 of one row of a TC block) -> four packed fp16x2 registers holding 2.0 / 0.0.
+// 2.0 = 0x4000 is a single bit, so the expansion is shift + mask only; the accumulators are scaled by 0.5 once at the
+// store (exact: scaling by a power of two commutes with every fp32 rounding of the sum).
+constexpr float kAScaleInv = 0.5f;
+__device__ __forceinline__ half8_t nibbles_to_half8_x2(unsigned nl, unsigned nh) {
+  const unsigned zl = nl | (nl << 15), zh = nh | (nh << 15);  // bit i and bit 15+i = column i
   uint4_t r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const unsigned pair = ((bits8 >> (2 * i)) & 1u) | (((bits8 >> (2 * i + 1)) & 1u) << 16);
-    r[i] = pair * 0x3C00u;  // 0x3C00 = fp16 1.0
-  }
+  r[0] = (zl << 14) & 0x40004000u;  // columns 0, 1
+  r[1] = (zl << 12) & 0x40004000u;  // columns 2, 3
+  r[2] = (zh << 14) & 0x40004000u;  // columns 4, 5
+  r[3] = (zh << 12) & 0x40004000u;  // columns 6, 7
   return __builtin_bit_cast(half8_t, r);
+}
+
+// LDS-DMA with an immediate offset: the instruction's offset field is added to BOTH the global address and the LDS
+// address (M0 + offset + lane * 16), so up to four 1-KiB pieces share one M0 value when the global pointer is
+// pre-decremented by the same constant.
+template <int OFF>
+__device__ __forceinline__ void dma_b128_off(const void* src, unsigned lds_byte_addr) {
+  __builtin_amdgcn_global_load_lds((gas_ptr)((const char*)src - OFF), (lds_ptr)(uintptr_t)lds_byte_addr, 16, OFF, 0);
 }
 
 __device__ __forceinline__ float lds_read_f32(unsigned addr) {
@@ -206,19 +217,29 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
     // hv: lane L holds the (sanitised) row of B for condensed column L & 31 of the stage
     auto issue_data = [&](int dslot, int hv) {
       const unsigned dst = lds0 + dslot * STAGE_BYTES;
+      auto piece = [&](auto kc, int ib) {           // DMA number ib + K of the stage, K = 0..3 sharing one M0
+        constexpr int K = decltype(kc)::value;
+        if constexpr (K < NDMA) {
+          const int i = ib + K;
+          const int r = i * RPD + lane / LPR;       // LDS row written by this lane
+          const int c = lane % LPR;                 // 16-byte chunk inside the row
+          int col;                                  // logical column of that chunk (swizzle on the SOURCE)
+          if constexpr (EB == 2)
+            col = fs0 + (((c >> 1) ^ slot_swizzle<SLOTS>(r)) * 16) + (c & 1) * 8;
+          else
+            col = fs0 + (((c >> 2) ^ (r & 1)) * 16) + (c & 3) * 4;
+          col = col < F ? col : fs0;                // F % FS tail: stay in bounds, results are not stored
+          int hrow = __shfl(hv, r, kWave);
+          if (VOLTRIX_DIAG & 2) hrow &= 1023;
+          dma_b128_off<K * 1024>(a.input + ((long long)hrow * F + col), dst + ib * 1024);
+        }
+      };
 #pragma unroll
-      for (int i = 0; i < NDMA; ++i) {
-        const int r = i * RPD + lane / LPR;           // LDS row written by this lane
-        const int c = lane % LPR;                     // 16-byte chunk inside the row
-        int col;                                      // logical column of that chunk (swizzle on the SOURCE)
-        if constexpr (EB == 2)
-          col = fs0 + (((c >> 1) ^ slot_swizzle<SLOTS>(r)) * 16) + (c & 1) * 8;
-        else
-          col = fs0 + (((c >> 2) ^ (r & 1)) * 16) + (c & 3) * 4;
-        col = col < F ? col : fs0;                    // F % FS tail: stay in bounds, results are not stored
-        int hrow = __shfl(hv, r, kWave);
-        if (VOLTRIX_DIAG & 2) hrow &= 1023;
-        dma_b128(a.input + ((long long)hrow * F + col), dst + i * 1024);
+      for (int ib = 0; ib < NDMA; ib += 4) {
+        piece(std::integral_constant<int, 0>{}, ib);
+        piece(std::integral_constant<int, 1>{}, ib);
+        piece(std::integral_constant<int, 2>{}, ib);
+        piece(std::integral_constant<int, 3>{}, ib);
       }
     };
 
@@ -267,18 +288,20 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
 
       const unsigned mt = meta0 + mslot * T::META_BYTES;
       const bool more = (t + D) < nst;  // wave-uniform
+      // padded hind slots exist only in a window's last TC block: every earlier stage takes hind as it is
+      const bool tail_stage = stage_block(t + D) + kTcbPerStage >= kb1;  // wave-uniform
       unsigned hraw = 0;
       uint2_t vw = {0u, 0u};
       if (more) {
         const unsigned md = meta0 + mslot_d * T::META_BYTES;
         hraw = lds_read_b32(md + 4 * k32);
-        vw = lds_read_b64(md + vword_off);
+        if (tail_stage) vw = lds_read_b64(md + vword_off);
       }
 
       if (VOLTRIX_DIAG & 1) {
         wait_lgkmcnt0();  // hraw / vw are inline-asm LDS reads: they must have landed before they become addresses
         issue_meta(t + 2 * D, mslot_2d);
-        if (more) issue_data(dslot, sanitise(t + D, hraw, vw));
+        if (more) issue_data(dslot, tail_stage ? sanitise(t + D, hraw, vw) : (int)hraw);
       } else if constexpr (EB == 2) {
         // A: lane -> row R of TC block g; its 8 bits are nibble R&7 of words t = R>>3 (cols 0-3), 2 + R>>3 (cols 4-7)
         const unsigned wlo = lds_read_b32(mt + 128 + 4 * (4 * g + (R >> 3)));
@@ -299,11 +322,11 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
 
         // refill: metadata for stage t+2D (always: keeps the vmcnt arithmetic static), rows for stage t+D
         issue_meta(t + 2 * D, mslot_2d);
-        if (more) issue_data(dslot, sanitise(t + D, hraw, vw));
+        if (more) issue_data(dslot, tail_stage ? sanitise(t + D, hraw, vw) : (int)hraw);
 
-        unsigned bits8 = ((wlo >> a_shift) & 0xFu) | (((whi >> a_shift) & 0xFu) << 4);
-        if (stage_block(t) + g >= kb1) bits8 = 0u;  // TC blocks past the window's end contribute zero
-        const half8_t afrag = bits_to_half8(bits8);
+        unsigned nl = (wlo >> a_shift) & 0xFu, nh = (whi >> a_shift) & 0xFu;
+        if (stage_block(t) + g >= kb1) nl = nh = 0u;  // TC blocks past the window's end contribute zero
+        const half8_t afrag = nibbles_to_half8_x2(nl, nh);
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
           const uint4_t bq = {blo[s][0], blo[s][1], bhi[s][0], bhi[s][1]};
@@ -334,7 +357,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
         wait_lgkmcnt0();
 
         issue_meta(t + 2 * D, mslot_2d);
-        if (more) issue_data(dslot, sanitise(t + D, hraw, vw));
+        if (more) issue_data(dslot, tail_stage ? sanitise(t + D, hraw, vw) : (int)hraw);
 
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
@@ -369,7 +392,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = orow0 + j;
-        if (row < a.num_nodes) a.output[(long long)row * F + col] = acc[s][j];
+        if (row < a.num_nodes) a.output[(long long)row * F + col] = (EB == 2) ? acc[s][j] * kAScaleInv : acc[s][j];
       }
     }
   }

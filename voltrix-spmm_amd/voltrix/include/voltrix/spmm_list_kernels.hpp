@@ -108,14 +108,24 @@ static __global__ __launch_bounds__(LT::Base::THREADS) void spmm_list_kernel(con
 
   auto issue_data = [&](int dslot, int hv) {
     const unsigned dst = lds0 + dslot * STAGE_BYTES;
+    auto piece = [&](auto kc, int ib) {
+      constexpr int K = decltype(kc)::value;
+      if constexpr (K < NDMA) {
+        const int i = ib + K;
+        const int r = i * RPD + lane / LPR;
+        const int c = lane % LPR;
+        int col = fs0 + (((c >> 1) ^ slot_swizzle<SLOTS>(r)) * 16) + (c & 1) * 8;
+        col = col < F ? col : fs0;
+        const int hrow = __shfl(hv, r, kWave);
+        dma_b128_off<K * 1024>(a.input + ((long long)hrow * F + col), dst + ib * 1024);
+      }
+    };
 #pragma unroll
-    for (int i = 0; i < NDMA; ++i) {
-      const int r = i * RPD + lane / LPR;
-      const int c = lane % LPR;
-      int col = fs0 + (((c >> 1) ^ slot_swizzle<SLOTS>(r)) * 16) + (c & 1) * 8;
-      col = col < F ? col : fs0;
-      const int hrow = __shfl(hv, r, kWave);
-      dma_b128(a.input + ((long long)hrow * F + col), dst + i * 1024);
+    for (int ib = 0; ib < NDMA; ib += 4) {
+      piece(std::integral_constant<int, 0>{}, ib);
+      piece(std::integral_constant<int, 1>{}, ib);
+      piece(std::integral_constant<int, 2>{}, ib);
+      piece(std::integral_constant<int, 3>{}, ib);
     }
   };
 
@@ -137,7 +147,7 @@ static __global__ __launch_bounds__(LT::Base::THREADS) void spmm_list_kernel(con
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int row = orow0 + j;
-          if (row < a.num_nodes) a.output[(long long)row * F + col] = set[s][j];
+          if (row < a.num_nodes) a.output[(long long)row * F + col] = set[s][j] * kAScaleInv;
         }
       }
       set[s] = float4_t{0.f, 0.f, 0.f, 0.f};
@@ -194,9 +204,9 @@ static __global__ __launch_bounds__(LT::Base::THREADS) void spmm_list_kernel(con
 
     const int cnt = e_c.y & 0xFF, gi = (e_c.y >> 8) & 0xFF;
     if (cnt > 0) {  // count 0: empty window or padding -- its LDS slot holds rows that must not reach the matrix core
-      unsigned bits8 = ((wlo >> a_shift) & 0xFu) | (((whi >> a_shift) & 0xFu) << 4);
-      if (g16 >= cnt) bits8 = 0u;
-      const half8_t afrag = bits_to_half8(bits8);
+      unsigned nl = (wlo >> a_shift) & 0xFu, nh = (whi >> a_shift) & 0xFu;
+      if (g16 >= cnt) nl = nh = 0u;
+      const half8_t afrag = nibbles_to_half8_x2(nl, nh);
 #pragma unroll
       for (int k = 0; k < G; ++k) {
         if (gi == k) {  // wave-uniform: accumulator sets are indexed statically
