@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument("--tile", default=None, help="fs,depth,waves[,sched] (default: quick sweep over the tile space)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for debugging)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: run all-gather and SpMM back to back on one stream (default: the all-gather of step k+1 "
+                         "runs on a second stream beside the SpMM of step k, double-buffered B)")
     ap.add_argument("--one-device", action="store_true",
                     help="debug: every rank uses cuda:0 (exercises the sharded path on a 1-GPU box, with --backend gloo)")
     return ap.parse_args()
@@ -157,8 +160,9 @@ def main():
     order = torch.empty((local_rows + 15) // 16, dtype=torch.int32, device=device)
     capi.launch_window_order(blk_offsets, local_rows, order, stream)
 
-    def spmm(tile):
-        rc = capi.launch_spmm(ptrs[0], ptrs[1], ptrs[2], local_rows, local_nnz, num_feats, gathered.data_ptr(),
+    def spmm(tile, b_full=None):
+        b_ptr = (gathered if b_full is None else b_full).data_ptr()
+        rc = capi.launch_spmm(ptrs[0], ptrs[1], ptrs[2], local_rows, local_nnz, num_feats, b_ptr,
                               out.data_ptr(), is_f16, tile[:3], stream, order.data_ptr() if tile[3] else 0)
         assert rc == 0, f"voltrix_launch_spmm rc={rc}"
 
@@ -191,14 +195,42 @@ def main():
         tile = best[1]
 
     in_place = args.backend == "nccl"  # only NCCL/RCCL defines the in-place (send == recv + rank * count) form
+    overlap = world > 1 and not args.no_overlap
+    main_stream = torch.cuda.current_stream()
+    if world > 1:
+        # two copies of the gather buffer: while the SpMM of step k reads one, the all-gather of step k+1 fills the other
+        bufs = [gathered, gathered.clone()] if overlap else [gathered]
+        sends = [b[rank * rows_padded:(rank + 1) * rows_padded] for b in bufs]
+        comm_stream = torch.cuda.Stream(device=device) if overlap else main_stream
+        ev_gathered = [None] * len(bufs)   # all-gather into buffer b finished
+        ev_consumed = [None] * len(bufs)   # SpMM that read buffer b finished
+    step_no = [0]
 
-    def exchange():
-        dist.all_gather_into_tensor(gathered, send if in_place else send.clone())
-
-    def step():
-        if world > 1:
-            exchange()
-        spmm(tile)
+    def step(record=None):
+        """One pass of the hot path: all-gather(B) (N > 1), then the SpMM that consumes exactly that gathered B."""
+        if world == 1:
+            if record is not None:
+                record[0].record()
+            spmm(tile)
+            if record is not None:
+                record[1].record()
+            return
+        b = step_no[0] % len(bufs)
+        step_no[0] += 1
+        with torch.cuda.stream(comm_stream):
+            if ev_consumed[b] is not None:
+                comm_stream.wait_event(ev_consumed[b])
+            dist.all_gather_into_tensor(bufs[b], sends[b] if in_place else sends[b].clone())
+            ev_gathered[b] = torch.cuda.Event()
+            ev_gathered[b].record(comm_stream)
+        main_stream.wait_event(ev_gathered[b])
+        if record is not None:
+            record[0].record()  # HIP events on the launch stream, live inside the timed region
+        spmm(tile, bufs[b])
+        if record is not None:
+            record[1].record()
+        ev_consumed[b] = torch.cuda.Event()
+        ev_consumed[b].record(main_stream)
 
     for _ in range(args.warmup):
         step()
@@ -210,13 +242,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        if world > 1:
-            exchange()
-        ks, ke = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ks.record()  # HIP events on the launch stream, live inside the timed region
-        spmm(tile)
-        ke.record()
-        kernel_events.append((ks, ke))
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        step(record=ev)
+        kernel_events.append(ev)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -225,6 +253,23 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+    # ---- outside the timed region: row-sum check of this rank's result against torch ops on the same gathered B -------
+    # (validates shard -> column remap -> all-gather -> SpMM end to end on every rank; fp32 index_add reference)
+    b_used = gathered if world == 1 else bufs[(step_no[0] - 1) % len(bufs)]
+    col_sums = b_used.float().sum(dim=1)
+    edge_rows = torch.repeat_interleave(torch.arange(local_rows, device=device),
+                                        (local_indptr[1:] - local_indptr[:-1]).long())
+    want = torch.zeros(local_rows, dtype=torch.float32, device=device).index_add_(0, edge_rows, col_sums[local_indices.long()])
+    got = out.sum(dim=1)
+    scale = torch.zeros(local_rows, dtype=torch.float32, device=device).index_add_(
+        0, edge_rows, b_used.float().abs().sum(dim=1)[local_indices.long()])
+    check_err = float(((got - want).abs() / (scale + 1e-6)).max()) if local_rows else 0.0
+    if world > 1:
+        t = torch.tensor([check_err], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        check_err = float(t)
+    assert check_err < 1e-4, f"row-sum check failed: {check_err}"
+
     kernel_ms = sum(s.elapsed_time(e) for s, e in kernel_events) / len(kernel_events)
     if world > 1:
         t = torch.tensor([kernel_ms], device=device, dtype=torch.float64)
@@ -258,8 +303,11 @@ def main():
                             f"{'fp16' if is_f16 else 'fp32'} -> fp32",
                 "num_nodes": num_nodes, "nnz": nnz, "feat": num_feats, "tc_blocks_rank0": total_blocks,
                 "tile": {"fs": tile[0], "depth": tile[1], "waves": tile[2], "balanced_schedule": bool(tile[3])},
-                "parallelism": f"row-window shards x{world}" + (" + RCCL all-gather(B) per step" if world > 1 else ""),
+                "parallelism": f"row-window shards x{world}" + (
+                    " + RCCL all-gather(B) per step" + (" (overlapped with the previous step's SpMM)" if overlap else "")
+                    if world > 1 else ""),
                 "preprocess_ms": preprocess_ms,
+                "rowsum_check_max_rel_err": check_err,
                 "hbm_gbs_algorithmic": synth_graphs.algorithmic_bytes(num_nodes, nnz, num_feats, in_bytes)
                 / (ms_per_step * 1e-3) / 1e9,
             },
