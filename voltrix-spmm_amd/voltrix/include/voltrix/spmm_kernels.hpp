@@ -114,9 +114,9 @@ __device__ __forceinline__ half8_t nibbles_to_half8_x2(unsigned nl, unsigned nh)
 // LDS-DMA with an immediate offset: the instruction's offset field is added to BOTH the global address and the LDS
 // address (M0 + offset + lane * 16), so up to four 1-KiB pieces share one M0 value when the global pointer is
 // pre-decremented by the same constant.
-template <int OFF>
+template <int OFF, int AUX = 0>
 __device__ __forceinline__ void dma_b128_off(const void* src, unsigned lds_byte_addr) {
-  __builtin_amdgcn_global_load_lds((gas_ptr)((const char*)src - OFF), (lds_ptr)(uintptr_t)lds_byte_addr, 16, OFF, 0);
+  __builtin_amdgcn_global_load_lds((gas_ptr)((const char*)src - OFF), (lds_ptr)(uintptr_t)lds_byte_addr, 16, OFF, AUX);
 }
 
 __device__ __forceinline__ float lds_read_f32(unsigned addr) {
