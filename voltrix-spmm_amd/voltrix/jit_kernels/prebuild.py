@@ -20,7 +20,7 @@ def _spmm_arg_defs(dtype):
             ("win_order", torch.int32), ("stream", torch.cuda.Stream))
 
 
-def jobs(feature_widths=(32, 64, 128)):
+def jobs(feature_widths=(32, 64, 128), modes=("default", "none")):
     """(name, arg_defs, code) of every kernel the operator API can ask for with the current VOLTRIX_TUNE_SPACE."""
     out = []
     for mod in (preprocess, hmat_gem, bmat_swizzle):
@@ -30,7 +30,16 @@ def jobs(feature_widths=(32, 64, 128)):
     seen = set()
     for dtype, eb in ((torch.float16, 2), (torch.float32, 4)):
         for width in feature_widths:
-            for point in spmm.tile_space(width, eb):
+            points = []
+            saved = os.environ.get("VOLTRIX_TUNE_SPACE")
+            for mode in modes:  # the tuned space and the single default tile (VOLTRIX_TUNE_SPACE=none)
+                os.environ["VOLTRIX_TUNE_SPACE"] = mode
+                points += list(spmm.tile_space(width, eb))
+            if saved is None:
+                os.environ.pop("VOLTRIX_TUNE_SPACE", None)
+            else:
+                os.environ["VOLTRIX_TUNE_SPACE"] = saved
+            for point in points:
                 key = (eb, point["FS"], point["DEPTH"], point["WAVES"], point["SCHED"])
                 if key in seen:
                     continue

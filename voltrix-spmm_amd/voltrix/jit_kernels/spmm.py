@@ -46,9 +46,10 @@ def tile_space(embedding_dim: int, elem_bytes: int):
     mode = os.getenv(TUNE_SPACE_FLAG, "default")
     fs_max = 128
     fs_fit = 32 if embedding_dim <= 32 else (64 if embedding_dim <= 64 else fs_max)
-    if mode == "none":
-        depth = 4 if elem_bytes == 2 else (2 if fs_fit == 128 else 4)
-        return ({"FS": fs_fit, "DEPTH": depth, "WAVES": 1, "EB": elem_bytes, "SCHED": 1},)
+    if mode == "none":  # the ahead-of-time library's default tile (csrc/capi_common.hpp::default_tile) + balance schedule
+        fs = 32 if embedding_dim <= 32 else 64
+        depth = (4 if fs == 32 else 3) if elem_bytes == 2 else 3
+        return ({"FS": fs, "DEPTH": depth, "WAVES": 4 if elem_bytes == 2 else 1, "EB": elem_bytes, "SCHED": 1},)
     if mode == "full":
         fs_list = sorted({fs_fit, max(32, fs_fit // 2), min(256, fs_fit * 2) if embedding_dim > 128 else fs_fit})
         depths, waves = (2, 3, 4), (1, 2, 4)
