@@ -27,12 +27,14 @@ def _emulate(sl, p1, packed, hind, n, feat):
     pad = 2 * sl.depth + 1
     for v in range(sl.num_waves):
         lst = ent[wp[v]:wp[v + 1]]
-        assert len(lst) >= pad and (lst[-pad:, 1] == 0).all()
+        assert len(lst) >= pad and ((lst[-pad:, 1] & 0xFF) == 0).all()  # padding: count 0 (tail bit set)
         acc = np.zeros((sl.groups, 16, feat.shape[1]))
         owner = [-1] * sl.groups
         for b0, info, w, _ in lst[:-pad] if pad else lst:
-            cnt, g, fl = info & 0xFF, (info >> 8) & 0xFF, (info >> 16) & 1
+            cnt, g, fl, tail = info & 0xFF, (info >> 8) & 0xFF, (info >> 16) & 1, (info >> 17) & 1
             assert 0 <= cnt <= 4 and g < sl.groups
+            # stages that can hold padded hind slots (window's last block / partial / empty) must take the tail path
+            assert tail or (cnt == 4 and b0 + 4 < p1[w + 1])
             assert owner[g] in (-1, w), "accumulator set shared by two live windows"
             owner[g] = w
             if cnt:

@@ -215,7 +215,8 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
     };
 
     // hv: lane L holds the (sanitised) row of B for condensed column L & 31 of the stage
-    auto issue_data = [&](int dslot, int hv) {
+    // hr[i]: row of B this lane gathers in DMA i of the stage (LDS row i * RPD + lane / LPR)
+    auto issue_data = [&](int dslot, const int (&hr)[NDMA]) {
       const unsigned dst = lds0 + dslot * STAGE_BYTES;
       auto piece = [&](auto kc, int ib) {           // DMA number ib + K of the stage, K = 0..3 sharing one M0
         constexpr int K = decltype(kc)::value;
@@ -229,7 +230,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
           else
             col = fs0 + (((c >> 2) ^ (r & 1)) * 16) + (c & 3) * 4;
           col = col < F ? col : fs0;                // F % FS tail: stay in bounds, results are not stored
-          int hrow = __shfl(hv, r, kWave);
+          int hrow = hr[i];
           if (VOLTRIX_DIAG & 2) hrow &= 1023;
           dma_b128_off<K * 1024>(a.input + ((long long)hrow * F + col), dst + ib * 1024);
         }
@@ -241,6 +242,17 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
         piece(std::integral_constant<int, 2>{}, ib);
         piece(std::integral_constant<int, 3>{}, ib);
       }
+    };
+    // tail stages only: rows come from the sanitised per-column values (lane L holds column L & 31) via the crossbar
+    auto rows_from_columns = [&](int hv, int (&hr)[NDMA]) {
+#pragma unroll
+      for (int i = 0; i < NDMA; ++i) hr[i] = __shfl(hv, i * RPD + lane / LPR, kWave);
+    };
+    // every other stage: each lane reads the hind words of its own DMA rows straight from the metadata slot
+    const unsigned hr_off = 4 * (lane / LPR);
+    auto read_rows = [&](unsigned mbase, int (&hr)[NDMA]) {
+#pragma unroll
+      for (int i = 0; i < NDMA; ++i) hr[i] = (int)lds_read_b32(mbase + hr_off + 4 * (i * RPD));
     };
 
     auto sanitise = [&](int tau, unsigned hraw, uint2_t vw) -> int {
@@ -261,7 +273,9 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
         const unsigned hraw = lds_read_b32(m + 4 * k32);
         const uint2_t vw = lds_read_b64(m + vword_off);
         wait_lgkmcnt0();
-        issue_data(j, sanitise(j, hraw, vw));
+        int hr[NDMA];
+        rows_from_columns(sanitise(j, hraw, vw), hr);
+        issue_data(j, hr);
       }
     }
 
@@ -292,16 +306,24 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
       const bool tail_stage = stage_block(t + D) + kTcbPerStage >= kb1;  // wave-uniform
       unsigned hraw = 0;
       uint2_t vw = {0u, 0u};
+      int hr[NDMA];
       if (more) {
         const unsigned md = meta0 + mslot_d * T::META_BYTES;
-        hraw = lds_read_b32(md + 4 * k32);
-        if (tail_stage) vw = lds_read_b64(md + vword_off);
+        if (tail_stage) {
+          hraw = lds_read_b32(md + 4 * k32);
+          vw = lds_read_b64(md + vword_off);
+        } else {
+          read_rows(md, hr);
+        }
       }
 
       if (VOLTRIX_DIAG & 1) {
         wait_lgkmcnt0();  // hraw / vw are inline-asm LDS reads: they must have landed before they become addresses
         issue_meta(t + 2 * D, mslot_2d);
-        if (more) issue_data(dslot, tail_stage ? sanitise(t + D, hraw, vw) : (int)hraw);
+        if (more) {
+          if (tail_stage) rows_from_columns(sanitise(t + D, hraw, vw), hr);
+          issue_data(dslot, hr);
+        }
       } else if constexpr (EB == 2) {
         // A: lane -> row R of TC block g; its 8 bits are nibble R&7 of words t = R>>3 (cols 0-3), 2 + R>>3 (cols 4-7)
         const unsigned wlo = lds_read_b32(mt + 128 + 4 * (4 * g + (R >> 3)));
@@ -322,7 +344,10 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
 
         // refill: metadata for stage t+2D (always: keeps the vmcnt arithmetic static), rows for stage t+D
         issue_meta(t + 2 * D, mslot_2d);
-        if (more) issue_data(dslot, tail_stage ? sanitise(t + D, hraw, vw) : (int)hraw);
+        if (more) {
+          if (tail_stage) rows_from_columns(sanitise(t + D, hraw, vw), hr);
+          issue_data(dslot, hr);
+        }
 
         unsigned nl = (wlo >> a_shift) & 0xFu, nh = (whi >> a_shift) & 0xFu;
         if (stage_block(t) + g >= kb1) nl = nh = 0u;  // TC blocks past the window's end contribute zero
@@ -357,7 +382,10 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
         wait_lgkmcnt0();
 
         issue_meta(t + 2 * D, mslot_2d);
-        if (more) issue_data(dslot, tail_stage ? sanitise(t + D, hraw, vw) : (int)hraw);
+        if (more) {
+          if (tail_stage) rows_from_columns(sanitise(t + D, hraw, vw), hr);
+          issue_data(dslot, hr);
+        }
 
 #pragma unroll
         for (int m = 0; m < 8; ++m) {

@@ -17,6 +17,7 @@
 //
 // Entry (int4): x = first TC block (global index), y = count (0..4 valid blocks; 0 = nothing to gather/multiply: empty
 // window or list padding) | g << 8 (accumulator set) | flush << 16 (after this stage: store set g to window z, clear it),
+// | tail << 17 (the stage may contain padded hind slots: a window's last block, a partial stage, count 0),
 // z = window id, w = unused.  Every wave's list ends with 2*DEPTH+1 padding entries (count 0, a valid block) so that
 // the pipeline issues exactly 1 + NDMA DMAs per step and one static s_waitcnt vmcnt immediate serves the whole list.
 #pragma once
@@ -106,7 +107,7 @@ static __global__ __launch_bounds__(LT::Base::THREADS) void spmm_list_kernel(con
     dma_b32(src, meta0 + mslot * T::META_BYTES);
   };
 
-  auto issue_data = [&](int dslot, int hv) {
+  auto issue_data = [&](int dslot, const int (&hr)[NDMA]) {
     const unsigned dst = lds0 + dslot * STAGE_BYTES;
     auto piece = [&](auto kc, int ib) {
       constexpr int K = decltype(kc)::value;
@@ -116,8 +117,7 @@ static __global__ __launch_bounds__(LT::Base::THREADS) void spmm_list_kernel(con
         const int c = lane % LPR;
         int col = fs0 + (((c >> 1) ^ slot_swizzle<SLOTS>(r)) * 16) + (c & 1) * 8;
         col = col < F ? col : fs0;
-        const int hrow = __shfl(hv, r, kWave);
-        dma_b128_off<K * 1024>(a.input + ((long long)hrow * F + col), dst + ib * 1024);
+        dma_b128_off<K * 1024>(a.input + ((long long)hr[i] * F + col), dst + ib * 1024);
       }
     };
 #pragma unroll
@@ -127,6 +127,15 @@ static __global__ __launch_bounds__(LT::Base::THREADS) void spmm_list_kernel(con
       piece(std::integral_constant<int, 2>{}, ib);
       piece(std::integral_constant<int, 3>{}, ib);
     }
+  };
+  auto rows_from_columns = [&](int hv, int (&hr)[NDMA]) {
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) hr[i] = __shfl(hv, i * RPD + lane / LPR, kWave);
+  };
+  const unsigned hr_off = 4 * (lane / LPR);
+  auto read_rows = [&](unsigned mbase, int (&hr)[NDMA]) {
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) hr[i] = (int)lds_read_b32(mbase + hr_off + 4 * (i * RPD));
   };
 
   // hraw: this lane's hind word; h_first: hind word 0 of the stage (first column of its first block: a real column of
@@ -166,24 +175,31 @@ static __global__ __launch_bounds__(LT::Base::THREADS) void spmm_list_kernel(con
     const unsigned hfirst = lds_read_b32(m);
     const uint2_t vw = lds_read_b64(m + vword_off);
     wait_lgkmcnt0();
-    issue_data(j, sanitise(ent[j], hraw, vw, (int)hfirst));
+    int hr[NDMA];
+    rows_from_columns(sanitise(ent[j], hraw, vw, (int)hfirst), hr);
+    issue_data(j, hr);
   }
 
   // ---- main loop: every step retires one stage and issues exactly 1 + NDMA DMAs ------------------------------------
   int dslot = 0, mslot = 0, mslot_d = D, mslot_2d = (2 * D) % MS;
   int4v_t e_c = ent[0], e_d = ent[D], e_m = ent[2 * D];
   for (int t = 0; t < nreal; ++t) {
-    // next step's entries: scalar loads issued now, consumed one iteration later
-    const int4v_t n_c = ent[t + 1], n_d = ent[t + 1 + D];
-    const int4v_t n_m = (t + 1 + 2 * D) < n_all ? ent[t + 1 + 2 * D] : ent[n_all - 1];
-
     wait_vmcnt<T::vm_behind(D - 1)>();
 
     const unsigned mt = meta0 + mslot * T::META_BYTES;
     const unsigned md = meta0 + mslot_d * T::META_BYTES;
-    const unsigned hraw = lds_read_b32(md + 4 * k32);
-    const unsigned hfirst = lds_read_b32(md);
-    const uint2_t vw = lds_read_b64(md + vword_off);
+    // bit 17 of the entry: the stage may hold padded / masked columns (a window's last block, a partial stage, count 0)
+    const bool tail_stage = (e_d.y >> 17) & 1;  // wave-uniform
+    unsigned hraw = 0, hfirst = 0;
+    uint2_t vw = {0u, 0u};
+    int hr[NDMA];
+    if (tail_stage) {
+      hraw = lds_read_b32(md + 4 * k32);
+      hfirst = lds_read_b32(md);
+      vw = lds_read_b64(md + vword_off);
+    } else {
+      read_rows(md, hr);
+    }
     const unsigned wlo = lds_read_b32(mt + 128 + 4 * (4 * g16 + (R >> 3)));
     const unsigned whi = lds_read_b32(mt + 128 + 4 * (4 * g16 + 2 + (R >> 3)));
     const int q = (lane >> 2) & 3, p = lane & 3;
@@ -199,8 +215,16 @@ static __global__ __launch_bounds__(LT::Base::THREADS) void spmm_list_kernel(con
     }
     wait_lgkmcnt0();
 
+    // next step's entries: scalar loads issued HERE, right after the only lgkmcnt(0) of the step, so that their
+    // latency hides under the DMA issue + MFMA phase (SMEM returns out of order: any lgkmcnt(0) drains it)
+    const int nt1 = t + 1;
+    const int4v_t n_c = ent[nt1], n_d = ent[nt1 + D];
+    const int4v_t n_m = (nt1 + 2 * D) < n_all ? ent[nt1 + 2 * D] : ent[n_all - 1];
+    __builtin_amdgcn_sched_barrier(0);
+
     issue_meta(e_m, mslot_2d);
-    issue_data(dslot, sanitise(e_d, hraw, vw, (int)hfirst));
+    if (tail_stage) rows_from_columns(sanitise(e_d, hraw, vw, (int)hfirst), hr);
+    issue_data(dslot, hr);
 
     const int cnt = e_c.y & 0xFF, gi = (e_c.y >> 8) & 0xFF;
     if (cnt > 0) {  // count 0: empty window or padding -- its LDS slot holds rows that must not reach the matrix core

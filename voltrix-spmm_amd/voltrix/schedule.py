@@ -26,7 +26,7 @@ NUM_XCD = 8
 
 @dataclass
 class StageList:
-    entries: torch.Tensor    # int32 [n, 4]: first block, count | g << 8 | flush << 16, window, 0
+    entries: torch.Tensor    # int32 [n, 4]: first block, count | g << 8 | flush << 16 | tail << 17, window, 0
     wave_ptr: torch.Tensor   # int32 [num_waves + 1]
     num_waves: int
     groups: int
@@ -136,7 +136,10 @@ def build_stage_list(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind:
                                                                                        include_self=False)
     flush = (last_pos[s_w] == pos).to(torch.int64)
     count = torch.where(empty_w[s_w], torch.zeros_like(s_count), s_count)
-    info = count | (w_g[s_w] << 8) | (flush << 16)
+    # tail: the stage contains the window's last TC block (the only one with padded hind slots), is partial, or is empty
+    holds_last = (s_block0 + s_count) >= p1[1:][s_w]
+    tail = (holds_last | (s_count < 4) | (count == 0)).to(torch.int64)
+    info = count | (w_g[s_w] << 8) | (flush << 16) | (tail << 17)
 
     # ---- per-wave lists with 2*depth+1 padding entries -----------------------------------------------------------------
     per_wave = torch.bincount(s_wave, minlength=num_waves)
@@ -156,4 +159,5 @@ def build_stage_list(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind:
     last_block[has] = s_block0[last_idx[has]]
     pad_dst = (wave_ptr[:-1] + per_wave)[:, None] + torch.arange(pad, device=dev, dtype=torch.int64)[None, :]
     entries[pad_dst.reshape(-1), 0] = last_block[:, None].expand(num_waves, pad).reshape(-1).to(torch.int32)
+    entries[pad_dst.reshape(-1), 1] = 1 << 17   # padding: count 0, tail path (rows = a valid row, nothing multiplied)
     return StageList(entries.contiguous(), wave_ptr.to(torch.int32), num_waves, groups, depth, mode, rounds, num_stages)
