@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""1-GPU sweep over the BASELINE.json workloads x feature widths (north_star: "GFLOP/s on ... graphs at
+feat_dim in {32,128,512} reported at 1 GPU ... alongside the CPU torch.sparse.mm baseline").
+
+    python harness/sweep.py [--workloads reddit_like,products_like] [--feats 32,128,512] [--cpu] [--vendor] > out.jsonl
+
+One JSON line per (workload, F): best tile of the tuned space (with / without the balance schedule), kernel ms (HIP
+events, median of 7 after 3 warm-ups), GFLOP/s = 2 nnz F / t, algorithmic GB/s and its fraction of 8 TB/s, gathered-row
+TB/s, optional CPU (torch.sparse.mm, all host threads, fp32) and GPU-vendor (hipSPARSE through torch.sparse.mm, fp32)
+baselines.  Bench infrastructure; the headline line the driver consumes is bench.py's.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "voltrix-spmm_amd")):
+    sys.path.insert(0, p)
+os.environ.setdefault("VOLTRIX_CACHE_DIR", os.path.join(REPO, "voltrix-spmm_amd", ".jit_cache"))
+
+import torch  # noqa: E402
+
+import synth_graphs  # noqa: E402
+import voltrix  # noqa: E402
+from voltrix import capi  # noqa: E402
+from voltrix.jit_kernels.spmm import tile_space  # noqa: E402
+
+
+def median_ms(fn, iters=7, warm=3):
+    for _ in range(warm):
+        fn()
+    times = []
+    for _ in range(iters):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        e.synchronize()
+        times.append(s.elapsed_time(e))
+    return sorted(times)[len(times) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workloads", default="reddit_like,reddit_uniform,products_like")
+    ap.add_argument("--feats", default="32,128,512")
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--vendor", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    for name in args.workloads.split(","):
+        indptr, indices, cfg = synth_graphs.generate(name, device=dev, scale=args.scale)
+        n, nnz = indptr.numel() - 1, indices.numel()
+        t0 = time.perf_counter()
+        p1, packed, hind, _ = voltrix.csr_fused_preprocess_kernel(indptr, indices, n)
+        torch.cuda.synchronize()
+        prep_ms = (time.perf_counter() - t0) * 1e3
+        total_blocks = int(p1[-1])
+        order = torch.empty((n + 15) // 16, dtype=torch.int32, device=dev)
+        capi.launch_window_order(p1, n, order, stream)
+        for f in [int(x) for x in args.feats.split(",")]:
+            feat = torch.randn(n, f, device=dev).half()
+            out = torch.empty(n, f, device=dev)
+            aot = set(capi.tiles(True))
+            best = None
+            for p in tile_space(f, 2):
+                tile = (p["FS"], p["DEPTH"], p["WAVES"])
+                if tile not in aot:
+                    continue
+                ordp = order.data_ptr() if p["SCHED"] else 0
+
+                def run():
+                    rc = capi.launch_spmm(p1.data_ptr(), packed.data_ptr(), hind.data_ptr(), n, nnz, f,
+                                          feat.data_ptr(), out.data_ptr(), True, tile, stream, ordp)
+                    assert rc == 0
+                ms = median_ms(run, iters=3, warm=1)
+                if best is None or ms < best[0]:
+                    best = (ms, tile, p["SCHED"], run)
+            ms = median_ms(best[3])
+            alg = synth_graphs.algorithmic_bytes(n, nnz, f, 2)
+            line = {"workload": name, "scale": args.scale, "num_nodes": n, "nnz": nnz, "feat": f, "dtype": "f16",
+                    "tc_blocks": total_blocks, "preprocess_ms": prep_ms,
+                    "tile": {"fs": best[1][0], "depth": best[1][1], "waves": best[1][2], "balanced": bool(best[2])},
+                    "kernel_ms": ms, "gflops": 2.0 * nnz * f / ms / 1e6, "algorithmic_gbs": alg / ms / 1e6,
+                    "hbm_roofline_frac": alg / ms / 1e6 / 8000.0,
+                    "gather_tbs": 8.0 * total_blocks * f * 2 / ms / 1e9}
+            if args.vendor:
+                try:
+                    a = torch.sparse_csr_tensor(indptr, indices, torch.ones(nnz, device=dev), size=(n, n))
+                    f32 = feat.float()
+                    line["vendor_hipsparse_f32_ms"] = median_ms(lambda: a @ f32, iters=3, warm=1)
+                    del a, f32
+                except Exception as exc:
+                    line["vendor_hipsparse_error"] = str(exc)[:120]
+            if args.cpu:
+                from oracle import torch_ref  # baseline leg only
+
+                torch.set_num_threads(os.cpu_count())
+                a = torch_ref.csr_ones(indptr.cpu(), indices.cpu(), n, n)
+                fc = feat.float().cpu()
+                a @ fc
+                t0 = time.perf_counter()
+                a @ fc
+                a @ fc
+                cpu_ms = (time.perf_counter() - t0) * 500
+                line["cpu_torch_sparse_mm_f32_ms"] = cpu_ms
+                line["cpu_gflops"] = 2.0 * nnz * f / cpu_ms / 1e6
+                line["cpu_threads"] = os.cpu_count()
+            print(json.dumps(line), flush=True)
+            del feat, out
+
+
+if __name__ == "__main__":
+    main()
