@@ -38,7 +38,7 @@
 
 #include "voltrix/traits.hpp"
 
-// Diagnostic builds only (scratch/diag.py): bit 0 skips the consume side (LDS reads + MFMA), bit 1 folds every gathered
+// Diagnostic builds only (harness/experiments/diag.py): bit 0 skips the consume side (LDS reads + MFMA), bit 1 folds every gathered
 // row into the first 1024 rows of B (all L2 hits), bit 2 skips the output stores.  Results are wrong by design; the
 // shipped kernels use 0.
 #ifndef VOLTRIX_DIAG
