@@ -178,13 +178,20 @@ def main():
     ptrs = (blk_offsets.data_ptr(), hspa_packed.data_ptr(), hind.data_ptr())
 
     # "balance" schedule of this rank's handle (length-sorted windows inside 256-window chunks), computed on the GPU
-    order = torch.empty((local_rows + 15) // 16, dtype=torch.int32, device=device)
-    capi.launch_window_order(blk_offsets, local_rows, order, stream)
+    from voltrix.jit_kernels.spmm import ORDER_CHUNKS
+
+    orders = {0: 0}
+    order_keep = []
+    for sched, chunk in ORDER_CHUNKS.items():
+        o = torch.empty((local_rows + 15) // 16, dtype=torch.int32, device=device)
+        capi.launch_window_order(blk_offsets, local_rows, o, stream, chunk)
+        order_keep.append(o)
+        orders[sched] = o.data_ptr()
 
     def spmm(tile, b_full=None):
         b_ptr = (gathered if b_full is None else b_full).data_ptr()
         rc = capi.launch_spmm(ptrs[0], ptrs[1], ptrs[2], local_rows, local_nnz, num_feats, b_ptr,
-                              out.data_ptr(), is_f16, tile[:3], stream, order.data_ptr() if tile[3] else 0)
+                              out.data_ptr(), is_f16, tile[:3], stream, orders[tile[3]])
         assert rc == 0, f"voltrix_launch_spmm rc={rc}"
 
     # ---- tile: explicit, or a quick sweep over the instantiated space (what the autotuner does on first call) ----
@@ -323,7 +330,7 @@ def main():
                             f"SURVEY.md 8d generator, seed {cfg['seed']}) x dense F={num_feats} "
                             f"{'fp16' if is_f16 else 'fp32'} -> fp32",
                 "num_nodes": num_nodes, "nnz": nnz, "feat": num_feats, "tc_blocks_rank0": total_blocks,
-                "tile": {"fs": tile[0], "depth": tile[1], "waves": tile[2], "balanced_schedule": bool(tile[3])},
+                "tile": {"fs": tile[0], "depth": tile[1], "waves": tile[2], "balance_schedule_chunk": ORDER_CHUNKS.get(tile[3], 0)},
                 "parallelism": f"row-window shards x{world}" + (
                     " + RCCL all-gather(B) per step" + (" (overlapped with the previous step's SpMM)" if overlap else "")
                     if world > 1 else ""),

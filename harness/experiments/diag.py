@@ -7,7 +7,7 @@ from voltrix import jit
 from voltrix.jit_kernels import spmm as sp
 dev='cuda'
 def build(diag, tile, extra_defs=''):
-    arg_defs = (("blk_offsets", torch.int32), ("hspa_packed", torch.uint32), ("hind", torch.int32), ("num_nodes", int), ("num_edges", int), ("embedding_dim", int), ("input", torch.float16), ("output", torch.float), ("win_order", torch.int32), ("stream", torch.cuda.Stream))
+    arg_defs = (("blk_offsets", torch.int32), ("hspa_packed", torch.uint32), ("hind", torch.int32), ("num_nodes", int), ("num_edges", int), ("embedding_dim", int), ("input", torch.float16), ("output", torch.float), ("win_order_a", torch.int32), ("win_order_b", torch.int32), ("win_order_c", torch.int32), ("stream", torch.cuda.Stream))
     body = jit.cpp_format(sp.template, {"FS": tile[0], "DEPTH": tile[1], "WAVES": tile[2], "EB": 2, "SCHED": 0})
     code = jit.generate(sp.includes, arg_defs, body)
     code = f"#define VOLTRIX_DIAG {diag}\n{extra_defs}\n" + code
@@ -29,7 +29,7 @@ if __name__ == '__main__':
     for t in tiles:
         for d in diags:
             rt = build(d, t)
-            args = (p1, packed, hind, N, E, F, feat, out, torch.empty(0, dtype=torch.int32, device=dev), torch.cuda.current_stream())
+            args = (p1, packed, hind, N, E, F, feat, out, torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int32, device=dev), torch.cuda.current_stream())
             for _ in range(2): assert rt(*args) == 0
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()

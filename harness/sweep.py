@@ -60,8 +60,14 @@ def main():
         torch.cuda.synchronize()
         prep_ms = (time.perf_counter() - t0) * 1e3
         total_blocks = int(p1[-1])
-        order = torch.empty((n + 15) // 16, dtype=torch.int32, device=dev)
-        capi.launch_window_order(p1, n, order, stream)
+        from voltrix.jit_kernels.spmm import ORDER_CHUNKS
+
+        orders, keep = {0: 0}, []
+        for sched, chunk in ORDER_CHUNKS.items():
+            o = torch.empty((n + 15) // 16, dtype=torch.int32, device=dev)
+            capi.launch_window_order(p1, n, o, stream, chunk)
+            keep.append(o)
+            orders[sched] = o.data_ptr()
         for f in [int(x) for x in args.feats.split(",")]:
             feat = torch.randn(n, f, device=dev).half()
             out = torch.empty(n, f, device=dev)
@@ -71,7 +77,7 @@ def main():
                 tile = (p["FS"], p["DEPTH"], p["WAVES"])
                 if tile not in aot:
                     continue
-                ordp = order.data_ptr() if p["SCHED"] else 0
+                ordp = orders[p["SCHED"]]
 
                 def run():
                     rc = capi.launch_spmm(p1.data_ptr(), packed.data_ptr(), hind.data_ptr(), n, nnz, f,
@@ -84,7 +90,7 @@ def main():
             alg = synth_graphs.algorithmic_bytes(n, nnz, f, 2)
             line = {"workload": name, "scale": args.scale, "num_nodes": n, "nnz": nnz, "feat": f, "dtype": "f16",
                     "tc_blocks": total_blocks, "preprocess_ms": prep_ms,
-                    "tile": {"fs": best[1][0], "depth": best[1][1], "waves": best[1][2], "balanced": bool(best[2])},
+                    "tile": {"fs": best[1][0], "depth": best[1][1], "waves": best[1][2], "balance_chunk": ORDER_CHUNKS.get(best[2], 0)},
                     "kernel_ms": ms, "gflops": 2.0 * nnz * f / ms / 1e6, "algorithmic_gbs": alg / ms / 1e6,
                     "hbm_roofline_frac": alg / ms / 1e6 / 8000.0,
                     "gather_tbs": 8.0 * total_blocks * f * 2 / ms / 1e9}

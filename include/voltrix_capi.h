@@ -101,7 +101,7 @@ void voltrix_launch_spmm_f16_tile(void* blk_offsets, void* hspa_packed, void* hi
                                   void* window_order, void* stream, int* return_code);
 
 /* "Balance" schedule for a handle: order_out int32[W] (device) lists the windows of every XCD range, inside chunks of
- * `chunk` (1..1024) consecutive windows, by descending TC-block count, so that co-resident waves sweep their sorted
+ * `chunk` (1..4096) consecutive windows, by descending TC-block count, so that co-resident waves sweep their sorted
  * columns at a similar pace and share gathered rows through L2.  Depends on blk_offsets only; results of the SpMM are
  * bit-identical with or without it. */
 void voltrix_launch_window_order(void* blk_offsets, int num_nodes, int chunk, void* order_out, void* stream,

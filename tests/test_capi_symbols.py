@@ -102,8 +102,8 @@ def test_return_codes_on_bad_arguments():
     assert rc.value == 3
     lib.voltrix_launch_cast_f32_f16(z, z, ctypes.c_int64(12), z, ctypes.byref(rc))
     assert rc.value == 1
-    lib.voltrix_launch_window_order(z, ctypes.c_int(64), ctypes.c_int(4096), z, z, ctypes.byref(rc))
-    assert rc.value == 1  # chunk above the 1024-window LDS sort capacity
+    lib.voltrix_launch_window_order(z, ctypes.c_int(64), ctypes.c_int(8192), z, z, ctypes.byref(rc))
+    assert rc.value == 1  # chunk above the 4096-window LDS sort capacity
     assert capi.csr_preprocess_workspace_bytes(232965, 114615892) >= 4 * 114615892
     with pytest.raises(capi.VoltrixError, match="return code 3"):
         capi.check(3, "x")

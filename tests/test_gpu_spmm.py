@@ -189,7 +189,7 @@ def _reference_window_order(p1, num_windows, chunk):
     return order
 
 
-@pytest.mark.parametrize("chunk", [256, 1000, 7])
+@pytest.mark.parametrize("chunk", [128, 512, 2048, 1000, 7])
 def test_window_order_schedule_is_a_sorted_permutation_and_changes_no_bit(cuda_device, chunk):
     indptr, indices, _ = synth_graphs.generate("reddit_like", device="cuda", scale=0.15)
     n, e = indptr.numel() - 1, indices.numel()

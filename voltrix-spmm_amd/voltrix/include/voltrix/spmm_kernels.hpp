@@ -469,7 +469,7 @@ inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed,
 // have a similar number of TC blocks.  window_order[pos] lists, inside every XCD's window range and inside chunks of
 // `chunk` consecutive windows (row locality is kept at that granularity), the windows by descending block count.
 // Measured on MI355X: -7 % (reddit-like) ... -19 % (uniform columns) kernel time; results are bit-identical.
-constexpr int kOrderMaxChunk = 1024;
+constexpr int kOrderMaxChunk = 4096;
 
 static __global__ __launch_bounds__(256) void window_order_kernel(const int* __restrict__ blk_offsets,
                                                                  const int num_windows, const int windows_per_xcd,

@@ -17,7 +17,8 @@ from . import bmat_swizzle, hmat_gem, preprocess, spmm
 def _spmm_arg_defs(dtype):
     return (("blk_offsets", torch.int32), ("hspa_packed", torch.uint32), ("hind", torch.int32), ("num_nodes", int),
             ("num_edges", int), ("embedding_dim", int), ("input", dtype), ("output", torch.float),
-            ("win_order", torch.int32), ("stream", torch.cuda.Stream))
+            ("win_order_a", torch.int32), ("win_order_b", torch.int32), ("win_order_c", torch.int32),
+            ("stream", torch.cuda.Stream))
 
 
 def jobs(feature_widths=(32, 64, 128), modes=("default", "none")):

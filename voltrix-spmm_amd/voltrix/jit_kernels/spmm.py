@@ -18,10 +18,14 @@ includes = ('"voltrix/spmm_kernels.hpp"',)
 template = """
 __return_code = voltrix::launch_spmm_tc16<voltrix::SpmmTile<{FS}, {DEPTH}, {WAVES}, {EB}>>(
     blk_offsets, hspa_packed, hind,
-    num_nodes, embedding_dim, input, output, stream, {SCHED} ? win_order : nullptr);
+    num_nodes, embedding_dim, input, output, stream,
+    {SCHED} == 0 ? nullptr : ({SCHED} == 1 ? win_order_a : ({SCHED} == 2 ? win_order_b : win_order_c)));
 """
 
-ORDER_CHUNK = 256  # windows per length-sorted chunk of the "balance" schedule (spmm_kernels.hpp::launch_window_order)
+# windows per length-sorted chunk of the "balance" schedule (spmm_kernels.hpp::launch_window_order) for SCHED 1/2/3.
+# Small chunks keep row neighbours together (banded graphs, wide features), wide chunks equalise more (uniform columns).
+# Measured optimum on MI355X: reddit-like F=128 -> 512, F=512 -> 128, uniform columns -> 2048 (DESIGN.md section 5).
+ORDER_CHUNKS = {1: 128, 2: 512, 3: 2048}
 
 
 def feature_hash(feature: torch.Tensor) -> str:
@@ -49,7 +53,7 @@ def tile_space(embedding_dim: int, elem_bytes: int):
     if mode == "none":  # the ahead-of-time library's default tile (csrc/capi_common.hpp::default_tile) + balance schedule
         fs = 32 if embedding_dim <= 32 else 64
         depth = (4 if fs == 32 else 3) if elem_bytes == 2 else 3
-        return ({"FS": fs, "DEPTH": depth, "WAVES": 4 if elem_bytes == 2 else 1, "EB": elem_bytes, "SCHED": 1},)
+        return ({"FS": fs, "DEPTH": depth, "WAVES": 4 if elem_bytes == 2 else 1, "EB": elem_bytes, "SCHED": 2},)
     if mode == "full":
         fs_list = sorted({fs_fit, max(32, fs_fit // 2), min(256, fs_fit * 2) if embedding_dim > 128 else fs_fit})
         depths, waves = (2, 3, 4), (1, 2, 4)
@@ -62,22 +66,27 @@ def tile_space(embedding_dim: int, elem_bytes: int):
             for w in waves:
                 ndma = 32 * fs * elem_bytes // 1024
                 if _lds_bytes(fs, d, w, elem_bytes) <= 160 * 1024 and (1 + ndma) * (d - 1) <= 63:
-                    for sched in (0, 1):  # natural window order / length-balanced schedule
+                    for sched in (0,) + tuple(ORDER_CHUNKS):  # natural window order / balance schedule per chunk size
                         space.append({"FS": fs, "DEPTH": d, "WAVES": w, "EB": elem_bytes, "SCHED": sched})
     return tuple(space)
 
 
-def window_order(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, num_nodes: int) -> torch.Tensor:
-    """The handle's "balance" schedule, computed once on the GPU and cached on the ``hspa_packed`` tensor object."""
-    cached = getattr(hspa_packed, "_voltrix_window_order", None)
-    if cached is not None and cached[0] == blk_offsets.data_ptr() and cached[1] == num_nodes:
-        return cached[2]
+def window_order(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, num_nodes: int, sched: int = 1) -> torch.Tensor:
+    """The handle's "balance" schedule ``sched`` (key of ORDER_CHUNKS), computed once on the GPU and cached on the
+    ``hspa_packed`` tensor object."""
+    cache = getattr(hspa_packed, "_voltrix_window_order", None)
+    key = (blk_offsets.data_ptr(), num_nodes, sched)
+    if isinstance(cache, dict) and key in cache:
+        return cache[key]
     from .. import capi
 
     order = torch.empty((num_nodes + 15) // 16, dtype=torch.int32, device=blk_offsets.device)
-    capi.launch_window_order(blk_offsets, num_nodes, order, torch.cuda.current_stream().cuda_stream, ORDER_CHUNK)
+    capi.launch_window_order(blk_offsets, num_nodes, order, torch.cuda.current_stream().cuda_stream, ORDER_CHUNKS[sched])
     try:
-        hspa_packed._voltrix_window_order = (blk_offsets.data_ptr(), num_nodes, order)
+        if not isinstance(cache, dict):
+            cache = {}
+            hspa_packed._voltrix_window_order = cache
+        cache[key] = order
     except AttributeError:
         pass
     return order
@@ -95,7 +104,8 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
     assert embedding_dim % (16 // elem_bytes) == 0, "embedding_dim must keep rows 16-byte aligned (voltrix.spmm pads)"
 
     args = (blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, output,
-            window_order(blk_offsets, hspa_packed, num_nodes), torch.cuda.current_stream())
+            window_order(blk_offsets, hspa_packed, num_nodes, 1), window_order(blk_offsets, hspa_packed, num_nodes, 2),
+            window_order(blk_offsets, hspa_packed, num_nodes, 3), torch.cuda.current_stream())
     runtime = jit_tuner.compile_and_tune(
         name="spmm_kernel",
         keys={
@@ -115,7 +125,9 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
             ("embedding_dim", int),
             ("input", input.dtype),
             ("output", output.dtype),
-            ("win_order", torch.int32),
+            ("win_order_a", torch.int32),
+            ("win_order_b", torch.int32),
+            ("win_order_c", torch.int32),
             ("stream", torch.cuda.Stream),
         ),
         template=template,
