@@ -86,7 +86,7 @@ void voltrix_launch_spmm(void* blk_offsets, void* hspa_packed, void* hind, int n
 /* ---- gfx950 extensions ------------------------------------------------------------------------------------ */
 
 /* Same as voltrix_launch_spmm with an explicit tile: fs = feature slab per wave (32/64/128), depth = LDS ring
- * depth (2..4), waves = waves per workgroup (1/2/4); VOLTRIX_ERR_BAD_CONFIG if not instantiated.
+ * depth (2..4), waves = waves per workgroup (1/2/4/8); VOLTRIX_ERR_BAD_CONFIG if not instantiated.
  * window_order: NULL, or the int32[W] schedule written by voltrix_launch_window_order (changes speed only). */
 void voltrix_launch_spmm_f32_tile(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
                                   int embedding_dim, void* input, void* output, int fs, int depth, int waves,

@@ -37,7 +37,7 @@ def test_tile_space_enumeration_and_defaults():
     assert len(f16) == len(set(f16)) >= 30 and (128, 4, 1) in f16 and (256, 4, 4) not in f16
     assert (128, 2, 1) in f32 and all(fs <= 128 for fs, _, _ in f32)
     for fs, depth, waves in f16 + f32:
-        assert fs in (32, 64, 128, 256) and 2 <= depth <= 4 and waves in (1, 2, 4)
+        assert fs in (32, 64, 128, 256) and 2 <= depth <= 4 and waves in (1, 2, 4, 8)
     for f16_flag, tiles in ((True, f16), (False, f32)):
         for dim in (8, 32, 33, 64, 100, 128, 512, 1024):
             assert capi.default_tile(dim, f16_flag) in tiles

@@ -26,7 +26,8 @@ struct TileId {
   X(32, 2, 1) X(32, 2, 2) X(32, 2, 4) X(32, 3, 1) X(32, 3, 2) X(32, 3, 4) X(32, 4, 1) X(32, 4, 2) X(32, 4, 4)       \
   X(64, 2, 1) X(64, 2, 2) X(64, 2, 4) X(64, 3, 1) X(64, 3, 2) X(64, 3, 4) X(64, 4, 1) X(64, 4, 2) X(64, 4, 4)       \
   X(128, 2, 1) X(128, 2, 2) X(128, 2, 4) X(128, 3, 1) X(128, 3, 2) X(128, 3, 4) X(128, 4, 1) X(128, 4, 2) X(128, 4, 4) \
-  X(256, 2, 1) X(256, 2, 2) X(256, 2, 4) X(256, 3, 1) X(256, 3, 2) X(256, 3, 4) X(256, 4, 1) X(256, 4, 2) X(256, 4, 4)
+  X(256, 2, 1) X(256, 2, 2) X(256, 2, 4) X(256, 3, 1) X(256, 3, 2) X(256, 3, 4) X(256, 4, 1) X(256, 4, 2) X(256, 4, 4) \
+  X(32, 2, 8) X(32, 3, 8) X(32, 4, 8) X(64, 2, 8) X(64, 3, 8) X(64, 4, 8) X(128, 2, 8) X(128, 3, 8) X(128, 4, 8)
 
 template <int EB>
 inline int num_tiles() {
