@@ -5,7 +5,7 @@ feat_dim in {32,128,512} reported at 1 GPU ... alongside the CPU torch.sparse.mm
     python harness/sweep.py [--workloads reddit_like,products_like] [--feats 32,128,512] [--cpu] [--vendor] > out.jsonl
 
 One JSON line per (workload, F): best tile of the tuned space (with / without the balance schedule), kernel ms (HIP
-events, median of 7 after 3 warm-ups), GFLOP/s = 2 nnz F / t, algorithmic GB/s and its fraction of 8 TB/s, gathered-row
+events around batches of 5 back-to-back launches, median of 7 batches after 3 warm-ups), GFLOP/s = 2 nnz F / t, algorithmic GB/s and its fraction of 8 TB/s, gathered-row
 TB/s, optional CPU (torch.sparse.mm, all host threads, fp32) and GPU-vendor (hipSPARSE through torch.sparse.mm, fp32)
 baselines.  Bench infrastructure; the headline line the driver consumes is bench.py's.
 """
@@ -28,17 +28,21 @@ from voltrix import capi  # noqa: E402
 from voltrix.jit_kernels.spmm import tile_space  # noqa: E402
 
 
-def median_ms(fn, iters=7, warm=3):
+def median_ms(fn, iters=7, warm=3, batch=5):
+    """Median over `iters` batches of `batch` back-to-back launches (one HIP event pair per batch): the bench.py
+    protocol.  Synchronising the host after every single launch lets the clocks drop between launches and reads
+    10-15 % high on MI355X."""
     for _ in range(warm):
         fn()
     times = []
     for _ in range(iters):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        fn()
+        for _ in range(batch):
+            fn()
         e.record()
         e.synchronize()
-        times.append(s.elapsed_time(e))
+        times.append(s.elapsed_time(e) / batch)
     return sorted(times)[len(times) // 2]
 
 
@@ -79,7 +83,7 @@ def main():
                     continue
                 ordp = orders[p["SCHED"]]
 
-                def run():
+                def run(tile=tile, ordp=ordp):  # bind now: the best candidate is re-timed after the loop
                     rc = capi.launch_spmm(p1.data_ptr(), packed.data_ptr(), hind.data_ptr(), n, nnz, f,
                                           feat.data_ptr(), out.data_ptr(), True, tile, stream, ordp)
                     assert rc == 0
