@@ -35,6 +35,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "voltrix/traits.hpp"
 
@@ -70,6 +71,16 @@ __device__ __forceinline__ unsigned lds_read_b32(unsigned addr) {
   asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
   return v;
 }
+template <int OFF>
+__device__ __forceinline__ unsigned lds_read_b32_off(unsigned addr) {
+  unsigned v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+  return v;
+}
+template <int STRIDE, int N, int... I>  // out[i] = LDS word at addr + i * STRIDE (immediate offsets: one address VGPR)
+__device__ __forceinline__ void lds_read_b32_strided(unsigned addr, int (&out)[N], std::integer_sequence<int, I...>) {
+  ((out[I] = (int)lds_read_b32_off<STRIDE * I>(addr)), ...);
+}
 __device__ __forceinline__ uint2_t lds_read_b64(unsigned addr) {
   uint2_t v;
   asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory");
@@ -102,7 +113,11 @@ __device__ __forceinline__ constexpr int slot_swizzle(int r) {
 // store (exact: scaling by a power of two commutes with every fp32 rounding of the sum).
 constexpr float kAScaleInv = 0.5f;
 __device__ __forceinline__ half8_t nibbles_to_half8_x2(unsigned nl, unsigned nh) {
-  const unsigned zl = nl | (nl << 15), zh = nh | (nh << 15);  // bit i and bit 15+i = column i
+  // bit i and bit 15+i = column i.  Written as v_lshl_or_b32: left to itself hipcc turns n | n << 15 into a
+  // quarter-rate v_mul_lo_u32 by 0x8001 << k.
+  unsigned zl, zh;
+  asm("v_lshl_or_b32 %0, %1, 15, %1" : "=v"(zl) : "v"(nl));
+  asm("v_lshl_or_b32 %0, %1, 15, %1" : "=v"(zh) : "v"(nh));
   uint4_t r;
   r[0] = (zl << 14) & 0x40004000u;  // columns 0, 1
   r[1] = (zl << 12) & 0x40004000u;  // columns 2, 3
@@ -199,10 +214,17 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
     const unsigned a_shift = 4 * (R & 7);
     const int mj = (lane - 32) & 15;         // metadata DMA: lanes 32-63 fetch bitmap words (48-63 duplicate)
 
+    // metadata of a stage that lies fully inside the window: lane address = base + tau * stride (one 64-bit mad);
+    // lanes 0-31 fetch hind[8 * block + k32] (32 ints / stage), lanes 32-63 the 16 bitmap words of the stage
+    const char* const meta_base = lane < 32 ? (const char*)(a.hind + (8ll * kb0 + k32))
+                                            : (const char*)(a.hspa_packed + (4ll * kb0 + mj));
+    const unsigned meta_stride = lane < 32 ? 4u * 8u * kTcbPerStage : 4u * 4u * kTcbPerStage;
     auto issue_meta = [&](int tau, int mslot) {
       const void* src;
       const int sb = stage_block(tau);
-      if (lane < 32) {
+      if (sb + kTcbPerStage <= kb1) {  // wave-uniform
+        src = meta_base + (unsigned long long)(unsigned)tau * meta_stride;
+      } else if (lane < 32) {
         int blk = sb + kblk;
         blk = blk < kb1 ? blk : kb1 - 1;  // stay inside the window: stages past its end re-read its last block
         src = a.hind + (8ll * blk + kcol);
@@ -216,23 +238,35 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
 
     // hv: lane L holds the (sanitised) row of B for condensed column L & 31 of the stage
     // hr[i]: row of B this lane gathers in DMA i of the stage (LDS row i * RPD + lane / LPR)
+    // Lane constants of the row gathers: DMA i of a stage reads 16 bytes at column col(i, lane) of row hr[i], i.e.
+    // address = cbase[i] + hr[i] * row_bytes -- one v_mad_u64_u32 per DMA.  cbase[i] already carries the -K KiB that
+    // the instruction's immediate offset (K = i % 4, shared M0) adds back.
+    const unsigned row_bytes = (unsigned)F * EB;
+    const char* cbase[NDMA];
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+      const int r = i * RPD + lane / LPR;       // LDS row written by this lane
+      const int c = lane % LPR;                 // 16-byte chunk inside the row
+      int col;                                  // logical column of that chunk (swizzle on the SOURCE)
+      if constexpr (EB == 2)
+        col = fs0 + (((c >> 1) ^ slot_swizzle<SLOTS>(r)) * 16) + (c & 1) * 8;
+      else
+        col = fs0 + (((c >> 2) ^ (r & 1)) * 16) + (c & 3) * 4;
+      col = col < F ? col : fs0;                // F % FS tail: stay in bounds, results are not stored
+      unsigned long long cb = (unsigned long long)((const char*)a.input + ((long long)col * EB - (i & 3) * 1024));
+      asm volatile("" : "+v"(cb));              // one VGPR pair per DMA: no base + uniform-delta re-derivation in the loop
+      cbase[i] = (const char*)cb;
+    }
     auto issue_data = [&](int dslot, const int (&hr)[NDMA]) {
       const unsigned dst = lds0 + dslot * STAGE_BYTES;
       auto piece = [&](auto kc, int ib) {           // DMA number ib + K of the stage, K = 0..3 sharing one M0
         constexpr int K = decltype(kc)::value;
         if constexpr (K < NDMA) {
           const int i = ib + K;
-          const int r = i * RPD + lane / LPR;       // LDS row written by this lane
-          const int c = lane % LPR;                 // 16-byte chunk inside the row
-          int col;                                  // logical column of that chunk (swizzle on the SOURCE)
-          if constexpr (EB == 2)
-            col = fs0 + (((c >> 1) ^ slot_swizzle<SLOTS>(r)) * 16) + (c & 1) * 8;
-          else
-            col = fs0 + (((c >> 2) ^ (r & 1)) * 16) + (c & 3) * 4;
-          col = col < F ? col : fs0;                // F % FS tail: stay in bounds, results are not stored
-          int hrow = hr[i];
-          if (VOLTRIX_DIAG & 2) hrow &= 1023;
-          dma_b128_off<K * 1024>(a.input + ((long long)hrow * F + col), dst + ib * 1024);
+          unsigned hrow = (unsigned)hr[i];
+          if (VOLTRIX_DIAG & 2) hrow &= 1023u;
+          const char* src = cbase[i] + (unsigned long long)hrow * row_bytes;
+          __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(uintptr_t)(dst + ib * 1024), 16, K * 1024, 0);
         }
       };
 #pragma unroll
@@ -251,8 +285,8 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
     // every other stage: each lane reads the hind words of its own DMA rows straight from the metadata slot
     const unsigned hr_off = 4 * (lane / LPR);
     auto read_rows = [&](unsigned mbase, int (&hr)[NDMA]) {
-#pragma unroll
-      for (int i = 0; i < NDMA; ++i) hr[i] = (int)lds_read_b32(mbase + hr_off + 4 * (i * RPD));
+      const unsigned base = mbase + hr_off;
+      lds_read_b32_strided<4 * RPD>(base, hr, std::make_integer_sequence<int, NDMA>{});
     };
 
     auto sanitise = [&](int tau, unsigned hraw, uint2_t vw) -> int {
@@ -284,24 +318,11 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
     int mslot = 0;                  // t % MS
     int mslot_d = D;                // (t + D) % MS
     int mslot_2d = (2 * D) % MS;    // (t + 2D) % MS
-    for (int t = 0; t < nst; ++t) {
-      // stage t's rows and stage t+D's metadata were issued D steps ago; everything younger may stay in flight:
-      // (D-1) metadata DMAs + NDMA per younger row stage (at most D-1 of them)
-      const int rem = nst - 1 - t;
-      if (rem >= D - 1) {
-        wait_vmcnt<T::vm_behind(D - 1)>();
-      } else {
-        switch (rem) {  // rem <= D-2
-          case 0: wait_vmcnt<T::vm_behind(0)>(); break;
-          case 1: wait_vmcnt<T::vm_behind(1)>(); break;
-          case 2: wait_vmcnt<T::vm_behind(2)>(); break;
-          case 3: wait_vmcnt<T::vm_behind(3)>(); break;
-          default: wait_vmcnt<T::vm_behind(4)>(); break;
-        }
-      }
-
+    // One step = consume stage t, refill its ring slot with stage t+D.  MORE (= t + D < nst) is static: the steady
+    // loop always refills and always waits with the same count, the last D steps only drain.
+    auto step = [&](int t, auto more_c) {
+      constexpr bool more = decltype(more_c)::value;
       const unsigned mt = meta0 + mslot * T::META_BYTES;
-      const bool more = (t + D) < nst;  // wave-uniform
       // padded hind slots exist only in a window's last TC block: every earlier stage takes hind as it is
       const bool tail_stage = stage_block(t + D) + kTcbPerStage >= kb1;  // wave-uniform
       unsigned hraw = 0;
@@ -402,6 +423,23 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
       mslot = mslot + 1 == MS ? 0 : mslot + 1;
       mslot_d = mslot_d + 1 == MS ? 0 : mslot_d + 1;
       mslot_2d = mslot_2d + 1 == MS ? 0 : mslot_2d + 1;
+    };
+    // stage t's rows and stage t+D's metadata were issued D steps ago; everything younger may stay in flight:
+    // (D-1) metadata DMAs + NDMA per younger row stage (at most D-1 of them)
+    int t = 0;
+    for (; t < nst - D; ++t) {
+      wait_vmcnt<T::vm_behind(D - 1)>();
+      step(t, std::true_type{});
+    }
+    for (; t < nst; ++t) {
+      switch (nst - 1 - t) {  // younger row stages still in flight: 0 .. D-1
+        case 0: wait_vmcnt<T::vm_behind(0)>(); break;
+        case 1: wait_vmcnt<T::vm_behind(1)>(); break;
+        case 2: wait_vmcnt<T::vm_behind(2)>(); break;
+        case 3: wait_vmcnt<T::vm_behind(3)>(); break;
+        default: wait_vmcnt<T::vm_behind(D - 1)>(); break;
+      }
+      step(t, std::false_type{});
     }
     wait_vmcnt<0>();  // the trailing metadata DMAs must have landed before the wave's LDS is released
   }
