@@ -159,7 +159,9 @@ def main():
         local_indices = vdist.remap_columns(local_indices, parts, rows_padded)
     local_rows, local_nnz = r1 - r0, local_indices.numel()
     t0 = time.perf_counter()
-    blk_offsets, hspa_packed, hind, _ = voltrix.csr_fused_preprocess_kernel(local_indptr, local_indices, local_rows)
+    num_cols = world * rows_padded if world > 1 else num_nodes   # ids index the gathered B (padded shards) when sharded
+    blk_offsets, hspa_packed, hind, _ = voltrix.csr_fused_preprocess_kernel(local_indptr, local_indices, local_rows,
+                                                                            num_cols=num_cols)
     torch.cuda.synchronize()
     preprocess_ms = (time.perf_counter() - t0) * 1e3
     total_blocks = int(blk_offsets[-1])

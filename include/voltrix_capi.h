@@ -128,17 +128,24 @@ void voltrix_launch_cast_f32_f16(void* src, void* dst, int64_t count, void* stre
 /* Fused GPU preprocess: CSR on the DEVICE -> (pointer1, hspa_packed, hind) without the reference's host
  * preprocess, the O(TCb*E) rescan or the 512-byte/TC-block fp32 `hspa` intermediate.  Two phases because the
  * caller owns every buffer and T is data dependent:
- *   phase 1  voltrix_launch_csr_window_count: block_partition[W], pointer1[W+1] (device int32)
- *            workspace: voltrix_csr_preprocess_workspace_bytes(num_nodes, num_edges) bytes, device, 16-B aligned
- *   (caller reads T = pointer1[W], allocates hspa_packed uint32[4T] and hind int32[8T])
- *   phase 2  voltrix_launch_csr_fill: writes hspa_packed and hind (every word), same workspace.
- * Output is bit-identical to preprocess + hmat_gen + hmat_packed_swizzle. */
-int64_t voltrix_csr_preprocess_workspace_bytes(int num_nodes, int64_t num_edges);
-void voltrix_launch_csr_window_count(void* node_pointer, void* edge_list, int num_nodes, int64_t num_edges,
-                                     void* workspace, void* block_partition, void* pointer1, void* stream,
+ *   phase 1  voltrix_launch_csr_window_count: block_partition[W], pointer1[W+1], status[1] (device int32)
+ *            workspace: voltrix_csr_preprocess_workspace_bytes(num_nodes, num_cols, num_edges) bytes, device, 16-B aligned
+ *   (caller reads T = pointer1[W] and status[0], allocates hspa_packed uint32[4T] and hind int32[8T])
+ *   phase 2  voltrix_launch_csr_fill: writes hspa_packed and hind (every word), same workspace, same num_cols.
+ * num_cols = the column universe: every id in edge_list lies in [0, num_cols) (square adjacency: num_nodes; a row shard
+ * whose ids index a gathered B: the rows of that buffer).  num_cols <= 0 = unknown.  The condensed-column ranks come
+ * from an LDS bitmap + popcounts when the universe fits LDS (num_cols <= 2^19) and is small next to a window's edge
+ * list, otherwise from a per-window sort (needs the 4-byte-per-edge key workspace); VOLTRIX_CSR_PATH=sort|bitmap in
+ * the environment overrides the choice.  status[0] = number of edges with an id outside [0, num_cols) (outside
+ * [0, 2^28) when num_cols <= 0): the handle is valid only if it is 0 (callers retry with num_cols = 0 or reject).
+ * Output is bit-identical to preprocess + hmat_gen + hmat_packed_swizzle on both paths. */
+int64_t voltrix_csr_preprocess_workspace_bytes(int num_nodes, int num_cols, int64_t num_edges);
+void voltrix_launch_csr_window_count(void* node_pointer, void* edge_list, int num_nodes, int num_cols, int64_t num_edges,
+                                     void* workspace, void* block_partition, void* pointer1, void* status, void* stream,
                                      int* return_code);
-void voltrix_launch_csr_fill(void* node_pointer, void* edge_list, int num_nodes, int64_t num_edges, void* workspace,
-                             void* pointer1, void* hspa_packed, void* hind, void* stream, int* return_code);
+void voltrix_launch_csr_fill(void* node_pointer, void* edge_list, int num_nodes, int num_cols, int64_t num_edges,
+                             void* workspace, void* pointer1, void* hspa_packed, void* hind, void* stream,
+                             int* return_code);
 
 #ifdef __cplusplus
 }

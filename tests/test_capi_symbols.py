@@ -87,7 +87,7 @@ def test_host_preprocess_multithreaded_is_deterministic(monkeypatch):
         assert (x == y).all()
 
 
-def test_return_codes_on_bad_arguments():
+def test_return_codes_on_bad_arguments(monkeypatch):
     lib = capi.lib()
     rc = ctypes.c_int(-1)
     z = ctypes.c_void_p(0)
@@ -104,6 +104,10 @@ def test_return_codes_on_bad_arguments():
     assert rc.value == 1
     lib.voltrix_launch_window_order(z, ctypes.c_int(64), ctypes.c_int(8192), z, z, ctypes.byref(rc))
     assert rc.value == 1  # chunk above the 4096-window LDS sort capacity
-    assert capi.csr_preprocess_workspace_bytes(232965, 114615892) >= 4 * 114615892
+    # sort path (column universe too large for the LDS bitmap): one uint32 key per edge; bitmap path: scan scratch only
+    assert capi.csr_preprocess_workspace_bytes(2449029, 2449029, 123718280) >= 4 * 123718280
+    assert 0 < capi.csr_preprocess_workspace_bytes(232965, 232965, 114615892) < 1 << 20
+    monkeypatch.setenv("VOLTRIX_CSR_PATH", "sort")
+    assert capi.csr_preprocess_workspace_bytes(232965, 232965, 114615892) >= 4 * 114615892
     with pytest.raises(capi.VoltrixError, match="return code 3"):
         capi.check(3, "x")

@@ -24,7 +24,8 @@ def _cases():
     out["dups_unsorted"] = (np.array([0, 4, 4, 9, 9] + [9] * 30), np.array([5, 1, 5, 1, 33, 2, 2, 0, 33]), 34)
     a = sp.random(700, 700, density=0.05, format="csr", random_state=7)
     out["sp700"] = (a.indptr, a.indices, 700)
-    # one window with more than 8192 edges (LDS sort capacity) next to tiny ones -> global-memory sort path
+    # one window with more than 8192 edges (LDS sort capacity) next to tiny ones -> global-memory sort path; its 9000
+    # distinct columns = 1125 TC blocks also exceed the bitmap path's LDS stage (1024 blocks) -> global atomics there
     deg = np.zeros(96, dtype=np.int64)
     deg[16:32] = 700
     deg[40] = 3
@@ -50,9 +51,20 @@ def _check(handle, indptr, indices, n):
     assert np.array_equal(packed.cpu().numpy(), opacked)
 
 
-@pytest.mark.parametrize("route", ["fused", "reference"])
+ROUTES = ["fused-sort", "fused-bitmap", "fused-auto", "reference"]
+
+
+def _set_route(monkeypatch, route):
+    """fused-sort / fused-bitmap force one of the two rank algorithms of the fused preprocess (VOLTRIX_CSR_PATH)."""
+    monkeypatch.setenv("VOLTRIX_PREPROCESS", route.split("-")[0])
+    monkeypatch.delenv("VOLTRIX_CSR_PATH", raising=False)
+    if route in ("fused-sort", "fused-bitmap"):
+        monkeypatch.setenv("VOLTRIX_CSR_PATH", route.split("-")[1])
+
+
+@pytest.mark.parametrize("route", ROUTES)
 def test_fixtures_bit_exact(cuda_device, csr_fixture, route, monkeypatch):
-    monkeypatch.setenv("VOLTRIX_PREPROCESS", route)
+    _set_route(monkeypatch, route)
     g = csr_fixture
     n = int(g["num_nodes"])
     handle = voltrix.csr_preprocess(torch.from_numpy(g["indptr"]), torch.from_numpy(g["indices"]), n)
@@ -61,14 +73,28 @@ def test_fixtures_bit_exact(cuda_device, csr_fixture, route, monkeypatch):
         assert np.array_equal(got.cpu().numpy(), want)  # the committed golden handle itself
 
 
-@pytest.mark.parametrize("route", ["fused", "reference"])
+@pytest.mark.parametrize("route", ROUTES)
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_edge_cases_bit_exact(cuda_device, name, route, monkeypatch):
-    monkeypatch.setenv("VOLTRIX_PREPROCESS", route)
+    _set_route(monkeypatch, route)
     indptr, indices, n = CASES[name]
     handle = voltrix.csr_preprocess(torch.as_tensor(np.asarray(indptr), dtype=torch.int32),
                                     torch.as_tensor(np.asarray(indices), dtype=torch.int32), n)
     _check(handle, indptr, indices, n)
+
+
+@pytest.mark.parametrize("path", ["sort", "bitmap"])
+def test_non_square_universe_and_unstaged_window(cuda_device, path, monkeypatch):
+    """96 rows x 12000 columns: with the universe declared, the bitmap path takes its global-atomics branch for the
+    1125-block window; without it (default universe = num_nodes) out-of-universe ids are detected and the sort path
+    redoes the work -- both give the oracle's bytes."""
+    monkeypatch.setenv("VOLTRIX_CSR_PATH", path)
+    indptr, indices, n = CASES["huge_window"]
+    ip = torch.as_tensor(np.asarray(indptr), dtype=torch.int32).cuda()
+    ix = torch.as_tensor(np.asarray(indices), dtype=torch.int32).cuda()
+    for num_cols in (12000, None, 0):
+        handle = voltrix.csr_fused_preprocess_kernel(ip, ix, n, num_cols=num_cols)[:3]
+        _check(handle, indptr, indices, n)
 
 
 def test_low_level_kernel_wrappers_like_reference_test(cuda_device):
@@ -100,7 +126,9 @@ def test_low_level_kernel_wrappers_like_reference_test(cuda_device):
     assert np.array_equal(packed.cpu().numpy(), oracle_c.hmat_packed_swizzle(op1, ohspa))
 
 
-def test_fused_preprocess_mid_size_with_large_windows(cuda_device):
+@pytest.mark.parametrize("path", ["sort", "bitmap"])
+def test_fused_preprocess_mid_size_with_large_windows(cuda_device, path, monkeypatch):
+    monkeypatch.setenv("VOLTRIX_CSR_PATH", path)
     indptr, indices, _ = synth_graphs.generate("reddit_like", device="cuda", scale=0.02)
     n = indptr.numel() - 1
     assert int((indptr[16::16] - indptr[:-16:16]).max()) > 8192  # exercises the global-memory sort

@@ -97,23 +97,25 @@ def tiles(is_f16: bool):
     return out
 
 
-def csr_preprocess_workspace_bytes(num_nodes: int, num_edges: int) -> int:
-    return int(lib().voltrix_csr_preprocess_workspace_bytes(ctypes.c_int(num_nodes), ctypes.c_int64(num_edges)))
+def csr_preprocess_workspace_bytes(num_nodes: int, num_cols: int, num_edges: int) -> int:
+    return int(lib().voltrix_csr_preprocess_workspace_bytes(ctypes.c_int(num_nodes), ctypes.c_int(num_cols),
+                                                            ctypes.c_int64(num_edges)))
 
 
-def launch_csr_window_count(indptr, indices, num_nodes, workspace, block_partition, pointer1, stream) -> None:
+def launch_csr_window_count(indptr, indices, num_nodes, num_cols, workspace, block_partition, pointer1, status,
+                            stream) -> None:
     rc = ctypes.c_int(-1)
-    lib().voltrix_launch_csr_window_count(_ptr(indptr), _ptr(indices), ctypes.c_int(num_nodes),
+    lib().voltrix_launch_csr_window_count(_ptr(indptr), _ptr(indices), ctypes.c_int(num_nodes), ctypes.c_int(num_cols),
                                           ctypes.c_int64(indices.numel()), _ptr(workspace), _ptr(block_partition),
-                                          _ptr(pointer1), ctypes.c_void_p(stream), ctypes.byref(rc))
+                                          _ptr(pointer1), _ptr(status), ctypes.c_void_p(stream), ctypes.byref(rc))
     check(rc.value, "voltrix_launch_csr_window_count")
 
 
-def launch_csr_fill(indptr, indices, num_nodes, workspace, pointer1, hspa_packed, hind, stream) -> None:
+def launch_csr_fill(indptr, indices, num_nodes, num_cols, workspace, pointer1, hspa_packed, hind, stream) -> None:
     rc = ctypes.c_int(-1)
-    lib().voltrix_launch_csr_fill(_ptr(indptr), _ptr(indices), ctypes.c_int(num_nodes), ctypes.c_int64(indices.numel()),
-                                  _ptr(workspace), _ptr(pointer1), _ptr(hspa_packed), _ptr(hind),
-                                  ctypes.c_void_p(stream), ctypes.byref(rc))
+    lib().voltrix_launch_csr_fill(_ptr(indptr), _ptr(indices), ctypes.c_int(num_nodes), ctypes.c_int(num_cols),
+                                  ctypes.c_int64(indices.numel()), _ptr(workspace), _ptr(pointer1), _ptr(hspa_packed),
+                                  _ptr(hind), ctypes.c_void_p(stream), ctypes.byref(rc))
     check(rc.value, "voltrix_launch_csr_fill")
 
 

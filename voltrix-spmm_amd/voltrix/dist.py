@@ -86,7 +86,11 @@ class RowShardedSpMM:
         local_indices = remap_columns(local_indices, self.parts, self.rows_padded)
         self.local_edges = int(local_indices.numel())
         if local_preprocess is None:
-            from .spmm import csr_preprocess as local_preprocess  # HIP path; raises if the extension is missing
+            from .spmm import csr_preprocess  # HIP path; raises if the extension is missing
+            gathered_rows = self.world_size * self.rows_padded  # remapped ids index the all-gather buffer
+
+            def local_preprocess(ip, ix, n_rows):
+                return csr_preprocess(ip, ix, n_rows, num_cols=gathered_rows)
         if local_spmm is None:
             from .spmm import spmm as _spmm
 

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "voltrix/traits.hpp"
 
@@ -72,8 +73,10 @@ __device__ __forceinline__ void bitonic_sort_ascending(Ptr keys, const int n, co
 static __global__ __launch_bounds__(kSortThreads) void csr_window_sort_kernel(const int* __restrict__ indptr,
                                                                        const int* __restrict__ indices,
                                                                        const int num_nodes, const int num_windows,
+                                                                       const unsigned col_limit,
                                                                        uint32_t* __restrict__ keys_ws,
-                                                                       int* __restrict__ block_partition) {
+                                                                       int* __restrict__ block_partition,
+                                                                       int* __restrict__ status) {
   __shared__ uint32_t lkeys[kSortLdsKeys];
   __shared__ int rowptr[kBlkH + 1];
   __shared__ int wave_cnt[kSortThreads / kWave];
@@ -92,7 +95,9 @@ static __global__ __launch_bounds__(kSortThreads) void csr_window_sort_kernel(co
       int rl = 0;
 #pragma unroll
       for (int k = 1; k < kBlkH; ++k) rl += (rowptr[k] <= e) ? 1 : 0;  // local row of edge e
-      const uint32_t key = ((uint32_t)indices[e] << 4) | (uint32_t)rl;
+      const uint32_t col = (uint32_t)indices[e];
+      if (col >= col_limit) atomicAdd(status, 1);  // outside the caller's column universe / the 28-bit key
+      const uint32_t key = (col << 4) | (uint32_t)rl;
       if (in_lds) lkeys[i] = key; else dst[i] = key;
     }
     __syncthreads();
@@ -241,13 +246,210 @@ static __global__ __launch_bounds__(kSortThreads) void csr_window_fill_kernel(co
   }
 }
 
+// ---- bitmap path: rank columns with an LDS bitmap instead of a sort ---------------------------------------------
+// When the column universe fits LDS (num_cols <= kBmMaxCols) and is not much larger than a window's edge list, the
+// condensed column of an edge is a population count: every edge of the window sets bit `column` of an LDS bitmap;
+// rank(c) = #set bits below c = prefix[c / 128] + popcount inside the 128-bit group.  Work per window is
+// O(edges + num_nodes / 32) LDS operations, no sort, no key workspace, and the handle is written exactly once
+// (bitmap words of a window are staged in LDS, hind comes out of the bitmap scan in rank order).  Same output, bit
+// for bit, as the sort path and as the reference pipeline.
+constexpr int kBmThreads = 512;
+constexpr int kBmWaves = kBmThreads / kWave;
+constexpr int kBmStageWords = 4096;      // 16 KiB: up to 1024 TC blocks of one window staged in LDS
+constexpr int kBmMaxCols = 1 << 19;      // 64 KiB bitmap + 16 KiB group prefixes + 16 KiB stage
+
+__host__ __device__ inline int bm_groups(int num_cols) { return (num_cols + 127) / 128; }   // 128 columns = uint4
+inline size_t bm_count_lds(int num_cols) { return (size_t)bm_groups(num_cols) * 16; }
+inline size_t bm_fill_lds(int num_cols) { return (size_t)bm_groups(num_cols) * 20 + kBmStageWords * 4; }
+
+__device__ __forceinline__ int popc4(const uint4 v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+
+template <bool COUNT_INVALID>
+__device__ __forceinline__ void bm_mark_window(uint32_t* bitmap, const int* __restrict__ indices, const long long lo,
+                                               const long long hi, const int num_cols, int* status) {
+  for (long long e = lo + threadIdx.x; e < hi; e += kBmThreads) {
+    const int c = indices[e];
+    if ((unsigned)c < (unsigned)num_cols) atomicOr(&bitmap[c >> 5], 1u << (c & 31));
+    else if (COUNT_INVALID) atomicAdd(status, 1);  // ids outside the column universe are skipped and reported
+  }
+}
+
+static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_count_kernel(const int* __restrict__ indptr,
+                                                                      const int* __restrict__ indices,
+                                                                      const int num_nodes, const int num_cols,
+                                                                      const int num_windows,
+                                                                      int* __restrict__ block_partition,
+                                                                      int* __restrict__ status) {
+  extern __shared__ uint4 bm_lds[];
+  __shared__ int wave_cnt[kBmWaves];
+  uint4* const bitmap4 = bm_lds;
+  uint32_t* const bitmap = reinterpret_cast<uint32_t*>(bm_lds);
+  const int ng = bm_groups(num_cols);
+  const int tid = threadIdx.x;
+  for (int i = tid; i < ng; i += kBmThreads) bitmap4[i] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  for (int w = blockIdx.x; w < num_windows; w += gridDim.x) {
+    const long long r0 = (long long)w * kBlkH, r1 = r0 + kBlkH;
+    const long long lo = indptr[r0 < num_nodes ? r0 : num_nodes], hi = indptr[r1 < num_nodes ? r1 : num_nodes];
+    bm_mark_window<true>(bitmap, indices, lo, hi, num_cols, status);
+    __syncthreads();
+    int cnt = 0;
+    for (int i = tid; i < ng; i += kBmThreads) {  // count and clear in one sweep
+      cnt += popc4(bitmap4[i]);
+      bitmap4[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, kWave);
+    if ((tid & (kWave - 1)) == 0) wave_cnt[tid / kWave] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+      int u = 0;
+#pragma unroll
+      for (int i = 0; i < kBmWaves; ++i) u += wave_cnt[i];
+      block_partition[w] = u == 0 ? 1 : (u + kBlkW - 1) / kBlkW;  // no columns -> 1 block (reference quirk, :252)
+    }
+    __syncthreads();
+  }
+}
+
+static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_fill_kernel(const int* __restrict__ indptr,
+                                                                     const int* __restrict__ indices,
+                                                                     const int num_nodes, const int num_cols,
+                                                                     const int num_windows,
+                                                                     const int* __restrict__ pointer1,
+                                                                     uint32_t* __restrict__ hspa_packed,
+                                                                     int* __restrict__ hind) {
+  extern __shared__ uint4 bm_lds[];
+  __shared__ int wave_tot[kBmWaves];
+  const int ng = bm_groups(num_cols);
+  uint4* const bitmap4 = bm_lds;                                        // [ng]   128 columns per entry
+  uint32_t* const bitmap = reinterpret_cast<uint32_t*>(bm_lds);
+  uint4* const stage4 = bm_lds + ng;                                    // [kBmStageWords / 4] packed words of the window
+  uint32_t* const stage = reinterpret_cast<uint32_t*>(stage4);
+  int* const prefix = reinterpret_cast<int*>(stage4 + kBmStageWords / 4);  // [ng] distinct columns before the group
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = tid; i < ng; i += kBmThreads) bitmap4[i] = zero4;
+  for (int i = tid; i < kBmStageWords / 4; i += kBmThreads) stage4[i] = zero4;
+  __syncthreads();
+
+  for (int w = blockIdx.x; w < num_windows; w += gridDim.x) {
+    const long long r0 = (long long)w * kBlkH;
+    int rp[kBlkH + 1];  // wave-uniform row pointers of the window (scalar loads)
+#pragma unroll
+    for (int k = 0; k <= kBlkH; ++k) rp[k] = indptr[r0 + k < num_nodes ? r0 + k : num_nodes];
+    const long long lo = rp[0], hi = rp[kBlkH];
+    const long long p0 = pointer1[w];
+    const int nb = pointer1[w + 1] - (int)p0;
+    uint4* const out4 = reinterpret_cast<uint4*>(hspa_packed) + p0;
+    const bool staged = 4 * (long long)nb <= kBmStageWords;  // workgroup-uniform
+    if (!staged) {  // huge window: OR straight into global memory, zeroed here first
+      for (int i = tid; i < nb; i += kBmThreads) out4[i] = zero4;
+      __threadfence();
+    }
+    bm_mark_window<false>(bitmap, indices, lo, hi, num_cols, nullptr);
+    __syncthreads();
+
+    // scan the bitmap: group prefixes for the rank lookups, and hind = the set bits in ascending (= rank) order
+    int carry = 0;
+    for (int base = 0; base < ng; base += kBmThreads) {
+      const int i = base + tid;
+      const uint4 v = i < ng ? bitmap4[i] : zero4;
+      const int pc = popc4(v);
+      const int incl = wave_inclusive_scan(pc);
+      if (lane == kWave - 1) wave_tot[wv] = incl;
+      __syncthreads();
+      int woff = 0, tot = 0;
+#pragma unroll
+      for (int k = 0; k < kBmWaves; ++k) {
+        woff += k < wv ? wave_tot[k] : 0;
+        tot += wave_tot[k];
+      }
+      if (i < ng) {
+        int r = carry + woff + incl - pc;
+        prefix[i] = r;
+        const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          uint32_t m = words[j];
+          while (m) {
+            const int b = __ffs(m) - 1;
+            m &= m - 1;
+            hind[8 * p0 + r] = (i * 4 + j) * 32 + b;
+            ++r;
+          }
+        }
+      }
+      carry += tot;
+      __syncthreads();
+    }
+    for (int k = carry + tid; k < 8 * nb; k += kBmThreads) hind[8 * p0 + k] = 0;  // unused slots of the last block
+
+    // every edge: rank of its column -> bit (row, rank) in the reference's swizzled word / bit position
+    for (long long e = lo + tid; e < hi; e += kBmThreads) {
+      const int c = indices[e];
+      if ((unsigned)c >= (unsigned)num_cols) continue;
+      int rl = 0;
+#pragma unroll
+      for (int k = 1; k < kBlkH; ++k) rl += (rp[k] <= e) ? 1 : 0;  // local row of edge e
+      const int g = c >> 7, wi = (c >> 5) & 3;
+      const uint4 v = bitmap4[g];
+      const uint32_t below = (1u << (c & 31)) - 1u;
+      const int rank = prefix[g] + __popc(v.x & (wi > 0 ? ~0u : (wi == 0 ? below : 0u))) +
+                       __popc(v.y & (wi > 1 ? ~0u : (wi == 1 ? below : 0u))) +
+                       __popc(v.z & (wi > 2 ? ~0u : (wi == 2 ? below : 0u))) + __popc(v.w & (wi == 3 ? below : 0u));
+      const int cc = rank & 7;
+      // reference bit order (bmat_kernels.cuh:180-188): word t = (r>>3) + 2*(c>>2), bit 4*(r&7) + (c&3)
+      const int word = 4 * (rank >> 3) + (rl >> 3) + 2 * (cc >> 2);
+      const uint32_t bit = 1u << (4 * (rl & 7) + (cc & 3));
+      if (staged) atomicOr(&stage[word], bit); else atomicOr(&hspa_packed[4 * p0 + word], bit);
+    }
+    __syncthreads();
+    if (staged) {
+      for (int i = tid; i < nb; i += kBmThreads) {
+        out4[i] = stage4[i];
+        stage4[i] = zero4;
+      }
+    }
+    for (int i = tid; i < ng; i += kBmThreads) bitmap4[i] = zero4;
+    __syncthreads();
+  }
+}
+
+// Path choice (the same in workspace_bytes / count / fill).  num_cols = the caller's column universe (every id is in
+// [0, num_cols); <= 0: unknown -> sort path).  Bitmap when the universe fits LDS and one sweep of num_cols / 32 words per
+// window is cheaper than sorting the window's edges.  VOLTRIX_CSR_PATH=sort|bitmap overrides (bitmap is honoured only
+// when 0 < num_cols <= kBmMaxCols).
+inline bool csr_use_bitmap(int num_nodes, int num_cols, long long num_edges) {
+  if (num_cols > kBmMaxCols || num_cols <= 0 || num_nodes <= 0) return false;
+  if (const char* e = std::getenv("VOLTRIX_CSR_PATH")) {
+    if (e[0] == 's') return false;
+    if (e[0] == 'b') return true;
+  }
+  const long long W = ((long long)num_nodes + kBlkH - 1) / kBlkH;
+  const double per_window = (double)num_edges / (double)W;       // mean edges per window
+  double lg = 1.0;
+  for (double x = 2.0; x < per_window; x *= 2.0) lg += 1.0;      // ~ log2
+  const double sort_passes = lg * (lg + 1.0) / 2.0;              // bitonic compare-exchange sweeps
+  return (double)num_cols / 32.0 <= per_window * (sort_passes > 4.0 ? sort_passes / 4.0 : 1.0);
+}
+
+template <class K>
+inline int bm_set_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+    return kErrBadConfig;
+  return kOk;
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------
 inline long long align16(long long x) { return (x + 15) & ~15ll; }
 
-inline long long csr_preprocess_workspace_bytes(int num_nodes, long long num_edges) {
+inline long long csr_preprocess_workspace_bytes(int num_nodes, int num_cols, long long num_edges) {
   const long long W = ((long long)num_nodes + kBlkH - 1) / kBlkH;
   const long long nchunks = (W + kScanChunk - 1) / kScanChunk + 1;
-  return align16(num_edges * 4) + align16(nchunks * 4) + 16;
+  const long long keys = csr_use_bitmap(num_nodes, num_cols, num_edges) ? 0 : align16(num_edges * 4);  // sort path only
+  return keys + align16(nchunks * 4) + 16;
 }
 
 inline int csr_check(int num_nodes, long long num_edges) {
@@ -258,33 +460,53 @@ inline int csr_check(int num_nodes, long long num_edges) {
   return kOk;
 }
 
-inline int csr_window_count(const int* indptr, const int* indices, int num_nodes, long long num_edges, void* workspace,
-                            int* block_partition, int* pointer1, hipStream_t stream) {
+// status[0] <- number of edges whose column id lies outside [0, num_cols) (num_cols <= 0: outside [0, 2^28)); the
+// handle is only meaningful when it is 0 (the bitmap path skips such edges, the sort path truncates them).
+inline int csr_window_count(const int* indptr, const int* indices, int num_nodes, int num_cols, long long num_edges,
+                            void* workspace, int* block_partition, int* pointer1, int* status, hipStream_t stream) {
   if (int rc = csr_check(num_nodes, num_edges)) return rc;
-  if ((uintptr_t)workspace & 15) return kErrBadShape;
+  if (((uintptr_t)workspace & 15) || status == nullptr || num_cols > (1 << 28)) return kErrBadShape;
   const int W = (num_nodes + kBlkH - 1) / kBlkH;
+  if (hipMemsetAsync(status, 0, sizeof(int), stream) != hipSuccess) return kErrLaunch;
   if (W == 0) {
     return hipMemsetAsync(pointer1, 0, sizeof(int), stream) == hipSuccess ? kOk : kErrLaunch;
   }
+  const bool bitmap = csr_use_bitmap(num_nodes, num_cols, num_edges);
   uint32_t* keys = reinterpret_cast<uint32_t*>(workspace);
-  int* chunk_sums = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + align16(num_edges * 4));
+  int* chunk_sums = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + (bitmap ? 0 : align16(num_edges * 4)));
   const int nchunks = (W + kScanChunk - 1) / kScanChunk;
-  const int grid = W < 256 * 8 ? W : 256 * 8;
-  hipLaunchKernelGGL(csr_window_sort_kernel, dim3(grid), dim3(kSortThreads), 0, stream, indptr, indices, num_nodes, W,
-                     keys, block_partition);
+  if (bitmap) {
+    const size_t lds = bm_count_lds(num_cols);
+    if (int rc = bm_set_lds(csr_bitmap_count_kernel, lds)) return rc;
+    const int grid = W < 256 * 4 ? W : 256 * 4;
+    hipLaunchKernelGGL(csr_bitmap_count_kernel, dim3(grid), dim3(kBmThreads), lds, stream, indptr, indices, num_nodes,
+                       num_cols, W, block_partition, status);
+  } else {
+    const int grid = W < 256 * 8 ? W : 256 * 8;
+    const unsigned col_limit = num_cols > 0 ? (unsigned)num_cols : (1u << 28);
+    hipLaunchKernelGGL(csr_window_sort_kernel, dim3(grid), dim3(kSortThreads), 0, stream, indptr, indices, num_nodes,
+                       W, col_limit, keys, block_partition, status);
+  }
   hipLaunchKernelGGL(scan_chunk_sums_kernel, dim3(nchunks), dim3(256), 0, stream, block_partition, W, chunk_sums);
   hipLaunchKernelGGL(scan_chunk_offsets_kernel, dim3(1), dim3(256), 0, stream, chunk_sums, nchunks);
   hipLaunchKernelGGL(scan_apply_kernel, dim3(nchunks), dim3(256), 0, stream, block_partition, W, chunk_sums, pointer1);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
-inline int csr_fill(const int* indptr, const int* indices, int num_nodes, long long num_edges, void* workspace,
-                    const int* pointer1, uint32_t* hspa_packed, int* hind, hipStream_t stream) {
-  (void)indices;
+inline int csr_fill(const int* indptr, const int* indices, int num_nodes, int num_cols, long long num_edges,
+                    void* workspace, const int* pointer1, uint32_t* hspa_packed, int* hind, hipStream_t stream) {
   if (int rc = csr_check(num_nodes, num_edges)) return rc;
   if (((uintptr_t)workspace & 15) || ((uintptr_t)hspa_packed & 15) || ((uintptr_t)hind & 15)) return kErrBadShape;
   const int W = (num_nodes + kBlkH - 1) / kBlkH;
   if (W == 0) return kOk;
+  if (csr_use_bitmap(num_nodes, num_cols, num_edges)) {
+    const size_t lds = bm_fill_lds(num_cols);
+    if (int rc = bm_set_lds(csr_bitmap_fill_kernel, lds)) return rc;
+    const int grid = W < 256 * 4 ? W : 256 * 4;
+    hipLaunchKernelGGL(csr_bitmap_fill_kernel, dim3(grid), dim3(kBmThreads), lds, stream, indptr, indices, num_nodes,
+                       num_cols, W, pointer1, hspa_packed, hind);
+    return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+  }
   const uint32_t* keys = reinterpret_cast<const uint32_t*>(workspace);
   hipLaunchKernelGGL(csr_handle_zero_kernel, dim3(256 * 8), dim3(256), 0, stream, pointer1, W, hspa_packed, hind);
   const int grid = W < 256 * 8 ? W : 256 * 8;

@@ -21,9 +21,10 @@ BLK_H = 16
 BLK_W = 8
 
 
-def csr_preprocess(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int):
+def csr_preprocess(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None):
     """CSR (CPU int32, as in the reference :21-22) -> ``(blk_offsets int32 [W+1], hspa_packed uint32 [4T],
-    hind int32 [8T])`` on the current CUDA device.
+    hind int32 [8T])`` on the current CUDA device.  ``num_cols`` (extension, default ``num_nodes``): the column
+    universe when the ids index something else than the ``num_nodes`` rows (row shards over a gathered B).
 
     Default: one H2D copy of the CSR and the fused GPU preprocess.  ``VOLTRIX_PREPROCESS=reference`` runs the
     reference's own three-stage pipeline (host ``preprocess_kernel``, ``hmat_gen_kernel``,
@@ -36,7 +37,7 @@ def csr_preprocess(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int):
 
     if os.getenv(PREPROCESS_FLAG, "fused") != "reference":
         pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(
-            indptr.contiguous().cuda(), indices.contiguous().cuda(), num_nodes)
+            indptr.contiguous().cuda(), indices.contiguous().cuda(), num_nodes, num_cols)
         return pointer1, hspa_packed, hind
 
     num_edges = indices.numel()
