@@ -7,12 +7,20 @@
 //   * the O(TC blocks x window edges) rescan in hmat_cuda_kernel (:66,:94),
 //   * the transient fp32 `hspa` (512 bytes per TC block).
 //
-// Algorithm (one workgroup per 16-row window, grid-strided):
+// Two rank algorithms, chosen per call by csr_use_bitmap() (one workgroup per 16-row window, grid-strided, both):
+//  bitmap (column universe <= 2^19 and not much larger than a window's edge list; e.g. reddit):
+//   1. csr_bitmap_count_kernel  every edge sets bit `column` of an LDS bitmap; distinct columns = popcount.
+//   2. scan_* kernels           pointer1 = exclusive prefix sum (wave shuffles + LDS, three small launches).
+//   3. csr_bitmap_fill_kernel   bitmap again; group prefixes by a workgroup scan; hind = set bits in rank order (staged
+//                               in LDS, coalesced copy-out); per edge rank = prefix + popcount -> bit OR-ed into an LDS
+//                               stage of the window's packed words, written once.  No sort, no key workspace, no global
+//                               atomics, no device-scope fences (one __threadfence per window cost 3x: it writes back L2).
+//  sort (any universe up to 2^28):
 //   1. csr_window_sort_kernel   key = (column << 4) | (row & 15) for every edge of the window; bitonic sort
 //                               (all-ascending network, virtual +inf padding) in LDS, or in the global workspace when
 //                               the window has more than kSortLdsKeys edges; sorted keys -> workspace; distinct
 //                               columns counted with wave ballots -> block_partition[w] = ceil(U_w / 8) (0 -> 1).
-//   2. scan_* kernels           pointer1 = exclusive prefix sum (wave shuffles + LDS, three small launches).
+//   2. scan_* kernels           as above.
 //   3. csr_handle_zero_kernel   zero hspa_packed / hind (T read on the device from pointer1[W]).
 //      csr_window_fill_kernel   per sorted key: "first of its column" flags -> ballot/popcount prefix sum = condensed
 //                               column rank; hind[8*pointer1[w] + rank] = column; bit (row, rank) OR-ed into the
@@ -255,7 +263,9 @@ static __global__ __launch_bounds__(kSortThreads) void csr_window_fill_kernel(co
 // for bit, as the sort path and as the reference pipeline.
 constexpr int kBmThreads = 512;
 constexpr int kBmWaves = kBmThreads / kWave;
-constexpr int kBmStageWords = 4096;      // 16 KiB: up to 1024 TC blocks of one window staged in LDS
+constexpr int kBmStageWords = 4096;      // 16 KiB: the packed words of kBmStageBlocks TC blocks / one sweep of hind
+constexpr int kBmStageBlocks = kBmStageWords / 4;
+constexpr int kBmGrid = 4096;            // grid-strided; ~5 rounds of workgroups even out the window sizes (measured)
 constexpr int kBmMaxCols = 1 << 19;      // 64 KiB bitmap + 16 KiB group prefixes + 16 KiB stage
 
 __host__ __device__ inline int bm_groups(int num_cols) { return (num_cols + 127) / 128; }   // 128 columns = uint4
@@ -264,13 +274,25 @@ inline size_t bm_fill_lds(int num_cols) { return (size_t)bm_groups(num_cols) * 2
 
 __device__ __forceinline__ int popc4(const uint4 v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
 
+constexpr int kBmBatch = 8;  // independent global loads in flight per thread (the loops are latency-bound otherwise)
+
 template <bool COUNT_INVALID>
 __device__ __forceinline__ void bm_mark_window(uint32_t* bitmap, const int* __restrict__ indices, const long long lo,
                                                const long long hi, const int num_cols, int* status) {
-  for (long long e = lo + threadIdx.x; e < hi; e += kBmThreads) {
-    const int c = indices[e];
-    if ((unsigned)c < (unsigned)num_cols) atomicOr(&bitmap[c >> 5], 1u << (c & 31));
-    else if (COUNT_INVALID) atomicAdd(status, 1);  // ids outside the column universe are skipped and reported
+  for (long long base = lo + threadIdx.x; base < hi; base += (long long)kBmBatch * kBmThreads) {
+    int c[kBmBatch];
+#pragma unroll
+    for (int k = 0; k < kBmBatch; ++k) {
+      const long long e = base + (long long)k * kBmThreads;
+      c[k] = e < hi ? indices[e] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kBmBatch; ++k) {
+      if (base + (long long)k * kBmThreads < hi) {
+        if ((unsigned)c[k] < (unsigned)num_cols) atomicOr(&bitmap[c[k] >> 5], 1u << (c[k] & 31));
+        else if (COUNT_INVALID) atomicAdd(status, 1);  // ids outside the column universe are skipped and reported
+      }
+    }
   }
 }
 
@@ -342,11 +364,6 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_fill_kernel(cons
     const long long p0 = pointer1[w];
     const int nb = pointer1[w + 1] - (int)p0;
     uint4* const out4 = reinterpret_cast<uint4*>(hspa_packed) + p0;
-    const bool staged = 4 * (long long)nb <= kBmStageWords;  // workgroup-uniform
-    if (!staged) {  // huge window: OR straight into global memory, zeroed here first
-      for (int i = tid; i < nb; i += kBmThreads) out4[i] = zero4;
-      __threadfence();
-    }
     bm_mark_window<false>(bitmap, indices, lo, hi, num_cols, nullptr);
     __syncthreads();
 
@@ -365,6 +382,7 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_fill_kernel(cons
         woff += k < wv ? wave_tot[k] : 0;
         tot += wave_tot[k];
       }
+      const bool via_lds = tot <= kBmStageWords;  // workgroup-uniform: this sweep's columns fit the (zeroed) stage
       if (i < ng) {
         int r = carry + woff + incl - pc;
         prefix[i] = r;
@@ -375,9 +393,17 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_fill_kernel(cons
           while (m) {
             const int b = __ffs(m) - 1;
             m &= m - 1;
-            hind[8 * p0 + r] = (i * 4 + j) * 32 + b;
+            const int col = (i * 4 + j) * 32 + b;
+            if (via_lds) stage[r - carry] = (uint32_t)col; else hind[8 * p0 + r] = col;
             ++r;
           }
+        }
+      }
+      if (via_lds) {  // coalesced copy-out of this sweep's `tot` columns; the stage goes back to zero
+        __syncthreads();
+        for (int k = tid; k < tot; k += kBmThreads) {
+          hind[8 * p0 + carry + k] = (int)stage[k];
+          stage[k] = 0u;
         }
       }
       carry += tot;
@@ -385,31 +411,45 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_fill_kernel(cons
     }
     for (int k = carry + tid; k < 8 * nb; k += kBmThreads) hind[8 * p0 + k] = 0;  // unused slots of the last block
 
-    // every edge: rank of its column -> bit (row, rank) in the reference's swizzled word / bit position
-    for (long long e = lo + tid; e < hi; e += kBmThreads) {
-      const int c = indices[e];
-      if ((unsigned)c >= (unsigned)num_cols) continue;
-      int rl = 0;
+    // every edge: rank of its column -> bit (row, rank) in the reference's swizzled word / bit position, OR-ed into the
+    // LDS stage and copied out once.  A window with more than kBmStageBlocks TC blocks takes one pass over its edges
+    // per kBmStageBlocks blocks (no global atomics, no fences; the edge list is re-read from L2).
+    for (int pass0 = 0; pass0 < nb; pass0 += kBmStageBlocks) {
+      const int pass_nb = nb - pass0 < kBmStageBlocks ? nb - pass0 : kBmStageBlocks;
+      for (long long base = lo + tid; base < hi; base += (long long)kBmBatch * kBmThreads) {
+        int cs[kBmBatch];
 #pragma unroll
-      for (int k = 1; k < kBlkH; ++k) rl += (rp[k] <= e) ? 1 : 0;  // local row of edge e
-      const int g = c >> 7, wi = (c >> 5) & 3;
-      const uint4 v = bitmap4[g];
-      const uint32_t below = (1u << (c & 31)) - 1u;
-      const int rank = prefix[g] + __popc(v.x & (wi > 0 ? ~0u : (wi == 0 ? below : 0u))) +
-                       __popc(v.y & (wi > 1 ? ~0u : (wi == 1 ? below : 0u))) +
-                       __popc(v.z & (wi > 2 ? ~0u : (wi == 2 ? below : 0u))) + __popc(v.w & (wi == 3 ? below : 0u));
-      const int cc = rank & 7;
-      // reference bit order (bmat_kernels.cuh:180-188): word t = (r>>3) + 2*(c>>2), bit 4*(r&7) + (c&3)
-      const int word = 4 * (rank >> 3) + (rl >> 3) + 2 * (cc >> 2);
-      const uint32_t bit = 1u << (4 * (rl & 7) + (cc & 3));
-      if (staged) atomicOr(&stage[word], bit); else atomicOr(&hspa_packed[4 * p0 + word], bit);
-    }
-    __syncthreads();
-    if (staged) {
-      for (int i = tid; i < nb; i += kBmThreads) {
-        out4[i] = stage4[i];
+        for (int k = 0; k < kBmBatch; ++k) {
+          const long long e = base + (long long)k * kBmThreads;
+          cs[k] = e < hi ? indices[e] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < kBmBatch; ++k) {
+          const long long e = base + (long long)k * kBmThreads;
+          const int c = cs[k];
+          if (e >= hi || (unsigned)c >= (unsigned)num_cols) continue;
+          const int g = c >> 7, wi = (c >> 5) & 3;
+          const uint4 v = bitmap4[g];
+          const uint32_t below = (1u << (c & 31)) - 1u;
+          const int rank = prefix[g] + __popc(v.x & (wi > 0 ? ~0u : (wi == 0 ? below : 0u))) +
+                           __popc(v.y & (wi > 1 ? ~0u : (wi == 1 ? below : 0u))) +
+                           __popc(v.z & (wi > 2 ? ~0u : (wi == 2 ? below : 0u))) + __popc(v.w & (wi == 3 ? below : 0u));
+          const int blk = (rank >> 3) - pass0;
+          if ((unsigned)blk >= (unsigned)kBmStageBlocks) continue;  // another pass owns this TC block
+          int rl = 0;
+#pragma unroll
+          for (int q = 1; q < kBlkH; ++q) rl += (rp[q] <= e) ? 1 : 0;  // local row of edge e
+          const int cc = rank & 7;
+          // reference bit order (bmat_kernels.cuh:180-188): word t = (r>>3) + 2*(c>>2), bit 4*(r&7) + (c&3)
+          atomicOr(&stage[4 * blk + (rl >> 3) + 2 * (cc >> 2)], 1u << (4 * (rl & 7) + (cc & 3)));
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < pass_nb; i += kBmThreads) {
+        out4[pass0 + i] = stage4[i];
         stage4[i] = zero4;
       }
+      if (pass0 + kBmStageBlocks < nb) __syncthreads();  // the stage is reused by the next pass
     }
     for (int i = tid; i < ng; i += kBmThreads) bitmap4[i] = zero4;
     __syncthreads();
@@ -478,7 +518,7 @@ inline int csr_window_count(const int* indptr, const int* indices, int num_nodes
   if (bitmap) {
     const size_t lds = bm_count_lds(num_cols);
     if (int rc = bm_set_lds(csr_bitmap_count_kernel, lds)) return rc;
-    const int grid = W < 256 * 4 ? W : 256 * 4;
+    const int grid = W < kBmGrid ? W : kBmGrid;
     hipLaunchKernelGGL(csr_bitmap_count_kernel, dim3(grid), dim3(kBmThreads), lds, stream, indptr, indices, num_nodes,
                        num_cols, W, block_partition, status);
   } else {
@@ -502,7 +542,7 @@ inline int csr_fill(const int* indptr, const int* indices, int num_nodes, int nu
   if (csr_use_bitmap(num_nodes, num_cols, num_edges)) {
     const size_t lds = bm_fill_lds(num_cols);
     if (int rc = bm_set_lds(csr_bitmap_fill_kernel, lds)) return rc;
-    const int grid = W < 256 * 4 ? W : 256 * 4;
+    const int grid = W < kBmGrid ? W : kBmGrid;
     hipLaunchKernelGGL(csr_bitmap_fill_kernel, dim3(grid), dim3(kBmThreads), lds, stream, indptr, indices, num_nodes,
                        num_cols, W, pointer1, hspa_packed, hind);
     return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
