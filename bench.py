@@ -158,12 +158,15 @@ def main():
     if world > 1:
         local_indices = vdist.remap_columns(local_indices, parts, rows_padded)
     local_rows, local_nnz = r1 - r0, local_indices.numel()
-    t0 = time.perf_counter()
     num_cols = world * rows_padded if world > 1 else num_nodes   # ids index the gathered B (padded shards) when sharded
-    blk_offsets, hspa_packed, hind, _ = voltrix.csr_fused_preprocess_kernel(local_indptr, local_indices, local_rows,
-                                                                            num_cols=num_cols)
-    torch.cuda.synchronize()
-    preprocess_ms = (time.perf_counter() - t0) * 1e3
+    preprocess_ms = None
+    for _ in range(2):   # first call pays library load / allocator warm-up; report the second (host wall clock, sync'd)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        blk_offsets, hspa_packed, hind, _ = voltrix.csr_fused_preprocess_kernel(local_indptr, local_indices,
+                                                                                local_rows, num_cols=num_cols)
+        torch.cuda.synchronize()
+        preprocess_ms = (time.perf_counter() - t0) * 1e3
     total_blocks = int(blk_offsets[-1])
 
     gen = torch.Generator(device=device).manual_seed(1234 + rank)

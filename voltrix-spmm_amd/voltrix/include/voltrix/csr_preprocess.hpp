@@ -21,10 +21,12 @@
 //                               the window has more than kSortLdsKeys edges; sorted keys -> workspace; distinct
 //                               columns counted with wave ballots -> block_partition[w] = ceil(U_w / 8) (0 -> 1).
 //   2. scan_* kernels           as above.
-//   3. csr_handle_zero_kernel   zero hspa_packed / hind (T read on the device from pointer1[W]).
-//      csr_window_fill_kernel   per sorted key: "first of its column" flags -> ballot/popcount prefix sum = condensed
+//   3. csr_window_fill_kernel   zero the window's part of the handle; per sorted key: "first of its column" flags -> ballot/popcount prefix sum = condensed
 //                               column rank; hind[8*pointer1[w] + rank] = column; bit (row, rank) OR-ed into the
 //                               reference's swizzled word/bit position.
+//   Windows with <= kWsKeys edges take the csr_wave_* twins of steps 1 and 3: one WAVE per window -- the sort is a
+//   register-resident bitonic network (cross-lane shuffles, no LDS, no barriers), the fill stages the packed words in a
+//   wave-private LDS slice and writes them once.
 // Limits: num_nodes <= 2^28 (the packed key keeps the column in 28 bits), num_edges + W <= INT32_MAX.
 #pragma once
 
@@ -42,39 +44,261 @@ constexpr int kSortLdsKeys = 8192;   // 32 KiB of LDS per workgroup -> 4 workgro
 constexpr int kScanChunk = 2048;     // elements per scan workgroup (256 threads x 8)
 
 // All-ascending bitonic network over keys[0..n): every comparator moves the smaller key to the lower index, so
-// indices >= n can be treated as +inf and skipped (no power-of-two padding is materialised).
-template <class Ptr>
-__device__ __forceinline__ void bitonic_sort_ascending(Ptr keys, const int n, const int tid) {
-  int P = 1;
-  while (P < n) P <<= 1;
-  const int half = P >> 1;
-  for (int k = 2; k <= P; k <<= 1) {
-    const int hk = k >> 1;
-    for (int i = tid; i < half; i += kSortThreads) {  // "flip" step: partner mirrored inside the k-block
-      const int base = (i / hk) * k, off = i % hk;
-      const int lo = base + off, hi = base + k - 1 - off;
-      if (hi < n) {
-        const uint32_t x = keys[lo], y = keys[hi];
-        if (x > y) {
-          keys[lo] = y;
-          keys[hi] = x;
+// indices >= n can be treated as +inf and skipped (no power-of-two padding is materialised).  THREADS cooperating
+// threads (a workgroup with __syncthreads, or one wave on a wave-private LDS slice with a wave-level sync).
+struct WorkgroupSync {
+  __device__ __forceinline__ void operator()() const { __syncthreads(); }
+};
+struct WaveSync {  // LDS operations of one wave execute in order; this only pins the compiler's ordering
+  __device__ __forceinline__ void operator()() const {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+};
+
+// lk_first: first merge stage to run (blocks of 1 << (lk_first - 1) keys are already sorted ascending).
+template <int THREADS, class Ptr, class Sync>
+__device__ __forceinline__ void bitonic_sort_ascending(Ptr keys, const int n, const int tid, const Sync sync,
+                                                       const int lk_first = 1) {
+  constexpr int U = 4;  // independent compare-exchanges in flight per thread (hides the LDS / memory round trip)
+  int lp = 0;
+  while ((1 << lp) < n) ++lp;
+  const int half = (1 << lp) >> 1;
+  auto exchange = [&](auto index_pair) {
+    for (int i0 = tid; i0 < half; i0 += U * THREADS) {
+      int lo[U], hi[U];
+      uint32_t x[U], y[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * THREADS;
+        index_pair(i, lo[u], hi[u]);
+        if (i >= half || hi[u] >= n) hi[u] = -1;  // nothing to do (partner is virtual +inf padding)
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (hi[u] >= 0) {
+          x[u] = keys[lo[u]];
+          y[u] = keys[hi[u]];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (hi[u] >= 0 && x[u] > y[u]) {
+          keys[lo[u]] = y[u];
+          keys[hi[u]] = x[u];
         }
       }
     }
-    __syncthreads();
-    for (int j = k >> 2; j > 0; j >>= 1) {  // "shear" steps: partner at distance j
-      for (int i = tid; i < half; i += kSortThreads) {
-        const int lo = (i / j) * 2 * j + (i % j), hi = lo + j;
-        if (hi < n) {
-          const uint32_t x = keys[lo], y = keys[hi];
-          if (x > y) {
-            keys[lo] = y;
-            keys[hi] = x;
+    sync();
+  };
+  for (int lk = lk_first; lk <= lp; ++lk) {  // k = 1 << lk
+    const int lh = lk - 1, hmask = (1 << lh) - 1;
+    exchange([&](const int i, int& lo, int& hi) {  // "flip" step: partner mirrored inside the k-block
+      const int base = (i >> lh) << lk, off = i & hmask;
+      lo = base + off;
+      hi = base + (2 << lh) - 1 - off;
+    });
+    for (int lj = lk - 2; lj >= 0; --lj) {  // "shear" steps: partner at distance j = 1 << lj
+      const int jmask = (1 << lj) - 1;
+      exchange([&](const int i, int& lo, int& hi) {
+        lo = ((i >> lj) << (lj + 1)) + (i & jmask);
+        hi = lo + (1 << lj);
+      });
+    }
+  }
+}
+
+// Row pointers of window w (wave-uniform -> scalar loads, one round trip): rp[q] = indptr[min(16w + q, num_nodes)].
+__device__ __forceinline__ void load_window_rowptr(const int* __restrict__ indptr, const int w, const int num_nodes,
+                                                   int (&rp)[kBlkH + 1]) {
+  const long long r0 = (long long)w * kBlkH;
+  if (r0 + kBlkH <= num_nodes) {
+    const int* const p = indptr + r0;
+#pragma unroll
+    for (int q = 0; q <= kBlkH; ++q) rp[q] = p[q];
+  } else {  // the last, partial window
+#pragma unroll
+    for (int q = 0; q <= kBlkH; ++q) rp[q] = indptr[r0 + q < num_nodes ? r0 + q : num_nodes];
+  }
+}
+
+__device__ __forceinline__ int local_row(const int (&rp)[kBlkH + 1], const int e) {
+  int rl = 0;
+#pragma unroll
+  for (int q = 1; q < kBlkH; ++q) rl += (rp[q] <= e) ? 1 : 0;
+  return rl;
+}
+
+// ---- small windows: one WAVE per window on a wave-private LDS slice (no workgroup barriers) ----------------------
+constexpr int kWsBatch = 4;     // independent global loads in flight per lane
+constexpr int kWsKeys = 2048;   // edges per window handled by the wave path (32 keys per lane in registers)
+constexpr int kWsWaves = 4;     // waves per workgroup (independent windows)
+constexpr int kWsGrid = 256 * 16;  // grid-strided
+
+// Bitonic sort of 64 * C keys held in registers, C consecutive keys per lane (index = lane * C + r).  Compare-exchange
+// steps at distance < C stay inside a lane (register pairs, fully unrolled); distance >= C pairs lane with
+// lane ^ (distance / C) through one cross-lane shuffle per register.  No LDS round trips, no barriers.
+template <int C>
+__device__ __forceinline__ void wave_bitonic_sort(uint32_t (&v)[C], const int lane) {
+  constexpr int P = C * kWave;
+#pragma unroll
+  for (int k = 2; k <= P; k <<= 1) {
+    // keys whose index has bit k set sort descending (k == P: one ascending run)
+    const bool lane_desc = (k >= C && k < P) ? ((lane & (k / C)) != 0) : false;
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= C) {
+        const int lj = j / C;
+        const bool take_max = ((lane & lj) != 0) != lane_desc;
+#pragma unroll
+        for (int r = 0; r < C; ++r) {
+          const uint32_t other = (uint32_t)__shfl_xor((int)v[r], lj, kWave);
+          const uint32_t mn = v[r] < other ? v[r] : other, mx = v[r] < other ? other : v[r];
+          v[r] = take_max ? mx : mn;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < C; ++r) {
+          if ((r & j) == 0) {
+            const uint32_t x = v[r], y = v[r | j];
+            const uint32_t mn = x < y ? x : y, mx = x < y ? y : x;
+            const bool desc = k < C ? ((r & k) != 0) : lane_desc;
+            v[r] = desc ? mx : mn;
+            v[r | j] = desc ? mn : mx;
           }
         }
       }
-      __syncthreads();
     }
+  }
+}
+
+// One window of n <= 64 * C edges: keys (column << 4 | local row) -> sorted -> workspace; returns the distinct columns.
+template <int C>
+__device__ __forceinline__ int wave_sort_window(const int* __restrict__ indices, const int lo, const int n,
+                                                const int (&rp)[kBlkH + 1], const unsigned col_limit,
+                                                int* __restrict__ status, uint32_t* __restrict__ dst, const int lane) {
+  uint32_t v[C];
+#pragma unroll
+  for (int r = 0; r < C; ++r) {
+    const int i = lane * C + r;
+    v[r] = i < n ? (uint32_t)indices[lo + i] : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < C; ++r) {
+    const int i = lane * C + r;
+    if (i < n) {
+      if (v[r] >= col_limit) atomicAdd(status, 1);  // outside the caller's column universe / the 28-bit key
+      v[r] = (v[r] << 4) | (uint32_t)local_row(rp, lo + i);
+    } else {
+      v[r] = 0xFFFFFFFFu;  // padding sorts last
+    }
+  }
+  wave_bitonic_sort<C>(v, lane);
+  const uint32_t prev_last = (uint32_t)__shfl_up((int)v[C - 1], 1, kWave);
+  int cnt = 0;
+#pragma unroll
+  for (int r = 0; r < C; ++r) {
+    const int i = lane * C + r;
+    if (i < n) {
+      dst[i] = v[r];
+      const uint32_t prev = r ? v[r - 1] : prev_last;
+      cnt += (i == 0 || (v[r] >> 4) != (prev >> 4)) ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, kWave);
+  return cnt;
+}
+
+// Windows above kWsKeys edges are queued for the workgroup kernels: queue[0 .. *queue_count) (workspace).  Order inside
+// the queue is irrelevant (windows are independent, results are deterministic).
+// (Measured: splitting this kernel into a low-VGPR pass for n <= 512 and a second pass for the rest does not pay --
+// the small-window sort is VALU-bound, not latency-bound.)
+static __global__ __launch_bounds__(kWsWaves* kWave) void csr_wave_sort_kernel(const int* __restrict__ indptr,
+                                                                        const int* __restrict__ indices,
+                                                                        const int num_nodes, const int num_windows,
+                                                                        const unsigned col_limit,
+                                                                        uint32_t* __restrict__ keys_ws,
+                                                                        int* __restrict__ block_partition,
+                                                                        int* __restrict__ status,
+                                                                        int* __restrict__ queue_count,
+                                                                        int* __restrict__ queue) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+  for (int w = blockIdx.x * kWsWaves + wv; w < num_windows; w += gridDim.x * kWsWaves) {
+    int rp[kBlkH + 1];
+    load_window_rowptr(indptr, w, num_nodes, rp);
+    const int lo = rp[0], n = rp[kBlkH] - lo;
+    if (n > kWsKeys) {  // csr_window_sort_kernel's share
+      if (lane == 0) queue[atomicAdd(queue_count, 1)] = w;
+      continue;
+    }
+    uint32_t* const dst = keys_ws + lo;
+    int u;  // distinct columns (wave-uniform)
+    if (n <= 4 * kWave) u = wave_sort_window<4>(indices, lo, n, rp, col_limit, status, dst, lane);
+    else if (n <= 8 * kWave) u = wave_sort_window<8>(indices, lo, n, rp, col_limit, status, dst, lane);
+    else if (n <= 16 * kWave) u = wave_sort_window<16>(indices, lo, n, rp, col_limit, status, dst, lane);
+    else u = wave_sort_window<32>(indices, lo, n, rp, col_limit, status, dst, lane);
+    if (lane == 0) block_partition[w] = n == 0 ? 1 : (u + kBlkW - 1) / kBlkW;  // empty window -> 1 (reference quirk)
+  }
+}
+
+static __global__ __launch_bounds__(kWsWaves* kWave) void csr_wave_fill_kernel(const int* __restrict__ indptr,
+                                                                        const int num_nodes, const int num_windows,
+                                                                        const uint32_t* __restrict__ keys_ws,
+                                                                        const int* __restrict__ pointer1,
+                                                                        uint32_t* __restrict__ hspa_packed,
+                                                                        int* __restrict__ hind) {
+  __shared__ uint4 lstage4[kWsWaves][kWsKeys / kBlkW];  // packed words of up to kWsKeys / 8 TC blocks per wave
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+  uint4* const stage4 = lstage4[wv];
+  uint32_t* const stage = reinterpret_cast<uint32_t*>(stage4);
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  const WaveSync sync;
+  for (int i = lane; i < kWsKeys / kBlkW; i += kWave) stage4[i] = zero4;
+  sync();
+  for (int w = blockIdx.x * kWsWaves + wv; w < num_windows; w += gridDim.x * kWsWaves) {
+    const long long r0 = (long long)w * kBlkH, r1 = r0 + kBlkH;
+    const int lo = indptr[r0 < num_nodes ? r0 : num_nodes];
+    const int n = indptr[r1 < num_nodes ? r1 : num_nodes] - lo;
+    if (n > kWsKeys) continue;  // csr_window_fill_kernel's share (queued by csr_wave_sort_kernel)
+    const long long p0 = pointer1[w];
+    const int nb = pointer1[w + 1] - (int)p0;
+    int carry = 0;  // distinct columns before `base` (wave-uniform)
+    for (int base = 0; base < n; base += kWave * kWsBatch) {
+      uint32_t keys[kWsBatch], prevs[kWsBatch];
+#pragma unroll
+      for (int u = 0; u < kWsBatch; ++u) {
+        const int i = base + u * kWave + lane;
+        keys[u] = i < n ? keys_ws[lo + i] : 0u;
+        prevs[u] = (i < n && i > 0) ? keys_ws[lo + i - 1] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < kWsBatch; ++u) {
+        const int i = base + u * kWave + lane;
+        const bool valid = i < n;
+        const uint32_t key = keys[u];
+        const bool first = valid && (i == 0 || (key >> 4) != (prevs[u] >> 4));  // first key of its column
+        const unsigned long long m = __ballot(first);
+        if (valid) {
+          const int rank = carry + __popcll(m & (~0ull >> (kWave - 1 - lane))) - 1;  // reference edgeToColumn
+          const int r = key & 15, c = rank & 7, b = rank >> 3;
+          if (first) hind[8 * (p0 + b) + c] = (int)(key >> 4);
+          // reference bit order (bmat_kernels.cuh:180-188): word t = (r>>3) + 2*(c>>2), bit 4*(r&7) + (c&3)
+          atomicOr(&stage[4 * b + (r >> 3) + 2 * (c >> 2)], 1u << (4 * (r & 7) + (c & 3)));
+        }
+        carry += __popcll(m);
+      }
+    }
+    for (int q = carry + lane; q < 8 * nb; q += kWave) hind[8 * p0 + q] = 0;  // unused slots of the last block
+    sync();
+    uint4* const out4 = reinterpret_cast<uint4*>(hspa_packed) + p0;
+    for (int i = lane; i < nb; i += kWave) {
+      out4[i] = stage4[i];
+      stage4[i] = zero4;
+    }
+    sync();
   }
 }
 
@@ -84,12 +308,16 @@ static __global__ __launch_bounds__(kSortThreads) void csr_window_sort_kernel(co
                                                                        const unsigned col_limit,
                                                                        uint32_t* __restrict__ keys_ws,
                                                                        int* __restrict__ block_partition,
-                                                                       int* __restrict__ status) {
+                                                                       int* __restrict__ status,
+                                                                       const int* __restrict__ counts,
+                                                                       const int* __restrict__ queue) {
   __shared__ uint32_t lkeys[kSortLdsKeys];
   __shared__ int rowptr[kBlkH + 1];
   __shared__ int wave_cnt[kSortThreads / kWave];
   const int tid = threadIdx.x;
-  for (int w = blockIdx.x; w < num_windows; w += gridDim.x) {
+  const int num_big = *counts;  // windows above kWsKeys edges, queued by csr_wave_sort_kernel
+  for (int q = blockIdx.x; q < num_big; q += gridDim.x) {
+    const int w = queue[q];
     if (tid <= kBlkH) {
       const long long r = (long long)w * kBlkH + tid;
       rowptr[tid] = indptr[r < num_nodes ? r : num_nodes];
@@ -109,7 +337,32 @@ static __global__ __launch_bounds__(kSortThreads) void csr_window_sort_kernel(co
       if (in_lds) lkeys[i] = key; else dst[i] = key;
     }
     __syncthreads();
-    if (in_lds) bitonic_sort_ascending(lkeys, n, tid); else bitonic_sort_ascending(dst, n, tid);
+    // chunks of kWsKeys keys: sorted by one wave each in registers (stages k <= kWsKeys of the network) ...
+    auto sort_chunks = [&](auto keys) {
+      const int lane = tid & (kWave - 1), wv = tid / kWave;
+      for (int c = wv; c * kWsKeys < n; c += kSortThreads / kWave) {
+        constexpr int C = kWsKeys / kWave;
+        uint32_t v[C];
+        const int base = c * kWsKeys + lane * C;
+#pragma unroll
+        for (int r = 0; r < C; ++r) v[r] = base + r < n ? keys[base + r] : 0xFFFFFFFFu;
+        wave_bitonic_sort<C>(v, lane);
+#pragma unroll
+        for (int r = 0; r < C; ++r)
+          if (base + r < n) keys[base + r] = v[r];
+      }
+      __syncthreads();
+    };
+    // ... then the remaining merge stages (k = 2 * kWsKeys and up) by the whole workgroup
+    constexpr int kFirstStage = 12;
+    static_assert((1 << (kFirstStage - 1)) == kWsKeys, "chunk size = 2^(first workgroup stage - 1)");
+    if (in_lds) {
+      sort_chunks(lkeys);
+      bitonic_sort_ascending<kSortThreads>(lkeys, n, tid, WorkgroupSync{}, kFirstStage);
+    } else {
+      sort_chunks(dst);
+      bitonic_sort_ascending<kSortThreads>(dst, n, tid, WorkgroupSync{}, kFirstStage);
+    }
 
     int cnt = 0;  // distinct columns seen by this thread
     for (int i = tid; i < n; i += kSortThreads) {
@@ -198,31 +451,31 @@ static __global__ __launch_bounds__(256) void scan_apply_kernel(const int* __res
 }
 
 // ---- fill ----------------------------------------------------------------------------------------------------
-static __global__ __launch_bounds__(256) void csr_handle_zero_kernel(const int* __restrict__ pointer1, const int num_windows,
-                                                              uint32_t* __restrict__ hspa_packed,
-                                                              int* __restrict__ hind) {
-  const long long total = pointer1[num_windows];
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  uint4* p4 = reinterpret_cast<uint4*>(hspa_packed);
-  for (long long i = gid; i < total; i += stride) p4[i] = make_uint4(0u, 0u, 0u, 0u);
-  int4* h4 = reinterpret_cast<int4*>(hind);
-  for (long long i = gid; i < total * 2; i += stride) h4[i] = make_int4(0, 0, 0, 0);
-}
-
 static __global__ __launch_bounds__(kSortThreads) void csr_window_fill_kernel(const int* __restrict__ indptr,
                                                                        const int num_nodes, const int num_windows,
                                                                        const uint32_t* __restrict__ keys_ws,
                                                                        const int* __restrict__ pointer1,
                                                                        uint32_t* __restrict__ hspa_packed,
-                                                                       int* __restrict__ hind) {
+                                                                       int* __restrict__ hind,
+                                                                       const int* __restrict__ counts,
+                                                                       const int* __restrict__ queue) {
   __shared__ int wave_tot[kSortThreads / kWave];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
-  for (int w = blockIdx.x; w < num_windows; w += gridDim.x) {
+  const int num_big = *counts;
+  for (int q = blockIdx.x; q < num_big; q += gridDim.x) {
+    const int w = queue[q];
     const long long r0 = (long long)w * kBlkH, r1 = r0 + kBlkH;
     const int lo = indptr[r0 < num_nodes ? r0 : num_nodes];
     const int n = indptr[r1 < num_nodes ? r1 : num_nodes] - lo;
     const long long p0 = pointer1[w];
+    {  // zero this window's part of the handle; the barrier (stores acknowledged by L2, same CU) orders it before the ORs
+      const int nb = pointer1[w + 1] - (int)p0;
+      uint4* const z4 = reinterpret_cast<uint4*>(hspa_packed) + p0;
+      uint4* const h4 = reinterpret_cast<uint4*>(hind) + 2 * p0;
+      for (int i = tid; i < nb; i += kSortThreads) z4[i] = make_uint4(0u, 0u, 0u, 0u);
+      for (int i = tid; i < 2 * nb; i += kSortThreads) h4[i] = make_uint4(0u, 0u, 0u, 0u);
+      __syncthreads();
+    }
     int carry = 0;  // distinct columns in the keys before `base` (workgroup-uniform)
     for (int base = 0; base < n; base += kSortThreads) {
       const int i = base + tid;
@@ -485,11 +738,33 @@ inline int bm_set_lds(K kernel, size_t bytes) {
 // ---- host side -------------------------------------------------------------------------------------------------
 inline long long align16(long long x) { return (x + 15) & ~15ll; }
 
-inline long long csr_preprocess_workspace_bytes(int num_nodes, int num_cols, long long num_edges) {
+// workspace: [sort path: keys uint32[E]] [scan scratch int[nchunks]] [sort path: queue count (16 B), queue int[W]]
+struct CsrWorkspace {
+  uint32_t* keys;
+  int* chunk_sums;
+  int* counts;
+  int* queue;
+  long long bytes;
+};
+inline CsrWorkspace csr_workspace(void* base, int num_nodes, int num_cols, long long num_edges) {
   const long long W = ((long long)num_nodes + kBlkH - 1) / kBlkH;
   const long long nchunks = (W + kScanChunk - 1) / kScanChunk + 1;
-  const long long keys = csr_use_bitmap(num_nodes, num_cols, num_edges) ? 0 : align16(num_edges * 4);  // sort path only
-  return keys + align16(nchunks * 4) + 16;
+  const bool bitmap = csr_use_bitmap(num_nodes, num_cols, num_edges);
+  char* p = static_cast<char*>(base);
+  CsrWorkspace ws;
+  ws.keys = reinterpret_cast<uint32_t*>(p);
+  p += bitmap ? 0 : align16(num_edges * 4);
+  ws.chunk_sums = reinterpret_cast<int*>(p);
+  p += align16(nchunks * 4);
+  ws.counts = reinterpret_cast<int*>(p);
+  p += 16;
+  ws.queue = reinterpret_cast<int*>(p);
+  p += bitmap ? 0 : align16(W * 4);
+  ws.bytes = p - static_cast<char*>(base);
+  return ws;
+}
+inline long long csr_preprocess_workspace_bytes(int num_nodes, int num_cols, long long num_edges) {
+  return csr_workspace(nullptr, num_nodes, num_cols, num_edges).bytes;
 }
 
 inline int csr_check(int num_nodes, long long num_edges) {
@@ -512,8 +787,9 @@ inline int csr_window_count(const int* indptr, const int* indices, int num_nodes
     return hipMemsetAsync(pointer1, 0, sizeof(int), stream) == hipSuccess ? kOk : kErrLaunch;
   }
   const bool bitmap = csr_use_bitmap(num_nodes, num_cols, num_edges);
-  uint32_t* keys = reinterpret_cast<uint32_t*>(workspace);
-  int* chunk_sums = reinterpret_cast<int*>(reinterpret_cast<char*>(workspace) + (bitmap ? 0 : align16(num_edges * 4)));
+  const CsrWorkspace ws = csr_workspace(workspace, num_nodes, num_cols, num_edges);
+  uint32_t* const keys = ws.keys;
+  int* const chunk_sums = ws.chunk_sums;
   const int nchunks = (W + kScanChunk - 1) / kScanChunk;
   if (bitmap) {
     const size_t lds = bm_count_lds(num_cols);
@@ -522,10 +798,14 @@ inline int csr_window_count(const int* indptr, const int* indices, int num_nodes
     hipLaunchKernelGGL(csr_bitmap_count_kernel, dim3(grid), dim3(kBmThreads), lds, stream, indptr, indices, num_nodes,
                        num_cols, W, block_partition, status);
   } else {
-    const int grid = W < 256 * 8 ? W : 256 * 8;
     const unsigned col_limit = num_cols > 0 ? (unsigned)num_cols : (1u << 28);
+    const int wgs = (W + kWsWaves - 1) / kWsWaves;  // small windows: one wave each
+    if (hipMemsetAsync(ws.counts, 0, sizeof(int), stream) != hipSuccess) return kErrLaunch;
+    hipLaunchKernelGGL(csr_wave_sort_kernel, dim3(wgs < kWsGrid ? wgs : kWsGrid), dim3(kWsWaves * kWave), 0, stream,
+                       indptr, indices, num_nodes, W, col_limit, keys, block_partition, status, ws.counts, ws.queue);
+    const int grid = W < 256 * 8 ? W : 256 * 8;  // windows above kWsKeys edges (queued above): one workgroup each
     hipLaunchKernelGGL(csr_window_sort_kernel, dim3(grid), dim3(kSortThreads), 0, stream, indptr, indices, num_nodes,
-                       W, col_limit, keys, block_partition, status);
+                       W, col_limit, keys, block_partition, status, ws.counts, ws.queue);
   }
   hipLaunchKernelGGL(scan_chunk_sums_kernel, dim3(nchunks), dim3(256), 0, stream, block_partition, W, chunk_sums);
   hipLaunchKernelGGL(scan_chunk_offsets_kernel, dim3(1), dim3(256), 0, stream, chunk_sums, nchunks);
@@ -547,11 +827,14 @@ inline int csr_fill(const int* indptr, const int* indices, int num_nodes, int nu
                        num_cols, W, pointer1, hspa_packed, hind);
     return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
   }
-  const uint32_t* keys = reinterpret_cast<const uint32_t*>(workspace);
-  hipLaunchKernelGGL(csr_handle_zero_kernel, dim3(256 * 8), dim3(256), 0, stream, pointer1, W, hspa_packed, hind);
+  const CsrWorkspace ws = csr_workspace(workspace, num_nodes, num_cols, num_edges);
+  const uint32_t* const keys = ws.keys;
+  const int wgs = (W + kWsWaves - 1) / kWsWaves;
+  hipLaunchKernelGGL(csr_wave_fill_kernel, dim3(wgs < kWsGrid ? wgs : kWsGrid), dim3(kWsWaves * kWave), 0, stream, indptr,
+                     num_nodes, W, keys, pointer1, hspa_packed, hind);
   const int grid = W < 256 * 8 ? W : 256 * 8;
   hipLaunchKernelGGL(csr_window_fill_kernel, dim3(grid), dim3(kSortThreads), 0, stream, indptr, num_nodes, W, keys,
-                     pointer1, hspa_packed, hind);
+                     pointer1, hspa_packed, hind, ws.counts, ws.queue);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
