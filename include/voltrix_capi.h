@@ -90,7 +90,7 @@ void voltrix_launch_spmm(void* blk_offsets, void* hspa_packed, void* hind, int n
  * window_order: NULL, or the int32[W] schedule written by voltrix_launch_window_order (changes speed only). */
 void voltrix_launch_spmm_f32_tile(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
                                   int embedding_dim, void* input, void* output, int fs, int depth, int waves,
-                                  void* window_order, void* stream, int* return_code);
+                                  void* window_order, void* out_scale, void* stream, int* return_code);
 
 /* fp16 dense operand (BASELINE.json's headline configuration): input _Float16 [*, embedding_dim], output float32.
  * v_mfma_f32_16x16x32_f16, fp32 accumulate.  embedding_dim % 8 == 0, input 16-byte aligned. */
@@ -98,7 +98,7 @@ void voltrix_launch_spmm_f16(void* blk_offsets, void* hspa_packed, void* hind, i
                              int embedding_dim, void* input, void* output, void* stream, int* return_code);
 void voltrix_launch_spmm_f16_tile(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
                                   int embedding_dim, void* input, void* output, int fs, int depth, int waves,
-                                  void* window_order, void* stream, int* return_code);
+                                  void* window_order, void* out_scale, void* stream, int* return_code);
 
 /* "Balance" schedule for a handle: order_out int32[W] (device) lists the windows of every XCD range, inside chunks of
  * `chunk` (1..4096) consecutive windows, by descending TC-block count, so that co-resident waves sweep their sorted
@@ -124,6 +124,14 @@ void voltrix_spmm_tile_at(int is_f16, int index, int* fs, int* depth, int* waves
 
 /* fp32 -> fp16 cast of the dense operand into a caller-provided buffer (count % 8 == 0). */
 void voltrix_launch_cast_f32_f16(void* src, void* dst, int64_t count, void* stream, int* return_code);
+
+/* Range-safe variant (what voltrix.spmm uses for fp32 features): dst = fp16(src * 2^-e) with one power-of-two scale
+ * per call, e = exponent(max |src|) - 14, so fp32 magnitudes beyond fp16's range neither overflow nor flush while the
+ * 10-bit mantissa (= the reference's TF32 rounding, spmm_kernels.cuh:1671) is kept.  scale: device float[2], 8-byte
+ * aligned; scale[0] <- 2^e, to be passed as `out_scale` of voltrix_launch_spmm_f16_tile (multiplied into every output
+ * element in the epilogue; exact).  No host sync.  Inf / NaN in src: scale 1, they propagate as in fp32. */
+void voltrix_launch_cast_f32_f16_scaled(void* src, void* dst, int64_t count, void* scale, void* stream,
+                                        int* return_code);
 
 /* Fused GPU preprocess: CSR on the DEVICE -> (pointer1, hspa_packed, hind) without the reference's host
  * preprocess, the O(TCb*E) rescan or the 512-byte/TC-block fp32 `hspa` intermediate.  Two phases because the

@@ -172,6 +172,11 @@ def round_operand(x, mode):
         return round_tf32_rna(x)
     if mode == "fp16":
         return x.astype(np.float16).astype(np.float32)
+    if mode == "fp16-scaled":  # voltrix.spmm's fp32 operand: one power-of-two scale per tensor (voltrix_capi.h)
+        amax = float(np.abs(x).max()) if x.size else 0.0
+        e = 0 if (amax == 0.0 or not np.isfinite(amax)) else max(int(np.frexp(np.float32(amax))[1]) - 1 - 14, -100)
+        with np.errstate(over="ignore", under="ignore"):
+            return np.ldexp(np.ldexp(x, -e).astype(np.float16).astype(np.float32), e).astype(np.float32)
     if mode == "bf16":
         import torch
         return torch.from_numpy(x.copy()).to(torch.bfloat16).to(torch.float32).numpy()

@@ -95,12 +95,14 @@ def test_return_codes_on_bad_arguments(monkeypatch):
     assert rc.value == 1
     # embedding_dim not a multiple of 8 halves / unknown tile: rejected on the host, before any HIP call
     lib.voltrix_launch_spmm_f16_tile(z, z, z, ctypes.c_int(16), ctypes.c_int(0), ctypes.c_int(12), z, z,
-                                     ctypes.c_int(128), ctypes.c_int(4), ctypes.c_int(1), z, z, ctypes.byref(rc))
+                                     ctypes.c_int(128), ctypes.c_int(4), ctypes.c_int(1), z, z, z, ctypes.byref(rc))
     assert rc.value == 1
     lib.voltrix_launch_spmm_f16_tile(z, z, z, ctypes.c_int(16), ctypes.c_int(0), ctypes.c_int(16), z, z,
-                                     ctypes.c_int(48), ctypes.c_int(4), ctypes.c_int(1), z, z, ctypes.byref(rc))
+                                     ctypes.c_int(48), ctypes.c_int(4), ctypes.c_int(1), z, z, z, ctypes.byref(rc))
     assert rc.value == 3
     lib.voltrix_launch_cast_f32_f16(z, z, ctypes.c_int64(12), z, ctypes.byref(rc))
+    assert rc.value == 1
+    lib.voltrix_launch_cast_f32_f16_scaled(z, z, ctypes.c_int64(16), z, z, ctypes.byref(rc))  # no scale buffer
     assert rc.value == 1
     lib.voltrix_launch_window_order(z, ctypes.c_int(64), ctypes.c_int(8192), z, z, ctypes.byref(rc))
     assert rc.value == 1  # chunk above the 4096-window LDS sort capacity

@@ -33,13 +33,15 @@ def _bounds(indptr, indices, feat, n, operand_rounded):
 
 
 def _assert_close(out, indptr, indices, feat32, n, mode):
-    """mode: 'fp16' (operand rounded to fp16 somewhere), 'exact' (fp32 operand, exact products)."""
+    """mode: 'fp16' (fp16 operand), 'fp16-scaled' (fp32 operand rounded to fp16 after voltrix.spmm's power-of-two
+    rescale), 'exact' (fp32 operand, exact products)."""
     out = out.detach().cpu().numpy().astype(np.float64)
     ref = torch_ref.spmm(indptr, indices, feat32, n).numpy().astype(np.float64)
     assert not np.isnan(out).any()
-    if mode == "fp16":
-        ref_same = torch_ref.spmm(indptr, indices, feat32, n, operand_rounding="fp16").numpy().astype(np.float64)
-        assert (np.abs(out - ref_same) <= _bounds(indptr, indices, feat32.half().float(), n, True)).all()
+    if mode in ("fp16", "fp16-scaled"):
+        ref_same = torch_ref.spmm(indptr, indices, feat32, n, operand_rounding=mode).numpy().astype(np.float64)
+        rounded = feat32.half().float() if mode == "fp16" else torch_ref.round_fp16_scaled(feat32)
+        assert (np.abs(out - ref_same) <= _bounds(indptr, indices, rounded, n, True)).all()
         assert (np.abs(out - ref) <= _bounds(indptr, indices, feat32, n, False)).all()
         if np.linalg.norm(ref) > 0:
             assert np.linalg.norm(out - ref) / np.linalg.norm(ref) <= 1e-3
@@ -51,7 +53,8 @@ def _assert_close(out, indptr, indices, feat32, n, mode):
         assert abs(oracle_np.calc_diff(out, ref)) <= 1e-5
 
 
-@pytest.mark.parametrize("dtype,mode", [(torch.float16, "fp16"), (torch.float32, "fp16"), (torch.float32, "exact")])
+@pytest.mark.parametrize("dtype,mode", [(torch.float16, "fp16"), (torch.float32, "fp16-scaled"),
+                                        (torch.float32, "exact")])
 def test_operator_api_on_fixtures(cuda_device, csr_fixture, dtype, mode, monkeypatch):
     monkeypatch.setenv("VOLTRIX_FP32_MODE", "exact" if mode == "exact" else "fp16")
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
@@ -81,7 +84,7 @@ def test_reference_test_inputs_with_autotune(cuda_device, monkeypatch):
     blk_offsets, hspa_packed, hind = voltrix.csr_preprocess(indptr, indices, n)
     hspa_packed.hash_tag = "test_20_8192_0.01"
     out = voltrix.spmm(blk_offsets, hspa_packed, hind, num_nodes=n, num_edges=indices.numel(), feat=feat.cuda())
-    _assert_close(out, a.indptr, a.indices, feat, n, "fp16")
+    _assert_close(out, a.indptr, a.indices, feat, n, "fp16-scaled")
     ref = torch_ref.spmm(a.indptr, a.indices, feat, n)
     assert float(voltrix.utils.calc_diff(out.cpu(), ref)) * 100 < 1e-3  # "difference rate: 0.000%"
     # second call reuses the tuned kernel and gives the same bits
@@ -127,6 +130,52 @@ def test_feature_widths_including_padding(cuda_device, num_feats, monkeypatch):
     out = voltrix.spmm(*handle, num_nodes=n, num_edges=len(g["indices"]), feat=feat32.half().cuda())
     assert out.shape == (n, num_feats) and out.is_contiguous()
     _assert_close(out, g["indptr"], g["indices"], feat32, n, "fp16")
+
+
+@pytest.mark.parametrize("magnitude", [1e-30, 1e-10, 1.0, 3e4, 1e10, 1e30])
+def test_fp32_features_keep_fp32_range(cuda_device, magnitude, monkeypatch):
+    """The reference multiplies in TF32 (fp32's exponent range).  fp32 features far outside fp16's range must neither
+    overflow nor flush on the default (fp16 MFMA) path: voltrix.spmm rescales by a power of two per call."""
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    monkeypatch.setenv("VOLTRIX_FP32_MODE", "fp16")
+    g = load_csr_fixture("cora_like")
+    n = int(g["num_nodes"])
+    handle = voltrix.csr_preprocess(torch.from_numpy(g["indptr"]), torch.from_numpy(g["indices"]), n)
+    handle[1].hash_tag = "cora_like"
+    torch.manual_seed(3)
+    feat32 = torch.randn(n, 64) * magnitude
+    out = voltrix.spmm(*handle, num_nodes=n, num_edges=len(g["indices"]), feat=feat32.cuda())
+    assert torch.isfinite(out).all()
+    _assert_close(out, g["indptr"], g["indices"], feat32, n, "fp16-scaled")
+
+
+def test_fp32_features_with_inf_and_nan_do_not_disturb_the_rescale(cuda_device, monkeypatch):
+    """Inf / NaN in an fp32 operand: the power-of-two rescale is skipped (scale 1) and they stay non-finite where
+    torch.sparse.mm has them.  Like the reference's mma (A = 0 times B = Inf is NaN), the other rows of a 16-row window
+    that gathers such a row of B may turn NaN too; windows that do not reference it are unaffected."""
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    monkeypatch.setenv("VOLTRIX_FP32_MODE", "fp16")
+    g = load_csr_fixture("cora_like")
+    n = int(g["num_nodes"])
+    indptr, cols = np.asarray(g["indptr"]), np.asarray(g["indices"])
+    handle = voltrix.csr_preprocess(torch.from_numpy(g["indptr"]), torch.from_numpy(g["indices"]), n)
+    handle[1].hash_tag = "cora_like"
+    torch.manual_seed(5)
+    feat32 = torch.randn(n, 16)
+    bad_inf, bad_nan = int(cols[0]), int(cols[-1])
+    feat32[bad_inf, 3] = float("inf")
+    feat32[bad_nan, 5] = float("nan")
+    out = voltrix.spmm(*handle, num_nodes=n, num_edges=len(cols), feat=feat32.cuda()).cpu()
+    ref = torch_ref.spmm(g["indptr"], g["indices"], feat32, n)
+    assert not torch.isfinite(out[~torch.isfinite(ref)]).any()          # nothing non-finite became finite
+    rows = np.repeat(np.arange(n), np.diff(indptr))
+    touched = np.unique(rows[(cols == bad_inf) | (cols == bad_nan)] // 16)  # windows that gather a bad row
+    clean = np.ones(n, dtype=bool)
+    for w in touched:
+        clean[16 * w:16 * w + 16] = False
+    assert clean.sum() > n // 2
+    assert torch.isfinite(out[clean]).all()
+    assert torch.allclose(out[clean], ref[clean], rtol=2e-3, atol=2e-3)
 
 
 def test_every_output_row_is_written_and_empty_windows_are_zero(cuda_device):

@@ -7,20 +7,21 @@ extern "C" {
 
 void voltrix_launch_spmm_f16_tile(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
                                   int embedding_dim, void* input, void* output, int fs, int depth, int waves,
-                                  void* window_order, void* stream, int* return_code) {
+                                  void* window_order, void* out_scale, void* stream, int* return_code) {
   (void)num_edges;  // unused by the reference's live kernels as well
   *return_code = dispatch_spmm<2, _Float16>(fs, depth, waves, static_cast<const int*>(blk_offsets),
                                             static_cast<const uint32_t*>(hspa_packed), static_cast<const int*>(hind),
                                             num_nodes, embedding_dim, static_cast<const _Float16*>(input),
                                             static_cast<float*>(output), static_cast<hipStream_t>(stream),
-                                            static_cast<const int*>(window_order));
+                                            static_cast<const int*>(window_order),
+                                            static_cast<const float*>(out_scale));
 }
 
 void voltrix_launch_spmm_f16(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
                              int embedding_dim, void* input, void* output, void* stream, int* return_code) {
   const TileId t = default_tile(embedding_dim, true);
   voltrix_launch_spmm_f16_tile(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, output, t.fs,
-                               t.depth, t.waves, nullptr, stream, return_code);
+                               t.depth, t.waves, nullptr, nullptr, stream, return_code);
 }
 
 void voltrix_launch_window_order(void* blk_offsets, int num_nodes, int chunk, void* order_out, void* stream,
@@ -32,6 +33,12 @@ void voltrix_launch_window_order(void* blk_offsets, int num_nodes, int chunk, vo
 void voltrix_launch_cast_f32_f16(void* src, void* dst, int64_t count, void* stream, int* return_code) {
   *return_code = voltrix::cast_f32_to_f16(static_cast<const float*>(src), static_cast<_Float16*>(dst), count,
                                           static_cast<hipStream_t>(stream));
+}
+
+void voltrix_launch_cast_f32_f16_scaled(void* src, void* dst, int64_t count, void* scale, void* stream,
+                                        int* return_code) {
+  *return_code = voltrix::cast_f32_to_f16_scaled(static_cast<const float*>(src), static_cast<_Float16*>(dst), count,
+                                                 static_cast<float*>(scale), static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -14,13 +14,13 @@ int voltrix_abi_version(void) { return VOLTRIX_ABI_VERSION; }
 
 void voltrix_launch_spmm_f32_tile(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
                                   int embedding_dim, void* input, void* output, int fs, int depth, int waves,
-                                  void* window_order, void* stream, int* return_code) {
+                                  void* window_order, void* out_scale, void* stream, int* return_code) {
   (void)num_edges;
   *return_code = dispatch_spmm<4, float>(fs, depth, waves, static_cast<const int*>(blk_offsets),
                                          static_cast<const uint32_t*>(hspa_packed), static_cast<const int*>(hind),
                                          num_nodes, embedding_dim, static_cast<const float*>(input),
                                          static_cast<float*>(output), static_cast<hipStream_t>(stream),
-                                            static_cast<const int*>(window_order));
+                                         static_cast<const int*>(window_order), static_cast<const float*>(out_scale));
 }
 
 // the reference's launch() argument list (voltrix/jit_kernels/spmm.py:78-88)
@@ -28,7 +28,7 @@ void voltrix_launch_spmm(void* blk_offsets, void* hspa_packed, void* hind, int n
                          int embedding_dim, void* input, void* output, void* stream, int* return_code) {
   const TileId t = default_tile(embedding_dim, false);
   voltrix_launch_spmm_f32_tile(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, output, t.fs,
-                               t.depth, t.waves, nullptr, stream, return_code);
+                               t.depth, t.waves, nullptr, nullptr, stream, return_code);
 }
 
 void voltrix_spmm_default_tile(int embedding_dim, int is_f16, int* fs, int* depth, int* waves) {

@@ -33,6 +33,7 @@ SYMBOLS = (
     "voltrix_spmm_tile_at",
     "voltrix_launch_window_order",
     "voltrix_launch_cast_f32_f16",
+    "voltrix_launch_cast_f32_f16_scaled",
     "voltrix_csr_preprocess_workspace_bytes",
     "voltrix_launch_csr_window_count",
     "voltrix_launch_csr_fill",
@@ -120,15 +121,16 @@ def launch_csr_fill(indptr, indices, num_nodes, num_cols, workspace, pointer1, h
 
 
 def launch_spmm(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input_ptr, output_ptr, is_f16,
-                tile, stream, window_order=0) -> int:
+                tile, stream, window_order=0, out_scale=0) -> int:
     """Raw-pointer launch (used by bench.py and the tests); ``window_order`` is 0 (natural) or the device pointer of
-    the schedule written by :func:`launch_window_order`.  Returns the return code."""
+    the schedule written by :func:`launch_window_order`; ``out_scale`` is 0 or the device pointer of the float written
+    by :func:`launch_cast_f32_f16_scaled`.  Returns the return code."""
     rc = ctypes.c_int(-1)
     fn = lib().voltrix_launch_spmm_f16_tile if is_f16 else lib().voltrix_launch_spmm_f32_tile
     fn(ctypes.c_void_p(blk_offsets), ctypes.c_void_p(hspa_packed), ctypes.c_void_p(hind), ctypes.c_int(num_nodes),
        ctypes.c_int(num_edges), ctypes.c_int(embedding_dim), ctypes.c_void_p(input_ptr), ctypes.c_void_p(output_ptr),
        ctypes.c_int(tile[0]), ctypes.c_int(tile[1]), ctypes.c_int(tile[2]), ctypes.c_void_p(window_order),
-       ctypes.c_void_p(stream), ctypes.byref(rc))
+       ctypes.c_void_p(out_scale), ctypes.c_void_p(stream), ctypes.byref(rc))
     return rc.value
 
 
@@ -156,3 +158,11 @@ def launch_cast_f32_f16(src, dst, stream) -> None:
     lib().voltrix_launch_cast_f32_f16(_ptr(src), _ptr(dst), ctypes.c_int64(src.numel()), ctypes.c_void_p(stream),
                                       ctypes.byref(rc))
     check(rc.value, "voltrix_launch_cast_f32_f16")
+
+
+def launch_cast_f32_f16_scaled(src, dst, scale, stream) -> None:
+    """dst = fp16(src * 2^-e), scale[0] = 2^e (``scale``: float32[2] device tensor); see include/voltrix_capi.h."""
+    rc = ctypes.c_int(-1)
+    lib().voltrix_launch_cast_f32_f16_scaled(_ptr(src), _ptr(dst), ctypes.c_int64(src.numel()), _ptr(scale),
+                                             ctypes.c_void_p(stream), ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_cast_f32_f16_scaled")

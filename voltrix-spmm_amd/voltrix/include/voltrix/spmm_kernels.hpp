@@ -154,6 +154,7 @@ struct SpmmArgs {
   int num_slabs;
   int windows_per_xcd;           // ceil(num_windows / 8)
   const int* window_order;       // optional schedule: position -> window id (launch_window_order); nullptr = natural
+  const float* out_scale;        // optional device scalar multiplied into every output (cast_f32_to_f16_scaled); nullptr = 1
 };
 
 // One wave64 = one (row window, FS-column slab) unit.  EB == 2: fp16 operand, v_mfma_f32_16x16x32_f16.
@@ -451,6 +452,8 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
   }
   const int orow0 = w * kBlkH + 4 * (lane >> 4);
   const int ocol0 = fs0 + (lane & 15);
+  // powers of two: exact (barring overflow / underflow of the result itself)
+  const float oscale = (EB == 2 ? kAScaleInv : 1.0f) * (a.out_scale ? *a.out_scale : 1.0f);
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     const int col = ocol0 + 16 * s;
@@ -458,7 +461,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = orow0 + j;
-        if (row < a.num_nodes) a.output[(long long)row * F + col] = (EB == 2) ? acc[s][j] * kAScaleInv : acc[s][j];
+        if (row < a.num_nodes) a.output[(long long)row * F + col] = acc[s][j] * oscale;
       }
     }
   }
@@ -469,7 +472,8 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
 template <class T>
 inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed, const int* hind, int num_nodes,
                             int embedding_dim, const typename SpmmArgs<T>::in_t* input, float* output,
-                            hipStream_t stream, const int* window_order = nullptr) {
+                            hipStream_t stream, const int* window_order = nullptr,
+                            const float* out_scale = nullptr) {
   if (num_nodes < 0 || embedding_dim < 0) return kErrBadShape;
   if (num_nodes == 0 || embedding_dim == 0) return kOk;
   if (embedding_dim % (16 / T::EB) != 0) return kErrBadShape;  // 16-byte row chunks
@@ -486,6 +490,7 @@ inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed,
   a.num_slabs = (embedding_dim + T::FS - 1) / T::FS;
   a.windows_per_xcd = (a.num_windows + kNumXcd - 1) / kNumXcd;
   a.window_order = window_order;
+  a.out_scale = out_scale;
   const long long blocks_per_xcd = ((long long)a.windows_per_xcd * a.num_slabs + T::WAVES - 1) / T::WAVES;
   const long long grid = blocks_per_xcd * kNumXcd;
   if (grid > 0x7FFFFFFFll) return kErrBadShape;
@@ -583,6 +588,68 @@ inline int cast_f32_to_f16(const float* src, _Float16* dst, long long n, hipStre
   const long long n8 = n / 8;
   const int blocks = (int)(n8 / 256 + 1 < 256 * 16 ? n8 / 256 + 1 : 256 * 16);
   hipLaunchKernelGGL(cast_f32_to_f16_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, n8);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+// ---- range-safe fp32 -> fp16 operand: dst = fp16(src * 2^-e), scale[0] = 2^e with e = exponent(max |src|) - 14 --------
+// The reference multiplies in TF32 (8-bit exponent); a plain fp16 cast would overflow above 65504 and flush below
+// 6e-8.  A binary A makes the product linear in B, so one power-of-two scale per launch (exact, undone in the SpMM
+// epilogue through SpmmArgs::out_scale) moves the operand's largest magnitude to [2^14, 2^15) and keeps the 10-bit
+// mantissa (= TF32's) for everything within 2^-28 of it.  All on the stream, no host sync.  Inf / NaN operands:
+// scale 1 (they propagate as in fp32).  scale[1] is scratch (max |src| bits).
+static __global__ __launch_bounds__(256) void amax_abs_f32_kernel(const float* __restrict__ src, const long long n4,
+                                                           unsigned* __restrict__ amax_bits) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  unsigned m = 0u;  // |x| as bits: non-negative floats order like unsigned integers (NaN > Inf > finite)
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const uint4 x = reinterpret_cast<const uint4*>(src)[i];
+    const unsigned a = x.x & 0x7FFFFFFFu, b = x.y & 0x7FFFFFFFu, c = x.z & 0x7FFFFFFFu, d = x.w & 0x7FFFFFFFu;
+    const unsigned ab = a > b ? a : b, cd = c > d ? c : d, abcd = ab > cd ? ab : cd;
+    m = m > abcd ? m : abcd;
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    const unsigned o = (unsigned)__shfl_xor((int)m, off, kWave);
+    m = m > o ? m : o;
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0 && m != 0u) atomicMax(amax_bits, m);
+}
+
+__device__ __forceinline__ int operand_scale_exponent(const unsigned amax_bits) {
+  if (amax_bits == 0u || amax_bits >= 0x7F800000u) return 0;   // all zero, or Inf / NaN present: leave as is
+  const int e = (int)(amax_bits >> 23) - 127 - 14;              // subnormal maxima: biased exponent 0 -> e = -141
+  return e < -100 ? -100 : e;                                   // 2^100 / 2^-113 stay normal floats
+}
+
+static __global__ __launch_bounds__(256) void cast_f32_to_f16_scaled_kernel(const float* __restrict__ src,
+                                                                      _Float16* __restrict__ dst, const long long n8,
+                                                                      float* __restrict__ scale) {
+  typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+  const int e = operand_scale_exponent(reinterpret_cast<const unsigned*>(scale)[1]);
+  const float down = __builtin_ldexpf(1.0f, -e);
+  if (blockIdx.x == 0 && threadIdx.x == 0) scale[0] = __builtin_ldexpf(1.0f, e);
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    const float4 x = reinterpret_cast<const float4*>(src)[2 * i];
+    const float4 y = reinterpret_cast<const float4*>(src)[2 * i + 1];
+    h8 o = {(_Float16)(x.x * down), (_Float16)(x.y * down), (_Float16)(x.z * down), (_Float16)(x.w * down),
+            (_Float16)(y.x * down), (_Float16)(y.y * down), (_Float16)(y.z * down), (_Float16)(y.w * down)};
+    reinterpret_cast<h8*>(dst)[i] = o;
+  }
+}
+
+// scale: device float[2], 8-byte aligned.  scale[0] <- 2^e (pass it to launch_spmm_tc16 as out_scale).
+inline int cast_f32_to_f16_scaled(const float* src, _Float16* dst, long long n, float* scale, hipStream_t stream) {
+  if (n < 0 || (n % 8) != 0 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15) || scale == nullptr ||
+      ((uintptr_t)scale & 7))
+    return kErrBadShape;
+  if (hipMemsetAsync(scale, 0, 2 * sizeof(float), stream) != hipSuccess) return kErrLaunch;
+  const long long n8 = n / 8;
+  const int blocks = (int)(n8 / 256 + 1 < 256 * 16 ? n8 / 256 + 1 : 256 * 16);
+  if (n > 0)
+    hipLaunchKernelGGL(amax_abs_f32_kernel, dim3(blocks), dim3(256), 0, stream, src, n / 4,
+                       reinterpret_cast<unsigned*>(scale) + 1);
+  hipLaunchKernelGGL(cast_f32_to_f16_scaled_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, n8, scale);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

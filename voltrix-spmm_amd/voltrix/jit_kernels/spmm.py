@@ -19,7 +19,7 @@ template = """
 __return_code = voltrix::launch_spmm_tc16<voltrix::SpmmTile<{FS}, {DEPTH}, {WAVES}, {EB}>>(
     blk_offsets, hspa_packed, hind,
     num_nodes, embedding_dim, input, output, stream,
-    {SCHED} == 0 ? nullptr : ({SCHED} == 1 ? win_order_a : ({SCHED} == 2 ? win_order_b : win_order_c)));
+    {SCHED} == 0 ? nullptr : ({SCHED} == 1 ? win_order_a : ({SCHED} == 2 ? win_order_b : win_order_c)), out_scale);
 """
 
 # windows per length-sorted chunk of the "balance" schedule (spmm_kernels.hpp::launch_window_order) for SCHED 1/2/3.
@@ -92,7 +92,20 @@ def window_order(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, num_nodes
     return order
 
 
-def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, output):
+_UNIT_SCALE = {}
+
+
+def unit_scale(device) -> torch.Tensor:
+    """float32[2] = {1, 0} on ``device``: the neutral ``out_scale`` (operands that were not rescaled)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _UNIT_SCALE:
+        _UNIT_SCALE[key] = torch.tensor([1.0, 0.0], dtype=torch.float32, device=device)
+    return _UNIT_SCALE[key]
+
+
+def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, output, out_scale=None):
+    """``out_scale`` (extension): float32 device tensor whose first element multiplies every output element (the
+    power-of-two written by ``capi.launch_cast_f32_f16_scaled``); default 1."""
     assert blk_offsets.is_cuda and blk_offsets.dtype == torch.int32
     assert hspa_packed.is_cuda and hspa_packed.dtype == torch.uint32
     assert hind.is_cuda and hind.dtype == torch.int32
@@ -102,10 +115,13 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
     assert output.shape[0] == num_nodes and output.shape[1] == embedding_dim
     elem_bytes = input.element_size()
     assert embedding_dim % (16 // elem_bytes) == 0, "embedding_dim must keep rows 16-byte aligned (voltrix.spmm pads)"
+    if out_scale is None:
+        out_scale = unit_scale(input.device)
+    assert out_scale.is_cuda and out_scale.dtype == torch.float32 and out_scale.numel() >= 1
 
     args = (blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, output,
             window_order(blk_offsets, hspa_packed, num_nodes, 1), window_order(blk_offsets, hspa_packed, num_nodes, 2),
-            window_order(blk_offsets, hspa_packed, num_nodes, 3), torch.cuda.current_stream())
+            window_order(blk_offsets, hspa_packed, num_nodes, 3), out_scale, torch.cuda.current_stream())
     runtime = jit_tuner.compile_and_tune(
         name="spmm_kernel",
         keys={
@@ -128,6 +144,7 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
             ("win_order_a", torch.int32),
             ("win_order_b", torch.int32),
             ("win_order_c", torch.int32),
+            ("out_scale", torch.float32),
             ("stream", torch.cuda.Stream),
         ),
         template=template,

@@ -15,6 +15,7 @@ from ..jit_kernels import (
     preprocess_kernel,
     spmm_kernel,
 )
+from .. import capi
 from ..project import FP32_MODE_FLAG, PREPROCESS_FLAG
 
 BLK_H = 16
@@ -70,8 +71,8 @@ def spmm(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tenso
 
     ``feat``: CUDA, 2-D, contiguous; float32 (the reference's only dtype, jit_kernels/spmm.py:53) or float16
     (BASELINE.json's headline).  float32 is rounded to fp16 for the MFMA -- the same 10-bit mantissa as the
-    reference's TF32 rounding (spmm_kernels.cuh:1671) -- unless ``VOLTRIX_FP32_MODE=exact``, which keeps exact
-    fp32 products.  Every output row is written, including the ``num_nodes % 16`` tail the reference skips.
+    reference's TF32 rounding (spmm_kernels.cuh:1671), after a per-call power-of-two rescale that keeps fp32's range --
+    unless ``VOLTRIX_FP32_MODE=exact``, which keeps exact fp32 products.  Every output row is written, including the ``num_nodes % 16`` tail the reference skips.
     """
     assert feat.is_cuda and feat.dim() == 2
     feat = feat.contiguous()
@@ -79,13 +80,21 @@ def spmm(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tenso
     assert feat.dtype in (torch.float32, torch.float16), f"unsupported feature dtype {feat.dtype}"
 
     exact = feat.dtype == torch.float32 and os.getenv(FP32_MODE_FLAG, "fp16") == "exact"
-    operand = feat if (exact or feat.dtype == torch.float16) else feat.to(torch.float16)
-    align = 16 // operand.element_size()
+    align = 4 if exact else 8
     padded = (num_feats + align - 1) // align * align
     if padded != num_feats:  # keep gathered rows 16-byte aligned
-        operand = torch.nn.functional.pad(operand, (0, padded - num_feats))
+        feat = torch.nn.functional.pad(feat, (0, padded - num_feats))
+    out_scale = None
+    if exact or feat.dtype == torch.float16:
+        operand = feat
+    else:
+        # fp32 -> fp16 with one power-of-two scale per call (undone in the kernel's epilogue): keeps fp32's range, which
+        # the reference's TF32 multiply has and a plain fp16 cast has not; on the stream, no host sync.
+        operand = torch.empty(feat.shape, dtype=torch.float16, device=feat.device)
+        out_scale = torch.empty(2, dtype=torch.float32, device=feat.device)
+        capi.launch_cast_f32_f16_scaled(feat, operand, out_scale, torch.cuda.current_stream().cuda_stream)
     output = torch.empty((num_nodes, padded), dtype=torch.float32, device=feat.device)
 
     spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes=num_nodes, num_edges=num_edges, embedding_dim=padded,
-                input=operand, output=output)
+                input=operand, output=output, out_scale=out_scale)
     return output if padded == num_feats else output[:, :num_feats].contiguous()
