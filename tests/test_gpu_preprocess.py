@@ -97,6 +97,35 @@ def test_non_square_universe_and_unstaged_window(cuda_device, path, monkeypatch)
         _check(handle, indptr, indices, n)
 
 
+def test_bitmap_path_with_several_column_ranges(cuda_device, monkeypatch):
+    """Universe of 1.3 M columns = 3 bitmap ranges of 2^19: columns clustered so that some ranges are empty for some
+    windows, partial TC blocks straddle range boundaries, one window exceeds the LDS stage inside a single range and
+    one window's columns all sit in the first range (pending partial block flushed at the end)."""
+    monkeypatch.setenv("VOLTRIX_CSR_PATH", "bitmap")
+    rng = np.random.default_rng(5)
+    ncols, nrows = 1_300_000, 80
+    deg = rng.integers(0, 60, nrows)
+    deg[0:16] = 700          # window 0: 11200 edges over all ranges (> 1024 blocks)
+    deg[16:32] = 0           # window 1: empty
+    rows = []
+    for r, d in enumerate(deg):
+        if 32 <= r < 48:     # window 2: first range only, odd number of distinct columns overall
+            rows.append(np.sort(rng.choice(500_000, d, replace=False)))
+        elif 48 <= r < 64:   # window 3: straddles the 2^19 and 2^20 boundaries tightly
+            rows.append(np.sort(rng.choice(np.arange(524_288 - 40, 524_288 + 40), min(d, 60), replace=False)))
+        else:
+            rows.append(np.sort(rng.choice(ncols, d, replace=False)))
+    indptr = np.concatenate([[0], np.cumsum([len(x) for x in rows])])
+    indices = np.concatenate(rows)
+    ip = torch.as_tensor(indptr, dtype=torch.int32).cuda()
+    ix = torch.as_tensor(indices, dtype=torch.int32).cuda()
+    handle = voltrix.csr_fused_preprocess_kernel(ip, ix, nrows, num_cols=ncols)[:3]
+    _check(handle, indptr, indices, nrows)
+    monkeypatch.setenv("VOLTRIX_CSR_PATH", "sort")
+    handle = voltrix.csr_fused_preprocess_kernel(ip, ix, nrows, num_cols=ncols)[:3]
+    _check(handle, indptr, indices, nrows)
+
+
 def test_low_level_kernel_wrappers_like_reference_test(cuda_device):
     """tests/test_spmm_kernel.py:45-113 flow with the four public *_kernel wrappers and caller-allocated buffers
     (hspa / hind pre-filled with garbage: the kernels must write every element)."""

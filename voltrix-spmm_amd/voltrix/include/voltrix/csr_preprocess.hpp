@@ -522,16 +522,26 @@ constexpr int kBmGrid = 4096;            // grid-strided; ~5 rounds of workgroup
 constexpr int kBmMaxCols = 1 << 19;      // 64 KiB bitmap + 16 KiB group prefixes + 16 KiB stage
 
 __host__ __device__ inline int bm_groups(int num_cols) { return (num_cols + 127) / 128; }   // 128 columns = uint4
-inline size_t bm_count_lds(int num_cols) { return (size_t)bm_groups(num_cols) * 16; }
-inline size_t bm_fill_lds(int num_cols) { return (size_t)bm_groups(num_cols) * 20 + kBmStageWords * 4; }
+inline size_t bm_count_lds(int num_cols) { return (size_t)bm_groups(num_cols < kBmMaxCols ? num_cols : kBmMaxCols) * 16; }
+inline size_t bm_fill_lds(int num_cols) {
+  return (size_t)bm_groups(num_cols < kBmMaxCols ? num_cols : kBmMaxCols) * 20 + kBmStageWords * 4;
+}
 
 __device__ __forceinline__ int popc4(const uint4 v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
 
 constexpr int kBmBatch = 8;  // independent global loads in flight per thread (the loops are latency-bound otherwise)
+constexpr int kBmSweeps = kBmMaxCols / 128 / kBmThreads;  // 128-column groups per thread in a full range
+static_assert(kBmSweeps * kBmThreads * 128 == kBmMaxCols, "range = whole sweeps");
 
+// Universes above kBmMaxCols are covered in column RANGES of kBmMaxCols: one bitmap pass per range, the distinct-column
+// count carried from range to range (the window's edges are re-read from L2 by every pass).
+__host__ __device__ inline int bm_range_cols(int num_cols) { return num_cols < kBmMaxCols ? num_cols : kBmMaxCols; }
+
+// marks bit (c - c0) for every edge of the window with c in [c0, c0 + range)
 template <bool COUNT_INVALID>
 __device__ __forceinline__ void bm_mark_window(uint32_t* bitmap, const int* __restrict__ indices, const long long lo,
-                                               const long long hi, const int num_cols, int* status) {
+                                               const long long hi, const int c0, const int range, const int num_cols,
+                                               int* status) {
   for (long long base = lo + threadIdx.x; base < hi; base += (long long)kBmBatch * kBmThreads) {
     int c[kBmBatch];
 #pragma unroll
@@ -542,8 +552,10 @@ __device__ __forceinline__ void bm_mark_window(uint32_t* bitmap, const int* __re
 #pragma unroll
     for (int k = 0; k < kBmBatch; ++k) {
       if (base + (long long)k * kBmThreads < hi) {
-        if ((unsigned)c[k] < (unsigned)num_cols) atomicOr(&bitmap[c[k] >> 5], 1u << (c[k] & 31));
-        else if (COUNT_INVALID) atomicAdd(status, 1);  // ids outside the column universe are skipped and reported
+        const unsigned rel = (unsigned)(c[k] - c0);
+        if (rel < (unsigned)range) atomicOr(&bitmap[rel >> 5], 1u << (rel & 31));
+        else if (COUNT_INVALID && c0 == 0 && (unsigned)c[k] >= (unsigned)num_cols)
+          atomicAdd(status, 1);  // ids outside the column universe are skipped and reported (once: first range)
       }
     }
   }
@@ -559,19 +571,24 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_count_kernel(con
   __shared__ int wave_cnt[kBmWaves];
   uint4* const bitmap4 = bm_lds;
   uint32_t* const bitmap = reinterpret_cast<uint32_t*>(bm_lds);
-  const int ng = bm_groups(num_cols);
+  const int range_cols = bm_range_cols(num_cols);
+  const int ng = bm_groups(range_cols);
   const int tid = threadIdx.x;
   for (int i = tid; i < ng; i += kBmThreads) bitmap4[i] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
   for (int w = blockIdx.x; w < num_windows; w += gridDim.x) {
     const long long r0 = (long long)w * kBlkH, r1 = r0 + kBlkH;
     const long long lo = indptr[r0 < num_nodes ? r0 : num_nodes], hi = indptr[r1 < num_nodes ? r1 : num_nodes];
-    bm_mark_window<true>(bitmap, indices, lo, hi, num_cols, status);
-    __syncthreads();
     int cnt = 0;
-    for (int i = tid; i < ng; i += kBmThreads) {  // count and clear in one sweep
-      cnt += popc4(bitmap4[i]);
-      bitmap4[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int c0 = 0; c0 < num_cols; c0 += range_cols) {
+      const int range = num_cols - c0 < range_cols ? num_cols - c0 : range_cols;
+      bm_mark_window<true>(bitmap, indices, lo, hi, c0, range, num_cols, status);
+      __syncthreads();
+      for (int i = tid; i < ng; i += kBmThreads) {  // count and clear in one sweep
+        cnt += popc4(bitmap4[i]);
+        bitmap4[i] = make_uint4(0u, 0u, 0u, 0u);
+      }
+      __syncthreads();
     }
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, kWave);
@@ -595,136 +612,208 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_fill_kernel(cons
                                                                      uint32_t* __restrict__ hspa_packed,
                                                                      int* __restrict__ hind) {
   extern __shared__ uint4 bm_lds[];
-  __shared__ int wave_tot[kBmWaves];
-  const int ng = bm_groups(num_cols);
+  __shared__ int wave_tot[kBmSweeps][kBmWaves];
+  const int range_cols = bm_range_cols(num_cols);
+  const int ng = bm_groups(range_cols);
   uint4* const bitmap4 = bm_lds;                                        // [ng]   128 columns per entry
   uint32_t* const bitmap = reinterpret_cast<uint32_t*>(bm_lds);
-  uint4* const stage4 = bm_lds + ng;                                    // [kBmStageWords / 4] packed words of the window
+  uint4* const stage4 = bm_lds + ng;                                    // [kBmStageBlocks] packed words of TC blocks
   uint32_t* const stage = reinterpret_cast<uint32_t*>(stage4);
-  int* const prefix = reinterpret_cast<int*>(stage4 + kBmStageWords / 4);  // [ng] distinct columns before the group
+  int* const prefix = reinterpret_cast<int*>(stage4 + kBmStageBlocks);  // [ng] distinct columns before the group
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
   const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
   for (int i = tid; i < ng; i += kBmThreads) bitmap4[i] = zero4;
-  for (int i = tid; i < kBmStageWords / 4; i += kBmThreads) stage4[i] = zero4;
+  for (int i = tid; i < kBmStageBlocks; i += kBmThreads) stage4[i] = zero4;
   __syncthreads();
 
   for (int w = blockIdx.x; w < num_windows; w += gridDim.x) {
-    const long long r0 = (long long)w * kBlkH;
     int rp[kBlkH + 1];  // wave-uniform row pointers of the window (scalar loads)
-#pragma unroll
-    for (int k = 0; k <= kBlkH; ++k) rp[k] = indptr[r0 + k < num_nodes ? r0 + k : num_nodes];
+    load_window_rowptr(indptr, w, num_nodes, rp);
     const long long lo = rp[0], hi = rp[kBlkH];
     const long long p0 = pointer1[w];
     const int nb = pointer1[w + 1] - (int)p0;
     uint4* const out4 = reinterpret_cast<uint4*>(hspa_packed) + p0;
-    bm_mark_window<false>(bitmap, indices, lo, hi, num_cols, nullptr);
-    __syncthreads();
+    int* const hind_w = hind + 8 * p0;
 
-    // scan the bitmap: group prefixes for the rank lookups, and hind = the set bits in ascending (= rank) order
-    int carry = 0;
-    for (int base = 0; base < ng; base += kBmThreads) {
-      const int i = base + tid;
-      const uint4 v = i < ng ? bitmap4[i] : zero4;
-      const int pc = popc4(v);
-      const int incl = wave_inclusive_scan(pc);
-      if (lane == kWave - 1) wave_tot[wv] = incl;
+    int carry = 0;    // distinct columns of the ranges before the current one
+    int flushed = 0;  // TC blocks of this window already written; block `flushed` starts at stage4[0]
+    for (int c0 = 0; c0 < num_cols; c0 += range_cols) {
+      const int range = num_cols - c0 < range_cols ? num_cols - c0 : range_cols;
+      const bool last_range = c0 + range_cols >= num_cols;
+      const int ngr = bm_groups(range);
+      bm_mark_window<false>(bitmap, indices, lo, hi, c0, range, num_cols, nullptr);
       __syncthreads();
-      int woff = 0, tot = 0;
-#pragma unroll
-      for (int k = 0; k < kBmWaves; ++k) {
-        woff += k < wv ? wave_tot[k] : 0;
-        tot += wave_tot[k];
+
+      // scan the bitmap: group prefixes for the rank lookups, and hind = the set bits in ascending (= rank) order.
+      // Group i = j * kBmThreads + tid belongs to sweep j; all sweeps are scanned behind ONE barrier.
+      const int sweeps = (ngr + kBmThreads - 1) / kBmThreads;  // <= kBmSweeps
+      for (int j = 0; j < sweeps; ++j) {
+        const int i = j * kBmThreads + tid;
+        const int pc = i < ngr ? popc4(bitmap4[i]) : 0;
+        const int incl = wave_inclusive_scan(pc);
+        if (i < ngr) prefix[i] = incl - pc;  // rank inside this wave's 64 groups; completed below
+        if (lane == kWave - 1) wave_tot[j][wv] = incl;
       }
-      const bool via_lds = tot <= kBmStageWords;  // workgroup-uniform: this sweep's columns fit the (zeroed) stage
-      if (i < ng) {
-        int r = carry + woff + incl - pc;
-        prefix[i] = r;
-        const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+      __syncthreads();
+      int seen = carry;
+      for (int j = 0; j < sweeps; ++j) {
+        int woff = 0, tot = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          uint32_t m = words[j];
-          while (m) {
-            const int b = __ffs(m) - 1;
-            m &= m - 1;
-            const int col = (i * 4 + j) * 32 + b;
-            if (via_lds) stage[r - carry] = (uint32_t)col; else hind[8 * p0 + r] = col;
-            ++r;
+        for (int k = 0; k < kBmWaves; ++k) {
+          const int t = wave_tot[j][k];
+          woff += k < wv ? t : 0;
+          tot += t;
+        }
+        const int i = j * kBmThreads + tid;
+        if (i < ngr) prefix[i] += seen + woff;
+        seen += tot;
+      }
+      const int new_carry = seen;
+      // hind: through LDS (coalesced copy-out) when the columns fit BEHIND the pending partial TC block (stage words
+      // 0-3) -- the whole range at once, else sweep by sweep, else straight to global memory.  Each thread reads back
+      // only its own prefix entries, so no barrier is needed before the emission.
+      constexpr int kSpare = kBmStageWords - 4;
+      auto sweep_total = [&](const int j) {
+        int tot = 0;
+#pragma unroll
+        for (int k = 0; k < kBmWaves; ++k) tot += wave_tot[j][k];
+        return tot;
+      };
+      auto emit = [&](const int j, const int stage_base) {  // stage_base < 0: global
+        const int i = j * kBmThreads + tid;
+        if (i < ngr) {
+          int r = prefix[i];
+          const uint4 v = bitmap4[i];
+          const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            uint32_t m = words[q];
+            while (m) {
+              const int b = __ffs(m) - 1;
+              m &= m - 1;
+              const int col = c0 + (i * 4 + q) * 32 + b;
+              if (stage_base >= 0) stage[4 + r - stage_base] = (uint32_t)col; else hind_w[r] = col;
+              ++r;
+            }
           }
         }
-      }
-      if (via_lds) {  // coalesced copy-out of this sweep's `tot` columns; the stage goes back to zero
+      };
+      auto copy_out = [&](const int first, const int count) {  // stage[4 .. 4 + count) -> hind_w[first ..); re-zero
         __syncthreads();
-        for (int k = tid; k < tot; k += kBmThreads) {
-          hind[8 * p0 + carry + k] = (int)stage[k];
-          stage[k] = 0u;
+        for (int k = tid; k < count; k += kBmThreads) {
+          hind_w[first + k] = (int)stage[4 + k];
+          stage[4 + k] = 0u;
         }
+        __syncthreads();
+      };
+      if (new_carry - carry <= kSpare) {
+        for (int j = 0; j < sweeps; ++j) emit(j, carry);
+        copy_out(carry, new_carry - carry);
+      } else {
+        int first = carry;
+        for (int j = 0; j < sweeps; ++j) {
+          const int tot = sweep_total(j);
+          if (tot <= kSpare) {
+            emit(j, first);
+            copy_out(first, tot);
+          } else {
+            emit(j, -1);
+          }
+          first += tot;
+        }
+        __syncthreads();
       }
-      carry += tot;
-      __syncthreads();
-    }
-    for (int k = carry + tid; k < 8 * nb; k += kBmThreads) hind[8 * p0 + k] = 0;  // unused slots of the last block
 
-    // every edge: rank of its column -> bit (row, rank) in the reference's swizzled word / bit position, OR-ed into the
-    // LDS stage and copied out once.  A window with more than kBmStageBlocks TC blocks takes one pass over its edges
-    // per kBmStageBlocks blocks (no global atomics, no fences; the edge list is re-read from L2).
-    for (int pass0 = 0; pass0 < nb; pass0 += kBmStageBlocks) {
-      const int pass_nb = nb - pass0 < kBmStageBlocks ? nb - pass0 : kBmStageBlocks;
-      for (long long base = lo + tid; base < hi; base += (long long)kBmBatch * kBmThreads) {
-        int cs[kBmBatch];
+      // every edge of the range: rank of its column -> bit (row, rank) in the reference's swizzled word / bit position,
+      // OR-ed into the LDS stage (TC blocks [pass0, pass0 + kBmStageBlocks)) and copied out once.  More blocks than the
+      // stage holds: one pass over the edges per stage-full (no global atomics, no fences; edges re-read from L2).
+      if (new_carry > carry) {
+        const int last_blk = (new_carry - 1) >> 3;
+        for (int pass0 = flushed;;) {
+          for (long long base = lo + tid; base < hi; base += (long long)kBmBatch * kBmThreads) {
+            int cs[kBmBatch];
 #pragma unroll
-        for (int k = 0; k < kBmBatch; ++k) {
-          const long long e = base + (long long)k * kBmThreads;
-          cs[k] = e < hi ? indices[e] : -1;
-        }
+            for (int k = 0; k < kBmBatch; ++k) {
+              const long long e = base + (long long)k * kBmThreads;
+              cs[k] = e < hi ? indices[e] : -1;
+            }
 #pragma unroll
-        for (int k = 0; k < kBmBatch; ++k) {
-          const long long e = base + (long long)k * kBmThreads;
-          const int c = cs[k];
-          if (e >= hi || (unsigned)c >= (unsigned)num_cols) continue;
-          const int g = c >> 7, wi = (c >> 5) & 3;
-          const uint4 v = bitmap4[g];
-          const uint32_t below = (1u << (c & 31)) - 1u;
-          const int rank = prefix[g] + __popc(v.x & (wi > 0 ? ~0u : (wi == 0 ? below : 0u))) +
-                           __popc(v.y & (wi > 1 ? ~0u : (wi == 1 ? below : 0u))) +
-                           __popc(v.z & (wi > 2 ? ~0u : (wi == 2 ? below : 0u))) + __popc(v.w & (wi == 3 ? below : 0u));
-          const int blk = (rank >> 3) - pass0;
-          if ((unsigned)blk >= (unsigned)kBmStageBlocks) continue;  // another pass owns this TC block
-          int rl = 0;
-#pragma unroll
-          for (int q = 1; q < kBlkH; ++q) rl += (rp[q] <= e) ? 1 : 0;  // local row of edge e
-          const int cc = rank & 7;
-          // reference bit order (bmat_kernels.cuh:180-188): word t = (r>>3) + 2*(c>>2), bit 4*(r&7) + (c&3)
-          atomicOr(&stage[4 * blk + (rl >> 3) + 2 * (cc >> 2)], 1u << (4 * (rl & 7) + (cc & 3)));
+            for (int k = 0; k < kBmBatch; ++k) {
+              const long long e = base + (long long)k * kBmThreads;
+              const unsigned rel = (unsigned)(cs[k] - c0);
+              if (e >= hi || rel >= (unsigned)range) continue;
+              const int g = rel >> 7, wi = (rel >> 5) & 3;
+              const uint4 v = bitmap4[g];
+              const uint32_t below = (1u << (rel & 31)) - 1u;
+              const int rank = prefix[g] + __popc(v.x & (wi > 0 ? ~0u : (wi == 0 ? below : 0u))) +
+                               __popc(v.y & (wi > 1 ? ~0u : (wi == 1 ? below : 0u))) +
+                               __popc(v.z & (wi > 2 ? ~0u : (wi == 2 ? below : 0u))) +
+                               __popc(v.w & (wi == 3 ? below : 0u));
+              const int blk = (rank >> 3) - pass0;
+              if ((unsigned)blk >= (unsigned)kBmStageBlocks) continue;  // another pass owns this TC block
+              const int rl = local_row(rp, (int)e);
+              const int cc = rank & 7;
+              // reference bit order (bmat_kernels.cuh:180-188): word t = (r>>3) + 2*(c>>2), bit 4*(r&7) + (c&3)
+              atomicOr(&stage[4 * blk + (rl >> 3) + 2 * (cc >> 2)], 1u << (4 * (rl & 7) + (cc & 3)));
+            }
+          }
+          __syncthreads();
+          const bool final_pass = pass0 + kBmStageBlocks > last_blk;
+          const int pass_end = final_pass ? last_blk + 1 : pass0 + kBmStageBlocks;  // blocks [pass0, pass_end) touched
+          // the last touched block is complete unless later ranges can still add columns to it
+          const int done_end = (final_pass && !last_range && (new_carry & 7)) ? pass_end - 1 : pass_end;
+          for (int i = tid; i < done_end - pass0; i += kBmThreads) {
+            out4[pass0 + i] = stage4[i];
+            stage4[i] = zero4;
+          }
+          __syncthreads();
+          if (done_end < pass_end && done_end > pass0) {  // keep the pending partial block at stage4[0]
+            if (tid == 0) {
+              stage4[0] = stage4[done_end - pass0];
+              stage4[done_end - pass0] = zero4;
+            }
+            __syncthreads();
+          }
+          flushed = done_end;
+          if (final_pass) break;
+          pass0 = flushed;
         }
       }
+      for (int i = tid; i < ngr; i += kBmThreads) bitmap4[i] = zero4;
+      carry = new_carry;
       __syncthreads();
-      for (int i = tid; i < pass_nb; i += kBmThreads) {
-        out4[pass0 + i] = stage4[i];
-        stage4[i] = zero4;
-      }
-      if (pass0 + kBmStageBlocks < nb) __syncthreads();  // the stage is reused by the next pass
     }
-    for (int i = tid; i < ng; i += kBmThreads) bitmap4[i] = zero4;
-    __syncthreads();
+    // at most one block is left: the pending partial block at stage4[0] when the ranges after it added nothing, or --
+    // no valid column at all -- the window's single all-zero TC block (reference quirk; the stage is zero then)
+    for (int i = flushed + tid; i < nb; i += kBmThreads) {
+      out4[i] = stage4[i - flushed];
+      stage4[i - flushed] = zero4;
+    }
+    for (int k = carry + tid; k < 8 * nb; k += kBmThreads) hind_w[k] = 0;  // unused slots of the last block
   }
 }
 
 // Path choice (the same in workspace_bytes / count / fill).  num_cols = the caller's column universe (every id is in
-// [0, num_cols); <= 0: unknown -> sort path).  Bitmap when the universe fits LDS and one sweep of num_cols / 32 words per
-// window is cheaper than sorting the window's edges.  VOLTRIX_CSR_PATH=sort|bitmap overrides (bitmap is honoured only
-// when 0 < num_cols <= kBmMaxCols).
+// [0, num_cols); <= 0: unknown -> sort path).  Bitmap when its sweeps (one per 2^19-column range) cost less than sorting
+// the window's edges.  VOLTRIX_CSR_PATH=sort|bitmap overrides (bitmap is honoured only when 0 < num_cols <= 2^25).
 inline bool csr_use_bitmap(int num_nodes, int num_cols, long long num_edges) {
-  if (num_cols > kBmMaxCols || num_cols <= 0 || num_nodes <= 0) return false;
+  if (num_cols <= 0 || num_nodes <= 0) return false;
+  const long long passes = ((long long)num_cols + kBmMaxCols - 1) / kBmMaxCols;  // column ranges per window
+  if (passes > 64) return false;
   if (const char* e = std::getenv("VOLTRIX_CSR_PATH")) {
     if (e[0] == 's') return false;
     if (e[0] == 'b') return true;
   }
   const long long W = ((long long)num_nodes + kBlkH - 1) / kBlkH;
   const double per_window = (double)num_edges / (double)W;       // mean edges per window
+  // rough per-window costs in LDS word operations: a bitmap pass sweeps its range's 128-column groups and touches every
+  // edge; the register sort of a window <= kWsKeys edges is cheap, the workgroup sort pays ~lg^2 / 2 sweeps of the keys
+  const double range_groups = (double)(num_cols < kBmMaxCols ? num_cols : kBmMaxCols) / 128.0;
+  const double bitmap_cost = (double)passes * (range_groups + per_window);
   double lg = 1.0;
   for (double x = 2.0; x < per_window; x *= 2.0) lg += 1.0;      // ~ log2
-  const double sort_passes = lg * (lg + 1.0) / 2.0;              // bitonic compare-exchange sweeps
-  return (double)num_cols / 32.0 <= per_window * (sort_passes > 4.0 ? sort_passes / 4.0 : 1.0);
+  const double sort_cost = per_window <= (double)kWsKeys ? 2.0 * per_window : per_window * lg * (lg + 1.0) / 8.0;
+  return bitmap_cost <= sort_cost;
 }
 
 template <class K>
