@@ -178,6 +178,33 @@ def test_fp32_features_with_inf_and_nan_do_not_disturb_the_rescale(cuda_device, 
     assert torch.allclose(out[clean], ref[clean], rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_operator_is_graph_capturable(cuda_device, dtype, monkeypatch):
+    """Launch-bound use (small graphs, many calls): after one warm call (tuner, module load) voltrix.spmm issues only
+    stream-ordered work -- cast (amax memset + 2 kernels), SpMM -- so it can be captured in a HIP graph and replayed
+    with new feature values in the same buffer."""
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    g = load_csr_fixture("cora_like")
+    n = int(g["num_nodes"])
+    handle = voltrix.csr_preprocess(torch.from_numpy(g["indptr"]), torch.from_numpy(g["indices"]), n)
+    handle[1].hash_tag = "cora_like"
+    torch.manual_seed(11)
+    feat = torch.randn(n, 32, device="cuda").to(dtype)
+    voltrix.spmm(*handle, num_nodes=n, num_edges=len(g["indices"]), feat=feat)  # warm: tuner + first launch
+    graph, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            out = voltrix.spmm(*handle, num_nodes=n, num_edges=len(g["indices"]), feat=feat)
+    torch.cuda.current_stream().wait_stream(side)
+    for scale in (1.0, -3.0):
+        feat.copy_((torch.randn(n, 32, device="cuda") * scale).to(dtype))
+        graph.replay()
+        torch.cuda.synchronize()
+        mode = "fp16" if dtype == torch.float16 else "fp16-scaled"
+        _assert_close(out, g["indptr"], g["indices"], feat.float().cpu(), n, mode)
+
+
 def test_every_output_row_is_written_and_empty_windows_are_zero(cuda_device):
     g = load_csr_fixture("toy40")  # rows 16..31 empty (one all-zero TC block), N % 16 = 8
     n, e = 40, len(g["indices"])
