@@ -100,6 +100,14 @@ void voltrix_launch_spmm_f16_tile(void* blk_offsets, void* hspa_packed, void* hi
                                   int embedding_dim, void* input, void* output, int fs, int depth, int waves,
                                   void* window_order, void* out_scale, void* stream, int* return_code);
 
+/* bfloat16 dense operand (extension; 8-bit mantissa, fp32's exponent range): input bfloat16 [*, embedding_dim], output
+ * float32, v_mfma_f32_16x16x32_bf16.  Same tiles, shapes and arguments as the fp16 entry points. */
+void voltrix_launch_spmm_bf16(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
+                              int embedding_dim, void* input, void* output, void* stream, int* return_code);
+void voltrix_launch_spmm_bf16_tile(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
+                                   int embedding_dim, void* input, void* output, int fs, int depth, int waves,
+                                   void* window_order, void* out_scale, void* stream, int* return_code);
+
 /* "Balance" schedule for a handle: order_out int32[W] (device) lists the windows of every XCD range, inside chunks of
  * `chunk` (1..4096) consecutive windows, by descending TC-block count, so that co-resident waves sweep their sorted
  * columns at a similar pace and share gathered rows through L2.  Depends on blk_offsets only; results of the SpMM are

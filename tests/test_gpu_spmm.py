@@ -53,7 +53,7 @@ def _assert_close(out, indptr, indices, feat32, n, mode):
         assert abs(oracle_np.calc_diff(out, ref)) <= 1e-5
 
 
-@pytest.mark.parametrize("dtype,mode", [(torch.float16, "fp16"), (torch.float32, "fp16-scaled"),
+@pytest.mark.parametrize("dtype,mode", [(torch.float16, "fp16"), (torch.bfloat16, "exact"), (torch.float32, "fp16-scaled"),
                                         (torch.float32, "exact")])
 def test_operator_api_on_fixtures(cuda_device, csr_fixture, dtype, mode, monkeypatch):
     monkeypatch.setenv("VOLTRIX_FP32_MODE", "exact" if mode == "exact" else "fp16")
@@ -63,8 +63,8 @@ def test_operator_api_on_fixtures(cuda_device, csr_fixture, dtype, mode, monkeyp
     handle = voltrix.csr_preprocess(torch.from_numpy(g["indptr"]), torch.from_numpy(g["indices"]), n)
     handle[1].hash_tag = f"fixture_{n}_{len(g['indices'])}"
     feat32 = torch.from_numpy(g["feat"]).float()
-    if dtype == torch.float16:
-        feat32 = feat32.half().float()  # the caller's data IS fp16
+    if dtype != torch.float32:
+        feat32 = feat32.to(dtype).float()  # the caller's data IS fp16 / bfloat16
     out = voltrix.spmm(*handle, num_nodes=n, num_edges=len(g["indices"]), feat=feat32.to(dtype).cuda())
     assert out.dtype == torch.float32 and out.shape == (n, feat32.shape[1]) and out.is_cuda
     _assert_close(out, g["indptr"], g["indices"], feat32, n, mode)
@@ -100,23 +100,23 @@ def _launch(handle, n, e, feat, is_f16, tile, stream=None, prefill=float("nan"))
     return rc, out
 
 
-@pytest.mark.parametrize("is_f16", [True, False])
-def test_every_ahead_of_time_tile_through_the_c_abi(cuda_device, is_f16):
+@pytest.mark.parametrize("kind", ["f16", "bf16", "f32"])
+def test_every_ahead_of_time_tile_through_the_c_abi(cuda_device, kind):
     g = load_csr_fixture("skewed_1005")  # N % 16 = 13, empty rows, windows from 1 to >100 TC blocks
     n, e = int(g["num_nodes"]), len(g["indices"])
     handle = voltrix.csr_fused_preprocess_kernel(torch.from_numpy(g["indptr"]).cuda(),
                                                  torch.from_numpy(g["indices"]).cuda(), n)[:3]
     feat32 = torch.randn(n, 136)  # 136 = 128 + 8: slab tail for every FS
-    if is_f16:
-        feat32 = feat32.half().float()
-    dev_feat = (feat32.half() if is_f16 else feat32).cuda()
-    tiles = capi.tiles(is_f16)
+    dtype = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[kind]
+    feat32 = feat32.to(dtype).float()       # the caller's data IS of the operand type: no operand rounding left
+    dev_feat = feat32.to(dtype).cuda()
+    tiles = capi.tiles(kind != "f32")
     assert len(tiles) >= 20
     for tile in tiles:
-        rc, out = _launch(handle, n, e, dev_feat, is_f16, tile)
+        rc, out = _launch(handle, n, e, dev_feat, {"f16": True, "bf16": "bf16", "f32": False}[kind], tile)
         torch.cuda.synchronize()
         assert rc == 0, tile
-        _assert_close(out, g["indptr"], g["indices"], feat32, n, "fp16" if is_f16 else "exact")
+        _assert_close(out, g["indptr"], g["indices"], feat32, n, "exact")  # only fp32 accumulation-order error
 
 
 @pytest.mark.parametrize("num_feats", [8, 24, 32, 40, 64, 100, 128, 200, 256, 512])

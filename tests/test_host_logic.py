@@ -38,8 +38,9 @@ def test_tile_space_is_valid_and_bounded(monkeypatch):
                     assert spmm_mod._lds_bytes(p["FS"], p["DEPTH"], p["WAVES"], p["EB"]) <= 160 * 1024
                     assert p["EB"] == eb and p["FS"] in (32, 64, 128, 256) and p["SCHED"] in (0, 1, 2, 3)
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
-    assert spmm_mod.tile_space(128, 2) == ({"FS": 64, "DEPTH": 3, "WAVES": 4, "EB": 2, "SCHED": 2},)
-    assert spmm_mod.tile_space(16, 4) == ({"FS": 32, "DEPTH": 3, "WAVES": 1, "EB": 4, "SCHED": 2},)
+    assert spmm_mod.tile_space(128, 2) == ({"FS": 64, "DEPTH": 3, "WAVES": 4, "EB": 2, "SCHED": 2, "BF16": 0},)
+    assert spmm_mod.tile_space(128, 2, bf16=True) == ({"FS": 64, "DEPTH": 3, "WAVES": 4, "EB": 2, "SCHED": 2, "BF16": 1},)
+    assert spmm_mod.tile_space(16, 4) == ({"FS": 32, "DEPTH": 3, "WAVES": 1, "EB": 4, "SCHED": 2, "BF16": 0},)
 
 
 def test_feature_hash_uses_tag_then_address():

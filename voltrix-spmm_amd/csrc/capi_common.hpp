@@ -54,12 +54,12 @@ inline bool tile_at(int index, TileId* out) {
   return false;
 }
 
-template <int FS, int D, int W, int EB, class In>
+template <int FS, int D, int W, int EB, class In, bool BF16 = false>
 inline int launch_if_ok(const int* blk_offsets, const uint32_t* hspa_packed, const int* hind, int num_nodes,
                         int embedding_dim, const In* input, float* output, hipStream_t stream, const int* order,
                         const float* out_scale) {
   if constexpr (tile_ok<FS, D, W, EB>()) {
-    return voltrix::launch_spmm_tc16<voltrix::SpmmTile<FS, D, W, EB>>(blk_offsets, hspa_packed, hind, num_nodes,
+    return voltrix::launch_spmm_tc16<voltrix::SpmmTile<FS, D, W, EB, BF16>>(blk_offsets, hspa_packed, hind, num_nodes,
                                                                        embedding_dim, input, output, stream, order,
                                                                        out_scale);
   } else {
@@ -67,13 +67,13 @@ inline int launch_if_ok(const int* blk_offsets, const uint32_t* hspa_packed, con
   }
 }
 
-template <int EB, class In>
+template <int EB, class In, bool BF16 = false>
 inline int dispatch_spmm(int fs, int depth, int waves, const int* blk_offsets, const uint32_t* hspa_packed,
                          const int* hind, int num_nodes, int embedding_dim, const In* input, float* output,
                          hipStream_t stream, const int* order, const float* out_scale = nullptr) {
 #define X(FS, D, W)                                  \
   if (fs == FS && depth == D && waves == W)          \
-    return launch_if_ok<FS, D, W, EB, In>(blk_offsets, hspa_packed, hind, num_nodes, embedding_dim, input, output, stream, order, out_scale);
+    return launch_if_ok<FS, D, W, EB, In, BF16>(blk_offsets, hspa_packed, hind, num_nodes, embedding_dim, input, output, stream, order, out_scale);
   VOLTRIX_TILE_SPACE(X)
 #undef X
   return voltrix::kErrBadConfig;

@@ -32,6 +32,8 @@ SYMBOLS = (
     "voltrix_spmm_num_tiles",
     "voltrix_spmm_tile_at",
     "voltrix_launch_window_order",
+    "voltrix_launch_spmm_bf16",
+    "voltrix_launch_spmm_bf16_tile",
     "voltrix_launch_cast_f32_f16",
     "voltrix_launch_cast_f32_f16_scaled",
     "voltrix_csr_preprocess_workspace_bytes",
@@ -126,7 +128,10 @@ def launch_spmm(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
     the schedule written by :func:`launch_window_order`; ``out_scale`` is 0 or the device pointer of the float written
     by :func:`launch_cast_f32_f16_scaled`.  Returns the return code."""
     rc = ctypes.c_int(-1)
-    fn = lib().voltrix_launch_spmm_f16_tile if is_f16 else lib().voltrix_launch_spmm_f32_tile
+    if is_f16 == "bf16":  # operand kind: True = fp16, False = fp32, "bf16" = bfloat16 (same tiles as fp16)
+        fn = lib().voltrix_launch_spmm_bf16_tile
+    else:
+        fn = lib().voltrix_launch_spmm_f16_tile if is_f16 else lib().voltrix_launch_spmm_f32_tile
     fn(ctypes.c_void_p(blk_offsets), ctypes.c_void_p(hspa_packed), ctypes.c_void_p(hind), ctypes.c_int(num_nodes),
        ctypes.c_int(num_edges), ctypes.c_int(embedding_dim), ctypes.c_void_p(input_ptr), ctypes.c_void_p(output_ptr),
        ctypes.c_int(tile[0]), ctypes.c_int(tile[1]), ctypes.c_int(tile[2]), ctypes.c_void_p(window_order),

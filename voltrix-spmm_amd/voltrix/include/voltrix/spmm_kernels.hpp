@@ -49,6 +49,8 @@
 namespace voltrix {
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef uint16_t bfloat16_bits;  // bfloat16 storage type of the dense operand (pointer arithmetic only)
 typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
 typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
@@ -142,7 +144,8 @@ __device__ __forceinline__ float lds_read_f32(unsigned addr) {
 
 template <class T>
 struct SpmmArgs {
-  using in_t = typename std::conditional<T::EB == 2, _Float16, float>::type;
+  using in_t = typename std::conditional<T::EB == 4, float,
+                                         typename std::conditional<T::BF16, bfloat16_bits, _Float16>::type>::type;
   const int* blk_offsets;        // [W+1]  (reference Pointer1)
   const uint32_t* hspa_packed;   // [4T]   swizzled bitmaps
   const int* hind;               // [8T]   condensed column -> row of B
@@ -157,7 +160,7 @@ struct SpmmArgs {
   const float* out_scale;        // optional device scalar multiplied into every output (cast_f32_to_f16_scaled); nullptr = 1
 };
 
-// One wave64 = one (row window, FS-column slab) unit.  EB == 2: fp16 operand, v_mfma_f32_16x16x32_f16.
+// One wave64 = one (row window, FS-column slab) unit.  EB == 2: fp16 (or bfloat16) operand, v_mfma_f32_16x16x32_f16 (_bf16).
 // EB == 4: fp32 operand, exact products on v_mfma_f32_16x16x4_f32 (k-step m of a stage uses LDS rows 4m + lane/16).
 template <class T>
 static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const SpmmArgs<T> a) {
@@ -377,7 +380,12 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
           const uint4_t bq = {blo[s][0], blo[s][1], bhi[s][0], bhi[s][1]};
-          acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, __builtin_bit_cast(half8_t, bq), acc[s], 0, 0, 0);
+          // 2.0 is 0x4000 in fp16 AND in bfloat16, so the A fragment is the same bits for both operand types
+          if constexpr (T::BF16)
+            acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, afrag),
+                                                             __builtin_bit_cast(bf16x8_t, bq), acc[s], 0, 0, 0);
+          else
+            acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, __builtin_bit_cast(half8_t, bq), acc[s], 0, 0, 0);
         }
       } else {
         // A: k-step m covers condensed columns 4m+g: TC block m>>1, column 4(m&1)+g -> word 2(m&1) + R>>3, bit
@@ -471,8 +479,8 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
 // Host launcher for one tile configuration.
 template <class T>
 inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed, const int* hind, int num_nodes,
-                            int embedding_dim, const typename SpmmArgs<T>::in_t* input, float* output,
-                            hipStream_t stream, const int* window_order = nullptr,
+                            int embedding_dim, const void* input /* SpmmArgs<T>::in_t[rows][embedding_dim] */,
+                            float* output, hipStream_t stream, const int* window_order = nullptr,
                             const float* out_scale = nullptr) {
   if (num_nodes < 0 || embedding_dim < 0) return kErrBadShape;
   if (num_nodes == 0 || embedding_dim == 0) return kOk;
@@ -482,7 +490,7 @@ inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed,
   a.blk_offsets = blk_offsets;
   a.hspa_packed = hspa_packed;
   a.hind = hind;
-  a.input = input;
+  a.input = static_cast<const typename SpmmArgs<T>::in_t*>(input);
   a.output = output;
   a.num_nodes = num_nodes;
   a.num_windows = (num_nodes + kBlkH - 1) / kBlkH;

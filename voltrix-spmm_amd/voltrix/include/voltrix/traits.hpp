@@ -38,12 +38,15 @@ enum ReturnCode : int {
 //   WAVES  waves per workgroup (each wave owns its (row window, slab) unit; no barriers)
 //   EB     bytes per element of the dense operand in LDS: 2 (fp16, v_mfma_f32_16x16x32_f16) or
 //          4 (fp32, exact v_mfma_f32_16x16x4_f32)
-template <int FS_, int DEPTH_, int WAVES_, int EB_ = 2>
+//   BF16   EB == 2 only: the 16-bit operand is bfloat16 (v_mfma_f32_16x16x32_bf16) instead of fp16
+template <int FS_, int DEPTH_, int WAVES_, int EB_ = 2, bool BF16_ = false>
 struct SpmmTile {
   static constexpr int FS = FS_;
   static constexpr int DEPTH = DEPTH_;
   static constexpr int WAVES = WAVES_;
   static constexpr int EB = EB_;
+  static constexpr bool BF16 = BF16_;
+  static_assert(!BF16 || EB == 2, "bfloat16 is a 2-byte operand");
   static_assert(FS == 32 || FS == 64 || FS == 128 || FS == 256, "feature slab");
   static_assert(EB == 2 || EB == 4, "element bytes");
   static_assert(DEPTH >= 2 && DEPTH <= 6, "ring depth");

@@ -29,19 +29,19 @@ def jobs(feature_widths=(32, 64, 128), modes=("default", "none")):
                 bmat_swizzle: "hmat_packed_swizzle_kernel"}[mod]
         out.append((name, mod.arg_defs, generate(mod.includes, mod.arg_defs, mod.template)))
     seen = set()
-    for dtype, eb in ((torch.float16, 2), (torch.float32, 4)):
+    for dtype, eb in ((torch.float16, 2), (torch.bfloat16, 2), (torch.float32, 4)):
         for width in feature_widths:
             points = []
             saved = os.environ.get("VOLTRIX_TUNE_SPACE")
             for mode in modes:  # the tuned space and the single default tile (VOLTRIX_TUNE_SPACE=none)
                 os.environ["VOLTRIX_TUNE_SPACE"] = mode
-                points += list(spmm.tile_space(width, eb))
+                points += list(spmm.tile_space(width, eb, dtype == torch.bfloat16))
             if saved is None:
                 os.environ.pop("VOLTRIX_TUNE_SPACE", None)
             else:
                 os.environ["VOLTRIX_TUNE_SPACE"] = saved
             for point in points:
-                key = (eb, point["FS"], point["DEPTH"], point["WAVES"], point["SCHED"])
+                key = (eb, point["BF16"], point["FS"], point["DEPTH"], point["WAVES"], point["SCHED"])
                 if key in seen:
                     continue
                 seen.add(key)

@@ -16,7 +16,7 @@ from .tuner import jit_tuner
 
 includes = ('"voltrix/spmm_kernels.hpp"',)
 template = """
-__return_code = voltrix::launch_spmm_tc16<voltrix::SpmmTile<{FS}, {DEPTH}, {WAVES}, {EB}>>(
+__return_code = voltrix::launch_spmm_tc16<voltrix::SpmmTile<{FS}, {DEPTH}, {WAVES}, {EB}, {BF16} != 0>>(
     blk_offsets, hspa_packed, hind,
     num_nodes, embedding_dim, input, output, stream,
     {SCHED} == 0 ? nullptr : ({SCHED} == 1 ? win_order_a : ({SCHED} == 2 ? win_order_b : win_order_c)), out_scale);
@@ -45,8 +45,12 @@ def _lds_bytes(fs, depth, waves, eb):
     return waves * (depth * 32 * fs * eb + (2 * depth + 1) * 256)
 
 
-def tile_space(embedding_dim: int, elem_bytes: int):
-    """Points of the tile space worth trying for this feature width."""
+def tile_space(embedding_dim: int, elem_bytes: int, bf16: bool = False):
+    """Points of the tile space worth trying for this feature width (``bf16``: the 2-byte operand is bfloat16)."""
+    return tuple(dict(point, BF16=int(bf16)) for point in _tile_space(embedding_dim, elem_bytes))
+
+
+def _tile_space(embedding_dim: int, elem_bytes: int):
     mode = os.getenv(TUNE_SPACE_FLAG, "default")
     fs_max = 128
     fs_fit = 32 if embedding_dim <= 32 else (64 if embedding_dim <= 64 else fs_max)
@@ -109,7 +113,7 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
     assert blk_offsets.is_cuda and blk_offsets.dtype == torch.int32
     assert hspa_packed.is_cuda and hspa_packed.dtype == torch.uint32
     assert hind.is_cuda and hind.dtype == torch.int32
-    assert input.is_cuda and input.dtype in (torch.float, torch.float16) and input.is_contiguous()
+    assert input.is_cuda and input.dtype in (torch.float, torch.float16, torch.bfloat16) and input.is_contiguous()
     assert output.is_cuda and output.dtype == torch.float and output.is_contiguous()
     assert input.dim() == 2 and input.shape[1] == embedding_dim
     assert output.shape[0] == num_nodes and output.shape[1] == embedding_dim
@@ -130,7 +134,7 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
             "dtype": str(input.dtype),
             "device": torch.cuda.get_device_name(input.device),
         },
-        space=tile_space(embedding_dim, elem_bytes),
+        space=tile_space(embedding_dim, elem_bytes, input.dtype == torch.bfloat16),
         includes=includes,
         arg_defs=(
             ("blk_offsets", blk_offsets.dtype),

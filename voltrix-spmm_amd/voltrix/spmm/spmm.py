@@ -69,15 +69,15 @@ def spmm(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tenso
          feat: torch.Tensor):
     """``csr(ones) @ feat`` -> new float32 ``[num_nodes, F]`` on ``feat.device``, on the current stream.
 
-    ``feat``: CUDA, 2-D, contiguous; float32 (the reference's only dtype, jit_kernels/spmm.py:53) or float16
-    (BASELINE.json's headline).  float32 is rounded to fp16 for the MFMA -- the same 10-bit mantissa as the
+    ``feat``: CUDA, 2-D, contiguous; float32 (the reference's only dtype, jit_kernels/spmm.py:53), float16
+    (BASELINE.json's headline) or bfloat16.  float32 is rounded to fp16 for the MFMA -- the same 10-bit mantissa as the
     reference's TF32 rounding (spmm_kernels.cuh:1671), after a per-call power-of-two rescale that keeps fp32's range --
     unless ``VOLTRIX_FP32_MODE=exact``, which keeps exact fp32 products.  Every output row is written, including the ``num_nodes % 16`` tail the reference skips.
     """
     assert feat.is_cuda and feat.dim() == 2
     feat = feat.contiguous()
     num_feats = feat.shape[1]
-    assert feat.dtype in (torch.float32, torch.float16), f"unsupported feature dtype {feat.dtype}"
+    assert feat.dtype in (torch.float32, torch.float16, torch.bfloat16), f"unsupported feature dtype {feat.dtype}"
 
     exact = feat.dtype == torch.float32 and os.getenv(FP32_MODE_FLAG, "fp16") == "exact"
     align = 4 if exact else 8
@@ -85,7 +85,7 @@ def spmm(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tenso
     if padded != num_feats:  # keep gathered rows 16-byte aligned
         feat = torch.nn.functional.pad(feat, (0, padded - num_feats))
     out_scale = None
-    if exact or feat.dtype == torch.float16:
+    if exact or feat.dtype in (torch.float16, torch.bfloat16):
         operand = feat
     else:
         # fp32 -> fp16 with one power-of-two scale per call (undone in the kernel's epilogue): keeps fp32's range, which
