@@ -123,6 +123,28 @@ void voltrix_launch_spmm_f16_list(void* hspa_packed, void* hind, int num_nodes, 
                                   void* output, void* entries, void* wave_ptr, int num_waves, int fs, int depth,
                                   int groups, void* stream, int* return_code);
 
+/* Panel kernel: the shared-column half of the two-level condensed format (spmm_panel_kernels.hpp; no reference
+ * counterpart).  A panel = waves * row_blocks * 16 consecutive rows; per panel the plan lists the columns referenced by
+ * several of its rows, cut into k-steps of 32:
+ *   panel_ptr  int32 [NP+1]                  first k-step of every panel, S = panel_ptr[NP]
+ *   panel_cols int32 [32 * (S + 2)]          row of `input` per (k-step, k); unused slots repeat a real column; 2 k-steps
+ *                                            of padding (valid row ids) at the end
+ *   panel_bits uint32 [(S + 1) * waves * 64] word (k-step, wave v, lane 16 g + R), byte j, bit c <=> edge (row
+ *                                            16 (row_blocks v + j) + R of the panel, column 8 g + c of the k-step)
+ *   panel_order int32 [NP] or NULL           launch position -> panel
+ * output [num_nodes, embedding_dim] float32: accumulate != 0 adds onto it (the window kernel's result for the remaining
+ * edges), accumulate == 0 overwrites every row.  input _Float16 (bfloat16 for _bf16) [*, embedding_dim], 16-byte
+ * aligned, embedding_dim % 8 == 0.  Tile: fs in {32,64,128}, depth = ring slots, ksteps per ring slot in {1,2};
+ * VOLTRIX_ERR_BAD_CONFIG if the combination is not instantiated.  out_scale as for voltrix_launch_spmm_f16_tile. */
+void voltrix_launch_spmm_panel_f16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order,
+                                   int num_nodes, int embedding_dim, void* input, void* output, int accumulate, int fs,
+                                   int depth, int waves, int row_blocks, int ksteps, void* out_scale, void* stream,
+                                   int* return_code);
+void voltrix_launch_spmm_panel_bf16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order,
+                                    int num_nodes, int embedding_dim, void* input, void* output, int accumulate, int fs,
+                                    int depth, int waves, int row_blocks, int ksteps, void* out_scale, void* stream,
+                                    int* return_code);
+
 /* Default tile for a feature width; is_f16 selects the operand type.  Always succeeds. */
 void voltrix_spmm_default_tile(int embedding_dim, int is_f16, int* fs, int* depth, int* waves);
 

@@ -243,3 +243,83 @@ def forward_error_bound(indptr, indices, feat, num_nodes, rounding="fp16"):
     deg = np.diff(np.asarray(indptr, dtype=np.int64))[:num_nodes].astype(np.float64)
     aabs = spmm_csr(indptr, indices, np.abs(np.asarray(feat, dtype=np.float64)), num_nodes)
     return (u + deg[:, None] * 2.0 ** -24) * aabs + 1e-30
+
+
+# --------------------------------------------------------------------------- two-level format (no reference counterpart)
+# The panel plan is this build's own extension (voltrix/hybrid.py, spmm_panel_kernels.hpp); these functions state its
+# DEFINITION with plain loops, so that the device builder is checked bit for bit and the panel kernel is checked
+# against an interpreter written from the consumer side of the layout.  The numerical oracle stays the reference's:
+# csr(ones) @ feat on the FULL matrix (torch_ref.spmm).
+def panel_split(indptr, indices, num_nodes, panel_rows, tau):
+    """-> ``(resid_indptr int32, resid_indices int32, shared)`` with ``shared[p]`` = sorted list of
+    ``(col, [rows in panel, ascending])`` for the columns referenced by >= tau distinct rows of panel p.
+    Duplicate (row, col) entries count once (reference quirk 5)."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    indices = np.asarray(indices, dtype=np.int64)
+    num_panels = (num_nodes + panel_rows - 1) // panel_rows
+    shared = []
+    r_rows = [[] for _ in range(num_nodes)]
+    for p in range(num_panels):
+        r0, r1 = p * panel_rows, min((p + 1) * panel_rows, num_nodes)
+        users = {}
+        for r in range(r0, r1):
+            for c in sorted(set(indices[indptr[r]:indptr[r + 1]].tolist())):
+                users.setdefault(c, []).append(r - r0)
+        sh = []
+        for c in sorted(users):
+            if len(users[c]) >= tau:
+                sh.append((c, users[c]))
+            else:
+                for rp in users[c]:
+                    r_rows[r0 + rp].append(c)
+        shared.append(sh)
+    resid_indptr = np.zeros(num_nodes + 1, dtype=np.int32)
+    resid_indices = []
+    for r in range(num_nodes):
+        cs = sorted(r_rows[r])
+        resid_indices.extend(cs)
+        resid_indptr[r + 1] = len(resid_indices)
+    return resid_indptr, np.asarray(resid_indices, dtype=np.int32), shared
+
+
+def panel_plan(indptr, indices, num_nodes, waves, row_blocks, tau):
+    """-> ``(resid_indptr, resid_indices, panel_ptr int32 [NP+1], panel_cols int32 [32 (S+2)], panel_bits uint32
+    [(S+1) waves 64])`` -- the layout documented in spmm_panel_kernels.hpp / include/voltrix_capi.h."""
+    panel_rows = waves * row_blocks * 16
+    resid_indptr, resid_indices, shared = panel_split(indptr, indices, num_nodes, panel_rows, tau)
+    panel_ptr = np.zeros(len(shared) + 1, dtype=np.int32)
+    for p, sh in enumerate(shared):
+        panel_ptr[p + 1] = panel_ptr[p] + (len(sh) + 31) // 32
+    s_total = int(panel_ptr[-1])
+    panel_cols = np.zeros(32 * (s_total + 2), dtype=np.int32)
+    panel_bits = np.zeros((s_total + 1) * waves * 64, dtype=np.uint32)
+    for p, sh in enumerate(shared):
+        base = int(panel_ptr[p])
+        if sh:
+            panel_cols[32 * base:32 * int(panel_ptr[p + 1])] = sh[0][0]  # unused slots repeat the first shared column
+        for rank, (c, rows) in enumerate(sh):
+            ks, k = base + rank // 32, rank % 32
+            panel_cols[32 * ks + k] = c
+            for rp in rows:
+                v, j, r16 = rp // (16 * row_blocks), (rp % (16 * row_blocks)) // 16, rp % 16
+                panel_bits[(ks * waves + v) * 64 + (k // 8) * 16 + r16] |= np.uint32(1 << (8 * j + k % 8))
+    return resid_indptr, resid_indices, panel_ptr, panel_cols, panel_bits
+
+
+def panel_to_edges(panel_ptr, panel_cols, panel_bits, num_nodes, waves, row_blocks):
+    """Consumer-side interpreter of the plan (what spmm_panel_kernel multiplies): sorted list of (row, col)."""
+    panel_rows = waves * row_blocks * 16
+    edges = []
+    for p in range(len(panel_ptr) - 1):
+        for ks in range(int(panel_ptr[p]), int(panel_ptr[p + 1])):
+            for v in range(waves):
+                for lane in range(64):
+                    word = int(panel_bits[(ks * waves + v) * 64 + lane])
+                    g, r16 = lane >> 4, lane & 15
+                    for j in range(row_blocks):
+                        for c in range(8):
+                            if (word >> (8 * j + c)) & 1:
+                                row = p * panel_rows + 16 * (row_blocks * v + j) + r16
+                                assert row < num_nodes
+                                edges.append((row, int(panel_cols[32 * ks + 8 * g + c])))
+    return sorted(edges)

@@ -1,0 +1,109 @@
+"""GPU: two-level format (panel kernel + window kernel) against the oracle.
+
+The numerical oracle is the reference's own: ``csr(ones) @ feat`` on the CPU (torch_ref.spmm) for the FULL matrix; the
+panel kernel alone is checked against the same oracle on the edges the plan's consumer-side interpreter
+(oracle_np.panel_to_edges) reads out of the plan.  Tolerances as in test_gpu_spmm.py (fp16 operand: element-wise
+(2^-11 + deg 2^-23)(A|B|) + deg 2^-25, norm-wise 1e-3; same-rounded operand: deg 2^-23 (A|B|))."""
+import numpy as np
+import pytest
+import torch
+
+import synth_graphs
+import voltrix
+from oracle import oracle_np, torch_ref
+from test_gpu_spmm import _assert_close
+from test_hybrid_plan import _random_csr
+from voltrix import hybrid
+
+pytestmark = pytest.mark.gpu
+
+# (waves, row_blocks, (fs, depth, ksteps), F)
+PANEL_CASES = [
+    (8, 4, (128, 6, 1), 128), (8, 4, (128, 4, 1), 256), (8, 4, (128, 8, 1), 128), (4, 4, (128, 6, 1), 128),
+    (8, 2, (128, 6, 1), 128), (4, 2, (128, 6, 1), 384), (4, 4, (64, 6, 1), 64), (8, 4, (64, 6, 2), 64),
+    (4, 4, (64, 6, 2), 128), (4, 4, (32, 6, 2), 32), (8, 4, (32, 6, 2), 32), (8, 4, (128, 6, 1), 96),
+]
+
+
+def _edges_to_csr(edges, n):
+    indptr = np.zeros(n + 1, np.int32)
+    for r, _ in edges:
+        indptr[r + 1] += 1
+    indptr = np.cumsum(indptr).astype(np.int32)
+    return indptr, np.asarray([c for _, c in edges], np.int32)
+
+
+@pytest.mark.parametrize("waves,rb,tile,feat_dim", PANEL_CASES)
+def test_panel_kernel_alone(cuda_device, waves, rb, tile, feat_dim):
+    n = 1100  # several panels + a partial one; per-panel k-step counts from 0 to > depth
+    indptr, indices = _random_csr(n, 90, seed=waves + rb + feat_dim)
+    indptr[300:513] = indptr[300]  # a stretch of empty rows is dropped below by rebuilding the CSR
+    _, _, plan = hybrid.build_panel_plan(torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda(), n, None, waves,
+                                         rb, 2)
+    shared = oracle_np.panel_to_edges(plan.panel_ptr.cpu().numpy(), plan.panel_cols.cpu().numpy(),
+                                      plan.panel_bits.view(torch.int32).cpu().numpy().view(np.uint32), n, waves, rb)
+    s_indptr, s_indices = _edges_to_csr(shared, n)
+    torch.manual_seed(feat_dim)
+    feat = torch.randn(n, feat_dim).half()
+    out = torch.full((n, feat_dim), 7.0, dtype=torch.float32, device=cuda_device)
+    hybrid.launch_panel(plan, feat.cuda(), out, accumulate=False, tile=tile)     # overwrite: every row written
+    _assert_close(out, s_indptr, s_indices, feat.float(), n, "fp16")
+    prior = torch.randn(n, feat_dim, device=cuda_device)
+    out2 = prior.clone()
+    hybrid.launch_panel(plan, feat.cuda(), out2, accumulate=True, tile=tile)     # accumulate: prior + the same product
+    assert torch.equal(out2, prior + out)
+
+
+@pytest.mark.parametrize("dtype,mode", [(torch.float16, "fp16"), (torch.bfloat16, "exact"), (torch.float32, "fp16-scaled")])
+@pytest.mark.parametrize("feat_dim", [32, 128, 200])
+def test_hybrid_operator(cuda_device, dtype, mode, feat_dim, monkeypatch):
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    indptr_t, indices_t, _ = synth_graphs.generate("reddit_like", scale=0.006)
+    n = indptr_t.numel() - 1
+    handle = voltrix.csr_preprocess_hybrid(indptr_t, indices_t, n, tau=40)  # small graph, dense panels: a high bar
+    plan = handle[1].panel_plan                                              # leaves edges on both sides
+    assert plan.num_shared_edges > 0 and plan.num_resid_edges > 0
+    handle[1].hash_tag = f"hybrid_{n}"
+    torch.manual_seed(1)
+    feat32 = torch.randn(n, feat_dim)
+    if dtype != torch.float32:
+        feat32 = feat32.to(dtype).float()
+    out = voltrix.spmm(*handle, num_nodes=n, num_edges=indices_t.numel(), feat=feat32.to(dtype).cuda())
+    assert out.shape == (n, feat_dim) and out.dtype == torch.float32
+    _assert_close(out, indptr_t.numpy(), indices_t.numpy(), feat32, n, mode)
+
+
+def test_hybrid_env_switch_and_fixtures(cuda_device, csr_fixture, monkeypatch):
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    monkeypatch.setenv("VOLTRIX_HYBRID", "1")
+    g = csr_fixture
+    n = int(g["num_nodes"])
+    handle = voltrix.csr_preprocess(torch.from_numpy(g["indptr"]), torch.from_numpy(g["indices"]), n)
+    assert hasattr(handle[1], "panel_plan")
+    handle[1].hash_tag = f"hybrid_fixture_{n}"
+    feat32 = torch.from_numpy(g["feat"]).float().half().float()
+    out = voltrix.spmm(*handle, num_nodes=n, num_edges=len(g["indices"]), feat=feat32.half().cuda())
+    _assert_close(out, g["indptr"], g["indices"], feat32, n, "fp16")
+
+
+def test_hybrid_full_size_properties(cuda_device, monkeypatch):
+    """reddit-like at a quarter of the full size: A.1 = degree exactly, exact on small integers (every partial sum is an
+    integer below 2^24), and the hybrid result equals the window-format result to accumulation order."""
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    indptr, indices, _ = synth_graphs.generate("reddit_like", device="cuda", scale=0.25)
+    n = indptr.numel() - 1
+    indptr_c, indices_c = indptr.cpu(), indices.cpu()
+    hyb = voltrix.csr_preprocess_hybrid(indptr_c, indices_c, n)
+    hyb[1].hash_tag = "hybrid_quarter"
+    plan = hyb[1].panel_plan
+    assert plan.num_shared_edges + plan.num_resid_edges == indices.numel()
+    ones = torch.ones(n, 128, dtype=torch.float16, device=cuda_device)
+    deg = (indptr[1:] - indptr[:-1]).float()
+    out = voltrix.spmm(*hyb, num_nodes=n, num_edges=indices.numel(), feat=ones)
+    assert torch.equal(out, deg[:, None].expand(n, 128))
+    ints = torch.randint(-3, 4, (n, 128), device=cuda_device).half()
+    ref_handle = voltrix.csr_preprocess(indptr_c, indices_c, n)
+    ref_handle[1].hash_tag = "window_quarter"
+    a = voltrix.spmm(*hyb, num_nodes=n, num_edges=indices.numel(), feat=ints)
+    b = voltrix.spmm(*ref_handle, num_nodes=n, num_edges=indices.numel(), feat=ints)
+    assert torch.equal(a, b)

@@ -1,0 +1,57 @@
+// libvoltrix_hip.so -- panel kernel entry points (include/voltrix_capi.h): the shared-column half of the two-level
+// condensed format (spmm_panel_kernels.hpp).
+#include <hip/hip_runtime.h>
+
+#include "voltrix/spmm_panel_kernels.hpp"
+#include "voltrix_capi.h"
+
+namespace {
+
+// X(FS, DEPTH, WAVES, RB, KS) over the ahead-of-time space
+#define VOLTRIX_PANEL_SPACE(X)                                                                       \
+  X(128, 3, 8, 4, 1) X(128, 4, 8, 4, 1) X(128, 6, 8, 4, 1) X(128, 8, 8, 4, 1) X(128, 4, 4, 4, 1) X(128, 6, 4, 4, 1) X(128, 8, 4, 4, 1) \
+  X(128, 4, 8, 2, 1) X(128, 6, 8, 2, 1) X(128, 8, 8, 2, 1) X(128, 6, 4, 2, 1)                                    \
+  X(64, 4, 4, 4, 1) X(64, 6, 4, 4, 1) X(64, 4, 8, 4, 2) X(64, 6, 8, 4, 2) X(64, 6, 4, 4, 2)                      \
+  X(32, 4, 4, 4, 2) X(32, 6, 4, 4, 2) X(32, 6, 8, 4, 2)
+
+template <bool BF16>
+int dispatch(int fs, int depth, int waves, int rb, int ks, const int* panel_ptr, const int* panel_cols,
+             const uint32_t* panel_bits, const int* panel_order, int num_nodes, int embedding_dim, const void* input,
+             float* output, int accumulate, const float* out_scale, hipStream_t stream) {
+#define X(FS, D, W, RB, KS)                                                                                          \
+  if (fs == FS && depth == D && waves == W && rb == RB && ks == KS)                                                  \
+    return voltrix::launch_spmm_panel<voltrix::PanelTile<FS, D, W, RB, KS, BF16>>(                                   \
+        panel_ptr, panel_cols, panel_bits, panel_order, num_nodes, embedding_dim, input, output, accumulate, out_scale, \
+        stream);
+  VOLTRIX_PANEL_SPACE(X)
+#undef X
+  return voltrix::kErrBadConfig;
+}
+
+}  // namespace
+
+extern "C" {
+
+void voltrix_launch_spmm_panel_f16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order,
+                                   int num_nodes, int embedding_dim, void* input, void* output, int accumulate, int fs,
+                                   int depth, int waves, int row_blocks, int ksteps, void* out_scale, void* stream,
+                                   int* return_code) {
+  *return_code = dispatch<false>(fs, depth, waves, row_blocks, ksteps, static_cast<const int*>(panel_ptr),
+                                 static_cast<const int*>(panel_cols), static_cast<const uint32_t*>(panel_bits),
+                                 static_cast<const int*>(panel_order), num_nodes, embedding_dim, input,
+                                 static_cast<float*>(output), accumulate, static_cast<const float*>(out_scale),
+                                 static_cast<hipStream_t>(stream));
+}
+
+void voltrix_launch_spmm_panel_bf16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order,
+                                    int num_nodes, int embedding_dim, void* input, void* output, int accumulate, int fs,
+                                    int depth, int waves, int row_blocks, int ksteps, void* out_scale, void* stream,
+                                    int* return_code) {
+  *return_code = dispatch<true>(fs, depth, waves, row_blocks, ksteps, static_cast<const int*>(panel_ptr),
+                                static_cast<const int*>(panel_cols), static_cast<const uint32_t*>(panel_bits),
+                                static_cast<const int*>(panel_order), num_nodes, embedding_dim, input,
+                                static_cast<float*>(output), accumulate, static_cast<const float*>(out_scale),
+                                static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -28,6 +28,8 @@ SYMBOLS = (
     "voltrix_launch_spmm_f16",
     "voltrix_launch_spmm_f16_tile",
     "voltrix_launch_spmm_f16_list",
+    "voltrix_launch_spmm_panel_f16",
+    "voltrix_launch_spmm_panel_bf16",
     "voltrix_spmm_default_tile",
     "voltrix_spmm_num_tiles",
     "voltrix_spmm_tile_at",
@@ -148,6 +150,20 @@ def launch_spmm_list(hspa_packed, hind, num_nodes, embedding_dim, input_ptr, out
                                        ctypes.c_void_p(output_ptr), _ptr(entries), _ptr(wave_ptr),
                                        ctypes.c_int(num_waves), ctypes.c_int(tile[0]), ctypes.c_int(tile[1]),
                                        ctypes.c_int(tile[2]), ctypes.c_void_p(stream), ctypes.byref(rc))
+    return rc.value
+
+
+def launch_spmm_panel(plan, input_ptr, output_ptr, embedding_dim, accumulate, bf16, tile, out_scale, stream) -> int:
+    """Panel kernel (shared-column half of the two-level format); ``plan`` = voltrix.hybrid.PanelPlan, ``tile`` =
+    (fs, depth, ksteps).  Returns the return code."""
+    rc = ctypes.c_int(-1)
+    fn = lib().voltrix_launch_spmm_panel_bf16 if bf16 else lib().voltrix_launch_spmm_panel_f16
+    order = plan.panel_order.data_ptr() if plan.panel_order is not None else 0
+    fn(_ptr(plan.panel_ptr), _ptr(plan.panel_cols), _ptr(plan.panel_bits), ctypes.c_void_p(order),
+       ctypes.c_int(plan.num_nodes), ctypes.c_int(embedding_dim), ctypes.c_void_p(input_ptr), ctypes.c_void_p(output_ptr),
+       ctypes.c_int(int(accumulate)), ctypes.c_int(tile[0]), ctypes.c_int(tile[1]), ctypes.c_int(plan.waves),
+       ctypes.c_int(plan.row_blocks), ctypes.c_int(tile[2]), ctypes.c_void_p(out_scale), ctypes.c_void_p(stream),
+       ctypes.byref(rc))
     return rc.value
 
 

@@ -1,0 +1,168 @@
+"""Two-level condensed format: row-panel "shared columns" + the reference's window format for the rest.
+
+No reference counterpart (the reference leans on externally reordered inputs to raise the
+TC-block fill; this raises the *reuse* of every gathered row instead).  A column that is referenced by at least ``tau``
+rows of a ``panel_rows``-row panel is gathered ONCE per panel by ``spmm_panel_kernel`` (spmm_panel_kernels.hpp) and
+multiplied into all the panel's 16-row blocks on the matrix cores; every other edge stays in a residual CSR that goes
+through the unchanged ``csr_preprocess`` -> ``spmm`` path.  ``C = A_resid @ B + A_shared @ B`` -- two addends per
+element.
+
+Host API:
+
+    handle = voltrix.csr_preprocess_hybrid(indptr, indices, num_nodes)        # same 3 tensors, of the RESIDUAL matrix
+    out = voltrix.spmm(*handle, num_nodes, num_edges, feat)                   # sees hspa_packed.panel_plan
+
+Plan layout: see spmm_panel_kernels.hpp; pinned bit-exactly by ``oracle/oracle_np.py::panel_plan``.
+"""
+from __future__ import annotations
+
+import dataclasses
+import os
+
+import torch
+
+from . import capi
+
+# (waves, row_blocks) of the plan <-> PanelTile<FS, DEPTH, WAVES, RB, KS>; panel_rows = waves * row_blocks * 16
+DEFAULT_WAVES = 8
+DEFAULT_ROW_BLOCKS = 4
+DEFAULT_TAU = 3
+KSTEP = 32
+
+
+@dataclasses.dataclass
+class PanelPlan:
+    panel_ptr: torch.Tensor      # int32 [NP+1]
+    panel_cols: torch.Tensor     # int32 [32 * (S + 2)]
+    panel_bits: torch.Tensor     # uint32 [(S + 1) * waves * 64]
+    panel_order: torch.Tensor    # int32 [NP] or None (natural)
+    num_nodes: int
+    waves: int
+    row_blocks: int
+    tau: int
+    num_ksteps: int
+    num_shared_cols: int         # (panel, column) pairs gathered by the panel kernel
+    num_shared_edges: int
+    num_resid_edges: int
+
+    @property
+    def panel_rows(self) -> int:
+        return self.waves * self.row_blocks * 16
+
+    @property
+    def num_panels(self) -> int:
+        return (self.num_nodes + self.panel_rows - 1) // self.panel_rows
+
+
+def split_shared_columns(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int, panel_rows: int,
+                         tau: int):
+    """Device CSR -> ``(resid_indptr int32, resid_indices int32, pc int64 [U], rp int64 [Es], inv int64 [Es])``:
+    the residual CSR (sorted, duplicate-free rows), the sorted shared (panel * num_cols + col) keys, and per shared edge
+    its row inside the panel and the index of its key."""
+    device = indptr.device
+    n, p = num_nodes, panel_rows
+    deg = (indptr[1:] - indptr[:-1]).to(torch.int64)
+    rows = torch.repeat_interleave(torch.arange(n, device=device, dtype=torch.int64), deg)
+    cols = indices.to(torch.int64)
+    key = ((rows // p) * num_cols + cols) * p + (rows % p)      # (panel, col, row in panel)
+    del rows, cols
+    key = torch.unique(key, sorted=True)                        # sorts; duplicate (row, col) entries count once
+    pc_all = key // p
+    uniq, inverse, counts = torch.unique_consecutive(pc_all, return_inverse=True, return_counts=True)
+    shared_u = counts >= tau
+    shared_e = shared_u[inverse]
+    # residual CSR: back to (row, col) order
+    rk = key[~shared_e]
+    r_pc = rk // p
+    r_row = (r_pc // num_cols) * p + (rk % p)
+    r_key = torch.sort(r_row * num_cols + (r_pc % num_cols)).values
+    resid_rows = r_key // num_cols
+    resid_indices = (r_key % num_cols).to(torch.int32)
+    resid_indptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    resid_indptr[1:] = torch.cumsum(torch.bincount(resid_rows, minlength=n), 0)
+    # shared part
+    new_index = torch.cumsum(shared_u.to(torch.int64), 0) - 1   # unique key -> index among the shared keys
+    sk = key[shared_e]
+    return (resid_indptr.to(torch.int32), resid_indices, uniq[shared_u], sk % p, new_index[inverse[shared_e]])
+
+
+def build_panel_plan(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
+                     waves: int = DEFAULT_WAVES, row_blocks: int = DEFAULT_ROW_BLOCKS, tau: int = DEFAULT_TAU,
+                     order: str = "natural"):
+    """CSR on the device -> ``(resid_indptr, resid_indices, PanelPlan)``."""
+    assert indptr.device == indices.device and indptr.dtype == torch.int32 and indices.dtype == torch.int32
+    assert waves in (4, 8) and row_blocks in (2, 4) and tau >= 1
+    device = indptr.device
+    num_cols = num_nodes if num_cols is None else int(num_cols)
+    p = waves * row_blocks * 16
+    num_panels = (num_nodes + p - 1) // p
+    resid_indptr, resid_indices, pc, rp, inv = split_shared_columns(indptr, indices, num_nodes, num_cols, p, tau)
+
+    su_panel = pc // num_cols
+    su_col = pc % num_cols
+    cnt = torch.bincount(su_panel, minlength=num_panels)
+    nks = (cnt + KSTEP - 1) // KSTEP
+    panel_ptr = torch.zeros(num_panels + 1, dtype=torch.int64, device=device)
+    panel_ptr[1:] = torch.cumsum(nks, 0)
+    total_ksteps = int(panel_ptr[-1].item())
+    assert total_ksteps < 2 ** 26, "k-step offsets are int32 (x 32 columns)"
+    col_start = torch.cumsum(cnt, 0) - cnt                        # first shared key of every panel
+    rank = torch.arange(pc.numel(), device=device, dtype=torch.int64) - col_start[su_panel]
+    slot = (panel_ptr[su_panel] + rank // KSTEP) * KSTEP + rank % KSTEP   # global (k-step, k) of every shared key
+
+    # unused slots of a panel's last k-step repeat its first shared column (finite data, zero adjacency bits)
+    panel_of_kstep = torch.repeat_interleave(torch.arange(num_panels, device=device), nks)
+    first_col = torch.zeros(num_panels, dtype=torch.int64, device=device)
+    has = cnt > 0
+    first_col[has] = su_col[col_start[has]]
+    panel_cols = torch.zeros(KSTEP * (total_ksteps + 2), dtype=torch.int64, device=device)
+    panel_cols[:KSTEP * total_ksteps] = first_col[panel_of_kstep].repeat_interleave(KSTEP)
+    panel_cols[slot] = su_col
+
+    # adjacency bits: word (k-step, wave, lane = 16 g + R), byte j, bit c
+    e_slot = slot[inv]
+    k = e_slot % KSTEP
+    v = rp // (16 * row_blocks)
+    j = (rp % (16 * row_blocks)) // 16
+    word = (e_slot // KSTEP) * (waves * 64) + v * 64 + (k // 8) * 16 + (rp % 16)
+    bits = torch.zeros((total_ksteps + 1) * waves * 64, dtype=torch.int64, device=device)
+    bits.index_add_(0, word, torch.ones_like(word) << (8 * j + k % 8))     # distinct bits: add == or
+    panel_bits = ((bits + 2 ** 31) % 2 ** 32 - 2 ** 31).to(torch.int32).view(torch.uint32)   # explicit wrap to 32 bits
+
+    panel_order = None
+    if order == "lpt":  # longest panels first (per XCD range the launcher keeps positions contiguous)
+        panel_order = torch.argsort(nks, descending=True, stable=True).to(torch.int32)
+    plan = PanelPlan(panel_ptr=panel_ptr.to(torch.int32), panel_cols=panel_cols.to(torch.int32), panel_bits=panel_bits,
+                     panel_order=panel_order, num_nodes=num_nodes, waves=waves, row_blocks=row_blocks, tau=tau,
+                     num_ksteps=total_ksteps, num_shared_cols=int(pc.numel()), num_shared_edges=int(rp.numel()),
+                     num_resid_edges=int(resid_indices.numel()))
+    return resid_indptr, resid_indices, plan
+
+
+# panel kernel tile per feature width: (fs, depth, ks); waves / row_blocks come from the plan
+def default_panel_tile(embedding_dim: int, waves: int):
+    if embedding_dim <= 32:
+        return (32, 6, 2)
+    if embedding_dim <= 64:
+        return (64, 6, 2)
+    return (128, 6, 1)
+
+
+def launch_panel(plan: PanelPlan, feat: torch.Tensor, output: torch.Tensor, accumulate: bool, out_scale=None,
+                 tile=None, stream=None) -> None:
+    """``output (+)= A_shared @ feat`` for fp16 / bfloat16 ``feat`` [*, F] and float32 ``output`` [N, F]."""
+    assert feat.is_cuda and feat.is_contiguous() and feat.dtype in (torch.float16, torch.bfloat16)
+    assert output.is_cuda and output.is_contiguous() and output.dtype == torch.float32
+    f = feat.shape[1]
+    assert output.shape == (plan.num_nodes, f)
+    tile = tile or default_panel_tile(f, plan.waves)
+    assert tile is not None, f"no panel tile for F={f} with {plan.waves} waves"
+    stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    rc = capi.launch_spmm_panel(plan, feat.data_ptr(), output.data_ptr(), f, bool(accumulate),
+                                feat.dtype == torch.bfloat16, tile, out_scale.data_ptr() if out_scale is not None else 0,
+                                stream)
+    capi.check(rc, "voltrix_launch_spmm_panel")
+
+
+def hybrid_enabled() -> bool:
+    return os.getenv("VOLTRIX_HYBRID", "0") not in ("0", "", "off")

@@ -15,7 +15,7 @@ from ..jit_kernels import (
     preprocess_kernel,
     spmm_kernel,
 )
-from .. import capi
+from .. import capi, hybrid
 from ..project import FP32_MODE_FLAG, PREPROCESS_FLAG
 
 BLK_H = 16
@@ -36,6 +36,8 @@ def csr_preprocess(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, 
     assert indices.is_cpu and indices.dtype == torch.int32
     assert indptr.numel() == num_nodes + 1
 
+    if hybrid.hybrid_enabled():  # VOLTRIX_HYBRID=1: two-level format (voltrix/hybrid.py); the handle is the residual's
+        return csr_preprocess_hybrid(indptr, indices, num_nodes, num_cols)
     if os.getenv(PREPROCESS_FLAG, "fused") != "reference":
         pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(
             indptr.contiguous().cuda(), indices.contiguous().cuda(), num_nodes, num_cols)
@@ -62,6 +64,24 @@ def csr_preprocess(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, 
     hmat_gen_kernel(node_pointer=indptr_d, edge_list=indices_d, block_partition=block_partition,
                     edge_to_column=edge_to_column, edge_to_row=edge_to_row, pointer1=pointer1, hspa=hspa, hind=hind)
     hmat_packed_swizzle_kernel(block_partition=block_partition, pointer1=pointer1, hspa=hspa, hspa_packed=hspa_packed)
+    return pointer1, hspa_packed, hind
+
+
+def csr_preprocess_hybrid(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
+                          waves: int = hybrid.DEFAULT_WAVES, row_blocks: int = hybrid.DEFAULT_ROW_BLOCKS,
+                          tau: int = hybrid.DEFAULT_TAU):
+    """Extension (no reference counterpart): two-level condensed format.  Columns referenced by >= ``tau`` rows of a
+    ``waves * row_blocks * 16``-row panel go to a panel plan (gathered once per panel, ``spmm_panel_kernel``); the
+    remaining edges go through the ordinary ``csr_preprocess``.  Returns the reference-format handle of the RESIDUAL
+    matrix with the plan attached as ``hspa_packed.panel_plan`` -- ``spmm`` adds both parts.  The same arguments and
+    assertions as ``csr_preprocess``."""
+    assert indptr.is_cpu and indptr.dtype == torch.int32
+    assert indices.is_cpu and indices.dtype == torch.int32
+    assert indptr.numel() == num_nodes + 1
+    resid_indptr, resid_indices, plan = hybrid.build_panel_plan(indptr.contiguous().cuda(), indices.contiguous().cuda(),
+                                                                num_nodes, num_cols, waves, row_blocks, tau)
+    pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(resid_indptr, resid_indices, num_nodes, num_cols)
+    hspa_packed.panel_plan = plan
     return pointer1, hspa_packed, hind
 
 
@@ -97,4 +117,10 @@ def spmm(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tenso
 
     spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes=num_nodes, num_edges=num_edges, embedding_dim=padded,
                 input=operand, output=output, out_scale=out_scale)
+    plan = getattr(hspa_packed, "panel_plan", None)
+    if plan is not None and plan.num_ksteps > 0:
+        # two-level format: the handle covers the residual edges, the panel kernel adds the shared-column part
+        assert not exact, "the panel kernel takes a 16-bit operand (unset VOLTRIX_FP32_MODE=exact or use csr_preprocess)"
+        assert plan.num_nodes == num_nodes
+        hybrid.launch_panel(plan, operand, output, accumulate=True, out_scale=out_scale)
     return output if padded == num_feats else output[:, :num_feats].contiguous()
