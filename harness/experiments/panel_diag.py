@@ -9,8 +9,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 PKG = os.path.join(REPO, "voltrix-spmm_amd")
 sys.path[:0] = [REPO, PKG]
-VARIANTS = {"full": 0, "no_mfma": 1, "no_rows": 2, "no_barrier": 4, "no_expand": 8, "no_fragreads": 16, "no_mfma_no_rows": 3,
-            "only_dma_barrier": 1 | 8 | 16, "no_rows_no_barrier": 6}
+VARIANTS = {"full": 0, "no_rows": 2, "no_bits": 32, "no_dma": 34, "no_dma_no_expand": 42, "no_dma_no_barrier": 38,
+            "no_dma_no_expand_no_barrier": 46, "mfma_only": 2 | 4 | 8 | 16 | 32}
+CONFIGS = [(8, 4, 4), (4, 4, 4)]  # (waves, rb, depth)
 
 
 def so(name, extra=""):
@@ -20,13 +21,16 @@ def so(name, extra=""):
 def build():
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     procs = []
-    for name, bits in VARIANTS.items():
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               f"-DVOLTRIX_PANEL_DIAG={bits}", f"-I{PKG}/voltrix/include", f"-I{REPO}/include",
-               os.path.join(HERE, "panel_diag.hip"), "-o", so(name)]
-        procs.append(subprocess.Popen(cmd))
-    for p in procs:
-        assert p.wait() == 0
+    for waves, rb, depth in CONFIGS:
+        for name, bits in VARIANTS.items():
+            cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                   f"-DVOLTRIX_PANEL_DIAG={bits}", f"-DPD_WAVES={waves}", f"-DPD_RB={rb}", f"-DPD_DEPTH={depth}",
+                   f"-I{PKG}/voltrix/include", f"-I{REPO}/include",
+                   os.path.join(HERE, "panel_diag.hip"), "-o", so(name, f"_{waves}_{rb}_{depth}")]
+            procs.append(subprocess.Popen(cmd))
+        for p in procs:
+            assert p.wait() == 0
+        procs = []
 
 
 def run():
@@ -37,11 +41,12 @@ def run():
     n = indptr.numel() - 1
     feat = torch.randn(n, 128, device="cuda").half()
     out = torch.zeros(n, 128, dtype=torch.float32, device="cuda")
-    _, _, plan = hybrid.build_panel_plan(indptr, indices, n, None, 8, 4, 4)
-    print(f"k-steps {plan.num_ksteps}, panels {plan.num_panels}", flush=True)
     stream = torch.cuda.current_stream().cuda_stream
-    for name in VARIANTS:
-        lib = ctypes.CDLL(so(name))
+    for waves, rb, depth in CONFIGS:
+      _, _, plan = hybrid.build_panel_plan(indptr, indices, n, None, waves, rb, 4)
+      print(f"waves {waves} rb {rb} depth {depth}: k-steps {plan.num_ksteps}, panels {plan.num_panels}", flush=True)
+      for name in VARIANTS:
+        lib = ctypes.CDLL(so(name, f"_{waves}_{rb}_{depth}"))
 
         def go():
             rc = lib.panel_diag_launch(ctypes.c_void_p(plan.panel_ptr.data_ptr()), ctypes.c_void_p(plan.panel_cols.data_ptr()),

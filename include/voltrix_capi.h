@@ -129,8 +129,9 @@ void voltrix_launch_spmm_f16_list(void* hspa_packed, void* hind, int num_nodes, 
  *   panel_ptr  int32 [NP+1]                  first k-step of every panel, S = panel_ptr[NP]
  *   panel_cols int32 [32 * (S + 2)]          row of `input` per (k-step, k); unused slots repeat a real column; 2 k-steps
  *                                            of padding (valid row ids) at the end
- *   panel_bits uint32 [(S + 1) * waves * 64] word (k-step, wave v, lane 16 g + R), byte j, bit c <=> edge (row
- *                                            16 (row_blocks v + j) + R of the panel, column 8 g + c of the k-step)
+ *   panel_bits uint32 [(S + 1) * waves * 64] word (k-step, wave v, lane 16 g + R), bit 16 (c & 1) + 4 j + (c >> 1) <=>
+ *                                            edge (row 16 (row_blocks v + j) + R of the panel, column 8 g + c of the
+ *                                            k-step), j < row_blocks, c < 8
  *   panel_order int32 [NP] or NULL           launch position -> panel
  * output [num_nodes, embedding_dim] float32: accumulate != 0 adds onto it (the window kernel's result for the remaining
  * edges), accumulate == 0 overwrites every row.  input _Float16 (bfloat16 for _bf16) [*, embedding_dim], 16-byte
@@ -144,6 +145,10 @@ void voltrix_launch_spmm_panel_bf16(void* panel_ptr, void* panel_cols, void* pan
                                     int num_nodes, int embedding_dim, void* input, void* output, int accumulate, int fs,
                                     int depth, int waves, int row_blocks, int ksteps, void* out_scale, void* stream,
                                     int* return_code);
+
+/* dst[i] += src[i], float32, count % 4 == 0, both 16-byte aligned: joins the two halves of the two-level format when
+ * the window kernel (-> dst) and the panel kernel (accumulate = 0 -> src) ran side by side on two streams. */
+void voltrix_launch_add_inplace_f32(void* dst, void* src, int64_t count, void* stream, int* return_code);
 
 /* Default tile for a feature width; is_f16 selects the operand type.  Always succeeds. */
 void voltrix_spmm_default_tile(int embedding_dim, int is_f16, int* fs, int* depth, int* waves);

@@ -302,7 +302,7 @@ def panel_plan(indptr, indices, num_nodes, waves, row_blocks, tau):
             panel_cols[32 * ks + k] = c
             for rp in rows:
                 v, j, r16 = rp // (16 * row_blocks), (rp % (16 * row_blocks)) // 16, rp % 16
-                panel_bits[(ks * waves + v) * 64 + (k // 8) * 16 + r16] |= np.uint32(1 << (8 * j + k % 8))
+                panel_bits[(ks * waves + v) * 64 + (k // 8) * 16 + r16] |= np.uint32(1 << (16 * (k % 2) + 4 * j + (k % 8) // 2))
     return resid_indptr, resid_indices, panel_ptr, panel_cols, panel_bits
 
 
@@ -318,7 +318,7 @@ def panel_to_edges(panel_ptr, panel_cols, panel_bits, num_nodes, waves, row_bloc
                     g, r16 = lane >> 4, lane & 15
                     for j in range(row_blocks):
                         for c in range(8):
-                            if (word >> (8 * j + c)) & 1:
+                            if (word >> (16 * (c & 1) + 4 * j + (c >> 1))) & 1:
                                 row = p * panel_rows + 16 * (row_blocks * v + j) + r16
                                 assert row < num_nodes
                                 edges.append((row, int(panel_cols[32 * ks + 8 * g + c])))

@@ -56,8 +56,10 @@ def test_panel_kernel_alone(cuda_device, waves, rb, tile, feat_dim):
 
 @pytest.mark.parametrize("dtype,mode", [(torch.float16, "fp16"), (torch.bfloat16, "exact"), (torch.float32, "fp16-scaled")])
 @pytest.mark.parametrize("feat_dim", [32, 128, 200])
-def test_hybrid_operator(cuda_device, dtype, mode, feat_dim, monkeypatch):
+@pytest.mark.parametrize("streams", ["1", "0"])
+def test_hybrid_operator(cuda_device, dtype, mode, feat_dim, streams, monkeypatch):
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    monkeypatch.setenv("VOLTRIX_HYBRID_STREAMS", streams)   # two streams + add pass / one stream, accumulate mode
     indptr_t, indices_t, _ = synth_graphs.generate("reddit_like", scale=0.006)
     n = indptr_t.numel() - 1
     handle = voltrix.csr_preprocess_hybrid(indptr_t, indices_t, n, tau=40)  # small graph, dense panels: a high bar
@@ -107,3 +109,23 @@ def test_hybrid_full_size_properties(cuda_device, monkeypatch):
     a = voltrix.spmm(*hyb, num_nodes=n, num_edges=indices.numel(), feat=ints)
     b = voltrix.spmm(*ref_handle, num_nodes=n, num_edges=indices.numel(), feat=ints)
     assert torch.equal(a, b)
+
+
+def test_hybrid_operator_is_graph_capturable(cuda_device, monkeypatch):
+    """The two-stream form forks and joins through events only: it replays from a HIP graph with the same result."""
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    indptr_t, indices_t, _ = synth_graphs.generate("reddit_like", scale=0.006)
+    n = indptr_t.numel() - 1
+    handle = voltrix.csr_preprocess_hybrid(indptr_t, indices_t, n, tau=40)
+    handle[1].hash_tag = f"hybrid_graph_{n}"
+    feat = torch.randn(n, 128, device=cuda_device).half()
+    eager = voltrix.spmm(*handle, num_nodes=n, num_edges=indices_t.numel(), feat=feat)   # warm-up: tuner, streams
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = voltrix.spmm(*handle, num_nodes=n, num_edges=indices_t.numel(), feat=feat)
+    feat.copy_(torch.randn(n, 128, device=cuda_device).half())
+    graph.replay()
+    torch.cuda.synchronize()
+    again = voltrix.spmm(*handle, num_nodes=n, num_edges=indices_t.numel(), feat=feat)
+    assert torch.equal(captured, again) and not torch.equal(captured, eager)

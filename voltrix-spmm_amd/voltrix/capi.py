@@ -30,6 +30,7 @@ SYMBOLS = (
     "voltrix_launch_spmm_f16_list",
     "voltrix_launch_spmm_panel_f16",
     "voltrix_launch_spmm_panel_bf16",
+    "voltrix_launch_add_inplace_f32",
     "voltrix_spmm_default_tile",
     "voltrix_spmm_num_tiles",
     "voltrix_spmm_tile_at",
@@ -165,6 +166,13 @@ def launch_spmm_panel(plan, input_ptr, output_ptr, embedding_dim, accumulate, bf
        ctypes.c_int(plan.row_blocks), ctypes.c_int(tile[2]), ctypes.c_void_p(out_scale), ctypes.c_void_p(stream),
        ctypes.byref(rc))
     return rc.value
+
+
+def launch_add_inplace_f32(dst, src, stream) -> None:
+    rc = ctypes.c_int(-1)
+    lib().voltrix_launch_add_inplace_f32(_ptr(dst), _ptr(src), ctypes.c_int64(dst.numel()), ctypes.c_void_p(stream),
+                                         ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_add_inplace_f32")
 
 
 def launch_window_order(blk_offsets, num_nodes, order_out, stream, chunk: int = 256) -> None:

@@ -119,14 +119,15 @@ def build_panel_plan(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int
     panel_cols[:KSTEP * total_ksteps] = first_col[panel_of_kstep].repeat_interleave(KSTEP)
     panel_cols[slot] = su_col
 
-    # adjacency bits: word (k-step, wave, lane = 16 g + R), byte j, bit c
+    # adjacency bits: word (k-step, wave, lane = 16 g + R), bit 16 (c & 1) + 4 j + (c >> 1), c = column inside the
+    # lane's group of 8
     e_slot = slot[inv]
     k = e_slot % KSTEP
     v = rp // (16 * row_blocks)
     j = (rp % (16 * row_blocks)) // 16
     word = (e_slot // KSTEP) * (waves * 64) + v * 64 + (k // 8) * 16 + (rp % 16)
     bits = torch.zeros((total_ksteps + 1) * waves * 64, dtype=torch.int64, device=device)
-    bits.index_add_(0, word, torch.ones_like(word) << (8 * j + k % 8))     # distinct bits: add == or
+    bits.index_add_(0, word, torch.ones_like(word) << (16 * (k % 2) + 4 * j + (k % 8) // 2))     # distinct bits: add == or
     panel_bits = ((bits + 2 ** 31) % 2 ** 32 - 2 ** 31).to(torch.int32).view(torch.uint32)   # explicit wrap to 32 bits
 
     panel_order = None
@@ -139,13 +140,60 @@ def build_panel_plan(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int
     return resid_indptr, resid_indices, plan
 
 
-# panel kernel tile per feature width: (fs, depth, ks); waves / row_blocks come from the plan
+# panel kernel tile per feature width: (fs, depth, ks); waves / row_blocks come from the plan.  Depth 3 at FS = 128 keeps
+# the workgroup at 44 KB of LDS and 183 registers, so that it fits on a CU NEXT TO a (128, 3, 4) window-kernel
+# workgroup (103 KB, 136 registers) -- the two kernels overlap when they run on two streams.
 def default_panel_tile(embedding_dim: int, waves: int):
     if embedding_dim <= 32:
         return (32, 6, 2)
     if embedding_dim <= 64:
         return (64, 6, 2)
-    return (128, 6, 1)
+    return (128, 3, 1) if waves == 8 else (128, 4, 1)
+
+
+_SIDE_STREAMS = {}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    """One extra stream per device for the panel kernel (the window kernel stays on the caller's stream)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
+def concurrent_enabled() -> bool:
+    """VOLTRIX_HYBRID_STREAMS=0: run the panel kernel after the window kernel on the caller's stream (accumulate mode)."""
+    return os.getenv("VOLTRIX_HYBRID_STREAMS", "1") not in ("0", "off")
+
+
+def spmm_two_level(plan: PanelPlan, operand: torch.Tensor, output: torch.Tensor, run_window, out_scale=None,
+                   tile=None) -> None:
+    """``output = A_resid @ operand + A_shared @ operand``.  ``run_window()`` enqueues the window kernel for the
+    residual handle on the current stream (writing every row of ``output``).
+
+    Default: the panel kernel runs on a side stream into a second buffer while the window kernel runs on the caller's
+    stream (the first is matrix-core bound, the second gather bound: they overlap on the same CUs), then one add pass
+    joins them.  Stream-ordered, no host sync; capturable (fork / join through events)."""
+    if plan.num_ksteps == 0:
+        run_window()
+        return
+    if not concurrent_enabled():
+        run_window()
+        launch_panel(plan, operand, output, accumulate=True, out_scale=out_scale, tile=tile)
+        return
+    main = torch.cuda.current_stream()
+    side = side_stream(operand.device)
+    shared_part = torch.empty_like(output)       # allocated on `main`; its last use (the add) is on `main` too
+    fork = torch.cuda.Event()
+    fork.record(main)
+    side.wait_event(fork)                        # operand / out_scale were produced on `main`
+    launch_panel(plan, operand, shared_part, accumulate=False, out_scale=out_scale, tile=tile, stream=side.cuda_stream)
+    join = torch.cuda.Event()
+    join.record(side)
+    run_window()
+    main.wait_event(join)
+    capi.launch_add_inplace_f32(output, shared_part, main.cuda_stream)
 
 
 def launch_panel(plan: PanelPlan, feat: torch.Tensor, output: torch.Tensor, accumulate: bool, out_scale=None,

@@ -12,7 +12,7 @@
 //                 panel_ptr  int32 [NP+1]            first k-step of every panel
 //                 panel_cols int32 [32 * (S + pad)]  row of B per (k-step, k); unused slots repeat a real column
 //                 panel_bits uint32 [(S + 1) * WAVES * 64] adjacency bits in MFMA A-operand order: word (k-step, wave v,
-//                                                    lane L = 16 g + R), byte j, bit c  <=>  edge (row 16 (RB v + j) + R
+//                                                    lane L = 16 g + R), bit 16 (c & 1) + 4 j + (c >> 1)  <=>  edge (row 16 (RB v + j) + R
 //                                                    of the panel, column 8 g + c of the k-step)
 //   everything else (columns below tau) stays in the reference's window format and runs through spmm_tc16_kernel; this
 //   kernel then adds its share onto C (accumulate = 1) -- two addends per element, so the sum does not depend on order.
@@ -34,14 +34,13 @@
 #include "voltrix/spmm_kernels.hpp"
 
 // Diagnostic builds only (harness/experiments/panel_diag.py): bit 0 skips the MFMAs, bit 1 the row DMAs, bit 2 the
-// barrier, bit 3 the adjacency expansion, bit 4 the fragment reads.  Results are wrong by design; shipped kernels use 0.
+// barrier.  Results are wrong by design; shipped kernels use 0.
 #ifndef VOLTRIX_PANEL_DIAG
 #define VOLTRIX_PANEL_DIAG 0
 #endif
 
 namespace voltrix {
 
-typedef int panel_int4_t __attribute__((ext_vector_type(4)));  // plain vector: loadable from the constant address space
 
 //   FS     feature slab per workgroup (columns of B / C): 32, 64 or 128
 //   DEPTH  ring slots (k-step groups of gathered rows in flight per workgroup)
@@ -69,16 +68,29 @@ struct PanelTile {
   static constexpr int ROWS_PER_DMA = 1024 / ROW_BYTES;
   static constexpr int LANES_PER_ROW = ROW_BYTES / 16;
   static constexpr int SLOTS = FS / 16;
-  static constexpr int CPW = DPW * ROWS_PER_DMA;                   // consecutive column ids a wave gathers per step
-  // wave-private ring of adjacency words: KS x 64 words per step, DEPTH steps (they travel with the step's rows)
-  static constexpr int BITS_BYTES = KS * 256;
-  static constexpr int VM_PER_STEP = DPW + KS;                     // LDS-DMAs per wave and step
+  // wave-private metadata slot: KS x 64 adjacency words, then 64 column ids (32 * KS used)
+  static constexpr int META_BYTES = KS * 256 + 256;
+  static constexpr int META_SLOTS = 2 * DEPTH - 1;
+  static constexpr int NMETA = KS + 1;                             // metadata DMAs per wave and step
+  static constexpr int VM_PER_STEP = DPW + NMETA;
   static constexpr int DATA_LDS = DEPTH * STAGE_BYTES;
-  static constexpr int BLOCK_LDS = DATA_LDS + WAVES * DEPTH * BITS_BYTES;
+  static constexpr int BLOCK_LDS = DATA_LDS + WAVES * META_SLOTS * META_BYTES;
   static_assert(BLOCK_LDS <= 160 * 1024, "LDS per CU");
   static_assert(VM_PER_STEP * (DEPTH - 2) <= 63, "vmcnt is a 6-bit counter on gfx9");
-  static_assert(CPW % 4 == 0 && CPW <= 16, "column ids are fetched with s_load_dwordx4/x8/x16");
 };
+
+// Adjacency word -> MFMA A fragment.  Bit p (p = 4 j + r) of the word is column 2 r, bit 16 + p column 2 r + 1 of row
+// block j, so one shift + one mask yields the packed fp16 pair {2.0 or 0.0} x 2 of register r (2.0 = 0x4000; the 0.5 is
+// applied once in the epilogue, as in spmm_tc16_kernel).
+__device__ __forceinline__ half8_t adjacency_to_half8_x2(unsigned w, int p0) {  // p0 = 4 j: constant after unrolling
+  uint4_t r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = p0 + i;
+    r[i] = (p <= 14 ? (w << (14 - p)) : (w >> (p - 14))) & 0x40004000u;
+  }
+  return __builtin_bit_cast(half8_t, r);
+}
 
 template <class T>
 struct PanelArgs {
@@ -99,7 +111,7 @@ struct PanelArgs {
 
 template <class T>
 static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const PanelArgs<T> a) {
-  constexpr int FS = T::FS, D = T::DEPTH, KS = T::KS, RB = T::RB;
+  constexpr int FS = T::FS, D = T::DEPTH, MS = T::META_SLOTS, KS = T::KS, RB = T::RB;
   constexpr int ROW_BYTES = T::ROW_BYTES, STAGE_BYTES = T::STAGE_BYTES, DPW = T::DPW;
   constexpr int RPD = T::ROWS_PER_DMA, LPR = T::LANES_PER_ROW, SLOTS = T::SLOTS;
 
@@ -129,51 +141,57 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
     for (int s = 0; s < SLOTS; ++s) acc[j][s] = float4_t{0.f, 0.f, 0.f, 0.f};
 
   const unsigned data0 = (unsigned)(uintptr_t)(lds_ptr)smem;
-  const unsigned bits0 = data0 + T::DATA_LDS + (unsigned)wave * (D * T::BITS_BYTES);
+  const unsigned meta0 = data0 + T::DATA_LDS + (unsigned)wave * (MS * T::META_BYTES);
 
   if (ngroups > 0) {
     // ---- lane constants ---------------------------------------------------------------------------------------
     const unsigned row_bytes = (unsigned)F * 2u;
     const int dma0 = (wave * DPW) % T::NDMA;      // this wave's first row DMA of a step: LDS bytes [dma0 KiB, ...)
-    const int lq = lane / LPR;                    // row of a DMA this lane copies
-    const char* cbase[DPW];                       // source of this lane's 16 bytes in row DMA d, before the row offset
+    const char* cbase[DPW];   // source of this lane's 16 bytes in row DMA d of a step, before the row offset
+    unsigned hr_off[DPW];     // byte offset of that DMA's row id inside the metadata slot's column list
 #pragma unroll
     for (int d = 0; d < DPW; ++d) {
-      const int r = (dma0 + d) * RPD + lq;        // gathered row inside the step (0 .. 32 KS - 1)
-      const int c = lane % LPR;                   // 16-byte chunk inside the row
+      const int r = (dma0 + d) * RPD + lane / LPR;  // gathered row inside the step (0 .. 32 KS - 1)
+      const int c = lane % LPR;                     // 16-byte chunk inside the row
       int col = fs0 + (((c >> 1) ^ slot_swizzle<SLOTS>(r & 31)) * 16) + (c & 1) * 8;  // swizzle on the SOURCE
-      col = col < F ? col : fs0;                  // F % FS tail: stay in bounds, never stored
+      col = col < F ? col : fs0;                    // F % FS tail: stay in bounds, never stored
       unsigned long long cb = (unsigned long long)((const char*)a.input + (long long)col * 2);
       asm volatile("" : "+v"(cb));
       cbase[d] = (const char*)cb;
+      hr_off[d] = KS * 256 + 4 * r;
     }
-    // Column ids: the CPW rows this wave gathers per step are wave-uniform -> scalar loads (constant address space:
-    // SMEM counts on lgkmcnt, so nothing with a VGPR destination enters the vmcnt stream of the LDS-DMAs).
-    using const_i4_ptr = const panel_int4_t __attribute__((address_space(4)))*;
-    const const_i4_ptr cols4 = (const_i4_ptr)(a.panel_cols + ((long long)ks0 * kStageK + dma0 * RPD));
-    struct Cols { panel_int4_t v[T::CPW / 4]; };
-    auto load_cols = [&](int s) {                 // ids of step s (k-step group s of the panel)
-      Cols c;
-#pragma unroll
-      for (int i = 0; i < T::CPW / 4; ++i) c.v[i] = cols4[(long long)s * (KS * kStageK / 4) + i];
-      return c;
-    };
+    // metadata DMAs of k-step group s (clamped to the panel's last group: the pipeline issues a static number of DMAs)
     const uint32_t* const bits_base = a.panel_bits + ((long long)ks0 * T::WAVES + wave) * kWave + lane;
-    // rows + adjacency words of step s: DPW + KS LDS-DMAs
-    auto issue_step = [&](int s, const Cols& c) {
-      const unsigned dst = data0 + (unsigned)(s % D) * STAGE_BYTES + (unsigned)dma0 * 1024u;
+    const int* const cols_base = a.panel_cols + (long long)ks0 * kStageK + lane;
+    auto issue_meta = [&](int s) {
+      const int sc = s < ngroups ? s : ngroups - 1;
+      const unsigned dst = meta0 + (unsigned)(s % MS) * T::META_BYTES;
 #pragma unroll
-      for (int d = 0; d < DPW; ++d) {
-        int hrow = c.v[(d * RPD) / 4][(d * RPD) % 4];
-#pragma unroll
-        for (int qq = 1; qq < RPD; ++qq) hrow = (lq == qq) ? c.v[(d * RPD + qq) / 4][(d * RPD + qq) % 4] : hrow;
-        if (!(VOLTRIX_PANEL_DIAG & 2)) dma_b128(cbase[d] + (unsigned long long)(unsigned)hrow * row_bytes, dst + d * 1024);
-        else asm volatile("" ::"v"(hrow));
-      }
-      const unsigned bdst = bits0 + (unsigned)(s % D) * T::BITS_BYTES;
-#pragma unroll
-      for (int k = 0; k < KS; ++k) dma_b32(bits_base + (long long)(s * KS + k) * (T::WAVES * kWave), bdst + 256 * k);
+      for (int k = 0; k < KS; ++k)
+        dma_b32(bits_base + (long long)(sc * KS + k) * (T::WAVES * kWave), dst + 256 * k);
+      dma_b32(cols_base + (long long)sc * (KS * kStageK), dst + 256 * KS);
     };
+    auto issue_rows = [&](int s) {
+      const unsigned mslot = meta0 + (unsigned)(s % MS) * T::META_BYTES;
+      const unsigned dst = data0 + (unsigned)(s % D) * STAGE_BYTES + (unsigned)dma0 * 1024u;
+      unsigned hrow[DPW];
+#pragma unroll
+      for (int d = 0; d < DPW; ++d) hrow[d] = lds_read_b32(mslot + hr_off[d]);
+      wait_lgkmcnt0();
+#pragma unroll
+      for (int d = 0; d < DPW; ++d)
+        if (!(VOLTRIX_PANEL_DIAG & 2)) dma_b128(cbase[d] + (unsigned long long)hrow[d] * row_bytes, dst + d * 1024);
+    };
+
+    // ---- prologue: metadata of groups 0 .. D-2, then the virtual steps -(D-1) .. -1 ------------------------------
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s) issue_meta(s);
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s) {
+      issue_rows(s);            // groups past the panel's end re-gather its last group (static DMA count)
+      issue_meta(s + D - 1);
+    }
 
     // MFMA lane roles (as in spmm_tc16_kernel): A row R of block g's 8 columns; B column R, rows 8g+q (+4)
     const int g = lane >> 4;
@@ -181,106 +199,67 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
     const int trow = 8 * g + q;
     const unsigned rd_off = trow * ROW_BYTES + 8 * p;
     const int tr_z = slot_swizzle<SLOTS>(trow);
-    struct Frags {
-      unsigned aw[KS];
-      uint2_t blo[KS][SLOTS], bhi[KS][SLOTS];
-    };
-    auto read_frags = [&](int s, Frags& f) {      // LDS -> registers, asynchronous (lgkmcnt)
-      const unsigned dt = data0 + (unsigned)(s % D) * STAGE_BYTES + rd_off;
-      const unsigned bt = bits0 + (unsigned)(s % D) * T::BITS_BYTES + 4 * lane;
-#pragma unroll
-      for (int k = 0; k < KS; ++k) {
-        f.aw[k] = lds_read_b32(bt + 256 * k);
-#pragma unroll
-        for (int sl = 0; sl < SLOTS; ++sl) {
-          const unsigned addr = dt + k * T::KSTEP_BYTES + ((sl ^ tr_z) << 5);
-          if (VOLTRIX_PANEL_DIAG & 16) {
-            f.blo[k][sl] = uint2_t{addr, addr};
-            f.bhi[k][sl] = uint2_t{addr, addr};
-            continue;
-          }
-          f.blo[k][sl] = lds_read_tr16_b64<0>(addr);
-          f.bhi[k][sl] = lds_read_tr16_b64<4 * ROW_BYTES>(addr);
+
+    for (int t = 0; t < ngroups; ++t) {
+      // rows of group t (issued D-1 steps ago) and the metadata of group t+D-1 must have landed; the D-2 younger
+      // steps may stay in flight.  Steps past ngroups-D+1 issue nothing.
+      const int young = ngroups - 1 - t;
+      if (young >= D - 2) {
+        wait_vmcnt<T::VM_PER_STEP*(D - 2)>();
+      } else {
+        switch (young) {
+          case 0: wait_vmcnt<0>(); break;
+          case 1: wait_vmcnt<T::VM_PER_STEP * 1>(); break;
+          case 2: wait_vmcnt<T::VM_PER_STEP * 2>(); break;
+          case 3: wait_vmcnt<T::VM_PER_STEP * 3>(); break;
+          case 4: wait_vmcnt<T::VM_PER_STEP * 4>(); break;
+          default: wait_vmcnt<T::VM_PER_STEP * 5>(); break;
         }
       }
-    };
-    auto multiply = [&](int s, const Frags& f) {
+      if (!(VOLTRIX_PANEL_DIAG & 4))
+        __builtin_amdgcn_s_barrier();  // every wave's share of group t has landed; everyone is done reading group t-1
+      __builtin_amdgcn_sched_barrier(0);
+
+      if (t + D - 1 < ngroups) {     // workgroup-uniform
+        issue_rows(t + D - 1);       // into the slot group t-1 has just left
+        issue_meta(t + 2 * D - 2);
+      }
+
+      const unsigned mt = meta0 + (unsigned)(t % MS) * T::META_BYTES;
+      const unsigned dt = data0 + (unsigned)(t % D) * STAGE_BYTES + rd_off;
 #pragma unroll
       for (int k = 0; k < KS; ++k) {
-        if (s * KS + k < nks) {                   // workgroup-uniform (a panel's last group may be partial)
+        if (t * KS + k < nks) {      // workgroup-uniform
+          const unsigned aw = lds_read_b32(mt + 256 * k + 4 * lane);
+          uint2_t blo[SLOTS], bhi[SLOTS];
+#pragma unroll
+          for (int s = 0; s < SLOTS; ++s) {
+            const unsigned addr = dt + k * T::KSTEP_BYTES + ((s ^ tr_z) << 5);
+            blo[s] = lds_read_tr16_b64<0>(addr);
+            bhi[s] = lds_read_tr16_b64<4 * ROW_BYTES>(addr);
+          }
+          wait_lgkmcnt0();
 #pragma unroll
           for (int j = 0; j < RB; ++j) {
-            const unsigned byte = (f.aw[k] >> (8 * j));
-            const half8_t afrag = (VOLTRIX_PANEL_DIAG & 8)
-                                      ? __builtin_bit_cast(half8_t, uint4_t{f.aw[k], f.aw[k], f.aw[k], f.aw[k]})
-                                      : nibbles_to_half8_x2(byte & 0xFu, (byte >> 4) & 0xFu);
+            const half8_t afrag = adjacency_to_half8_x2(aw, 4 * j);
 #pragma unroll
-            for (int sl = 0; sl < SLOTS; ++sl) {
-              const uint4_t bq = {f.blo[k][sl][0], f.blo[k][sl][1], f.bhi[k][sl][0], f.bhi[k][sl][1]};
+            for (int s = 0; s < SLOTS; ++s) {
+              const uint4_t bq = {blo[s][0], blo[s][1], bhi[s][0], bhi[s][1]};
               if (VOLTRIX_PANEL_DIAG & 1) {
                 asm volatile("" ::"v"(afrag), "v"(bq));
                 continue;
               }
               if constexpr (T::BF16)
-                acc[j][sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, afrag),
-                                                                     __builtin_bit_cast(bf16x8_t, bq), acc[j][sl], 0, 0, 0);
+                acc[j][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, afrag),
+                                                                    __builtin_bit_cast(bf16x8_t, bq), acc[j][s], 0, 0, 0);
               else
-                acc[j][sl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, __builtin_bit_cast(half8_t, bq), acc[j][sl],
-                                                                    0, 0, 0);
+                acc[j][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, __builtin_bit_cast(half8_t, bq), acc[j][s], 0,
+                                                                   0, 0);
             }
           }
         }
       }
-    };
-    // counted wait: everything but the `young` most recently issued steps has landed
-    auto wait_steps = [&](int young) {
-      switch (young < D - 2 ? young : D - 2) {
-        case 0: wait_vmcnt<0>(); break;
-        case 1: wait_vmcnt<T::VM_PER_STEP * 1>(); break;
-        case 2: wait_vmcnt<T::VM_PER_STEP * 2>(); break;
-        case 3: wait_vmcnt<T::VM_PER_STEP * 3>(); break;
-        case 4: wait_vmcnt<T::VM_PER_STEP * 4>(); break;
-        case 5: wait_vmcnt<T::VM_PER_STEP * 5>(); break;
-        default: wait_vmcnt<T::VM_PER_STEP * 6>(); break;
-      }
-    };
-
-    // ---- prologue: steps 0 .. D-2 in flight, fragments of step 0 in registers ------------------------------------
-    const int npro = ngroups < D - 1 ? ngroups : D - 1;
-    for (int s = 0; s < npro; ++s) issue_step(s, load_cols(s));
-    Cols cnext = load_cols(D - 1 < ngroups ? D - 1 : 0);
-    wait_steps(npro - 1);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    Frags fa, fb;
-    read_frags(0, fa);
-    wait_lgkmcnt0();
-
-    // One step: [rows of step t+1 landed] barrier; refill the slot step t-1 has left with step t+D-1; start reading
-    // step t+1's fragments; multiply step t (read one step ago) while those reads and the DMAs are in flight.
-    auto step = [&](int t, const Frags& cur, Frags& nxt) {
-      const bool has_next = t + 1 < ngroups;      // workgroup-uniform
-      if (has_next) {
-        const int issued_last = t + D - 2 < ngroups - 1 ? t + D - 2 : ngroups - 1;
-        wait_steps(issued_last - (t + 1));        // steps t+2 .. issued_last may stay in flight
-        if (!(VOLTRIX_PANEL_DIAG & 4))
-          __builtin_amdgcn_s_barrier();           // every wave's share of step t+1 landed; all reads of step t-1 done
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + D - 1 < ngroups) {
-          issue_step(t + D - 1, cnext);
-          if (t + D < ngroups) cnext = load_cols(t + D);
-        }
-        read_frags(t + 1, nxt);
-      }
-      multiply(t, cur);
-      wait_lgkmcnt0();                            // nxt (and cnext) have arrived
-    };
-    int t = 0;
-    for (; t + 1 < ngroups; t += 2) {
-      step(t, fa, fb);
-      step(t + 1, fb, fa);
     }
-    if (t < ngroups) step(t, fa, fb);
     wait_vmcnt<0>();  // nothing of this workgroup may still be writing LDS when it is released
   }
 
@@ -344,6 +323,31 @@ inline int launch_spmm_panel(const int* panel_ptr, const int* panel_cols, const 
   }
   hipLaunchKernelGGL(spmm_panel_kernel<T>, dim3((unsigned)(a.panels_per_xcd * kNumXcd), (unsigned)slabs),
                      dim3(T::THREADS), T::BLOCK_LDS, stream, a);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+// dst += src (float32, count % 4 == 0, 16-byte aligned): joins the two halves of the two-level format when the window
+// kernel and the panel kernel ran side by side on two streams into two buffers.
+static __global__ __launch_bounds__(256) void add_inplace_f32_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                                const long long n4) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 d = reinterpret_cast<float4*>(dst)[i];
+    const float4 x = reinterpret_cast<const float4*>(src)[i];
+    d.x += x.x;
+    d.y += x.y;
+    d.z += x.z;
+    d.w += x.w;
+    reinterpret_cast<float4*>(dst)[i] = d;
+  }
+}
+
+inline int add_inplace_f32(float* dst, const float* src, long long count, hipStream_t stream) {
+  if (count < 0 || (count % 4) != 0 || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) return kErrBadShape;
+  if (count == 0) return kOk;
+  const long long n4 = count / 4;
+  const int blocks = (int)(n4 / 256 + 1 < 256 * 16 ? n4 / 256 + 1 : 256 * 16);
+  hipLaunchKernelGGL(add_inplace_f32_kernel, dim3(blocks), dim3(256), 0, stream, dst, src, n4);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

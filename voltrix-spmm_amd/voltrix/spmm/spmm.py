@@ -115,12 +115,16 @@ def spmm(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tenso
         capi.launch_cast_f32_f16_scaled(feat, operand, out_scale, torch.cuda.current_stream().cuda_stream)
     output = torch.empty((num_nodes, padded), dtype=torch.float32, device=feat.device)
 
-    spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes=num_nodes, num_edges=num_edges, embedding_dim=padded,
-                input=operand, output=output, out_scale=out_scale)
+    def run_window():
+        spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes=num_nodes, num_edges=num_edges, embedding_dim=padded,
+                    input=operand, output=output, out_scale=out_scale)
+
     plan = getattr(hspa_packed, "panel_plan", None)
-    if plan is not None and plan.num_ksteps > 0:
+    if plan is None:
+        run_window()
+    else:
         # two-level format: the handle covers the residual edges, the panel kernel adds the shared-column part
         assert not exact, "the panel kernel takes a 16-bit operand (unset VOLTRIX_FP32_MODE=exact or use csr_preprocess)"
         assert plan.num_nodes == num_nodes
-        hybrid.launch_panel(plan, operand, output, accumulate=True, out_scale=out_scale)
+        hybrid.spmm_two_level(plan, operand, output, run_window, out_scale=out_scale)
     return output if padded == num_feats else output[:, :num_feats].contiguous()
