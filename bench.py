@@ -42,6 +42,9 @@ def parse_args():
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the node count (debug only)")
     ap.add_argument("--tile", default=None, help="fs,depth,waves[,sched] (default: quick sweep over the tile space)")
+    ap.add_argument("--format", default="auto", choices=["auto", "window", "two-level"],
+                    help="window: the reference's block format only; two-level: shared columns of 512-row panels on the "
+                         "panel kernel + the rest in the block format (voltrix/hybrid.py); auto: time both, keep the faster")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for debugging)")
     ap.add_argument("--no-overlap", action="store_true",
@@ -193,43 +196,108 @@ def main():
         order_keep.append(o)
         orders[sched] = o.data_ptr()
 
-    def spmm(tile, b_full=None):
-        b_ptr = (gathered if b_full is None else b_full).data_ptr()
-        rc = capi.launch_spmm(ptrs[0], ptrs[1], ptrs[2], local_rows, local_nnz, num_feats, b_ptr,
-                              out.data_ptr(), is_f16, tile[:3], stream, orders[tile[3]])
+    from voltrix import hybrid
+
+    def window_launch(handle_ptrs, handle_nnz, order_ptrs, tile, b_ptr, dst):
+        rc = capi.launch_spmm(handle_ptrs[0], handle_ptrs[1], handle_ptrs[2], local_rows, handle_nnz, num_feats, b_ptr,
+                              dst.data_ptr(), is_f16, tile[:3], stream, order_ptrs[tile[3]])
         assert rc == 0, f"voltrix_launch_spmm rc={rc}"
 
-    # ---- tile: explicit, or a quick sweep over the instantiated space (what the autotuner does on first call) ----
+    # ---- two-level format (voltrix/hybrid.py): plan + residual handle per (waves, row_blocks, tau), built on demand ----
+    two_level_cache = {}
+    side_stream = torch.cuda.Stream(device=device)
+    main_stream = torch.cuda.current_stream()
+
+    def two_level_state(waves, rb, tau):
+        key = (waves, rb, tau)
+        if key not in two_level_cache:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r_indptr, r_indices, plan = hybrid.build_panel_plan(local_indptr, local_indices, local_rows, num_cols, waves, rb,
+                                                                tau)
+            r_handle = voltrix.csr_fused_preprocess_kernel(r_indptr, r_indices, local_rows, num_cols=num_cols)
+            torch.cuda.synchronize()
+            build_ms = (time.perf_counter() - t0) * 1e3
+            r_orders, keep = {0: 0}, []
+            for sched, chunk in ORDER_CHUNKS.items():
+                o = torch.empty((local_rows + 15) // 16, dtype=torch.int32, device=device)
+                capi.launch_window_order(r_handle[0], local_rows, o, stream, chunk)
+                keep.append(o)
+                r_orders[sched] = o.data_ptr()
+            two_level_cache[key] = dict(plan=plan, handle=r_handle, nnz=r_indices.numel(), orders=r_orders, keep=keep,
+                                        shared=torch.empty(local_rows, num_feats, dtype=torch.float32, device=device),
+                                        build_ms=build_ms, blocks=int(r_handle[0][-1]))
+        return two_level_cache[key]
+
+    def spmm(cand, b_full=None):
+        """One SpMM in the candidate's format.  cand = ("window", fs, depth, waves, sched) or
+        ("two-level", fs, depth, waves, sched, plan_waves, row_blocks, tau, panel_depth)."""
+        b = gathered if b_full is None else b_full
+        if cand[0] == "window":
+            window_launch(ptrs, local_nnz, orders, cand[1:5], b.data_ptr(), out)
+            return
+        st = two_level_state(*cand[5:8])
+        plan, h = st["plan"], st["handle"]
+        if plan.num_ksteps == 0:
+            window_launch((h[0].data_ptr(), h[1].data_ptr(), h[2].data_ptr()), st["nnz"], st["orders"], cand[1:5],
+                          b.data_ptr(), out)
+            return
+        ptile = (min(128, cand[1]), cand[8], 1 if cand[1] >= 128 else 2)
+        fork = torch.cuda.Event()
+        fork.record(main_stream)
+        side_stream.wait_event(fork)
+        hybrid.launch_panel(plan, b, st["shared"], accumulate=False, tile=ptile, stream=side_stream.cuda_stream)
+        join = torch.cuda.Event()
+        join.record(side_stream)
+        window_launch((h[0].data_ptr(), h[1].data_ptr(), h[2].data_ptr()), st["nnz"], st["orders"], cand[1:5], b.data_ptr(),
+                      out)
+        main_stream.wait_event(join)
+        capi.launch_add_inplace_f32(out, st["shared"], stream)
+
+    # ---- candidate: explicit, or a quick sweep over the instantiated space (what the autotuner does on first call) ----
+    two_level_ok = is_f16 and args.format != "window"
     if args.tile:
         tile = tuple(int(x) for x in args.tile.split(","))
         tile = tile if len(tile) == 4 else tile + (1,)
+        cands = [("window",) + tile] if args.format != "two-level" else []
+        if two_level_ok and args.format == "two-level":
+            cands.append(("two-level",) + tile + (8, 4, 3, 3))
     else:
         from voltrix.jit_kernels.spmm import tile_space
 
         aot = set(capi.tiles(is_f16))
-        cands = sorted({(p["FS"], p["DEPTH"], p["WAVES"], p["SCHED"]) for p in tile_space(num_feats, in_bytes)
-                        if (p["FS"], p["DEPTH"], p["WAVES"]) in aot})
-        best = None
-        for cand in cands:
+        cands = []
+        if args.format != "two-level":
+            cands = [("window",) + c for c in sorted({(p["FS"], p["DEPTH"], p["WAVES"], p["SCHED"])
+                                                      for p in tile_space(num_feats, in_bytes)
+                                                      if (p["FS"], p["DEPTH"], p["WAVES"]) in aot})]
+        if two_level_ok:
+            fs = 32 if num_feats <= 32 else (64 if num_feats <= 64 else 128)
+            # window tile (fs, 3, 4) + panel depth 3 fit one CU together (LDS 103 + 44 KB, registers 136 + 2 x 183)
+            for tau in (3, 4):
+                for sched in (2, 3):
+                    cands.append(("two-level", fs, 3, 4, sched, 8, 4, tau, 3 if fs == 128 else 6))
+    best = None
+    for cand in cands:
+        spmm(cand)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(3):
             spmm(cand)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            for _ in range(3):
-                spmm(cand)
-            e.record()
-            e.synchronize()
-            ms = s.elapsed_time(e) / 3
-            if world > 1:
-                t = torch.tensor([ms], device=device)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                ms = float(t)
-            if best is None or ms < best[0]:
-                best = (ms, cand)
-        tile = best[1]
+        e.record()
+        e.synchronize()
+        ms = s.elapsed_time(e) / 3
+        if world > 1:
+            t = torch.tensor([ms], device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms = float(t)
+        if best is None or ms < best[0]:
+            best = (ms, cand)
+    cand = best[1]
+    tile = cand[1:5]
 
     in_place = args.backend == "nccl"  # only NCCL/RCCL defines the in-place (send == recv + rank * count) form
     overlap = world > 1 and not args.no_overlap
-    main_stream = torch.cuda.current_stream()
     if world > 1:
         # two copies of the gather buffer: while the SpMM of step k reads one, the all-gather of step k+1 fills the other
         bufs = [gathered, gathered.clone()] if overlap else [gathered]
@@ -244,7 +312,7 @@ def main():
         if world == 1:
             if record is not None:
                 record[0].record()
-            spmm(tile)
+            spmm(cand)
             if record is not None:
                 record[1].record()
             return
@@ -259,7 +327,7 @@ def main():
         main_stream.wait_event(ev_gathered[b])
         if record is not None:
             record[0].record()  # HIP events on the launch stream, live inside the timed region
-        spmm(tile, bufs[b])
+        spmm(cand, bufs[b])
         if record is not None:
             record[1].record()
         ev_consumed[b] = torch.cuda.Event()
@@ -316,7 +384,19 @@ def main():
         # algorithmic bytes = int32 CSR once + B once + C once
         alg_bytes = 4 * (local_nnz + local_rows + 1) + gathered.shape[0] * num_feats * in_bytes + local_rows * num_feats * 4
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        gather_bytes = 8 * total_blocks * num_feats * in_bytes  # rows actually gathered from L2 / Infinity Cache / HBM
+        two_level = cand[0] == "two-level"
+        if two_level:   # rows actually gathered: 8 per residual TC block + 32 per k-step of the panel plan
+            st = two_level_state(*cand[5:8])
+            gather_bytes = (8 * st["blocks"] + 32 * st["plan"].num_ksteps) * num_feats * in_bytes
+            fmt = {"format": "two-level (voltrix/hybrid.py): window kernel on the residual || panel kernel on the shared "
+                             "columns (two streams), + add pass",
+                   "panel_rows": st["plan"].panel_rows, "tau": st["plan"].tau, "panel_depth": cand[8],
+                   "shared_edge_fraction_rank0": st["plan"].num_shared_edges / max(1, local_nnz),
+                   "panel_ksteps_rank0": st["plan"].num_ksteps, "residual_tc_blocks_rank0": st["blocks"],
+                   "plan_build_ms": st["build_ms"]}
+        else:
+            gather_bytes = 8 * total_blocks * num_feats * in_bytes  # rows gathered from L2 / Infinity Cache / HBM
+            fmt = {"format": "window (the reference's block format)"}
         line = {
             "metric": "spmm_gflops",
             "value": flop / (ms_per_step * 1e-3) / 1e9,
@@ -336,6 +416,7 @@ def main():
                             f"{'fp16' if is_f16 else 'fp32'} -> fp32",
                 "num_nodes": num_nodes, "nnz": nnz, "feat": num_feats, "tc_blocks_rank0": total_blocks,
                 "tile": {"fs": tile[0], "depth": tile[1], "waves": tile[2], "balance_schedule_chunk": ORDER_CHUNKS.get(tile[3], 0)},
+                "sparse_format": fmt,
                 "parallelism": f"row-window shards x{world}" + (
                     " + RCCL all-gather(B) per step" + (" (overlapped with the previous step's SpMM)" if overlap else "")
                     if world > 1 else ""),
@@ -349,7 +430,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic(args.workload, num_feats, "f16" if is_f16 else "f32")
                 if (world == 1 and args.scale == 1.0) else None,
-                "kernel": "spmm_tc16_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
+                "kernel": ("spmm_tc16_kernel || spmm_panel_kernel, then add_inplace_f32_kernel (HIP events around the three "
+                           "launches on the launch stream)") if two_level else "spmm_tc16_kernel",
+                "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
                 "gather_bytes": gather_bytes, "gather_gbs": gather_bytes / (kernel_ms * 1e-3) / 1e9,
                 "note": "gather-bound: B rows are served by L2 / Infinity Cache (~8.6-19 TB/s row-gather ceilings), "
                         "see DESIGN.md Roofline",
