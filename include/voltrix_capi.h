@@ -146,6 +146,25 @@ void voltrix_launch_spmm_panel_bf16(void* panel_ptr, void* panel_cols, void* pan
                                     int depth, int waves, int row_blocks, int ksteps, void* out_scale, void* stream,
                                     int* return_code);
 
+/* Builder of the panel plan (panel_plan.hpp): CSR on the DEVICE (rows sorted, duplicate-free, ids in [0, num_cols),
+ * num_cols <= 2^22) -> residual CSR + plan, in two phases because the caller owns every buffer:
+ *   phase 1  voltrix_launch_panel_plan_count: panel_ptr int32[NP+1], resid_node_pointer int32[num_nodes+1], status[1];
+ *            workspace: voltrix_panel_plan_workspace_bytes(...) bytes, device, 16-byte aligned
+ *   (caller reads S = panel_ptr[NP], E_r = resid_node_pointer[num_nodes] and status[0] -- the number of input
+ *    violations, must be 0 -- and allocates resid_edge_list int32[E_r], panel_cols int32[32 (S + 2)],
+ *    panel_bits uint32[(S + 1) * waves * 64])
+ *   phase 2  voltrix_launch_panel_plan_fill: same arguments and workspace; every output element is written.
+ * A column is shared in a panel when >= tau (1..65535) of the panel's rows reference it; waves in {4, 8}, row_blocks in
+ * {2, 4}.  VOLTRIX_ERR_BAD_CONFIG: column universe above 2^22 (the two-level format is not built for it). */
+int64_t voltrix_panel_plan_workspace_bytes(int num_nodes, int waves, int row_blocks);
+void voltrix_launch_panel_plan_count(void* node_pointer, void* edge_list, int num_nodes, int num_cols, int64_t num_edges,
+                                     int waves, int row_blocks, int tau, void* workspace, void* panel_ptr,
+                                     void* resid_node_pointer, void* status, void* stream, int* return_code);
+void voltrix_launch_panel_plan_fill(void* node_pointer, void* edge_list, int num_nodes, int num_cols, int64_t num_edges,
+                                    int waves, int row_blocks, int tau, void* workspace, void* panel_ptr,
+                                    void* resid_node_pointer, int64_t total_ksteps, void* resid_edge_list,
+                                    void* panel_cols, void* panel_bits, void* stream, int* return_code);
+
 /* dst[i] += src[i], float32, count % 4 == 0, both 16-byte aligned: joins the two halves of the two-level format when
  * the window kernel (-> dst) and the panel kernel (accumulate = 0 -> src) ran side by side on two streams. */
 void voltrix_launch_add_inplace_f32(void* dst, void* src, int64_t count, void* stream, int* return_code);

@@ -25,6 +25,71 @@ PANEL_CASES = [
 ]
 
 
+def _plan_arrays(plan):
+    return (plan.panel_ptr.cpu().numpy(), plan.panel_cols.cpu().numpy(),
+            plan.panel_bits.view(torch.int32).cpu().numpy().view(np.uint32))
+
+
+def _check_hip_builder(indptr, indices, n, waves, rb, tau, ncols=None):
+    """HIP builder (panel_plan.hpp) == plain-loop oracle, bit for bit."""
+    ri, rx, plan = hybrid.build_panel_plan(torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda(), n, ncols,
+                                           waves, rb, tau)
+    o_ri, o_rx, o_ptr, o_cols, o_bits = oracle_np.panel_plan(indptr, indices, n, waves, rb, tau)
+    p_ptr, p_cols, p_bits = _plan_arrays(plan)
+    assert np.array_equal(ri.cpu().numpy(), o_ri) and np.array_equal(rx.cpu().numpy(), o_rx)
+    assert np.array_equal(p_ptr, o_ptr) and np.array_equal(p_cols, o_cols) and np.array_equal(p_bits, o_bits)
+    assert plan.num_ksteps == int(o_ptr[-1]) and plan.num_resid_edges == len(o_rx)
+    assert plan.num_shared_edges + plan.num_resid_edges == len(np.unique(
+        np.repeat(np.arange(n, dtype=np.int64), np.diff(indptr)) * (ncols or n) + indices))
+    return plan
+
+
+@pytest.mark.parametrize("waves,rb", [(4, 2), (8, 4), (4, 4), (8, 2)])
+@pytest.mark.parametrize("tau", [1, 2, 4, 40])
+def test_hip_plan_builder_matches_oracle(cuda_device, waves, rb, tau):
+    indptr, indices = _random_csr(700, 60, seed=waves * 10 + rb + tau)
+    _check_hip_builder(indptr, indices, 700, waves, rb, tau)
+
+
+def test_hip_plan_builder_edge_cases(cuda_device, csr_fixture):
+    g = csr_fixture
+    _check_hip_builder(g["indptr"], g["indices"], int(g["num_nodes"]), 4, 2, 2)
+    indptr, indices = _random_csr(300, 30, seed=5)
+    plan = _check_hip_builder(indptr, indices, 300, 4, 2, 60000)        # a threshold nothing reaches
+    assert plan.num_ksteps == 0
+    _check_hip_builder(np.zeros(41, np.int32), np.zeros(0, np.int32), 40, 4, 2, 2)   # no edges at all
+    indptr3, indices3 = _random_csr(200, 40, seed=9, ncols=200000)      # non-square, four column ranges
+    _check_hip_builder(indptr3, indices3, 200, 4, 2, 1, ncols=200000)
+    wide = np.arange(0, 200000, 7, dtype=np.int32)                      # two rows sharing 28 k columns across ranges
+    _check_hip_builder(np.array([0, len(wide), 2 * len(wide)] + [2 * len(wide)] * 30, np.int32), np.r_[wide, wide], 32,
+                       4, 2, 2, ncols=200000)
+    # unsorted rows with duplicates: detected on the device, canonicalised once, same plan as the clean input
+    rng = np.random.default_rng(3)
+    rows = [rng.permutation(np.r_[r, r[: len(r) // 3]]) for r in
+            (indices[indptr[i]:indptr[i + 1]] for i in range(300))]
+    d_indptr = np.zeros(301, np.int32)
+    d_indptr[1:] = np.cumsum([len(r) for r in rows])
+    ri, rx, plan = hybrid.build_panel_plan(torch.from_numpy(d_indptr).cuda(),
+                                           torch.from_numpy(np.concatenate(rows).astype(np.int32)).cuda(), 300, None, 4, 2, 2)
+    o = oracle_np.panel_plan(indptr, indices, 300, 4, 2, 2)
+    assert np.array_equal(ri.cpu().numpy(), o[0]) and np.array_equal(rx.cpu().numpy(), o[1])
+    assert all(np.array_equal(a, b) for a, b in zip(_plan_arrays(plan), o[2:]))
+    with pytest.raises(ValueError):
+        hybrid.build_panel_plan(torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda(), 300, 100, 4, 2, 2)
+
+
+def test_hip_plan_builder_equals_torch_form_at_size(cuda_device):
+    """A quarter-size reddit-like graph (27 M edges): HIP builder == torch-op form, every array."""
+    indptr, indices, _ = synth_graphs.generate("reddit_like", device="cuda", scale=0.25)
+    n = indptr.numel() - 1
+    for waves, rb, tau in ((8, 4, 3), (4, 4, 2)):
+        a = hybrid.build_panel_plan(indptr, indices, n, None, waves, rb, tau)
+        b = hybrid.build_panel_plan_torch(indptr, indices, n, None, waves, rb, tau)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert torch.equal(a[2].panel_ptr, b[2].panel_ptr) and torch.equal(a[2].panel_cols, b[2].panel_cols)
+        assert torch.equal(a[2].panel_bits.view(torch.int32), b[2].panel_bits.view(torch.int32))
+
+
 def _edges_to_csr(edges, n):
     indptr = np.zeros(n + 1, np.int32)
     for r, _ in edges:

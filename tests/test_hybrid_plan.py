@@ -1,4 +1,5 @@
-"""CPU: the two-level format's plan builder (voltrix/hybrid.py, torch ops on any device) against the plain-loop oracle
+"""CPU: the two-level format's plan in its torch-op form (hybrid.build_panel_plan_torch; the HIP builder is checked the
+same way on the GPU, tests/test_gpu_hybrid.py) against the plain-loop oracle
 (oracle_np.panel_plan), bit for bit, and the plan's consumer-side interpretation against the input CSR."""
 import numpy as np
 import pytest
@@ -20,7 +21,7 @@ def _random_csr(n, max_deg, seed, ncols=None):
 
 
 def _check(indptr, indices, n, waves, rb, tau, ncols=None):
-    ri, rx, plan = hybrid.build_panel_plan(torch.from_numpy(indptr), torch.from_numpy(indices), n, ncols, waves, rb, tau)
+    ri, rx, plan = hybrid.build_panel_plan_torch(torch.from_numpy(indptr), torch.from_numpy(indices), n, ncols, waves, rb, tau)
     o_ri, o_rx, o_ptr, o_cols, o_bits = oracle_np.panel_plan(indptr, indices, n, waves, rb, tau)
     assert np.array_equal(ri.numpy(), o_ri) and np.array_equal(rx.numpy(), o_rx)
     assert np.array_equal(plan.panel_ptr.numpy(), o_ptr)
@@ -68,6 +69,6 @@ def test_plan_edge_cases():
 def test_plan_scaled_reddit_like_shares_the_band():
     indptr, indices, _ = synth_graphs.generate("reddit_like", scale=0.01)
     n = indptr.numel() - 1
-    _, _, plan = hybrid.build_panel_plan(indptr, indices, n, None, 8, 4, 3)
+    _, _, plan = hybrid.build_panel_plan_torch(indptr, indices, n, None, 8, 4, 3)
     assert plan.num_shared_edges + plan.num_resid_edges == indices.numel()
     assert plan.num_shared_edges > 0.3 * indices.numel()

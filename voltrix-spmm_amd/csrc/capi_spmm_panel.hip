@@ -2,6 +2,7 @@
 // condensed format (spmm_panel_kernels.hpp).
 #include <hip/hip_runtime.h>
 
+#include "voltrix/panel_plan.hpp"
 #include "voltrix/spmm_panel_kernels.hpp"
 #include "voltrix_capi.h"
 
@@ -57,6 +58,30 @@ void voltrix_launch_spmm_panel_bf16(void* panel_ptr, void* panel_cols, void* pan
 void voltrix_launch_add_inplace_f32(void* dst, void* src, int64_t count, void* stream, int* return_code) {
   *return_code = voltrix::add_inplace_f32(static_cast<float*>(dst), static_cast<const float*>(src), count,
                                           static_cast<hipStream_t>(stream));
+}
+
+int64_t voltrix_panel_plan_workspace_bytes(int num_nodes, int waves, int row_blocks) {
+  return voltrix::panel_plan_workspace_bytes(num_nodes, waves, row_blocks);
+}
+
+void voltrix_launch_panel_plan_count(void* node_pointer, void* edge_list, int num_nodes, int num_cols, int64_t num_edges,
+                                     int waves, int row_blocks, int tau, void* workspace, void* panel_ptr,
+                                     void* resid_node_pointer, void* status, void* stream, int* return_code) {
+  *return_code = voltrix::panel_plan_count(static_cast<const int*>(node_pointer), static_cast<const int*>(edge_list),
+                                           num_nodes, num_cols, num_edges, waves, row_blocks, tau, workspace,
+                                           static_cast<int*>(panel_ptr), static_cast<int*>(resid_node_pointer),
+                                           static_cast<int*>(status), static_cast<hipStream_t>(stream));
+}
+
+void voltrix_launch_panel_plan_fill(void* node_pointer, void* edge_list, int num_nodes, int num_cols, int64_t num_edges,
+                                    int waves, int row_blocks, int tau, void* workspace, void* panel_ptr,
+                                    void* resid_node_pointer, int64_t total_ksteps, void* resid_edge_list,
+                                    void* panel_cols, void* panel_bits, void* stream, int* return_code) {
+  *return_code = voltrix::panel_plan_fill(static_cast<const int*>(node_pointer), static_cast<const int*>(edge_list),
+                                          num_nodes, num_cols, num_edges, waves, row_blocks, tau, workspace,
+                                          static_cast<const int*>(panel_ptr), static_cast<const int*>(resid_node_pointer),
+                                          total_ksteps, static_cast<int*>(resid_edge_list), static_cast<int*>(panel_cols),
+                                          static_cast<uint32_t*>(panel_bits), static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

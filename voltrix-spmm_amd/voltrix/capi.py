@@ -31,6 +31,9 @@ SYMBOLS = (
     "voltrix_launch_spmm_panel_f16",
     "voltrix_launch_spmm_panel_bf16",
     "voltrix_launch_add_inplace_f32",
+    "voltrix_panel_plan_workspace_bytes",
+    "voltrix_launch_panel_plan_count",
+    "voltrix_launch_panel_plan_fill",
     "voltrix_spmm_default_tile",
     "voltrix_spmm_num_tiles",
     "voltrix_spmm_tile_at",
@@ -63,6 +66,7 @@ def lib() -> ctypes.CDLL:
         _lib.voltrix_abi_version.restype = ctypes.c_int
         _lib.voltrix_spmm_num_tiles.restype = ctypes.c_int
         _lib.voltrix_csr_preprocess_workspace_bytes.restype = ctypes.c_int64
+        _lib.voltrix_panel_plan_workspace_bytes.restype = ctypes.c_int64
         for name in SYMBOLS:
             if name.startswith("voltrix_launch_") or name in ("voltrix_spmm_default_tile", "voltrix_spmm_tile_at"):
                 getattr(_lib, name).restype = None
@@ -166,6 +170,32 @@ def launch_spmm_panel(plan, input_ptr, output_ptr, embedding_dim, accumulate, bf
        ctypes.c_int(plan.row_blocks), ctypes.c_int(tile[2]), ctypes.c_void_p(out_scale), ctypes.c_void_p(stream),
        ctypes.byref(rc))
     return rc.value
+
+
+def panel_plan_workspace_bytes(num_nodes: int, waves: int, row_blocks: int) -> int:
+    return int(lib().voltrix_panel_plan_workspace_bytes(ctypes.c_int(num_nodes), ctypes.c_int(waves),
+                                                        ctypes.c_int(row_blocks)))
+
+
+def launch_panel_plan_count(indptr, indices, num_nodes, num_cols, waves, row_blocks, tau, workspace, panel_ptr,
+                            resid_indptr, status, stream) -> int:
+    rc = ctypes.c_int(-1)
+    lib().voltrix_launch_panel_plan_count(_ptr(indptr), _ptr(indices), ctypes.c_int(num_nodes), ctypes.c_int(num_cols),
+                                          ctypes.c_int64(indices.numel()), ctypes.c_int(waves), ctypes.c_int(row_blocks),
+                                          ctypes.c_int(tau), _ptr(workspace), _ptr(panel_ptr), _ptr(resid_indptr),
+                                          _ptr(status), ctypes.c_void_p(stream), ctypes.byref(rc))
+    return rc.value
+
+
+def launch_panel_plan_fill(indptr, indices, num_nodes, num_cols, waves, row_blocks, tau, workspace, panel_ptr,
+                           resid_indptr, total_ksteps, resid_indices, panel_cols, panel_bits, stream) -> None:
+    rc = ctypes.c_int(-1)
+    lib().voltrix_launch_panel_plan_fill(_ptr(indptr), _ptr(indices), ctypes.c_int(num_nodes), ctypes.c_int(num_cols),
+                                         ctypes.c_int64(indices.numel()), ctypes.c_int(waves), ctypes.c_int(row_blocks),
+                                         ctypes.c_int(tau), _ptr(workspace), _ptr(panel_ptr), _ptr(resid_indptr),
+                                         ctypes.c_int64(total_ksteps), _ptr(resid_indices), _ptr(panel_cols),
+                                         _ptr(panel_bits), ctypes.c_void_p(stream), ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_panel_plan_fill")
 
 
 def launch_add_inplace_f32(dst, src, stream) -> None:

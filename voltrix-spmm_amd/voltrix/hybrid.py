@@ -86,10 +86,78 @@ def split_shared_columns(indptr: torch.Tensor, indices: torch.Tensor, num_nodes:
     return (resid_indptr.to(torch.int32), resid_indices, uniq[shared_u], sk % p, new_index[inverse[shared_e]])
 
 
+MAX_PLAN_COLS = 1 << 22  # the HIP builder counts per column range of 2^16 (panel_plan.hpp); larger universes: no plan
+
+
+def canonical_csr(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int):
+    """Rows sorted, duplicate (row, col) entries dropped (they count once: reference quirk 5).  Only used when the
+    device-side input check of the builder reports unsorted / duplicate rows."""
+    deg = (indptr[1:] - indptr[:-1]).to(torch.int64)
+    rows = torch.repeat_interleave(torch.arange(num_nodes, device=indptr.device, dtype=torch.int64), deg)
+    key = torch.unique(rows * num_cols + indices.to(torch.int64), sorted=True)
+    rows = key // num_cols
+    out_indptr = torch.zeros(num_nodes + 1, dtype=torch.int64, device=indptr.device)
+    out_indptr[1:] = torch.cumsum(torch.bincount(rows, minlength=num_nodes), 0)
+    return out_indptr.to(torch.int32), (key - rows * num_cols).to(torch.int32)
+
+
+def empty_plan(num_nodes, waves, row_blocks, tau, device, num_edges):
+    np_ = (num_nodes + waves * row_blocks * 16 - 1) // (waves * row_blocks * 16)
+    return PanelPlan(panel_ptr=torch.zeros(np_ + 1, dtype=torch.int32, device=device),
+                     panel_cols=torch.zeros(2 * KSTEP, dtype=torch.int32, device=device),
+                     panel_bits=torch.zeros(waves * 64, dtype=torch.int32, device=device).view(torch.uint32),
+                     panel_order=None, num_nodes=num_nodes, waves=waves, row_blocks=row_blocks, tau=tau, num_ksteps=0,
+                     num_shared_cols=0, num_shared_edges=0, num_resid_edges=num_edges)
+
+
 def build_panel_plan(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
-                     waves: int = DEFAULT_WAVES, row_blocks: int = DEFAULT_ROW_BLOCKS, tau: int = DEFAULT_TAU,
-                     order: str = "natural"):
-    """CSR on the device -> ``(resid_indptr, resid_indices, PanelPlan)``."""
+                     waves: int = DEFAULT_WAVES, row_blocks: int = DEFAULT_ROW_BLOCKS, tau: int = DEFAULT_TAU):
+    """CSR on the GPU -> ``(resid_indptr, resid_indices, PanelPlan)`` with the HIP builder (panel_plan.hpp; two launches
+    around one host sync that sizes the outputs).  Universes above 2^22 columns get an empty plan (everything stays in
+    the window format)."""
+    assert indptr.is_cuda and indices.is_cuda and indptr.dtype == torch.int32 and indices.dtype == torch.int32
+    assert indptr.is_contiguous() and indices.is_contiguous() and indptr.numel() == num_nodes + 1
+    assert waves in (4, 8) and row_blocks in (2, 4) and 1 <= tau <= 65535
+    device = indptr.device
+    num_cols = num_nodes if num_cols is None else int(num_cols)
+    if num_cols > MAX_PLAN_COLS or num_nodes == 0:
+        return indptr, indices, empty_plan(num_nodes, waves, row_blocks, tau, device, indices.numel())
+    stream = torch.cuda.current_stream().cuda_stream
+    panel_rows = waves * row_blocks * 16
+    num_panels = (num_nodes + panel_rows - 1) // panel_rows
+    for attempt in range(2):
+        workspace = torch.empty(capi.panel_plan_workspace_bytes(num_nodes, waves, row_blocks), dtype=torch.uint8,
+                                device=device)
+        panel_ptr = torch.empty(num_panels + 1, dtype=torch.int32, device=device)
+        resid_indptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=device)
+        status = torch.empty(1, dtype=torch.int32, device=device)
+        rc = capi.launch_panel_plan_count(indptr, indices, num_nodes, num_cols, waves, row_blocks, tau, workspace, panel_ptr,
+                                          resid_indptr, status, stream)
+        capi.check(rc, "voltrix_launch_panel_plan_count")
+        total_ksteps, num_resid, bad = torch.cat([panel_ptr[-1:], resid_indptr[-1:], status]).tolist()  # the host sync
+        if bad == 0:
+            break
+        assert attempt == 0, f"build_panel_plan: {bad} column ids outside [0, {num_cols})"
+        if int(indices.min()) < 0 or int(indices.max()) >= num_cols:
+            raise ValueError(f"build_panel_plan: column ids outside [0, {num_cols})")
+        indptr, indices = canonical_csr(indptr, indices, num_nodes, num_cols)   # unsorted rows / duplicates: once
+    resid_indices = torch.empty(num_resid, dtype=torch.int32, device=device)
+    panel_cols = torch.empty(KSTEP * (total_ksteps + 2), dtype=torch.int32, device=device)
+    panel_bits = torch.empty((total_ksteps + 1) * waves * 64, dtype=torch.int32, device=device).view(torch.uint32)
+    capi.launch_panel_plan_fill(indptr, indices, num_nodes, num_cols, waves, row_blocks, tau, workspace, panel_ptr,
+                                resid_indptr, total_ksteps, resid_indices, panel_cols, panel_bits, stream)
+    plan = PanelPlan(panel_ptr=panel_ptr, panel_cols=panel_cols, panel_bits=panel_bits, panel_order=None,
+                     num_nodes=num_nodes, waves=waves, row_blocks=row_blocks, tau=tau, num_ksteps=total_ksteps,
+                     num_shared_cols=-1, num_shared_edges=indices.numel() - num_resid, num_resid_edges=num_resid)
+    return resid_indptr, resid_indices, plan
+
+
+def build_panel_plan_torch(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
+                           waves: int = DEFAULT_WAVES, row_blocks: int = DEFAULT_ROW_BLOCKS, tau: int = DEFAULT_TAU,
+                           order: str = "natural"):
+    """The same plan from torch tensor ops on any device (sort + run lengths): the first implementation, kept as an
+    independent cross-check of the HIP builder that also runs on the CPU (tests/test_hybrid_plan.py).  Not used by the
+    operator path."""
     assert indptr.device == indices.device and indptr.dtype == torch.int32 and indices.dtype == torch.int32
     assert waves in (4, 8) and row_blocks in (2, 4) and tau >= 1
     device = indptr.device
