@@ -15,7 +15,7 @@ import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob("$OUT/pass*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if 'spmm_tc16' in r['Kernel_Name']:
+        if any(k in r['Kernel_Name'] for k in ('spmm_tc16', 'spmm_panel', 'add_inplace')):
             agg[r['Kernel_Name'][:90]][r['Counter_Name']].append(float(r['Counter_Value']))
 with open("$OUT/summary.txt", "w") as out:
     for k, d in agg.items():
