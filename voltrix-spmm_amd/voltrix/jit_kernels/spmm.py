@@ -45,9 +45,19 @@ def _lds_bytes(fs, depth, waves, eb):
     return waves * (depth * 32 * fs * eb + (2 * depth + 1) * 256)
 
 
-def tile_space(embedding_dim: int, elem_bytes: int, bf16: bool = False):
-    """Points of the tile space worth trying for this feature width (``bf16``: the 2-byte operand is bfloat16)."""
-    return tuple(dict(point, BF16=int(bf16)) for point in _tile_space(embedding_dim, elem_bytes))
+# LDS a window-kernel workgroup may take when a panel-kernel workgroup (two-level format, 44 KB at FS = 128 / DEPTH 3)
+# has to fit on the same CU beside it
+TWO_LEVEL_LDS_BUDGET = 160 * 1024 - 44 * 1024
+
+
+def tile_space(embedding_dim: int, elem_bytes: int, bf16: bool = False, max_lds: int = None):
+    """Points of the tile space worth trying for this feature width (``bf16``: the 2-byte operand is bfloat16;
+    ``max_lds``: keep only tiles whose workgroup fits that many bytes of LDS)."""
+    points = tuple(dict(point, BF16=int(bf16)) for point in _tile_space(embedding_dim, elem_bytes))
+    if max_lds is not None:
+        fit = tuple(p for p in points if _lds_bytes(p["FS"], p["DEPTH"], p["WAVES"], p["EB"]) <= max_lds and p["WAVES"] >= 4)
+        points = fit or points
+    return points
 
 
 def _tile_space(embedding_dim: int, elem_bytes: int):
@@ -133,8 +143,11 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
             "embedding_dim": embedding_dim,
             "dtype": str(input.dtype),
             "device": torch.cuda.get_device_name(input.device),
+            "two_level": getattr(hspa_packed, "panel_plan", None) is not None,
         },
-        space=tile_space(embedding_dim, elem_bytes, input.dtype == torch.bfloat16),
+        # handles of the two-level format run beside the panel kernel: only tiles that leave it room on the CU
+        space=tile_space(embedding_dim, elem_bytes, input.dtype == torch.bfloat16,
+                         TWO_LEVEL_LDS_BUDGET if getattr(hspa_packed, "panel_plan", None) is not None else None),
         includes=includes,
         arg_defs=(
             ("blk_offsets", blk_offsets.dtype),
