@@ -275,9 +275,14 @@ def main():
         if two_level_ok:
             fs = 32 if num_feats <= 32 else (64 if num_feats <= 64 else 128)
             # window tile (fs, 3, 4) + panel depth 3 fit one CU together (LDS 103 + 44 KB, registers 136 + 2 x 183)
-            for tau in (3, 4):
+            plans = [(8, 4, 3, 3 if fs == 128 else 6), (8, 4, 4, 3 if fs == 128 else 6)]
+            if local_rows < 100_000 and fs == 128:
+                # a rank's shard of a multi-GPU run has too few 512-row panels to fill 256 CUs: shorter panels
+                # (measured on a 1/8 shard: profiles/r01/experiment_two_level_shard8.log)
+                plans += [(8, 2, 4, 4), (4, 2, 3, 6)]
+            for pw, prb, tau, pdepth in plans:
                 for sched in (2, 3):
-                    cands.append(("two-level", fs, 3, 4, sched, 8, 4, tau, 3 if fs == 128 else 6))
+                    cands.append(("two-level", fs, 3, 4, sched, pw, prb, tau, pdepth))
     best = None
     for cand in cands:
         spmm(cand)

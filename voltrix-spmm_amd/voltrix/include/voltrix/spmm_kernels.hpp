@@ -46,6 +46,7 @@
 #define VOLTRIX_DIAG 0
 #endif
 
+
 namespace voltrix {
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
