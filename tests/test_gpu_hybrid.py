@@ -194,3 +194,24 @@ def test_hybrid_operator_is_graph_capturable(cuda_device, monkeypatch):
     torch.cuda.synchronize()
     again = voltrix.spmm(*handle, num_nodes=n, num_edges=indices_t.numel(), feat=feat)
     assert torch.equal(captured, again) and not torch.equal(captured, eager)
+
+
+def test_hybrid_degenerate_plans(cuda_device, monkeypatch):
+    """No shared column at all (threshold out of reach), a column universe above the builder's limit (empty plan by
+    design), a row count that leaves a partial last panel and a feature width that needs padding: ``voltrix.spmm`` on a
+    two-level handle still equals the oracle."""
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    indptr, indices = _random_csr(777, 50, seed=11)
+    feat32 = torch.randn(777, 44).half().float()
+    for kwargs in (dict(tau=60000), dict(tau=2, waves=4, row_blocks=2), dict(tau=1)):
+        handle = voltrix.csr_preprocess_hybrid(torch.from_numpy(indptr), torch.from_numpy(indices), 777, **kwargs)
+        handle[1].hash_tag = f"degenerate_{sorted(kwargs.items())}"
+        out = voltrix.spmm(*handle, num_nodes=777, num_edges=len(indices), feat=feat32.half().cuda())
+        _assert_close(out, indptr, indices, feat32, 777, "fp16")
+    assert voltrix.csr_preprocess_hybrid(torch.from_numpy(indptr), torch.from_numpy(indices), 777, tau=60000)[1] \
+        .panel_plan.num_ksteps == 0
+    # universe above 2^22 columns: the plan is empty by design, everything stays in the window format
+    wide_cols = hybrid.MAX_PLAN_COLS + 1000
+    w_indptr, w_indices = _random_csr(200, 30, seed=12, ncols=wide_cols)
+    ri, rx, plan = hybrid.build_panel_plan(torch.from_numpy(w_indptr).cuda(), torch.from_numpy(w_indices).cuda(), 200, wide_cols)
+    assert plan.num_ksteps == 0 and torch.equal(rx.cpu(), torch.from_numpy(w_indices)) and plan.num_resid_edges == len(w_indices)

@@ -90,3 +90,36 @@ def test_remap_columns_addresses_the_padded_gather_buffer():
     cols = torch.tensor([0, 31, 32, 47, 48, 99], dtype=torch.int32)
     got = vdist.remap_columns(cols, parts, rows_padded).tolist()
     assert got == [0, 31, 52, 52 + 15, 104, 104 + 51]
+
+
+def test_tile_space_for_two_level_handles_leaves_room_for_the_panel_kernel():
+    """Handles of the two-level format run beside the panel kernel: the tuner only sees window tiles whose workgroup fits
+    the LDS the panel workgroup (44 KB) leaves on a CU."""
+    from voltrix.jit_kernels import spmm as spmm_mod
+
+    full = spmm_mod.tile_space(128, 2)
+    fit = spmm_mod.tile_space(128, 2, max_lds=spmm_mod.TWO_LEVEL_LDS_BUDGET)
+    assert fit and set(map(lambda p: tuple(sorted(p.items())), fit)) <= set(map(lambda p: tuple(sorted(p.items())), full))
+    for p in fit:
+        assert spmm_mod._lds_bytes(p["FS"], p["DEPTH"], p["WAVES"], p["EB"]) <= spmm_mod.TWO_LEVEL_LDS_BUDGET
+        assert p["WAVES"] >= 4
+    assert any(p["FS"] == 128 and p["DEPTH"] == 3 and p["WAVES"] == 4 for p in fit)
+
+
+def test_every_default_panel_tile_is_instantiated():
+    """voltrix.hybrid.default_panel_tile must only name tiles the ahead-of-time library instantiates
+    (csrc/capi_spmm_panel.hip), for every plan geometry and feature width."""
+    import os
+    import re
+
+    from conftest import PKG_ROOT
+    from voltrix import hybrid
+
+    src = open(os.path.join(PKG_ROOT, "csrc", "capi_spmm_panel.hip")).read()
+    inst = {tuple(map(int, m)) for m in re.findall(r"X\((\d+), (\d+), (\d+), (\d+), (\d+)\)", src)}
+    assert len(inst) > 10
+    for feat in (8, 32, 48, 64, 96, 128, 200, 512):
+        for waves in (4, 8):
+            for rb in (2, 4):
+                fs, depth, ksteps = hybrid.default_panel_tile(feat, waves, rb)
+                assert (fs, depth, waves, rb, ksteps) in inst, (feat, waves, rb)

@@ -13,7 +13,8 @@ namespace {
   X(128, 3, 8, 4, 1) X(128, 4, 8, 4, 1) X(128, 6, 8, 4, 1) X(128, 8, 8, 4, 1) X(128, 4, 4, 4, 1) X(128, 6, 4, 4, 1) X(128, 8, 4, 4, 1) \
   X(128, 4, 8, 2, 1) X(128, 6, 8, 2, 1) X(128, 8, 8, 2, 1) X(128, 6, 4, 2, 1)                                    \
   X(64, 4, 4, 4, 1) X(64, 6, 4, 4, 1) X(64, 4, 8, 4, 2) X(64, 6, 8, 4, 2) X(64, 6, 4, 4, 2)                      \
-  X(32, 4, 4, 4, 2) X(32, 6, 4, 4, 2) X(32, 6, 8, 4, 2)
+  X(32, 4, 4, 4, 2) X(32, 6, 4, 4, 2) X(32, 6, 8, 4, 2) X(64, 6, 4, 2, 2) X(64, 6, 8, 2, 2) X(32, 6, 4, 2, 2) X(32, 6, 8, 2, 2) \
+  X(128, 3, 4, 4, 1) X(128, 4, 4, 2, 1)
 
 template <bool BF16>
 int dispatch(int fs, int depth, int waves, int rb, int ks, const int* panel_ptr, const int* panel_cols,

@@ -211,12 +211,14 @@ def build_panel_plan_torch(indptr: torch.Tensor, indices: torch.Tensor, num_node
 # panel kernel tile per feature width: (fs, depth, ks); waves / row_blocks come from the plan.  Depth 3 at FS = 128 keeps
 # the workgroup at 44 KB of LDS and 183 registers, so that it fits on a CU NEXT TO a (128, 3, 4) window-kernel
 # workgroup (103 KB, 136 registers) -- the two kernels overlap when they run on two streams.
-def default_panel_tile(embedding_dim: int, waves: int):
+def default_panel_tile(embedding_dim: int, waves: int, row_blocks: int = DEFAULT_ROW_BLOCKS):
     if embedding_dim <= 32:
         return (32, 6, 2)
     if embedding_dim <= 64:
         return (64, 6, 2)
-    return (128, 3, 1) if waves == 8 else (128, 4, 1)
+    if waves == 8:
+        return (128, 3, 1) if row_blocks == 4 else (128, 4, 1)
+    return (128, 4, 1)
 
 
 _SIDE_STREAMS = {}
@@ -271,7 +273,7 @@ def launch_panel(plan: PanelPlan, feat: torch.Tensor, output: torch.Tensor, accu
     assert output.is_cuda and output.is_contiguous() and output.dtype == torch.float32
     f = feat.shape[1]
     assert output.shape == (plan.num_nodes, f)
-    tile = tile or default_panel_tile(f, plan.waves)
+    tile = tile or default_panel_tile(f, plan.waves, plan.row_blocks)
     assert tile is not None, f"no panel tile for F={f} with {plan.waves} waves"
     stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
     rc = capi.launch_spmm_panel(plan, feat.data_ptr(), output.data_ptr(), f, bool(accumulate),
