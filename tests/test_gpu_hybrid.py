@@ -125,6 +125,7 @@ def test_panel_kernel_alone(cuda_device, waves, rb, tile, feat_dim):
 def test_hybrid_operator(cuda_device, dtype, mode, feat_dim, streams, monkeypatch):
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
     monkeypatch.setenv("VOLTRIX_HYBRID_STREAMS", streams)   # two streams + add pass / one stream, accumulate mode
+    monkeypatch.setenv("VOLTRIX_HYBRID_MIN_SHARE", "0")
     indptr_t, indices_t, _ = synth_graphs.generate("reddit_like", scale=0.006)
     n = indptr_t.numel() - 1
     handle = voltrix.csr_preprocess_hybrid(indptr_t, indices_t, n, tau=40)  # small graph, dense panels: a high bar
@@ -179,6 +180,7 @@ def test_hybrid_full_size_properties(cuda_device, monkeypatch):
 def test_hybrid_operator_is_graph_capturable(cuda_device, monkeypatch):
     """The two-stream form forks and joins through events only: it replays from a HIP graph with the same result."""
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    monkeypatch.setenv("VOLTRIX_HYBRID_MIN_SHARE", "0")
     indptr_t, indices_t, _ = synth_graphs.generate("reddit_like", scale=0.006)
     n = indptr_t.numel() - 1
     handle = voltrix.csr_preprocess_hybrid(indptr_t, indices_t, n, tau=40)
@@ -203,6 +205,7 @@ def test_hybrid_degenerate_plans(cuda_device, monkeypatch):
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
     indptr, indices = _random_csr(777, 50, seed=11)
     feat32 = torch.randn(777, 44).half().float()
+    monkeypatch.setenv("VOLTRIX_HYBRID_MIN_SHARE", "0")
     for kwargs in (dict(tau=60000), dict(tau=2, waves=4, row_blocks=2), dict(tau=1)):
         handle = voltrix.csr_preprocess_hybrid(torch.from_numpy(indptr), torch.from_numpy(indices), 777, **kwargs)
         handle[1].hash_tag = f"degenerate_{sorted(kwargs.items())}"
@@ -210,6 +213,12 @@ def test_hybrid_degenerate_plans(cuda_device, monkeypatch):
         _assert_close(out, indptr, indices, feat32, 777, "fp16")
     assert voltrix.csr_preprocess_hybrid(torch.from_numpy(indptr), torch.from_numpy(indices), 777, tau=60000)[1] \
         .panel_plan.num_ksteps == 0
+    # below VOLTRIX_HYBRID_MIN_SHARE the plan is dropped and the handle is the window format of the whole matrix
+    monkeypatch.setenv("VOLTRIX_HYBRID_MIN_SHARE", "0.99")
+    dropped = voltrix.csr_preprocess_hybrid(torch.from_numpy(indptr), torch.from_numpy(indices), 777, tau=8)
+    plain = voltrix.csr_preprocess(torch.from_numpy(indptr), torch.from_numpy(indices), 777)
+    assert dropped[1].panel_plan.num_ksteps == 0 and all(torch.equal(a.view(torch.int32), b.view(torch.int32))
+                                                         for a, b in zip(dropped, plain))
     # universe above 2^22 columns: the plan is empty by design, everything stays in the window format
     wide_cols = hybrid.MAX_PLAN_COLS + 1000
     w_indptr, w_indices = _random_csr(200, 30, seed=12, ncols=wide_cols)

@@ -282,5 +282,10 @@ def launch_panel(plan: PanelPlan, feat: torch.Tensor, output: torch.Tensor, accu
     capi.check(rc, "voltrix_launch_spmm_panel")
 
 
+def min_shared_fraction() -> float:
+    """Below this fraction of edges in shared columns ``csr_preprocess_hybrid`` keeps the plain window format."""
+    return float(os.getenv("VOLTRIX_HYBRID_MIN_SHARE", "0.2"))
+
+
 def hybrid_enabled() -> bool:
     return os.getenv("VOLTRIX_HYBRID", "0") not in ("0", "", "off")

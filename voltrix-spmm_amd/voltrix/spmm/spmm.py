@@ -73,13 +73,20 @@ def csr_preprocess_hybrid(indptr: torch.Tensor, indices: torch.Tensor, num_nodes
     """Extension (no reference counterpart): two-level condensed format.  Columns referenced by >= ``tau`` rows of a
     ``waves * row_blocks * 16``-row panel go to a panel plan (gathered once per panel, ``spmm_panel_kernel``); the
     remaining edges go through the ordinary ``csr_preprocess``.  Returns the reference-format handle of the RESIDUAL
-    matrix with the plan attached as ``hspa_packed.panel_plan`` -- ``spmm`` adds both parts.  The same arguments and
-    assertions as ``csr_preprocess``."""
+    matrix with the plan attached as ``hspa_packed.panel_plan`` -- ``spmm`` adds both parts.  When fewer than
+    ``VOLTRIX_HYBRID_MIN_SHARE`` (default 0.2) of the edges land on the panel side the plan is dropped and the handle is
+    the plain window format of the whole matrix.  The same arguments and assertions as ``csr_preprocess``."""
     assert indptr.is_cpu and indptr.dtype == torch.int32
     assert indices.is_cpu and indices.dtype == torch.int32
     assert indptr.numel() == num_nodes + 1
-    resid_indptr, resid_indices, plan = hybrid.build_panel_plan(indptr.contiguous().cuda(), indices.contiguous().cuda(),
-                                                                num_nodes, num_cols, waves, row_blocks, tau)
+    indptr_d, indices_d = indptr.contiguous().cuda(), indices.contiguous().cuda()
+    resid_indptr, resid_indices, plan = hybrid.build_panel_plan(indptr_d, indices_d, num_nodes, num_cols, waves, row_blocks,
+                                                                tau)
+    if plan.num_shared_edges < hybrid.min_shared_fraction() * max(1, indices.numel()):
+        # too few edges sit in shared columns for the panel kernel to pay for itself (uniform-random graphs, low degrees):
+        # keep the whole matrix in the window format; the empty plan makes spmm skip the panel kernel
+        resid_indptr, resid_indices = indptr_d, indices_d
+        plan = hybrid.empty_plan(num_nodes, waves, row_blocks, tau, indptr_d.device, indices.numel())
     pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(resid_indptr, resid_indices, num_nodes, num_cols)
     hspa_packed.panel_plan = plan
     return pointer1, hspa_packed, hind
