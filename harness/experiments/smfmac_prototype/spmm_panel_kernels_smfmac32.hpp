@@ -1,0 +1,374 @@
+// Voltrix-SpMM for MI355X (gfx950) -- panel kernel: the "shared column" half of the two-level condensed format.
+//
+// The reference format (and spmm_tc16_kernel) condenses columns per 16-row window: a gathered row of B serves 16 rows
+// of A and, on graphs with a few hundred edges per row, about ONE of them (TC-block fill 6-7 %): every edge costs one
+// 2*F-byte row gather out of L2 / Infinity Cache, and that gather traffic -- not HBM, not the matrix cores -- is what
+// bounds the kernel.  Columns that are referenced by SEVERAL rows of a taller row panel (community /
+// band structure, hub columns) can do better: gathered once per panel into LDS, shared by all the panel's windows.
+//
+//   panel       PANEL_ROWS = WAVES * RB * 16 consecutive rows (256 or 512); one workgroup per (panel, feature slab)
+//   plan        per panel the sorted list of its shared columns (those with >= tau edges inside the panel; chosen by
+//               the plan builder, voltrix/hybrid.py), cut into k-steps of 32 columns:
+//                 panel_ptr  int32 [NP+1]            first k-step of every panel
+//                 panel_cols int32 [32 * (S + pad)]  row of B per (k-step, k); unused slots repeat a real column
+//                 panel_bits uint32 [(S + 1) * WAVES * 64] adjacency bits in MFMA A-operand order: word (k-step, wave v,
+//                                                    lane L = 16 g + R), bit 16 (c & 1) + 4 j + (c >> 1)  <=>  edge (row 16 (RB v + j) + R
+//                                                    of the panel, column 8 g + c of the k-step)
+//   everything else (columns below tau) stays in the reference's window format and runs through spmm_tc16_kernel; this
+//   kernel then adds its share onto C (accumulate = 1) -- two addends per element, so the sum does not depend on order.
+//
+// Per k-step the workgroup gathers 32 rows of B ONCE (8 KiB at FS = 128; LDS-DMA, every wave issues its share) and each
+// wave multiplies it into RB 16-row blocks: RB * FS/16 v_smfmac_f32_16x16x32_f16 per 2 * FS/16 transposed LDS reads.  The
+// ring is shared, so there is one raw s_barrier per step: counted vmcnt wait -> barrier -> reads (cdna_hip_programming.md
+// "Pipelining across barriers"); the metadata (this wave's 2 x 256 B of adjacency words, the step's 32 rows) is fetched
+// by wave-private LDS-DMAs a ring ahead, as in spmm_tc16_kernel.
+//
+// Bound: matrix cores (16 rows x 32 columns per MFMA at the panel's density), with 1/16 .. 1/32 of the window kernel's
+// gather traffic per covered edge.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "voltrix/spmm_kernels.hpp"
+
+// Diagnostic builds only (harness/experiments/panel_diag.py): bit 0 skips the MFMAs, bit 1 the row DMAs, bit 2 the
+// barrier.  Results are wrong by design; shipped kernels use 0.
+#ifndef VOLTRIX_PANEL_DIAG
+#define VOLTRIX_PANEL_DIAG 0
+#endif
+
+namespace voltrix {
+
+
+//   FS     feature slab per workgroup (columns of B / C): 32, 64 or 128
+//   DEPTH  ring slots (k-step groups of gathered rows in flight per workgroup)
+//   WAVES  waves per workgroup (4 or 8)
+//   RB     16-row blocks per wave (2 or 4): PANEL_ROWS = WAVES * RB * 16
+//   KS     k-steps (of 32 columns) per ring slot / barrier
+template <int FS_, int DEPTH_, int WAVES_, int RB_, int KS_ = 1, bool BF16_ = false>
+struct PanelTile {
+  static constexpr int FS = FS_, DEPTH = DEPTH_, WAVES = WAVES_, RB = RB_, KS = KS_;
+  static constexpr bool BF16 = BF16_;
+  static_assert(FS == 32 || FS == 64 || FS == 128, "feature slab");
+  static_assert(RB >= 1 && RB <= 4, "a lane's adjacency word holds four row blocks");
+  static_assert(KS == 1 || KS == 2, "one index DMA covers 64 columns");
+  static_assert(DEPTH >= 3 && DEPTH <= 8, "ring depth");
+  static constexpr int PANEL_ROWS = WAVES * RB * 16;
+  static constexpr int THREADS = WAVES * kWave;
+  static constexpr int ROW_BYTES = FS * 2;
+  static constexpr int KSTEP_BYTES = kStageK * ROW_BYTES;          // 32 gathered rows
+  static constexpr int STAGE_BYTES = KS * KSTEP_BYTES;
+  static constexpr int NDMA = STAGE_BYTES / 1024;                  // 1 KiB per global_load_lds_dwordx4
+  // every wave issues the same number of row DMAs (static vmcnt); with more waves than DMAs the surplus waves repeat
+  // the first ones (same bytes to the same place: harmless, and only at FS = 32 where a step is 2-4 KiB)
+  static_assert(NDMA % WAVES == 0 || WAVES % NDMA == 0, "row DMAs per step vs waves");
+  static constexpr int DPW = NDMA >= WAVES ? NDMA / WAVES : 1;     // row DMAs per wave and step
+  static constexpr int ROWS_PER_DMA = 1024 / ROW_BYTES;
+  static constexpr int LANES_PER_ROW = ROW_BYTES / 16;
+  static constexpr int SLOTS = FS / 16;
+  // wave-private metadata slot: KS x (64 value-mask words + 64 index words), then 64 column ids (32 * KS used)
+  static constexpr int META_BYTES = KS * 512 + 256;
+  static constexpr int META_SLOTS = 2 * DEPTH - 1;
+  static constexpr int NMETA = 2 * KS + 1;                         // metadata DMAs per wave and step
+  static constexpr int VM_PER_STEP = DPW + NMETA;
+  static constexpr int DATA_LDS = DEPTH * STAGE_BYTES;
+  static constexpr int BLOCK_LDS = DATA_LDS + WAVES * META_SLOTS * META_BYTES;
+  static_assert(BLOCK_LDS <= 160 * 1024, "LDS per CU");
+  static_assert(VM_PER_STEP * (DEPTH - 2) <= 63, "vmcnt is a 6-bit counter on gfx9");
+};
+
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+
+// Value-mask word -> structured-sparse A fragment.  Bit p (p = 2 j + q) of the word says that the first kept value of
+// group q of row block j is present, bit 16 + p the second, so one shift + one mask yields the packed fp16 pair
+// {2.0 or 0.0} x 2 of register q (2.0 = 0x4000; the 0.5 is applied once in the epilogue, as in spmm_tc16_kernel).
+__device__ __forceinline__ half4_t kept_values_to_half4_x2(unsigned w, int p0) {  // p0 = 2 j: constant after unrolling
+  uint2_t r;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) r[i] = (w << (14 - (p0 + i))) & 0x40004000u;
+  return __builtin_bit_cast(half4_t, r);
+}
+
+// acc += A(2:4 sparse, index byte ABID of idx) x B
+template <bool BF16, int ABID>
+__device__ __forceinline__ float4_t smfmac_16x16x32(half4_t a, uint4_t b, float4_t acc, int idx) {
+  if constexpr (BF16)
+    return __builtin_amdgcn_smfmac_f32_16x16x32_bf16(__builtin_bit_cast(bf16x4_t, a), __builtin_bit_cast(bf16x8_t, b), acc,
+                                                     idx, 0, ABID);
+  else
+    return __builtin_amdgcn_smfmac_f32_16x16x32_f16(a, __builtin_bit_cast(half8_t, b), acc, idx, 0, ABID);
+}
+
+template <class T>
+struct PanelArgs {
+  using in_t = typename std::conditional<T::BF16, bfloat16_bits, _Float16>::type;
+  const int* panel_ptr;        // [NP+1]
+  const int* panel_cols;       // [32 * (S + 2)]
+  const uint32_t* panel_bits;  // [(S + 1) * WAVES * 2 * 64]
+  const int* panel_order;      // optional: launch position -> panel (longest first); nullptr = natural
+  const in_t* input;
+  float* output;
+  const float* out_scale;      // optional device scalar (see SpmmArgs::out_scale)
+  int num_nodes;
+  int num_panels;
+  int panels_per_xcd;
+  int F;
+  int accumulate;              // 1: C += A_shared * B (C holds the window kernel's part); 0: C = A_shared * B
+};
+
+template <class T>
+static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const PanelArgs<T> a) {
+  constexpr int FS = T::FS, D = T::DEPTH, MS = T::META_SLOTS, KS = T::KS, RB = T::RB;
+  constexpr int ROW_BYTES = T::ROW_BYTES, STAGE_BYTES = T::STAGE_BYTES, DPW = T::DPW;
+  constexpr int RPD = T::ROWS_PER_DMA, LPR = T::LANES_PER_ROW, SLOTS = T::SLOTS;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+
+  // XCD x = blockIdx.x % 8 owns a contiguous range of launch positions: neighbouring panels share most of their
+  // columns (band / community structure), so they should share an L2.
+  const int xcd = blockIdx.x % kNumXcd;
+  const int pos = xcd * a.panels_per_xcd + (int)(blockIdx.x / kNumXcd);
+  const int pos_end = (xcd + 1) * a.panels_per_xcd < a.num_panels ? (xcd + 1) * a.panels_per_xcd : a.num_panels;
+  if (pos >= pos_end) return;  // workgroup-uniform
+  const int panel = a.panel_order ? a.panel_order[pos] : pos;
+  const int fs0 = blockIdx.y * FS;
+  const int F = a.F;
+
+  const int ks0 = a.panel_ptr[panel];
+  const int nks = a.panel_ptr[panel + 1] - ks0;
+  const int ngroups = (nks + KS - 1) / KS;
+  if (ngroups == 0 && a.accumulate) return;  // workgroup-uniform: nothing to add
+
+  float4_t acc[RB][SLOTS];
+#pragma unroll
+  for (int j = 0; j < RB; ++j)
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) acc[j][s] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+  const unsigned data0 = (unsigned)(uintptr_t)(lds_ptr)smem;
+  const unsigned meta0 = data0 + T::DATA_LDS + (unsigned)wave * (MS * T::META_BYTES);
+
+  if (ngroups > 0) {
+    // ---- lane constants ---------------------------------------------------------------------------------------
+    const unsigned row_bytes = (unsigned)F * 2u;
+    const int dma0 = (wave * DPW) % T::NDMA;      // this wave's first row DMA of a step: LDS bytes [dma0 KiB, ...)
+    const char* cbase[DPW];   // source of this lane's 16 bytes in row DMA d of a step, before the row offset
+    unsigned hr_off[DPW];     // byte offset of that DMA's row id inside the metadata slot's column list
+#pragma unroll
+    for (int d = 0; d < DPW; ++d) {
+      const int r = (dma0 + d) * RPD + lane / LPR;  // gathered row inside the step (0 .. 32 KS - 1)
+      const int c = lane % LPR;                     // 16-byte chunk inside the row
+      int col = fs0 + (((c >> 1) ^ slot_swizzle<SLOTS>(r & 31)) * 16) + (c & 1) * 8;  // swizzle on the SOURCE
+      col = col < F ? col : fs0;                    // F % FS tail: stay in bounds, never stored
+      unsigned long long cb = (unsigned long long)((const char*)a.input + (long long)col * 2);
+      asm volatile("" : "+v"(cb));
+      cbase[d] = (const char*)cb;
+      hr_off[d] = KS * 512 + 4 * r;
+    }
+    // metadata DMAs of k-step group s (clamped to the panel's last group: the pipeline issues a static number of DMAs)
+    const uint32_t* const bits_base = a.panel_bits + ((long long)ks0 * T::WAVES + wave) * (2 * kWave) + lane;
+    const int* const cols_base = a.panel_cols + (long long)ks0 * kStageK + lane;
+    auto issue_meta = [&](int s) {
+      const int sc = s < ngroups ? s : ngroups - 1;
+      const unsigned dst = meta0 + (unsigned)(s % MS) * T::META_BYTES;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        const uint32_t* src = bits_base + (long long)(sc * KS + k) * (T::WAVES * 2 * kWave);
+        dma_b32(src, dst + 512 * k);                 // value masks
+        dma_b32(src + kWave, dst + 512 * k + 256);   // position indices
+      }
+      dma_b32(cols_base + (long long)sc * (KS * kStageK), dst + 512 * KS);
+    };
+    auto issue_rows = [&](int s) {
+      const unsigned mslot = meta0 + (unsigned)(s % MS) * T::META_BYTES;
+      const unsigned dst = data0 + (unsigned)(s % D) * STAGE_BYTES + (unsigned)dma0 * 1024u;
+      unsigned hrow[DPW];
+#pragma unroll
+      for (int d = 0; d < DPW; ++d) hrow[d] = lds_read_b32(mslot + hr_off[d]);
+      wait_lgkmcnt0();
+#pragma unroll
+      for (int d = 0; d < DPW; ++d)
+        if (!(VOLTRIX_PANEL_DIAG & 2)) dma_b128(cbase[d] + (unsigned long long)hrow[d] * row_bytes, dst + d * 1024);
+    };
+
+    // ---- prologue: metadata of groups 0 .. D-2, then the virtual steps -(D-1) .. -1 ------------------------------
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s) issue_meta(s);
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s) {
+      issue_rows(s);            // groups past the panel's end re-gather its last group (static DMA count)
+      issue_meta(s + D - 1);
+    }
+
+    // MFMA lane roles (as in spmm_tc16_kernel): A row R of block g's 8 columns; B column R, rows 8g+q (+4)
+    const int g = lane >> 4;
+    const int q = (lane >> 2) & 3, p = lane & 3;
+    const int trow = 8 * g + q;
+    const unsigned rd_off = trow * ROW_BYTES + 8 * p;
+    const int tr_z = slot_swizzle<SLOTS>(trow);
+
+    for (int t = 0; t < ngroups; ++t) {
+      // rows of group t (issued D-1 steps ago) and the metadata of group t+D-1 must have landed; the D-2 younger
+      // steps may stay in flight.  Steps past ngroups-D+1 issue nothing.
+      const int young = ngroups - 1 - t;
+      if (young >= D - 2) {
+        wait_vmcnt<T::VM_PER_STEP*(D - 2)>();
+      } else {
+        switch (young) {
+          case 0: wait_vmcnt<0>(); break;
+          case 1: wait_vmcnt<T::VM_PER_STEP * 1>(); break;
+          case 2: wait_vmcnt<T::VM_PER_STEP * 2>(); break;
+          case 3: wait_vmcnt<T::VM_PER_STEP * 3>(); break;
+          case 4: wait_vmcnt<T::VM_PER_STEP * 4>(); break;
+          default: wait_vmcnt<T::VM_PER_STEP * 5>(); break;
+        }
+      }
+      if (!(VOLTRIX_PANEL_DIAG & 4))
+        __builtin_amdgcn_s_barrier();  // every wave's share of group t has landed; everyone is done reading group t-1
+      __builtin_amdgcn_sched_barrier(0);
+
+      if (t + D - 1 < ngroups) {     // workgroup-uniform
+        issue_rows(t + D - 1);       // into the slot group t-1 has just left
+        issue_meta(t + 2 * D - 2);
+      }
+
+      const unsigned mt = meta0 + (unsigned)(t % MS) * T::META_BYTES;
+      const unsigned dt = data0 + (unsigned)(t % D) * STAGE_BYTES + rd_off;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        if (t * KS + k < nks) {      // workgroup-uniform
+          const unsigned aw = lds_read_b32(mt + 512 * k + 4 * lane);        // kept-value masks of the RB row blocks
+          const int ix = (int)lds_read_b32(mt + 512 * k + 256 + 4 * lane);  // their positions: index byte j = row block j
+          // B fragments in two halves of the slab: 16 fewer registers (<= 184 lets two waves of this kernel per SIMD share
+          // it with one wave of the window kernel), and the second half's LDS reads overlap the first half's MFMAs,
+          // which are already queued on the matrix pipe
+          constexpr int HS = SLOTS > 4 ? SLOTS / 2 : SLOTS;
+#pragma unroll
+          for (int h = 0; h < SLOTS / HS; ++h) {
+            uint2_t blo[HS], bhi[HS];
+#pragma unroll
+            for (int s = 0; s < HS; ++s) {
+              const unsigned addr = dt + k * T::KSTEP_BYTES + (((h * HS + s) ^ tr_z) << 5);
+              blo[s] = lds_read_tr16_b64<0>(addr);
+              bhi[s] = lds_read_tr16_b64<4 * ROW_BYTES>(addr);
+            }
+            wait_lgkmcnt0();
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+              const half4_t afrag = kept_values_to_half4_x2(aw, 2 * j);
+#pragma unroll
+              for (int s = 0; s < HS; ++s) {
+                const uint4_t bq = {blo[s][0], blo[s][1], bhi[s][0], bhi[s][1]};
+                float4_t& c = acc[j][h * HS + s];
+                if (VOLTRIX_PANEL_DIAG & 1) {
+                  asm volatile("" ::"v"(afrag), "v"(bq));
+                  continue;
+                }
+                if (j == 0) c = smfmac_16x16x32<T::BF16, 0>(afrag, bq, c, ix);
+                if (j == 1) c = smfmac_16x16x32<T::BF16, 1>(afrag, bq, c, ix);
+                if (j == 2) c = smfmac_16x16x32<T::BF16, 2>(afrag, bq, c, ix);
+                if (j == 3) c = smfmac_16x16x32<T::BF16, 3>(afrag, bq, c, ix);
+              }
+            }
+          }
+        }
+      }
+    }
+    wait_vmcnt<0>();  // nothing of this workgroup may still be writing LDS when it is released
+  }
+
+  // ---- epilogue: D[row = 4*(lane>>4) + i][col = lane & 15] per (row block, 16-column slot) ------------------------
+  const float oscale = kAScaleInv * (a.out_scale ? *a.out_scale : 1.0f);
+  const int prow0 = panel * T::PANEL_ROWS + wave * (RB * 16) + 4 * (lane >> 4);
+  const int ocol0 = fs0 + (lane & 15);
+#pragma unroll
+  for (int j = 0; j < RB; ++j) {
+    // accumulate mode: all of a row block's loads first (one round trip, not one per element), then add and store
+    float prev[SLOTS][4];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = prow0 + 16 * j + i, col = ocol0 + 16 * s;
+        prev[s][i] = (a.accumulate && col < F && row < a.num_nodes) ? a.output[(long long)row * F + col] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = prow0 + 16 * j + i, col = ocol0 + 16 * s;
+        if (col < F && row < a.num_nodes) a.output[(long long)row * F + col] = prev[s][i] + acc[j][s][i] * oscale;
+      }
+    }
+  }
+}
+
+// Host launcher.  The plan arrays must be padded as the builder pads them: panel_cols by 2 k-steps (64 ints) and
+// panel_bits by one k-step beyond S = panel_ptr[NP] (the metadata DMAs fetch 64 column ids at a time).
+template <class T>
+inline int launch_spmm_panel(const int* panel_ptr, const int* panel_cols, const uint32_t* panel_bits,
+                             const int* panel_order, int num_nodes, int embedding_dim, const void* input, float* output,
+                             int accumulate, const float* out_scale, hipStream_t stream) {
+  if (num_nodes < 0 || embedding_dim < 0) return kErrBadShape;
+  if (num_nodes == 0 || embedding_dim == 0) return kOk;
+  if (embedding_dim % 8 != 0 || ((uintptr_t)input & 15)) return kErrBadShape;
+  PanelArgs<T> a;
+  a.panel_ptr = panel_ptr;
+  a.panel_cols = panel_cols;
+  a.panel_bits = panel_bits;
+  a.panel_order = panel_order;
+  a.input = static_cast<const typename PanelArgs<T>::in_t*>(input);
+  a.output = output;
+  a.out_scale = out_scale;
+  a.num_nodes = num_nodes;
+  a.num_panels = (num_nodes + T::PANEL_ROWS - 1) / T::PANEL_ROWS;
+  a.panels_per_xcd = (a.num_panels + kNumXcd - 1) / kNumXcd;
+  a.F = embedding_dim;
+  a.accumulate = accumulate;
+  const int slabs = (embedding_dim + T::FS - 1) / T::FS;
+  static bool attr_done = false;  // per instantiation
+  if (!attr_done) {
+    if (T::BLOCK_LDS > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_panel_kernel<T>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, T::BLOCK_LDS) != hipSuccess)
+      return kErrBadConfig;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(spmm_panel_kernel<T>, dim3((unsigned)(a.panels_per_xcd * kNumXcd), (unsigned)slabs),
+                     dim3(T::THREADS), T::BLOCK_LDS, stream, a);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+// dst += src (float32, count % 4 == 0, 16-byte aligned): joins the two halves of the two-level format when the window
+// kernel and the panel kernel ran side by side on two streams into two buffers.
+static __global__ __launch_bounds__(256) void add_inplace_f32_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                                const long long n4) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 d = reinterpret_cast<float4*>(dst)[i];
+    const float4 x = reinterpret_cast<const float4*>(src)[i];
+    d.x += x.x;
+    d.y += x.y;
+    d.z += x.z;
+    d.w += x.w;
+    reinterpret_cast<float4*>(dst)[i] = d;
+  }
+}
+
+inline int add_inplace_f32(float* dst, const float* src, long long count, hipStream_t stream) {
+  if (count < 0 || (count % 4) != 0 || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) return kErrBadShape;
+  if (count == 0) return kOk;
+  const long long n4 = count / 4;
+  const int blocks = (int)(n4 / 256 + 1 < 256 * 16 ? n4 / 256 + 1 : 256 * 16);
+  hipLaunchKernelGGL(add_inplace_f32_kernel, dim3(blocks), dim3(256), 0, stream, dst, src, n4);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+}  // namespace voltrix

@@ -16,7 +16,11 @@ __global__ __launch_bounds__(256) void rate(float* out, int iters, int idx) {
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      if (SPARSE) acc[s] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(a, b, acc[s], idx, 0, 0);
+      if (SPARSE == 2) {
+        typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+        half4_t a4 = {a[0], a[1], a[2], a[3]};
+        acc[s] = __builtin_amdgcn_smfmac_f32_16x16x32_f16(a4, b8, acc[s], idx, 0, 0);
+      } else if (SPARSE) acc[s] = __builtin_amdgcn_smfmac_f32_16x16x64_f16(a, b, acc[s], idx, 0, 0);
       else acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b8, acc[s], 0, 0, 0);
     }
   }
@@ -31,7 +35,8 @@ extern "C" float rate_ms(int sparse, int iters, void* out) {
   hipEventCreate(&b);
   for (int rep = 0; rep < 2; ++rep) {
     hipEventRecord(a, 0);
-    if (sparse) hipLaunchKernelGGL(rate<1>, dim3(256 * 2), dim3(256), 0, 0, (float*)out, iters, 0x4444);
+    if (sparse == 2) hipLaunchKernelGGL(rate<2>, dim3(256 * 2), dim3(256), 0, 0, (float*)out, iters, 0x4444);
+    else if (sparse) hipLaunchKernelGGL(rate<1>, dim3(256 * 2), dim3(256), 0, 0, (float*)out, iters, 0x4444);
     else hipLaunchKernelGGL(rate<0>, dim3(256 * 2), dim3(256), 0, 0, (float*)out, iters, 0);
     hipEventRecord(b, 0);
     hipEventSynchronize(b);
