@@ -58,10 +58,10 @@ def main():
         t_plan = time.time() - t0
         t_res, rblocks = window_time(ri, rx)
         line = (f"  panel {plan.panel_rows} rows (waves {waves}, rb {rb}) tau {tau}: shared {plan.num_shared_edges / nnz:.1%} "
-                f"of edges in {plan.num_shared_cols / 1e6:.2f} M cols / {plan.num_ksteps} k-steps; residual {t_res:.3f} ms "
+                f"of edges in {plan.num_ksteps} k-steps; residual {t_res:.3f} ms "
                 f"({rblocks} blocks); plan {t_plan * 1e3:.0f} ms; panel:")
         for depth in (4, 6, 8):
-            tile = (128 if f >= 128 else f, depth, 1 if f >= 128 else 2)
+            tile = (128 if f >= 128 else f, depth, 1 if f >= 128 else 2)  # (fs, depth, ksteps)
             try:
                 t_p = timed(lambda: hybrid.launch_panel(plan, feat, out, True, tile=tile))
             except Exception as e:  # tile not instantiated

@@ -35,13 +35,12 @@ class PanelPlan:
     panel_ptr: torch.Tensor      # int32 [NP+1]
     panel_cols: torch.Tensor     # int32 [32 * (S + 2)]
     panel_bits: torch.Tensor     # uint32 [(S + 1) * waves * 64]
-    panel_order: torch.Tensor    # int32 [NP] or None (natural)
+    panel_order: torch.Tensor    # int32 [NP] (launch position -> panel) or None = natural order
     num_nodes: int
     waves: int
     row_blocks: int
     tau: int
     num_ksteps: int
-    num_shared_cols: int         # (panel, column) pairs gathered by the panel kernel
     num_shared_edges: int
     num_resid_edges: int
 
@@ -107,7 +106,7 @@ def empty_plan(num_nodes, waves, row_blocks, tau, device, num_edges):
                      panel_cols=torch.zeros(2 * KSTEP, dtype=torch.int32, device=device),
                      panel_bits=torch.zeros(waves * 64, dtype=torch.int32, device=device).view(torch.uint32),
                      panel_order=None, num_nodes=num_nodes, waves=waves, row_blocks=row_blocks, tau=tau, num_ksteps=0,
-                     num_shared_cols=0, num_shared_edges=0, num_resid_edges=num_edges)
+                     num_shared_edges=0, num_resid_edges=num_edges)
 
 
 def build_panel_plan(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
@@ -148,13 +147,12 @@ def build_panel_plan(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int
                                 resid_indptr, total_ksteps, resid_indices, panel_cols, panel_bits, stream)
     plan = PanelPlan(panel_ptr=panel_ptr, panel_cols=panel_cols, panel_bits=panel_bits, panel_order=None,
                      num_nodes=num_nodes, waves=waves, row_blocks=row_blocks, tau=tau, num_ksteps=total_ksteps,
-                     num_shared_cols=-1, num_shared_edges=indices.numel() - num_resid, num_resid_edges=num_resid)
+                     num_shared_edges=indices.numel() - num_resid, num_resid_edges=num_resid)
     return resid_indptr, resid_indices, plan
 
 
 def build_panel_plan_torch(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
-                           waves: int = DEFAULT_WAVES, row_blocks: int = DEFAULT_ROW_BLOCKS, tau: int = DEFAULT_TAU,
-                           order: str = "natural"):
+                           waves: int = DEFAULT_WAVES, row_blocks: int = DEFAULT_ROW_BLOCKS, tau: int = DEFAULT_TAU):
     """The same plan from torch tensor ops on any device (sort + run lengths): the first implementation, kept as an
     independent cross-check of the HIP builder that also runs on the CPU (tests/test_hybrid_plan.py).  Not used by the
     operator path."""
@@ -198,12 +196,9 @@ def build_panel_plan_torch(indptr: torch.Tensor, indices: torch.Tensor, num_node
     bits.index_add_(0, word, torch.ones_like(word) << (16 * (k % 2) + 4 * j + (k % 8) // 2))     # distinct bits: add == or
     panel_bits = ((bits + 2 ** 31) % 2 ** 32 - 2 ** 31).to(torch.int32).view(torch.uint32)   # explicit wrap to 32 bits
 
-    panel_order = None
-    if order == "lpt":  # longest panels first (per XCD range the launcher keeps positions contiguous)
-        panel_order = torch.argsort(nks, descending=True, stable=True).to(torch.int32)
     plan = PanelPlan(panel_ptr=panel_ptr.to(torch.int32), panel_cols=panel_cols.to(torch.int32), panel_bits=panel_bits,
-                     panel_order=panel_order, num_nodes=num_nodes, waves=waves, row_blocks=row_blocks, tau=tau,
-                     num_ksteps=total_ksteps, num_shared_cols=int(pc.numel()), num_shared_edges=int(rp.numel()),
+                     panel_order=None, num_nodes=num_nodes, waves=waves, row_blocks=row_blocks, tau=tau,
+                     num_ksteps=total_ksteps, num_shared_edges=int(rp.numel()),
                      num_resid_edges=int(resid_indices.numel()))
     return resid_indptr, resid_indices, plan
 
