@@ -6,7 +6,9 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over the whole synthetic graph: (N > 1: RCCL all-gather of the dense operand B,
-then) the tiled SpMM accumulate on every rank's row-window shard.  Inputs are resident in HBM before the timed region;
+then) the tiled SpMM accumulate on every rank's row-window shard -- in the reference's window format, or in the two-level
+format (shared columns of 512-row panels on the panel kernel beside the window kernel); the sweep
+before the timed region times both and keeps the faster (--format window|two-level forces one).  Inputs are resident in HBM before the timed region;
 preprocessing (CSR -> block format) is done once, outside it, as in the reference's protocol (bench/bm_voltrix.py:17,36).
 Rank 0 prints ONE JSON line.  N > 1 shards the SAME matrix by row windows (strong scaling).
 """
