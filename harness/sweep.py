@@ -46,6 +46,51 @@ def median_ms(fn, iters=7, warm=3, batch=5):
     return sorted(times)[len(times) // 2]
 
 
+def two_level_best(indptr, indices, n, nnz, f, feat, out, dev):
+    """Best of a few two-level configurations: 512-row panels, tau 3 / 4, window tile (fs, 3, 4) on the residual with
+    each balance chunk, panel kernel on a side stream into a second buffer, add pass.  Returns a dict."""
+    from voltrix import hybrid
+    from voltrix.jit_kernels.spmm import ORDER_CHUNKS
+
+    main_s, side = torch.cuda.current_stream(), torch.cuda.Stream()
+    fs = 32 if f <= 32 else (64 if f <= 64 else 128)
+    shared = torch.empty_like(out)
+    best = None
+    for tau in (3, 4):
+        t0 = time.perf_counter()
+        ri, rx, plan = hybrid.build_panel_plan(indptr, indices, n, None, 8, 4, tau)
+        h = voltrix.csr_fused_preprocess_kernel(ri, rx, n)
+        torch.cuda.synchronize()
+        build_ms = (time.perf_counter() - t0) * 1e3
+        if plan.num_ksteps == 0:
+            continue
+        for sched, chunk in ORDER_CHUNKS.items():
+            order = torch.empty((n + 15) // 16, dtype=torch.int32, device=dev)
+            capi.launch_window_order(h[0], n, order, main_s.cuda_stream, chunk)
+
+            def run(plan=plan, h=h, rx=rx, order=order):
+                fork = torch.cuda.Event()
+                fork.record(main_s)
+                side.wait_event(fork)
+                hybrid.launch_panel(plan, feat, shared, accumulate=False, stream=side.cuda_stream)
+                join = torch.cuda.Event()
+                join.record(side)
+                rc = capi.launch_spmm(h[0].data_ptr(), h[1].data_ptr(), h[2].data_ptr(), n, rx.numel(), f, feat.data_ptr(),
+                                      out.data_ptr(), True, (fs, 3, 4), main_s.cuda_stream, order.data_ptr())
+                assert rc == 0
+                main_s.wait_event(join)
+                capi.launch_add_inplace_f32(out, shared, main_s.cuda_stream)
+            ms = median_ms(run, iters=3, warm=1)
+            if best is None or ms < best[0]:
+                best = (ms, run, {"panel_rows": plan.panel_rows, "tau": tau, "balance_chunk": chunk,
+                                  "shared_edge_fraction": plan.num_shared_edges / max(1, nnz),
+                                  "panel_ksteps": plan.num_ksteps, "preprocess_two_level_ms": build_ms}, (plan, h, rx, order))
+    if best is None:
+        return {"ms": None, "note": "no shared columns"}
+    ms = median_ms(best[1])
+    return dict(best[2], ms=ms, gflops=2.0 * nnz * f / ms / 1e6)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workloads", default="reddit_like,reddit_uniform,products_like")
@@ -53,6 +98,8 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--vendor", action="store_true")
+    ap.add_argument("--two-level", action="store_true",
+                    help="also time the two-level format (panel kernel beside the window kernel, voltrix/hybrid.py)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     stream = torch.cuda.current_stream().cuda_stream
@@ -98,6 +145,8 @@ def main():
                     "kernel_ms": ms, "gflops": 2.0 * nnz * f / ms / 1e6, "algorithmic_gbs": alg / ms / 1e6,
                     "hbm_roofline_frac": alg / ms / 1e6 / 8000.0,
                     "gather_tbs": 8.0 * total_blocks * f * 2 / ms / 1e9}
+            if args.two_level:
+                line["two_level"] = two_level_best(indptr, indices, n, nnz, f, feat, out, dev)
             if args.vendor:
                 try:
                     a = torch.sparse_csr_tensor(indptr, indices, torch.ones(nnz, device=dev), size=(n, n))
