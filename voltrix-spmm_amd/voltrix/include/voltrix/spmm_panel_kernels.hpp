@@ -8,7 +8,7 @@
 //
 //   panel       PANEL_ROWS = WAVES * RB * 16 consecutive rows (256 or 512); one workgroup per (panel, feature slab)
 //   plan        per panel the sorted list of its shared columns (those with >= tau edges inside the panel; chosen by
-//               the plan builder, voltrix/hybrid.py), cut into k-steps of 32 columns:
+//               the plan builder, panel_plan.hpp), cut into k-steps of 32 columns:
 //                 panel_ptr  int32 [NP+1]            first k-step of every panel
 //                 panel_cols int32 [32 * (S + pad)]  row of B per (k-step, k); unused slots repeat a real column
 //                 panel_bits uint32 [(S + 1) * WAVES * 64] adjacency bits in MFMA A-operand order: word (k-step, wave v,
@@ -24,7 +24,14 @@
 // wave-private LDS-DMAs a ring ahead, as in spmm_tc16_kernel.
 //
 // Bound: matrix cores (16 rows x 32 columns per MFMA at the panel's density), with 1/16 .. 1/32 of the window kernel's
-// gather traffic per covered edge.
+// gather traffic per covered edge.  Being MFMA-bound is what makes it a good neighbour: on a second stream it overlaps the
+// gather-bound window kernel on the same CUs (183 VGPRs x 2 waves per SIMD + 44 KB of LDS at DEPTH 3 leave room for a
+// (128, 3, 4) window workgroup).  The structured-sparse MFMAs were measured and are NOT used: they make this kernel
+// faster alone and the pair slower (harness/experiments/smfmac_prototype/README.md).
+//
+// Inline-asm note: every LDS read here is asynchronous asm whose outputs are all consumed after the lgkmcnt wait.  A read
+// with a dead output component (e.g. ds_read_b128 of three used words) lets the compiler hand that register out again
+// while the read is still in flight; the late write-back then lands in its new owner.
 #pragma once
 
 #include <hip/hip_runtime.h>
