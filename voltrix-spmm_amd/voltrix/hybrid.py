@@ -86,6 +86,7 @@ def split_shared_columns(indptr: torch.Tensor, indices: torch.Tensor, num_nodes:
 
 
 MAX_PLAN_COLS = 1 << 22  # the HIP builder counts per column range of 2^16 (panel_plan.hpp); larger universes: no plan
+MAX_PLAN_EDGE_PASSES = 2 * 10 ** 10  # ... and re-reads a panel's edges once per range: (ranges x edges) above this: no plan
 
 
 def canonical_csr(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int):
@@ -112,14 +113,15 @@ def empty_plan(num_nodes, waves, row_blocks, tau, device, num_edges):
 def build_panel_plan(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
                      waves: int = DEFAULT_WAVES, row_blocks: int = DEFAULT_ROW_BLOCKS, tau: int = DEFAULT_TAU):
     """CSR on the GPU -> ``(resid_indptr, resid_indices, PanelPlan)`` with the HIP builder (panel_plan.hpp; two launches
-    around one host sync that sizes the outputs).  Universes above 2^22 columns get an empty plan (everything stays in
-    the window format)."""
+    around one host sync that sizes the outputs).  Universes above 2^22 columns -- or (column ranges x edges) above 2e10,
+    the builder's cost -- get an empty plan (everything stays in the window format)."""
     assert indptr.is_cuda and indices.is_cuda and indptr.dtype == torch.int32 and indices.dtype == torch.int32
     assert indptr.is_contiguous() and indices.is_contiguous() and indptr.numel() == num_nodes + 1
     assert waves in (4, 8) and row_blocks in (2, 4) and 1 <= tau <= 65535
     device = indptr.device
     num_cols = num_nodes if num_cols is None else int(num_cols)
-    if num_cols > MAX_PLAN_COLS or num_nodes == 0:
+    if (num_cols > MAX_PLAN_COLS or num_nodes == 0
+            or ((num_cols + (1 << 16) - 1) >> 16) * indices.numel() > MAX_PLAN_EDGE_PASSES):
         return indptr, indices, empty_plan(num_nodes, waves, row_blocks, tau, device, indices.numel())
     stream = torch.cuda.current_stream().cuda_stream
     panel_rows = waves * row_blocks * 16
