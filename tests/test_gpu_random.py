@@ -76,3 +76,45 @@ def test_duplicate_entries_count_once_like_the_reference_format(cuda_device, mon
     feat = torch.tensor([[1.0] * 8, [10.0] * 8], dtype=torch.float16)
     out = voltrix.spmm(*handle, num_nodes=2, num_edges=4, feat=feat.cuda()).cpu()
     assert torch.equal(out[:, 0], torch.tensor([11.0, 10.0]))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_graphs_two_level_format(cuda_device, seed, monkeypatch):
+    """The same random graphs (hubs, empty rows, unsorted rows -- canonicalised by the plan builder) through the two-level
+    format with random plan geometry and threshold: plan + residual bit-exact against the plain-loop oracle, SpMM within
+    the stated bounds."""
+    from voltrix import hybrid
+
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    monkeypatch.setenv("VOLTRIX_HYBRID_MIN_SHARE", "0")
+    monkeypatch.setenv("VOLTRIX_HYBRID_STREAMS", str(seed % 2))
+    rng = np.random.default_rng(2000 + seed)
+    n = int(rng.integers(1, 900))
+    num_feats = int(rng.choice([1, 8, 17, 32, 50, 64, 96, 128, 160, 264]))
+    waves, rb = [(8, 4), (4, 4), (8, 2), (4, 2)][int(rng.integers(0, 4))]
+    tau = int(rng.choice([1, 2, 3, 5]))
+    indptr, indices = _random_csr(rng, n)
+    handle = voltrix.csr_preprocess_hybrid(torch.from_numpy(indptr), torch.from_numpy(indices), n, waves=waves,
+                                           row_blocks=rb, tau=tau)
+    handle[1].hash_tag = f"rand2l{seed}"
+    plan = handle[1].panel_plan
+    # canonical form of the input (sorted rows) for the oracle
+    s_indices = np.concatenate([np.sort(indices[indptr[r]:indptr[r + 1]]) for r in range(n)] + [np.zeros(0, np.int32)])
+    o_ri, o_rx, o_ptr, o_cols, o_bits = oracle_np.panel_plan(indptr, s_indices.astype(np.int32), n, waves, rb, tau)
+    assert np.array_equal(plan.panel_ptr.cpu().numpy(), o_ptr) and np.array_equal(plan.panel_cols.cpu().numpy(), o_cols)
+    assert np.array_equal(plan.panel_bits.view(torch.int32).cpu().numpy().view(np.uint32), o_bits)
+    op1, opacked, ohind = oracle_c.csr_preprocess(o_ri, o_rx, n)     # the residual's handle = the oracle's, bit for bit
+    assert np.array_equal(handle[0].cpu().numpy(), op1) and np.array_equal(handle[1].cpu().numpy(), opacked)
+    assert np.array_equal(handle[2].cpu().numpy(), ohind)
+
+    feat = torch.from_numpy(rng.standard_normal((n, num_feats)).astype(np.float32))
+    ref = torch_ref.spmm(indptr, indices, feat, n).numpy().astype(np.float64)
+    deg = np.diff(indptr.astype(np.int64)).astype(np.float64)
+    aabs = oracle_np.spmm_csr(indptr, indices, np.abs(feat.numpy().astype(np.float64)), n)
+    for dtype in (torch.float16, torch.float32):
+        out = voltrix.spmm(*handle, num_nodes=n, num_edges=len(indices), feat=feat.to(dtype).cuda())
+        assert out.shape == (n, num_feats) and out.dtype == torch.float32
+        got = out.cpu().numpy().astype(np.float64)
+        assert not np.isnan(got).any()
+        bound = (2.0 ** -11 * 1.0001 + (deg[:, None] + 1) * 2.0 ** -23) * aabs + deg[:, None] * 2.0 ** -25 + 1e-30
+        assert (np.abs(got - ref) <= bound).all(), (seed, dtype, float(np.abs(got - ref).max()))
