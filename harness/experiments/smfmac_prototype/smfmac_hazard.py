@@ -1,6 +1,6 @@
 import ctypes, os
 import numpy as np, torch
-lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "build", "smfmac_hazard.so"))
+lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "smfmac_hazard.so"))
 torch.manual_seed(0)
 dev = "cuda"
 # random structured operands; reference computed on the host from the decoded semantics

@@ -1,6 +1,6 @@
 import ctypes, os
 import numpy as np, torch
-lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "build", "smfmac_hazard2.so"))
+lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "build", "smfmac_hazard2.so"))
 torch.manual_seed(0)
 dev = "cuda"
 a = (torch.randint(0, 2, (64, 8)) * 2.0).half()

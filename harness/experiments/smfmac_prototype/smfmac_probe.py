@@ -4,7 +4,7 @@ import ctypes, os, sys
 import numpy as np
 import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
-lib = ctypes.CDLL(os.path.join(HERE, "build", "smfmac_probe.so"))
+lib = ctypes.CDLL(os.path.join(os.path.dirname(HERE), "build", "smfmac_probe.so"))
 dev = "cuda"
 b_ids = (torch.arange(64)[:, None] * 16 + torch.arange(16)[None, :]).to(torch.float16).to(dev).contiguous()
 d = torch.zeros(64, 4, dtype=torch.float32, device=dev)
