@@ -108,6 +108,35 @@ void voltrix_launch_spmm_bf16_tile(void* blk_offsets, void* hspa_packed, void* h
                                    int embedding_dim, void* input, void* output, int fs, int depth, int waves,
                                    void* window_order, void* out_scale, void* stream, int* return_code);
 
+/* Schedule / output extensions of the 16-bit-operand launches (no reference counterpart; the math is that of
+ * voltrix_launch_spmm_f16_tile):
+ *   atomic_out  0: every element of output is stored.  1: the result is ADDED to output with float atomics
+ *               (global_atomic_add_f32): the caller zero-fills output and lets the panel kernel (accumulate = 2) add its
+ *               part in any order -- two addends per element, so the sum does not depend on the order.
+ *   units       NULL, or a unit table int32[U][4] = {window, phase, stride, slot} (16-byte aligned) that replaces
+ *               window_order: a unit runs the stages phase, phase + stride, ... (a stage = 4 TC blocks) of its window.
+ *               A long window is cut into `stride` interleaved units of bounded length that each sweep the window's whole
+ *               (sorted) column range: no wave runs a window several times the usual length (the tail of the launch), and
+ *               units listed by length run in step and share gathered rows through L2.  slot < 0: the unit is the
+ *               whole window (stride 1) and its result goes to output; slot >= 0: the unit's [16][embedding_dim] float32
+ *               tile goes to partials + slot * 16 * embedding_dim, and voltrix_launch_combine_partials sums the tiles
+ *               of each cut window in unit order (deterministic) into output.  unit_ptr int32[9]: XCD x owns units
+ *               [unit_ptr[x], unit_ptr[x+1]); max_units_per_xcd = the largest of those eight counts.  Every stage of
+ *               every window must belong to exactly one unit. */
+void voltrix_launch_spmm_f16_sched(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
+                                   int embedding_dim, void* input, void* output, int fs, int depth, int waves,
+                                   void* window_order, void* out_scale, int atomic_out, void* units, void* unit_ptr,
+                                   int max_units_per_xcd, void* partials, void* stream, int* return_code);
+void voltrix_launch_spmm_bf16_sched(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
+                                    int embedding_dim, void* input, void* output, int fs, int depth, int waves,
+                                    void* window_order, void* out_scale, int atomic_out, void* units, void* unit_ptr,
+                                    int max_units_per_xcd, void* partials, void* stream, int* return_code);
+/* cuts int32[num_cuts][4] = {window, first slot, units, 0} (16-byte aligned): output rows of `window` = (accumulate ?
+ * output : 0) + partials[first slot] + partials[first slot + 1] + ... in that order.  Run it on the stream of the
+ * launch that wrote the partials, after the join with the panel kernel when accumulate != 0.  embedding_dim % 4 == 0. */
+void voltrix_launch_combine_partials(void* cuts, int num_cuts, void* partials, void* output, int num_nodes,
+                                     int embedding_dim, int accumulate, void* stream, int* return_code);
+
 /* "Balance" schedule for a handle: order_out int32[W] (device) lists the windows of every XCD range, inside chunks of
  * `chunk` (1..4096) consecutive windows, by descending TC-block count, so that co-resident waves sweep their sorted
  * columns at a similar pace and share gathered rows through L2.  Depends on blk_offsets only; results of the SpMM are
@@ -133,8 +162,9 @@ void voltrix_launch_spmm_f16_list(void* hspa_packed, void* hind, int num_nodes, 
  *                                            edge (row 16 (row_blocks v + j) + R of the panel, column 8 g + c of the
  *                                            k-step), j < row_blocks, c < 8
  *   panel_order int32 [NP] or NULL           launch position -> panel
- * output [num_nodes, embedding_dim] float32: accumulate != 0 adds onto it (the window kernel's result for the remaining
- * edges), accumulate == 0 overwrites every row.  input _Float16 (bfloat16 for _bf16) [*, embedding_dim], 16-byte
+ * output [num_nodes, embedding_dim] float32: accumulate == 0 overwrites every row; 1 adds onto it (read-add-store: output
+ * already holds the window kernel's result for the remaining edges); 2 adds with float atomics onto a pre-zeroed output that
+ * the window kernel (atomic_out = 1) adds to as well, in any order.  input _Float16 (bfloat16 for _bf16) [*, embedding_dim], 16-byte
  * aligned, embedding_dim % 8 == 0.  Tile: fs in {32,64,128}, depth = ring slots, ksteps per ring slot in {1,2};
  * VOLTRIX_ERR_BAD_CONFIG if the combination is not instantiated.  out_scale as for voltrix_launch_spmm_f16_tile. */
 void voltrix_launch_spmm_panel_f16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order,

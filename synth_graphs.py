@@ -3,6 +3,15 @@
 Bench / test infrastructure, not part of the product package.  Generators follow SURVEY.md section 8(d):
 every graph is a CSR with sorted, duplicate-free rows, int32 ``indptr`` / ``indices``; they run on any torch
 device (GPU for the full sizes, CPU for the scaled-down test cases).
+
+Degree laws: ``lognormal`` (sigma given; reddit / products / papers stand-ins) and ``zipf`` (P(d) ~ d^-alpha on
+[d_min, max_deg], d_min solved for the target mean; the power-law stress config).
+Every row ends up with EXACTLY its drawn degree: the duplicate edges that the first draw loses (3.4 % on the reddit
+stand-in, mostly in the saturated band of the hub rows) are topped up with uniformly drawn new columns, so the edge
+count of a config is the sum of its degrees (reddit-like: the quoted 114.6 M edges; round 1 ran 110.7 M).
+
+``rows=(r0, r1)`` generates only that row range (same degrees as the full graph, per-range edge stream): the
+multi-GPU bench lets every rank build its own shard instead of the whole graph.
 """
 from __future__ import annotations
 
@@ -21,8 +30,9 @@ CONFIGS = {
                           band=8192, feat=512, seed=2),
     "papers_like": dict(num_nodes=111059956, mean_deg=1615685872 / 111059956, sigma=1.0, max_deg=20000, band_frac=0.5,
                         band=32768, feat=128, seed=4),
-    "powerlaw_4m": dict(num_nodes=4000000, mean_deg=400.0, sigma=2.0, max_deg=400000, band_frac=0.0, band=0,
-                        feat=256, seed=3),
+    # density 1e-4 of 4 M x 4 M = 1.6e9 edges; Zipf alpha = 2 degrees up to 4e5, uniform columns (load-balance stress)
+    "powerlaw_4m": dict(num_nodes=4000000, mean_deg=400.0, law="zipf", alpha=2.0, sigma=0.0, max_deg=400000,
+                        band_frac=0.0, band=0, feat=256, seed=3),
 }
 
 
@@ -36,8 +46,78 @@ def lognormal_degrees(num_nodes, mean_deg, sigma, max_deg, gen, device):
     return (base * scale).clamp(1.0, float(max_deg)).round().to(torch.int64)
 
 
-def generate_csr(num_nodes, mean_deg, sigma, max_deg, band_frac, band, seed, device="cpu", scale=1.0, **_):
-    """Returns ``(indptr int32 [N+1], indices int32 [nnz])`` on ``device``.
+def zipf_degrees(num_nodes, mean_deg, alpha, max_deg, gen, device):
+    """Truncated power law P(d) ~ d^-alpha on [d_min, max_deg] by inverse-CDF sampling; d_min is solved (bisection on
+    the analytic mean) so that the mean degree is ``mean_deg``."""
+    u = torch.rand(num_nodes, generator=gen, device=device, dtype=torch.float64)
+    b = float(max_deg)
+
+    def sample(a):
+        if abs(alpha - 1.0) < 1e-9:
+            return a * torch.exp(u * math.log(b / a))
+        p = 1.0 - alpha
+        return (a ** p + u * (b ** p - a ** p)) ** (1.0 / p)
+
+    lo, hi = 1.0, min(b, float(mean_deg))
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        if float(sample(mid).mean()) < mean_deg:
+            lo = mid
+        else:
+            hi = mid
+    return sample(0.5 * (lo + hi)).clamp(1.0, b).round().to(torch.int64)
+
+
+def draw_degrees(n, mean_deg, sigma, max_deg, gen, device, law="lognormal", alpha=2.0):
+    if law == "zipf":
+        return zipf_degrees(n, mean_deg, alpha, max_deg, gen, device)
+    return lognormal_degrees(n, mean_deg, sigma, max_deg, gen, device)
+
+
+def _top_up(keys, deg, r0, n, gen, device, band_frac=0.0, half=0):
+    """``keys`` = sorted unique (row - r0) * n + col; adds new columns until every row has deg[row] edges (rows are
+    never over-full: the first draw makes at most deg[row] distinct ones).  The new columns follow the config's own
+    band / uniform mixture for six rounds, then they are uniform (a hub row can saturate its band)."""
+    nrows = deg.numel()
+    for round_no in range(14):
+        rows = torch.div(keys, n, rounding_mode="floor")
+        have = torch.bincount(rows, minlength=nrows)
+        del rows
+        deficit = deg - have
+        total = int(deficit.sum())
+        if total == 0:
+            break
+        # candidates: 1.25 x deficit + 4 per short row (a few collide with existing edges or with each other)
+        want = torch.where(deficit > 0, (deficit * 5) // 4 + 4, torch.zeros_like(deficit))
+        crow = torch.repeat_interleave(torch.arange(nrows, device=device, dtype=torch.int64), want)
+        ccol = torch.randint(0, n, (crow.numel(),), generator=gen, device=device, dtype=torch.int64)
+        if band_frac > 0 and half > 0 and round_no < 6:
+            local = crow + (r0 + torch.randint(-half, half + 1, (crow.numel(),), generator=gen, device=device,
+                                               dtype=torch.int64))
+            pick = torch.rand(crow.numel(), generator=gen, device=device) < band_frac
+            ccol = torch.where(pick, local.clamp_(0, n - 1), ccol)
+            del local, pick
+        cand = torch.unique(crow * n + ccol)
+        del crow, ccol
+        pos = torch.searchsorted(keys, cand).clamp_(max=keys.numel() - 1)
+        cand = cand[keys[pos] != cand]                      # new edges only
+        # keep a uniformly random subset of deficit[row] candidates per row: random priority, stable by row
+        prio = torch.rand(cand.numel(), generator=gen, device=device)
+        cand = cand[torch.argsort(prio)]
+        crow = torch.div(cand, n, rounding_mode="floor")
+        order = torch.argsort(crow, stable=True)
+        cand, crow = cand[order], crow[order]
+        first = torch.searchsorted(crow, torch.arange(nrows, device=device, dtype=torch.int64))
+        rank = torch.arange(cand.numel(), device=device, dtype=torch.int64) - first[crow]
+        cand = cand[rank < deficit[crow]]
+        keys = torch.sort(torch.cat([keys, cand])).values   # disjoint sets: still duplicate-free
+    return keys
+
+
+def generate_csr(num_nodes, mean_deg, sigma, max_deg, band_frac, band, seed, device="cpu", scale=1.0, law="lognormal",
+                 alpha=2.0, rows=None, exact_degrees=True, **_):
+    """Returns ``(indptr int32 [R+1], indices int32 [nnz])`` on ``device`` for the row range ``rows`` (default: all
+    ``R = N`` rows; column ids are always global).
 
     ``scale`` < 1 shrinks the node count (degrees are kept, capped at N/2) for CPU-sized test cases.
     """
@@ -47,33 +127,54 @@ def generate_csr(num_nodes, mean_deg, sigma, max_deg, band_frac, band, seed, dev
     mean_deg = min(mean_deg, max_deg / 2)
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
-    deg = lognormal_degrees(n, mean_deg, sigma, max_deg, gen, device)
-    rows = torch.repeat_interleave(torch.arange(n, device=device, dtype=torch.int64), deg)
-    e = rows.numel()
+    deg = draw_degrees(n, mean_deg, sigma, max_deg, gen, device, law, alpha)
+    r0, r1 = (0, n) if rows is None else (int(rows[0]), int(rows[1]))
+    assert 0 <= r0 <= r1 <= n
+    if rows is not None:
+        deg = deg[r0:r1].contiguous()
+        gen.manual_seed(seed * 1000003 + r0 + 1)             # the edge stream of a shard depends on its first row only
+    nrows = r1 - r0
+    lrow = torch.repeat_interleave(torch.arange(nrows, device=device, dtype=torch.int64), deg)
+    e = lrow.numel()
     cols = torch.randint(0, n, (e,), generator=gen, device=device, dtype=torch.int64)
-    if band_frac > 0 and band > 0:
-        half = min(band, max(1, n // 4))
-        local = rows + torch.randint(-half, half + 1, (e,), generator=gen, device=device, dtype=torch.int64)
+    half = min(band, max(1, n // 4)) if (band_frac > 0 and band > 0) else 0
+    if half > 0:
+        local = lrow + (r0 + torch.randint(-half, half + 1, (e,), generator=gen, device=device, dtype=torch.int64))
         local = local.clamp_(0, n - 1)
         pick = torch.rand(e, generator=gen, device=device) < band_frac
         cols = torch.where(pick, local, cols)
         del local, pick
-    keys = rows * n + cols
-    del rows, cols
+    keys = lrow * n + cols
+    del lrow, cols
     keys = torch.unique(keys, sorted=True)  # sorts by (row, col) and drops duplicate edges
-    rows = torch.div(keys, n, rounding_mode="floor")
-    indices = (keys - rows * n).to(torch.int32)
+    if exact_degrees:
+        keys = _top_up(keys, deg, r0, n, gen, device, band_frac, half)
+    lrow = torch.div(keys, n, rounding_mode="floor")
+    indices = (keys - lrow * n).to(torch.int32)
     del keys
-    counts = torch.bincount(rows, minlength=n)
-    indptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    counts = torch.bincount(lrow, minlength=nrows)
+    indptr = torch.zeros(nrows + 1, dtype=torch.int64, device=device)
     indptr[1:] = torch.cumsum(counts, 0)
     assert int(indptr[-1]) < 2 ** 31
     return indptr.to(torch.int32), indices
 
 
-def generate(name: str, device="cpu", scale: float = 1.0):
+def target_degrees(name: str, device="cpu", scale: float = 1.0) -> torch.Tensor:
+    """int64 [N]: the degree of every row of config ``name`` (what ``generate`` produces with exact degrees) -- lets
+    every rank of a sharded run compute the same edge-balanced row partition without building the graph."""
     cfg = dict(CONFIGS[name])
-    indptr, indices = generate_csr(device=device, scale=scale, **cfg)
+    device = torch.device(device)
+    n = max(16, int(round(cfg["num_nodes"] * scale)))
+    max_deg = int(min(cfg["max_deg"], max(1, n // 2)))
+    mean_deg = min(cfg["mean_deg"], max_deg / 2)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(cfg["seed"])
+    return draw_degrees(n, mean_deg, cfg["sigma"], max_deg, gen, device, cfg.get("law", "lognormal"), cfg.get("alpha", 2.0))
+
+
+def generate(name: str, device="cpu", scale: float = 1.0, rows=None):
+    cfg = dict(CONFIGS[name])
+    indptr, indices = generate_csr(device=device, scale=scale, rows=rows, **cfg)
     return indptr, indices, cfg
 
 

@@ -1,0 +1,151 @@
+"""GPU: every BASELINE.json configuration at its STATED size, through the C-ABI.
+
+No CPU oracle finishes at these sizes, so the checks are the size-independent properties of ``C = A @ B`` for a binary A:
+
+  (1) ``A @ 1 == degree`` exactly (sums of 1.0 up to 4e5 are exact in fp32) -- every row, so a 32-bit overflow of
+      ``row * F * 4`` (products-like F=512: N*F*4 = 5.0e9 > 2^31; the reference overflows at spmm_kernels.cuh:1568,1688),
+      of ``8 * block`` (power-law: 2e8 TC blocks, hind is 6.4 GB) or of a row of B (papers-like: B is 28 GB) shows up;
+  (2) linearity, bit-exact on small-integer operands (every partial sum is an integer below 2^24);
+  (3) checksum of checksums: the column sums of ``A @ x`` equal ``(A^T 1) . x`` computed from the in-degree of every column.
+
+Memory is bounded by checking in row chunks (papers-like: B 28 GB, C 57 GB per result).
+"""
+import pytest
+import torch
+
+import synth_graphs
+import voltrix
+from voltrix import capi
+
+pytestmark = pytest.mark.gpu
+
+CHUNK = 1 << 21
+
+
+def _launch(handle, n, e, feat, out, tile, order=0):
+    rc = capi.launch_spmm(handle[0].data_ptr(), handle[1].data_ptr(), handle[2].data_ptr(), n, e, feat.shape[1],
+                          feat.data_ptr(), out.data_ptr(), True, tile, torch.cuda.current_stream().cuda_stream, order)
+    assert rc == 0, f"voltrix_launch_spmm_f16_tile rc={rc}"
+    return out
+
+
+def _rows_equal(out, per_row):
+    """out[i, :] == per_row[i] for every i (chunked: no N x F temporary)."""
+    for r in range(0, out.shape[0], CHUNK):
+        if not bool((out[r:r + CHUNK] == per_row[r:r + CHUNK, None]).all()):
+            return False
+    return True
+
+
+def _equal_sum(a, b, c):
+    """a == b + c element-wise (chunked)."""
+    for r in range(0, a.shape[0], CHUNK):
+        if not torch.equal(a[r:r + CHUNK], b[r:r + CHUNK] + c[r:r + CHUNK]):
+            return False
+    return True
+
+
+def _column_sums(t, weights=None):
+    """float64 column sums of t (optionally row-weighted), chunked."""
+    acc = torch.zeros(t.shape[1], dtype=torch.float64, device=t.device)
+    for r in range(0, t.shape[0], CHUNK):
+        blk = t[r:r + CHUNK].double()
+        if weights is not None:
+            blk *= weights[r:r + CHUNK, None]
+        acc += blk.sum(dim=0)
+    return acc
+
+
+def _small_ints(n, f, seed):
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    return torch.empty(n, f, dtype=torch.float16, device="cuda").random_(-3, 4, generator=gen)
+
+
+def _check_properties(run, indptr, indices, n, f, linearity=True):
+    """``run(feat) -> out`` (a fresh or reused fp32 [n, f] tensor)."""
+    deg = (indptr[1:] - indptr[:-1]).float()
+    assert int(deg.max()) < 2 ** 24
+    ones = torch.ones(n, f, dtype=torch.float16, device="cuda")
+    out = run(ones)
+    assert _rows_equal(out, deg), "A @ 1 != degree"
+    del ones, out
+    x = _small_ints(n, f, 1)
+    ox = run(x).clone()
+    col_deg = torch.bincount(indices.long(), minlength=x.shape[0]).double()
+    assert torch.equal(_column_sums(ox), _column_sums(x, col_deg)), "column checksum"
+    del col_deg
+    if linearity:
+        y = _small_ints(n, f, 2)
+        oy = run(y).clone()
+        y += x                                   # exact: |x + y| <= 6
+        del x
+        oxy = run(y)
+        assert _equal_sum(oxy, ox, oy), "A @ (x + y) != A @ x + A @ y"
+
+
+def _window_runner(handle, n, e, f, tile, order_chunk=512):
+    out = torch.empty(n, f, dtype=torch.float32, device="cuda")
+    order = torch.empty((n + 15) // 16, dtype=torch.int32, device="cuda")
+    capi.launch_window_order(handle[0], n, order, torch.cuda.current_stream().cuda_stream, order_chunk)
+
+    def run(feat):
+        out.fill_(float("nan"))                  # every element must be written by the kernel
+        return _launch(handle, n, e, feat, out, tile, order.data_ptr())
+
+    return run
+
+
+def test_products_like_f512_full_size(cuda_device):
+    """BASELINE config 3: N = 2,449,029, 123.7 M edges, F = 512 fp16.  C is 5.0 GB: row * F * 4 passes 2^31 at row 1.05 M."""
+    indptr, indices, cfg = synth_graphs.generate("products_like", device="cuda")
+    n, e, f = indptr.numel() - 1, indices.numel(), 512
+    assert n == 2449029 and e == int(synth_graphs.target_degrees("products_like", device="cuda").sum())
+    assert n * f * 4 > 2 ** 31
+    handle = voltrix.csr_fused_preprocess_kernel(indptr, indices, n)[:3]
+    _check_properties(_window_runner(handle, n, e, f, capi.default_tile(f, True)), indptr, indices, n, f)
+
+
+def test_powerlaw_4m_f256_full_size(cuda_device):
+    """BASELINE config 4: 4 M rows, density 1e-4 (1.6e9 edges), Zipf alpha = 2 degrees up to 4e5, F = 256 fp16.
+    Windows reach tens of thousands of TC blocks; hind alone is 6.4 GB (8 * block passes 2^31 bytes early)."""
+    indptr, indices, cfg = synth_graphs.generate("powerlaw_4m", device="cuda")
+    n, e, f = indptr.numel() - 1, indices.numel(), 256
+    assert n == 4000000 and abs(e - 1.6e9) < 2e6
+    handle = voltrix.csr_fused_preprocess_kernel(indptr, indices, n)[:3]
+    blocks = handle[0][1:] - handle[0][:-1]
+    assert int(blocks.max()) > 20000 and int(handle[0][-1]) * 32 > 2 ** 32
+    _check_properties(_window_runner(handle, n, e, f, capi.default_tile(f, True), order_chunk=2048), indptr, indices, n, f)
+
+
+def test_papers_like_f128_one_gpu(cuda_device):
+    """BASELINE config 5 on ONE GPU: N = 111,059,956, 1.6e9 edges, F = 128 fp16 (B = 28.4 GB, C = 56.9 GB)."""
+    indptr, indices, cfg = synth_graphs.generate("papers_like", device="cuda")
+    n, e, f = indptr.numel() - 1, indices.numel(), 128
+    assert n == 111059956 and abs(e - 1615685872) < 2e6
+    handle = voltrix.csr_fused_preprocess_kernel(indptr, indices, n)[:3]
+    assert n * f * 2 > 2 ** 34
+    # linearity needs three 57 GB results at once: covered by the other configs; here A @ 1 and the column checksum
+    _check_properties(_window_runner(handle, n, e, f, capi.default_tile(f, True)), indptr, indices, n, f, linearity=False)
+
+
+def test_two_level_reddit_like_full_size(cuda_device, monkeypatch):
+    """BASELINE config 2 (the headline) at full size in the two-level format, through the operator (``voltrix.spmm``):
+    same properties, and bit-equality with the window format on integer operands."""
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    indptr, indices, cfg = synth_graphs.generate("reddit_like", device="cuda")
+    n, e, f = indptr.numel() - 1, indices.numel(), 128
+    assert n == 232965 and abs(e - 114615892) < 100000
+    indptr_c, indices_c = indptr.cpu(), indices.cpu()
+    two = voltrix.csr_preprocess_hybrid(indptr_c, indices_c, n)
+    assert two.plan.panel_rows == 512 and two.plan.num_shared_edges > 0.4 * e
+    assert two.plan.num_shared_edges + two.plan.num_resid_edges == e
+
+    def run(feat):
+        return voltrix.spmm_two_level(two, feat)
+
+    _check_properties(run, indptr, indices, n, f)
+    win = voltrix.csr_fused_preprocess_kernel(indptr, indices, n)[:3]
+    x = _small_ints(n, f, 7)
+    a = run(x)
+    b = _window_runner(win, n, e, f, capi.default_tile(f, True))(x)
+    assert torch.equal(a, b)

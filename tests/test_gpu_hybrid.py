@@ -74,8 +74,9 @@ def test_hip_plan_builder_edge_cases(cuda_device, csr_fixture):
     o = oracle_np.panel_plan(indptr, indices, 300, 4, 2, 2)
     assert np.array_equal(ri.cpu().numpy(), o[0]) and np.array_equal(rx.cpu().numpy(), o[1])
     assert all(np.array_equal(a, b) for a, b in zip(_plan_arrays(plan), o[2:]))
-    with pytest.raises(ValueError):
-        hybrid.build_panel_plan(torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda(), 300, 100, 4, 2, 2)
+    _, rx_out, plan_out = hybrid.build_panel_plan(torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda(), 300,
+                                                  100, 4, 2, 2)     # ids beyond the declared universe: no plan
+    assert plan_out.num_ksteps == 0 and torch.equal(rx_out.cpu(), torch.from_numpy(indices))
 
 
 def test_hip_plan_builder_equals_torch_form_at_size(cuda_device):
@@ -116,111 +117,167 @@ def test_panel_kernel_alone(cuda_device, waves, rb, tile, feat_dim):
     prior = torch.randn(n, feat_dim, device=cuda_device)
     out2 = prior.clone()
     hybrid.launch_panel(plan, feat.cuda(), out2, accumulate=True, tile=tile)     # accumulate: prior + the same product
+    out3 = prior.clone()
+    hybrid.launch_panel(plan, feat.cuda(), out3, accumulate=2, tile=tile)        # the same by float atomics
+    assert torch.equal(out3, out2)
     assert torch.equal(out2, prior + out)
 
 
 @pytest.mark.parametrize("dtype,mode", [(torch.float16, "fp16"), (torch.bfloat16, "exact"), (torch.float32, "fp16-scaled")])
 @pytest.mark.parametrize("feat_dim", [32, 128, 200])
-@pytest.mark.parametrize("streams", ["1", "0"])
-def test_hybrid_operator(cuda_device, dtype, mode, feat_dim, streams, monkeypatch):
+@pytest.mark.parametrize("join", ["atomic", "add", "one-stream"])
+def test_hybrid_operator(cuda_device, dtype, mode, feat_dim, join, monkeypatch):
+    """Explicit two-level handle through ``spmm_two_level``, the three ways the two halves can meet in C: float atomics
+    onto a zero-filled C (default), second buffer + add pass, one stream with a read-add-store panel epilogue."""
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
-    monkeypatch.setenv("VOLTRIX_HYBRID_STREAMS", streams)   # two streams + add pass / one stream, accumulate mode
-    monkeypatch.setenv("VOLTRIX_HYBRID_MIN_SHARE", "0")
+    monkeypatch.setenv("VOLTRIX_HYBRID_STREAMS", "0" if join == "one-stream" else "1")
+    monkeypatch.setenv("VOLTRIX_TWO_LEVEL_JOIN", "add" if join == "add" else "atomic")
     indptr_t, indices_t, _ = synth_graphs.generate("reddit_like", scale=0.006)
     n = indptr_t.numel() - 1
-    handle = voltrix.csr_preprocess_hybrid(indptr_t, indices_t, n, tau=40)  # small graph, dense panels: a high bar
-    plan = handle[1].panel_plan                                              # leaves edges on both sides
-    assert plan.num_shared_edges > 0 and plan.num_resid_edges > 0
-    handle[1].hash_tag = f"hybrid_{n}"
+    two = voltrix.csr_preprocess_hybrid(indptr_t, indices_t, n, tau=130)  # small graph, dense panels: a high bar
+    assert isinstance(two, voltrix.TwoLevelHandle)                        # leaves edges on both sides
+    assert two.plan.num_shared_edges > 0 and two.plan.num_resid_edges > 0
+    assert two.plan.num_shared_edges + two.plan.num_resid_edges == two.num_edges == indices_t.numel()
+    two.hash_tag = f"hybrid_{n}"
     torch.manual_seed(1)
     feat32 = torch.randn(n, feat_dim)
     if dtype != torch.float32:
         feat32 = feat32.to(dtype).float()
-    out = voltrix.spmm(*handle, num_nodes=n, num_edges=indices_t.numel(), feat=feat32.to(dtype).cuda())
+    out = voltrix.spmm_two_level(two, feat32.to(dtype).cuda())
     assert out.shape == (n, feat_dim) and out.dtype == torch.float32
     _assert_close(out, indptr_t.numpy(), indices_t.numpy(), feat32, n, mode)
+    again = voltrix.spmm_two_level(two, feat32.to(dtype).cuda())
+    assert torch.equal(out, again)   # two addends per element / fixed combine order: run-to-run identical
 
 
-def test_hybrid_env_switch_and_fixtures(cuda_device, csr_fixture, monkeypatch):
+def test_csr_preprocess_keeps_the_reference_handle_and_attaches_a_sidecar(cuda_device, csr_fixture, monkeypatch):
+    """VOLTRIX_HYBRID=1: ``csr_preprocess`` still returns the reference's handle of the WHOLE matrix (bit-exact against the
+    oracle); the two-level form rides along as a hint that ``voltrix.spmm`` uses.  Every other consumer of the three
+    tensors -- ``spmm_kernel``, a clone of the tensors, the C-ABI -- computes the same product without it."""
+    from oracle import oracle_c
+    from voltrix import capi
+
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
     monkeypatch.setenv("VOLTRIX_HYBRID", "1")
+    monkeypatch.setenv("VOLTRIX_HYBRID_MIN_SHARE", "0")
     g = csr_fixture
-    n = int(g["num_nodes"])
+    n, e = int(g["num_nodes"]), len(g["indices"])
     handle = voltrix.csr_preprocess(torch.from_numpy(g["indptr"]), torch.from_numpy(g["indices"]), n)
-    assert hasattr(handle[1], "panel_plan")
-    handle[1].hash_tag = f"hybrid_fixture_{n}"
+    op1, opacked, ohind = oracle_c.csr_preprocess(g["indptr"], g["indices"], n)
+    assert np.array_equal(handle[0].cpu().numpy(), op1) and np.array_equal(handle[2].cpu().numpy(), ohind)
+    assert np.array_equal(handle[1].view(torch.int32).cpu().numpy().view(np.uint32), opacked)
+    handle[1].hash_tag = f"sidecar_fixture_{n}"
     feat32 = torch.from_numpy(g["feat"]).float().half().float()
-    out = voltrix.spmm(*handle, num_nodes=n, num_edges=len(g["indices"]), feat=feat32.half().cuda())
+    feat = feat32.half().cuda()
+    out = voltrix.spmm(*handle, num_nodes=n, num_edges=e, feat=feat)
     _assert_close(out, g["indptr"], g["indices"], feat32, n, "fp16")
+    if e > 0 and n > 16:
+        hint = getattr(handle[1], "_voltrix_two_level", None)
+        assert hint is not None and hint[0].plan.num_shared_edges + hint[0].plan.num_resid_edges == e
+    # consumers that never see the side-car: a clone of the tensors, the L3 wrapper, the raw C-ABI launch
+    clone = tuple(t.clone() for t in handle)
+    clone[1].hash_tag = f"sidecar_clone_{n}"
+    assert not hasattr(clone[1], "_voltrix_two_level")
+    _assert_close(voltrix.spmm(*clone, num_nodes=n, num_edges=e, feat=feat), g["indptr"], g["indices"], feat32, n, "fp16")
+    f = feat.shape[1]
+    if f % 8 == 0:
+        raw = torch.full((n, f), float("nan"), device="cuda")
+        voltrix.spmm_kernel(*handle, num_nodes=n, num_edges=e, embedding_dim=f, input=feat, output=raw)
+        _assert_close(raw, g["indptr"], g["indices"], feat32, n, "fp16")
+        raw2 = torch.full((n, f), float("nan"), device="cuda")
+        rc = capi.launch_spmm(handle[0].data_ptr(), handle[1].data_ptr(), handle[2].data_ptr(), n, e, f, feat.data_ptr(),
+                              raw2.data_ptr(), True, capi.default_tile(f, True), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        _assert_close(raw2, g["indptr"], g["indices"], feat32, n, "fp16")
+    # VOLTRIX_HYBRID=0: no side-car, same handle bytes
+    monkeypatch.setenv("VOLTRIX_HYBRID", "0")
+    plain = voltrix.csr_preprocess(torch.from_numpy(g["indptr"]), torch.from_numpy(g["indices"]), n)
+    assert not hasattr(plain[1], "_voltrix_two_level")
+    assert all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(plain, handle))
 
 
-def test_hybrid_full_size_properties(cuda_device, monkeypatch):
-    """reddit-like at a quarter of the full size: A.1 = degree exactly, exact on small integers (every partial sum is an
-    integer below 2^24), and the hybrid result equals the window-format result to accumulation order."""
+def test_hybrid_quarter_size_properties(cuda_device, monkeypatch):
+    """reddit-like at a quarter of the full size (the full size: tests/test_gpu_full_size.py): A.1 = degree exactly,
+    exact on small integers (every partial sum is an integer below 2^24), and the two-level result equals the
+    window-format result to accumulation order; also through the side-car of ``csr_preprocess`` (auto mode)."""
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
     indptr, indices, _ = synth_graphs.generate("reddit_like", device="cuda", scale=0.25)
     n = indptr.numel() - 1
     indptr_c, indices_c = indptr.cpu(), indices.cpu()
-    hyb = voltrix.csr_preprocess_hybrid(indptr_c, indices_c, n)
-    hyb[1].hash_tag = "hybrid_quarter"
-    plan = hyb[1].panel_plan
-    assert plan.num_shared_edges + plan.num_resid_edges == indices.numel()
+    two = voltrix.csr_preprocess_hybrid(indptr_c, indices_c, n)
+    two.hash_tag = "hybrid_quarter"
+    assert two.plan.num_shared_edges + two.plan.num_resid_edges == indices.numel()
     ones = torch.ones(n, 128, dtype=torch.float16, device=cuda_device)
     deg = (indptr[1:] - indptr[:-1]).float()
-    out = voltrix.spmm(*hyb, num_nodes=n, num_edges=indices.numel(), feat=ones)
+    out = voltrix.spmm_two_level(two, ones)
     assert torch.equal(out, deg[:, None].expand(n, 128))
     ints = torch.randint(-3, 4, (n, 128), device=cuda_device).half()
+    monkeypatch.setenv("VOLTRIX_HYBRID", "0")
     ref_handle = voltrix.csr_preprocess(indptr_c, indices_c, n)
     ref_handle[1].hash_tag = "window_quarter"
-    a = voltrix.spmm(*hyb, num_nodes=n, num_edges=indices.numel(), feat=ints)
+    a = voltrix.spmm_two_level(two, ints)
     b = voltrix.spmm(*ref_handle, num_nodes=n, num_edges=indices.numel(), feat=ints)
     assert torch.equal(a, b)
+    monkeypatch.setenv("VOLTRIX_HYBRID", "auto")     # 28 M edges, mean degree 490: the side-car is built
+    auto = voltrix.csr_preprocess(indptr_c, indices_c, n)
+    auto[1].hash_tag = "auto_quarter"
+    assert hasattr(auto[1], "_voltrix_two_level")
+    assert all(torch.equal(x.view(torch.int32), y.view(torch.int32)) for x, y in zip(auto, ref_handle))
+    assert torch.equal(voltrix.spmm(*auto, num_nodes=n, num_edges=indices.numel(), feat=ints), b)
 
 
 def test_hybrid_operator_is_graph_capturable(cuda_device, monkeypatch):
     """The two-stream form forks and joins through events only: it replays from a HIP graph with the same result."""
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
-    monkeypatch.setenv("VOLTRIX_HYBRID_MIN_SHARE", "0")
     indptr_t, indices_t, _ = synth_graphs.generate("reddit_like", scale=0.006)
     n = indptr_t.numel() - 1
-    handle = voltrix.csr_preprocess_hybrid(indptr_t, indices_t, n, tau=40)
-    handle[1].hash_tag = f"hybrid_graph_{n}"
+    two = voltrix.csr_preprocess_hybrid(indptr_t, indices_t, n, tau=130)
+    two.hash_tag = f"hybrid_graph_{n}"
     feat = torch.randn(n, 128, device=cuda_device).half()
-    eager = voltrix.spmm(*handle, num_nodes=n, num_edges=indices_t.numel(), feat=feat)   # warm-up: tuner, streams
+    eager = voltrix.spmm_two_level(two, feat)   # warm-up: tuner, streams, unit table
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
-        captured = voltrix.spmm(*handle, num_nodes=n, num_edges=indices_t.numel(), feat=feat)
+        captured = voltrix.spmm_two_level(two, feat)
     feat.copy_(torch.randn(n, 128, device=cuda_device).half())
     graph.replay()
     torch.cuda.synchronize()
-    again = voltrix.spmm(*handle, num_nodes=n, num_edges=indices_t.numel(), feat=feat)
+    again = voltrix.spmm_two_level(two, feat)
     assert torch.equal(captured, again) and not torch.equal(captured, eager)
 
 
 def test_hybrid_degenerate_plans(cuda_device, monkeypatch):
-    """No shared column at all (threshold out of reach), a column universe above the builder's limit (empty plan by
-    design), a row count that leaves a partial last panel and a feature width that needs padding: ``voltrix.spmm`` on a
-    two-level handle still equals the oracle."""
+    """No shared column at all (threshold out of reach), a column universe above the builder's limit or ids outside the
+    declared universe (empty plan by design), a row count that leaves a partial last panel and a feature width that needs
+    padding: ``spmm_two_level`` still equals the oracle."""
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
     indptr, indices = _random_csr(777, 50, seed=11)
     feat32 = torch.randn(777, 44).half().float()
-    monkeypatch.setenv("VOLTRIX_HYBRID_MIN_SHARE", "0")
     for kwargs in (dict(tau=60000), dict(tau=2, waves=4, row_blocks=2), dict(tau=1)):
-        handle = voltrix.csr_preprocess_hybrid(torch.from_numpy(indptr), torch.from_numpy(indices), 777, **kwargs)
-        handle[1].hash_tag = f"degenerate_{sorted(kwargs.items())}"
-        out = voltrix.spmm(*handle, num_nodes=777, num_edges=len(indices), feat=feat32.half().cuda())
+        two = voltrix.csr_preprocess_hybrid(torch.from_numpy(indptr), torch.from_numpy(indices), 777, **kwargs)
+        two.hash_tag = f"degenerate_{sorted(kwargs.items())}"
+        out = voltrix.spmm_two_level(two, feat32.half().cuda())
         _assert_close(out, indptr, indices, feat32, 777, "fp16")
-    assert voltrix.csr_preprocess_hybrid(torch.from_numpy(indptr), torch.from_numpy(indices), 777, tau=60000)[1] \
-        .panel_plan.num_ksteps == 0
-    # below VOLTRIX_HYBRID_MIN_SHARE the plan is dropped and the handle is the window format of the whole matrix
-    monkeypatch.setenv("VOLTRIX_HYBRID_MIN_SHARE", "0.99")
-    dropped = voltrix.csr_preprocess_hybrid(torch.from_numpy(indptr), torch.from_numpy(indices), 777, tau=8)
+    empty = voltrix.csr_preprocess_hybrid(torch.from_numpy(indptr), torch.from_numpy(indices), 777, tau=60000)
+    assert empty.plan.num_ksteps == 0
+    # an empty plan leaves the whole matrix in the residual: its tensors ARE the reference handle, and exact-fp32 mode works
+    monkeypatch.setenv("VOLTRIX_HYBRID", "0")
     plain = voltrix.csr_preprocess(torch.from_numpy(indptr), torch.from_numpy(indices), 777)
-    assert dropped[1].panel_plan.num_ksteps == 0 and all(torch.equal(a.view(torch.int32), b.view(torch.int32))
-                                                         for a, b in zip(dropped, plain))
+    assert all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(empty.residual, plain))
+    monkeypatch.setenv("VOLTRIX_FP32_MODE", "exact")
+    empty.hash_tag = "degenerate_exact"
+    _assert_close(voltrix.spmm_two_level(empty, feat32.cuda()), indptr, indices, feat32, 777, "exact")
+    monkeypatch.delenv("VOLTRIX_FP32_MODE")
+    # below VOLTRIX_HYBRID_MIN_SHARE csr_preprocess attaches no side-car
+    monkeypatch.setenv("VOLTRIX_HYBRID", "1")
+    monkeypatch.setenv("VOLTRIX_HYBRID_MIN_SHARE", "0.99")
+    dropped = voltrix.csr_preprocess(torch.from_numpy(indptr), torch.from_numpy(indices), 777)
+    assert not hasattr(dropped[1], "_voltrix_two_level")
     # universe above 2^22 columns: the plan is empty by design, everything stays in the window format
     wide_cols = hybrid.MAX_PLAN_COLS + 1000
     w_indptr, w_indices = _random_csr(200, 30, seed=12, ncols=wide_cols)
     ri, rx, plan = hybrid.build_panel_plan(torch.from_numpy(w_indptr).cuda(), torch.from_numpy(w_indices).cuda(), 200, wide_cols)
     assert plan.num_ksteps == 0 and torch.equal(rx.cpu(), torch.from_numpy(w_indices)) and plan.num_resid_edges == len(w_indices)
+    # ids outside the declared universe (a rectangular operand declared too narrow): empty plan, like csr_preprocess's retry
+    ri, rx, plan = hybrid.build_panel_plan(torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda(), 777, 100, 4, 2, 2)
+    assert plan.num_ksteps == 0 and torch.equal(rx.cpu(), torch.from_numpy(indices))

@@ -54,7 +54,7 @@ def test_random_graphs_operator_api(cuda_device, seed, monkeypatch):
     for dtype, mode, u in ((torch.float16, "fp16", 2.0 ** -11), (torch.float32, "fp16", 2.0 ** -11),
                            (torch.float32, "exact", 0.0)):
         monkeypatch.setenv("VOLTRIX_FP32_MODE", "exact" if mode == "exact" else "fp16")
-        out = voltrix.spmm(*handle, num_nodes=n, num_edges=len(indices), feat=feat.to(dtype).cuda())
+        out = voltrix.spmm_two_level(handle, feat.to(dtype).cuda())
         assert out.shape == (n, num_feats) and out.dtype == torch.float32
         got = out.cpu().numpy().astype(np.float64)
         assert not np.isnan(got).any()
@@ -86,8 +86,8 @@ def test_random_graphs_two_level_format(cuda_device, seed, monkeypatch):
     from voltrix import hybrid
 
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
-    monkeypatch.setenv("VOLTRIX_HYBRID_MIN_SHARE", "0")
     monkeypatch.setenv("VOLTRIX_HYBRID_STREAMS", str(seed % 2))
+    monkeypatch.setenv("VOLTRIX_TWO_LEVEL_JOIN", "atomic" if seed % 4 < 2 else "add")
     rng = np.random.default_rng(2000 + seed)
     n = int(rng.integers(1, 900))
     num_feats = int(rng.choice([1, 8, 17, 32, 50, 64, 96, 128, 160, 264]))
@@ -96,23 +96,23 @@ def test_random_graphs_two_level_format(cuda_device, seed, monkeypatch):
     indptr, indices = _random_csr(rng, n)
     handle = voltrix.csr_preprocess_hybrid(torch.from_numpy(indptr), torch.from_numpy(indices), n, waves=waves,
                                            row_blocks=rb, tau=tau)
-    handle[1].hash_tag = f"rand2l{seed}"
-    plan = handle[1].panel_plan
+    handle.hash_tag = f"rand2l{seed}"
+    plan = handle.plan
     # canonical form of the input (sorted rows) for the oracle
     s_indices = np.concatenate([np.sort(indices[indptr[r]:indptr[r + 1]]) for r in range(n)] + [np.zeros(0, np.int32)])
     o_ri, o_rx, o_ptr, o_cols, o_bits = oracle_np.panel_plan(indptr, s_indices.astype(np.int32), n, waves, rb, tau)
     assert np.array_equal(plan.panel_ptr.cpu().numpy(), o_ptr) and np.array_equal(plan.panel_cols.cpu().numpy(), o_cols)
     assert np.array_equal(plan.panel_bits.view(torch.int32).cpu().numpy().view(np.uint32), o_bits)
     op1, opacked, ohind = oracle_c.csr_preprocess(o_ri, o_rx, n)     # the residual's handle = the oracle's, bit for bit
-    assert np.array_equal(handle[0].cpu().numpy(), op1) and np.array_equal(handle[1].cpu().numpy(), opacked)
-    assert np.array_equal(handle[2].cpu().numpy(), ohind)
+    assert np.array_equal(handle.blk_offsets.cpu().numpy(), op1) and np.array_equal(handle.hind.cpu().numpy(), ohind)
+    assert np.array_equal(handle.hspa_packed.view(torch.int32).cpu().numpy().view(np.uint32), opacked)
 
     feat = torch.from_numpy(rng.standard_normal((n, num_feats)).astype(np.float32))
     ref = torch_ref.spmm(indptr, indices, feat, n).numpy().astype(np.float64)
     deg = np.diff(indptr.astype(np.int64)).astype(np.float64)
     aabs = oracle_np.spmm_csr(indptr, indices, np.abs(feat.numpy().astype(np.float64)), n)
     for dtype in (torch.float16, torch.float32):
-        out = voltrix.spmm(*handle, num_nodes=n, num_edges=len(indices), feat=feat.to(dtype).cuda())
+        out = voltrix.spmm_two_level(handle, feat.to(dtype).cuda())
         assert out.shape == (n, num_feats) and out.dtype == torch.float32
         got = out.cpu().numpy().astype(np.float64)
         assert not np.isnan(got).any()

@@ -6,7 +6,6 @@ import os
 
 import numpy as np
 import pytest
-import scipy
 import scipy.sparse as sp
 import torch
 
@@ -14,18 +13,42 @@ from conftest import GOLDEN, load_csr_fixture
 from oracle import oracle_c, oracle_np, torch_ref
 
 
+def _load_sprandom_fixture(c):
+    """Committed adjacency (row bitmaps) of one of the reference's own seeded test inputs -> CSR with sorted rows, exactly
+    what ``np.random.seed(s); sp.random(N, N, density=d, format="csr")`` returns with the numpy / scipy of SURVEY.md 8c."""
+    g = np.load(os.path.join(GOLDEN, f"sprandom_N{c['N']}_d{c['density']}_seed{c['seed']}.npz"))
+    dense = np.unpackbits(g["bits"], axis=1)[:, : c["N"]].astype(bool)
+    rows, cols = np.nonzero(dense)          # row-major: rows ascending, columns ascending inside a row
+    indptr = np.zeros(c["N"] + 1, dtype=np.int32)
+    indptr[1:] = np.cumsum(np.bincount(rows, minlength=c["N"]))
+    return indptr, cols.astype(np.int32)
+
+
 def test_known_answers_from_reference_preprocess():
+    """The reference's own ``voltrix::preprocess`` answers recorded in SURVEY.md section 8c (nnz / W / T / TC blocks per
+    window) on the committed CSR arrays of its seeded test inputs -- no dependence on the installed sp.random stream."""
     ka = json.load(open(os.path.join(GOLDEN, "ref_known_answers.json")))
     for c in ka["cases"]:
-        np.random.seed(c["seed"])
-        a = sp.random(c["N"], c["N"], density=c["density"], format="csr")
-        if int(a.indices.astype(np.int64).sum()) != c["indices_sum"] or a.nnz != c["nnz"]:
-            pytest.skip(f"sp.random stream differs (numpy {np.__version__} / scipy {scipy.__version__})")
-        bp, e2c, e2r, p1 = oracle_c.preprocess(a.indptr, a.indices, c["N"])
+        indptr, indices = _load_sprandom_fixture(c)
+        assert len(indices) == c["nnz"] and int(indices.astype(np.int64).sum()) == c["indices_sum"]
+        assert int(indptr.astype(np.int64).sum()) == c["indptr_sum"]
+        bp, e2c, e2r, p1 = oracle_c.preprocess(indptr, indices, c["N"])
         assert len(bp) == c["W"]
         assert int(p1[-1]) == c["T"]
         assert int(bp.min()) == c["min"] and int(bp.max()) == c["max"]
-        assert (e2r == np.repeat(np.arange(c["N"]), np.diff(a.indptr))).all()
+        assert (e2r == np.repeat(np.arange(c["N"]), np.diff(indptr))).all()
+
+
+def test_committed_fixtures_are_the_seeded_inputs_when_the_stream_matches():
+    """Where the installed numpy / scipy still produce the recorded stream (they do in this image), the committed arrays
+    ARE ``sp.random``'s output; elsewhere the committed arrays stand on their own (checksums above)."""
+    ka = json.load(open(os.path.join(GOLDEN, "ref_known_answers.json")))
+    c = ka["cases"][0]
+    np.random.seed(c["seed"])
+    a = sp.random(c["N"], c["N"], density=c["density"], format="csr")
+    if a.nnz == c["nnz"] and int(a.indices.astype(np.int64).sum()) == c["indices_sum"]:
+        indptr, indices = _load_sprandom_fixture(c)
+        assert np.array_equal(indptr, a.indptr) and np.array_equal(indices, a.indices)
 
 
 def test_oracle_np_equals_oracle_c_and_fixture(csr_fixture):
@@ -45,6 +68,13 @@ def test_toy_empty_window_quirk():
     # rows 16..31 have no edge: the reference still gives that window one (all-zero) TC block
     assert g["block_partition"].tolist() == [2, 1, 1]
     assert g["pointer1"].tolist() == [0, 2, 3, 4]
+    # SURVEY.md section 8c, literally: what the reference's compiled preprocess printed for the toy case's 16 edges of
+    # window 0 (rows 0, 1, 2 and the unsorted row 15) -- computed here by both restatements, not read from the fixture
+    survey_edge_to_column = [3, 7, 11, 3, 0, 1, 2, 4, 5, 6, 8, 9, 10, 2, 1, 0]
+    for impl in (oracle_np, oracle_c):
+        bp, e2c, e2r, p1 = impl.preprocess(g["indptr"], g["indices"], int(g["num_nodes"]))
+        assert e2c[:16].tolist() == survey_edge_to_column
+        assert bp.tolist() == [2, 1, 1] and p1.tolist() == [0, 2, 3, 4]
     assert (g["hspa_packed"][8:12] == 0).all() and (g["hind"][16:24] == 0).all()
 
 

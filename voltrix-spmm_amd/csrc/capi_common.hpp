@@ -57,11 +57,13 @@ inline bool tile_at(int index, TileId* out) {
 template <int FS, int D, int W, int EB, class In, bool BF16 = false>
 inline int launch_if_ok(const int* blk_offsets, const uint32_t* hspa_packed, const int* hind, int num_nodes,
                         int embedding_dim, const In* input, float* output, hipStream_t stream, const int* order,
-                        const float* out_scale) {
+                        const float* out_scale, int atomic_out, const int* units, const int* unit_ptr,
+                        int max_units_per_xcd, float* partials) {
   if constexpr (tile_ok<FS, D, W, EB>()) {
     return voltrix::launch_spmm_tc16<voltrix::SpmmTile<FS, D, W, EB, BF16>>(blk_offsets, hspa_packed, hind, num_nodes,
                                                                        embedding_dim, input, output, stream, order,
-                                                                       out_scale);
+                                                                       out_scale, atomic_out, units, unit_ptr,
+                                                                       max_units_per_xcd, partials);
   } else {
     return voltrix::kErrBadConfig;
   }
@@ -70,23 +72,33 @@ inline int launch_if_ok(const int* blk_offsets, const uint32_t* hspa_packed, con
 template <int EB, class In, bool BF16 = false>
 inline int dispatch_spmm(int fs, int depth, int waves, const int* blk_offsets, const uint32_t* hspa_packed,
                          const int* hind, int num_nodes, int embedding_dim, const In* input, float* output,
-                         hipStream_t stream, const int* order, const float* out_scale = nullptr) {
+                         hipStream_t stream, const int* order, const float* out_scale = nullptr,
+                         int atomic_out = 0, const int* units = nullptr, const int* unit_ptr = nullptr,
+                         int max_units_per_xcd = 0, float* partials = nullptr) {
 #define X(FS, D, W)                                  \
   if (fs == FS && depth == D && waves == W)          \
-    return launch_if_ok<FS, D, W, EB, In, BF16>(blk_offsets, hspa_packed, hind, num_nodes, embedding_dim, input, output, stream, order, out_scale);
+    return launch_if_ok<FS, D, W, EB, In, BF16>(blk_offsets, hspa_packed, hind, num_nodes, embedding_dim, input, output, stream, order, out_scale, atomic_out, units, unit_ptr, max_units_per_xcd, partials);
   VOLTRIX_TILE_SPACE(X)
 #undef X
   return voltrix::kErrBadConfig;
 }
 
-// Default tile (measured on MI355X): 64-column slabs, 3-deep ring, 4 waves per workgroup for the
-// fp16 operand (reddit-like F=128: 2.30-2.46 ms vs 2.45-2.59 ms for 128-column slabs); the exact-fp32 path is
-// MFMA-heavier and prefers one wave per workgroup.
+// Default tile (measured on MI355X; profiles/r02/experiment_units_reddit.log): the widest slab
+// the feature width fills (up to 128 columns), a 3-deep ring, 4 waves per workgroup for the 16-bit operands -- (128, 3, 4)
+// is the fastest tile on every graph measured, alone (reddit-like F=128: 2.20 ms vs 2.40 ms for 64-column slabs) and
+// beside a panel-kernel workgroup (103 KB of LDS + 136 registers leave it room).  The exact-fp32 path is MFMA-heavier
+// and prefers one wave per workgroup and 64-column slabs.
 inline TileId default_tile(int embedding_dim, bool is_f16) {
   TileId t;
-  t.fs = embedding_dim <= 32 ? 32 : 64;
-  t.depth = is_f16 ? (t.fs == 32 ? 4 : 3) : 3;
-  t.waves = is_f16 ? 4 : 1;
+  if (is_f16) {
+    t.fs = embedding_dim <= 32 ? 32 : (embedding_dim <= 64 ? 64 : 128);
+    t.depth = t.fs == 32 ? 4 : 3;
+    t.waves = 4;
+  } else {
+    t.fs = embedding_dim <= 32 ? 32 : 64;
+    t.depth = 3;
+    t.waves = 1;
+  }
   return t;
 }
 

@@ -8,7 +8,9 @@ from .jit_kernels import *  # noqa: F401,F403
 from .jit_kernels import (csr_fused_preprocess_kernel, hmat_gen_kernel, hmat_packed_swizzle_kernel, jit_tuner,
                           preprocess_kernel, spmm_kernel)
 from .spmm import *  # noqa: F401,F403
-from .spmm import BLK_H, BLK_W, csr_preprocess, csr_preprocess_hybrid, spmm
+from .spmm import (BLK_H, BLK_W, csr_preprocess, csr_preprocess_device, csr_preprocess_hybrid, spmm, spmm_two_level,
+                   two_level_of)
+from .hybrid import TwoLevelHandle
 from . import hybrid, jit, utils
 
 __version__ = "0.1.0"

@@ -27,6 +27,9 @@ SYMBOLS = (
     "voltrix_launch_spmm_f32_tile",
     "voltrix_launch_spmm_f16",
     "voltrix_launch_spmm_f16_tile",
+    "voltrix_launch_spmm_f16_sched",
+    "voltrix_launch_spmm_bf16_sched",
+    "voltrix_launch_combine_partials",
     "voltrix_launch_spmm_f16_list",
     "voltrix_launch_spmm_panel_f16",
     "voltrix_launch_spmm_panel_bf16",
@@ -143,6 +146,35 @@ def launch_spmm(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
        ctypes.c_int(num_edges), ctypes.c_int(embedding_dim), ctypes.c_void_p(input_ptr), ctypes.c_void_p(output_ptr),
        ctypes.c_int(tile[0]), ctypes.c_int(tile[1]), ctypes.c_int(tile[2]), ctypes.c_void_p(window_order),
        ctypes.c_void_p(out_scale), ctypes.c_void_p(stream), ctypes.byref(rc))
+    return rc.value
+
+
+def launch_spmm_sched(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input_ptr, output_ptr, tile,
+                      stream, window_order=0, out_scale=0, atomic_out=False, bf16=False, table=None, partials=0) -> int:
+    """16-bit operand launch with the schedule / output extensions (include/voltrix_capi.h): ``atomic_out`` = add the
+    result onto a pre-zeroed output with float atomics (two-level format without a join pass); ``table`` = a
+    ``voltrix.schedule.UnitTable`` (replaces ``window_order``), ``partials`` = device pointer of its partial tiles.
+    Returns the return code."""
+    rc = ctypes.c_int(-1)
+    fn = lib().voltrix_launch_spmm_bf16_sched if bf16 else lib().voltrix_launch_spmm_f16_sched
+    fn(ctypes.c_void_p(blk_offsets), ctypes.c_void_p(hspa_packed), ctypes.c_void_p(hind), ctypes.c_int(num_nodes),
+       ctypes.c_int(num_edges), ctypes.c_int(embedding_dim), ctypes.c_void_p(input_ptr), ctypes.c_void_p(output_ptr),
+       ctypes.c_int(tile[0]), ctypes.c_int(tile[1]), ctypes.c_int(tile[2]), ctypes.c_void_p(window_order),
+       ctypes.c_void_p(out_scale), ctypes.c_int(int(atomic_out)),
+       ctypes.c_void_p(table.units.data_ptr() if table is not None else 0),
+       ctypes.c_void_p(table.unit_ptr.data_ptr() if table is not None else 0),
+       ctypes.c_int(table.max_units_per_xcd if table is not None else 0), ctypes.c_void_p(partials),
+       ctypes.c_void_p(stream), ctypes.byref(rc))
+    return rc.value
+
+
+def launch_combine_partials(table, partials_ptr, output_ptr, num_nodes, embedding_dim, accumulate, stream) -> int:
+    """Sum the partial tiles of the cut windows of ``table`` (a ``voltrix.schedule.UnitTable``) into the output."""
+    rc = ctypes.c_int(-1)
+    lib().voltrix_launch_combine_partials(ctypes.c_void_p(table.cuts.data_ptr()), ctypes.c_int(table.num_cuts),
+                                          ctypes.c_void_p(partials_ptr), ctypes.c_void_p(output_ptr),
+                                          ctypes.c_int(num_nodes), ctypes.c_int(embedding_dim),
+                                          ctypes.c_int(int(accumulate)), ctypes.c_void_p(stream), ctypes.byref(rc))
     return rc.value
 
 

@@ -9,8 +9,13 @@ element.
 
 Host API:
 
-    handle = voltrix.csr_preprocess_hybrid(indptr, indices, num_nodes)        # same 3 tensors, of the RESIDUAL matrix
-    out = voltrix.spmm(*handle, num_nodes, num_edges, feat)                   # sees hspa_packed.panel_plan
+    handle = voltrix.csr_preprocess(indptr, indices, num_nodes)      # the reference handle of the WHOLE matrix, byte for
+    out = voltrix.spmm(*handle, num_nodes, num_edges, feat)          # byte; when the graph pays for it the two-level form
+                                                                     # rides along as an acceleration side-car that only
+                                                                     # voltrix.spmm uses (any other consumer of the three
+                                                                     # tensors computes the same product from them)
+    two = voltrix.csr_preprocess_hybrid(indptr, indices, num_nodes)  # explicit: a TwoLevelHandle (residual + plan)
+    out = voltrix.spmm_two_level(two, feat)
 
 Plan layout: see spmm_panel_kernels.hpp; pinned bit-exactly by ``oracle/oracle_np.py::panel_plan``.
 """
@@ -51,6 +56,24 @@ class PanelPlan:
     @property
     def num_panels(self) -> int:
         return (self.num_nodes + self.panel_rows - 1) // self.panel_rows
+
+
+@dataclasses.dataclass(eq=False)
+class TwoLevelHandle:
+    """The two-level format as an explicit object: the reference-format tensors of the RESIDUAL matrix plus the panel
+    plan of the shared columns.  Deliberately not a tuple: the three tensors alone describe only part of the matrix, so
+    they cannot be unpacked into ``voltrix.spmm`` / ``spmm_kernel`` / the C-ABI by accident."""
+    blk_offsets: torch.Tensor    # int32 [W+1]   residual matrix
+    hspa_packed: torch.Tensor    # uint32 [4T]
+    hind: torch.Tensor           # int32 [8T]
+    plan: PanelPlan
+    num_nodes: int
+    num_edges: int               # of the whole matrix (shared + residual)
+    hash_tag: str = None         # tuner key of the residual launches (like hspa_packed.hash_tag in the reference)
+
+    @property
+    def residual(self):
+        return self.blk_offsets, self.hspa_packed, self.hind
 
 
 def split_shared_columns(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int, panel_rows: int,
@@ -138,9 +161,10 @@ def build_panel_plan(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int
         total_ksteps, num_resid, bad = torch.cat([panel_ptr[-1:], resid_indptr[-1:], status]).tolist()  # the host sync
         if bad == 0:
             break
-        assert attempt == 0, f"build_panel_plan: {bad} column ids outside [0, {num_cols})"
-        if int(indices.min()) < 0 or int(indices.max()) >= num_cols:
-            raise ValueError(f"build_panel_plan: column ids outside [0, {num_cols})")
+        if attempt == 1 or int(indices.min()) < 0 or int(indices.max()) >= num_cols:
+            # ids outside the declared universe (rectangular operands): no plan, the window format takes everything --
+            # exactly what csr_preprocess does with them (universe-free sort path)
+            return indptr, indices, empty_plan(num_nodes, waves, row_blocks, tau, device, indices.numel())
         indptr, indices = canonical_csr(indptr, indices, num_nodes, num_cols)   # unsorted rows / duplicates: once
     resid_indices = torch.empty(num_resid, dtype=torch.int32, device=device)
     panel_cols = torch.empty(KSTEP * (total_ksteps + 2), dtype=torch.int32, device=device)
@@ -234,38 +258,64 @@ def concurrent_enabled() -> bool:
     return os.getenv("VOLTRIX_HYBRID_STREAMS", "1") not in ("0", "off")
 
 
-def spmm_two_level(plan: PanelPlan, operand: torch.Tensor, output: torch.Tensor, run_window, out_scale=None,
-                   tile=None) -> None:
-    """``output = A_resid @ operand + A_shared @ operand``.  ``run_window()`` enqueues the window kernel for the
-    residual handle on the current stream (writing every row of ``output``).
+def join_mode() -> str:
+    """How the two halves meet in C.  ``atomic`` (default): C is zero-filled, both kernels add their part with float
+    atomics (two addends per element: the sum does not depend on who comes first) -- no second buffer, no extra pass.
+    ``add``: the panel kernel writes a second buffer that one more pass adds onto C (round 1)."""
+    mode = os.getenv("VOLTRIX_TWO_LEVEL_JOIN", "atomic")
+    assert mode in ("atomic", "add"), mode
+    return mode
 
-    Default: the panel kernel runs on a side stream into a second buffer while the window kernel runs on the caller's
-    stream (the first is matrix-core bound, the second gather bound: they overlap on the same CUs), then one add pass
-    joins them.  Stream-ordered, no host sync; capturable (fork / join through events)."""
+
+def run_two_level(plan: PanelPlan, operand: torch.Tensor, output: torch.Tensor, run_window, out_scale=None,
+                  tile=None) -> None:
+    """``output = A_resid @ operand + A_shared @ operand``.  ``run_window(atomic)`` enqueues the window kernel for the
+    residual handle on the current stream; with ``atomic`` it adds onto ``output``, otherwise it stores every row.  It
+    returns None or a ``PendingCombine`` (jit_kernels/spmm.py).
+
+    The panel kernel runs on a side stream while the window kernel runs on the caller's stream (the first is
+    matrix-core bound, the second gather bound: they overlap on the same CUs).  Stream-ordered, no host sync; capturable
+    (fork / join through events)."""
+    def finish(pending):
+        if pending is not None:      # cut windows of a unit-table schedule: sum their partial tiles (fixed order)
+            pending.run()
+
     if plan.num_ksteps == 0:
-        run_window()
+        finish(run_window(False))
         return
     if not concurrent_enabled():
-        run_window()
-        launch_panel(plan, operand, output, accumulate=True, out_scale=out_scale, tile=tile)
+        finish(run_window(False))
+        launch_panel(plan, operand, output, accumulate=1, out_scale=out_scale, tile=tile)
         return
     main = torch.cuda.current_stream()
     side = side_stream(operand.device)
-    shared_part = torch.empty_like(output)       # allocated on `main`; its last use (the add) is on `main` too
+    atomic = join_mode() == "atomic"
+    if atomic:
+        output.zero_()
+        target = output
+    else:
+        target = torch.empty_like(output)        # allocated on `main`; its last use (the add) is on `main` too
     fork = torch.cuda.Event()
     fork.record(main)
-    side.wait_event(fork)                        # operand / out_scale were produced on `main`
-    launch_panel(plan, operand, shared_part, accumulate=False, out_scale=out_scale, tile=tile, stream=side.cuda_stream)
+    side.wait_event(fork)                        # operand / out_scale / the zero fill were produced on `main`
+    launch_panel(plan, operand, target, accumulate=2 if atomic else 0, out_scale=out_scale, tile=tile,
+                 stream=side.cuda_stream)
     join = torch.cuda.Event()
     join.record(side)
-    run_window()
+    pending = run_window(atomic)
+    if not atomic:
+        finish(pending)                          # stores the cut windows' rows of `output`
     main.wait_event(join)
-    capi.launch_add_inplace_f32(output, shared_part, main.cuda_stream)
+    if atomic:
+        finish(pending)                          # adds onto rows that now hold the panel kernel's part, complete
+    else:
+        capi.launch_add_inplace_f32(output, target, main.cuda_stream)
 
 
-def launch_panel(plan: PanelPlan, feat: torch.Tensor, output: torch.Tensor, accumulate: bool, out_scale=None,
+def launch_panel(plan: PanelPlan, feat: torch.Tensor, output: torch.Tensor, accumulate, out_scale=None,
                  tile=None, stream=None) -> None:
-    """``output (+)= A_shared @ feat`` for fp16 / bfloat16 ``feat`` [*, F] and float32 ``output`` [N, F]."""
+    """``output (+)= A_shared @ feat`` for fp16 / bfloat16 ``feat`` [*, F] and float32 ``output`` [N, F].
+    ``accumulate``: 0 / False store, 1 / True read-add-store, 2 float atomics (include/voltrix_capi.h)."""
     assert feat.is_cuda and feat.is_contiguous() and feat.dtype in (torch.float16, torch.bfloat16)
     assert output.is_cuda and output.is_contiguous() and output.dtype == torch.float32
     f = feat.shape[1]
@@ -273,7 +323,7 @@ def launch_panel(plan: PanelPlan, feat: torch.Tensor, output: torch.Tensor, accu
     tile = tile or default_panel_tile(f, plan.waves, plan.row_blocks)
     assert tile is not None, f"no panel tile for F={f} with {plan.waves} waves"
     stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
-    rc = capi.launch_spmm_panel(plan, feat.data_ptr(), output.data_ptr(), f, bool(accumulate),
+    rc = capi.launch_spmm_panel(plan, feat.data_ptr(), output.data_ptr(), f, int(accumulate),
                                 feat.dtype == torch.bfloat16, tile, out_scale.data_ptr() if out_scale is not None else 0,
                                 stream)
     capi.check(rc, "voltrix_launch_spmm_panel")
@@ -284,5 +334,15 @@ def min_shared_fraction() -> float:
     return float(os.getenv("VOLTRIX_HYBRID_MIN_SHARE", "0.2"))
 
 
-def hybrid_enabled() -> bool:
-    return os.getenv("VOLTRIX_HYBRID", "0") not in ("0", "", "off")
+def hybrid_mode() -> str:
+    """``VOLTRIX_HYBRID``: ``auto`` (default) -- ``csr_preprocess`` also builds the two-level side-car when the graph is
+    big and dense enough for it to matter and enough of its edges sit in shared columns; ``1`` -- whenever enough edges
+    sit in shared columns; ``0`` -- never."""
+    v = os.getenv("VOLTRIX_HYBRID", "auto")
+    return "off" if v in ("0", "", "off") else ("on" if v in ("1", "on") else "auto")
+
+
+# auto mode: below this many edges, or this mean degree, the side-car is not even tried (its build costs a few ms and the
+# panel kernel needs columns that several rows of a 512-row panel share)
+AUTO_MIN_EDGES = 1 << 22
+AUTO_MIN_MEAN_DEGREE = 64

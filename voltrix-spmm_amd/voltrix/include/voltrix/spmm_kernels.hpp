@@ -34,8 +34,10 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include <utility>
+#include <vector>
 
 #include "voltrix/traits.hpp"
 
@@ -143,6 +145,24 @@ __device__ __forceinline__ float lds_read_f32(unsigned addr) {
   return v;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: remember per (kernel instantiation,
+// device) that it has been raised (one process may drive several GPUs; a function-local flag would cover the first only).
+template <class Tag = void>
+inline int ensure_dynamic_lds(const void* kernel, int bytes) {
+  if (bytes <= 64 * 1024) return kOk;
+  struct Seen { const void* k; int dev; };
+  static std::mutex mu;
+  static std::vector<Seen> seen;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return kErrLaunch;
+  std::lock_guard<std::mutex> lock(mu);
+  for (const Seen& s : seen)
+    if (s.k == kernel && s.dev == dev) return kOk;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return kErrBadConfig;
+  seen.push_back(Seen{kernel, dev});
+  return kOk;
+}
+
 template <class T>
 struct SpmmArgs {
   using in_t = typename std::conditional<T::EB == 4, float,
@@ -159,6 +179,13 @@ struct SpmmArgs {
   int windows_per_xcd;           // ceil(num_windows / 8)
   const int* window_order;       // optional schedule: position -> window id (launch_window_order); nullptr = natural
   const float* out_scale;        // optional device scalar multiplied into every output (cast_f32_to_f16_scaled); nullptr = 1
+  const int4* units;             // optional unit table {window, phase, stride, slot}: the unit runs stages phase, phase +
+                                 // stride, ... of the window (a long window cut into `stride` interleaved units of bounded
+                                 // length, each sweeping the whole column range); replaces window_order.  slot < 0: the
+                                 // result goes to C; slot >= 0: to tile `slot` of `partials` (combine_partials_kernel)
+  const int* unit_ptr;           // [9]: XCD x owns units [unit_ptr[x], unit_ptr[x + 1])
+  float* partials;               // [num partial tiles][16][F] fp32 (units with slot >= 0)
+  int atomic_out;                // 1: C += result by float atomics (C pre-zeroed; two-level format: no join pass)
 };
 
 // One wave64 = one (row window, FS-column slab) unit.  EB == 2: fp16 (or bfloat16) operand, v_mfma_f32_16x16x32_f16 (_bf16).
@@ -178,20 +205,35 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
   // side by side, so co-resident waves of one L2 gather overlapping row neighbourhoods and share the metadata.
   // (Measured alternatives that lost: slab-major order, non-temporal loads for far rows -- DESIGN.md section 5.)
   const int xcd = blockIdx.x % kNumXcd;
-  const int w_begin = xcd * a.windows_per_xcd;
-  const int w_count = (a.num_windows - w_begin) < a.windows_per_xcd ? (a.num_windows - w_begin) : a.windows_per_xcd;
-  const long long lu = (long long)(blockIdx.x / kNumXcd) * T::WAVES + wave;
-  if (w_count <= 0 || lu >= (long long)w_count * a.num_slabs) return;  // wave-uniform; the kernel has no barriers
-  const int wpos = w_begin + (int)(lu / a.num_slabs);
-  const int w = a.window_order ? a.window_order[wpos] : wpos;
+  int w_begin = xcd * a.windows_per_xcd;
+  int w_count = (a.num_windows - w_begin) < a.windows_per_xcd ? (a.num_windows - w_begin) : a.windows_per_xcd;
+  if (a.units) {  // unit table: the XCD's range of units instead of its range of windows
+    w_begin = a.unit_ptr[xcd];
+    w_count = a.unit_ptr[xcd + 1] - w_begin;
+  }
+  const int lu = (int)(blockIdx.x / kNumXcd) * T::WAVES + wave;      // unit of this wave inside the XCD's range
+  if (w_count <= 0 || lu >= w_count * a.num_slabs) return;           // wave-uniform; the kernel has no barriers (<= 2^30 units: launcher)
+  const int wpos = w_begin + lu / a.num_slabs;
+  int w, st0 = 0, st_step = 1, slot = -1;   // the unit runs stages st0, st0 + st_step, ... of window w
+  if (a.units) {
+    const int4 u = a.units[wpos];
+    w = u.x;
+    st0 = u.y;
+    st_step = u.z;
+    slot = u.w;
+  } else {
+    w = a.window_order ? a.window_order[wpos] : wpos;
+  }
   const int fs0 = (int)(lu % a.num_slabs) * FS;
 
   const int kb0 = a.blk_offsets[w];
   const int kb1 = a.blk_offsets[w + 1];
   const int nblk = kb1 - kb0;
-  const int nst = (nblk + kTcbPerStage - 1) / kTcbPerStage;
+  const int nst_window = (nblk + kTcbPerStage - 1) / kTcbPerStage;
+  const int nst = st0 < nst_window ? (nst_window - st0 + st_step - 1) / st_step : 0;
   const int F = a.F;
-  auto stage_block = [&](int tau) -> int { return kb0 + kTcbPerStage * tau; };  // first TC block of stage tau
+  auto stage_of = [&](int tau) -> int { return st0 + st_step * tau; };                         // stage of the window
+  auto stage_block = [&](int tau) -> int { return kb0 + kTcbPerStage * stage_of(tau); };       // its first TC block
 
   float4_t acc[SLOTS];
 #pragma unroll
@@ -207,7 +249,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
     empty = (w4.x | w4.y | w4.z | w4.w) == 0u;
   }
 
-  if (nblk > 0 && !empty) {
+  if (nst > 0 && !empty) {
     const int h_safe = a.hind[8ll * kb0];  // first real column of the window: finite data, gathered anyway
 
     // ---- lane constants -------------------------------------------------------------------------------------
@@ -228,7 +270,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
       const void* src;
       const int sb = stage_block(tau);
       if (sb + kTcbPerStage <= kb1) {  // wave-uniform
-        src = meta_base + (unsigned long long)(unsigned)tau * meta_stride;
+        src = meta_base + (unsigned long long)(unsigned)stage_of(tau) * meta_stride;
       } else if (lane < 32) {
         int blk = sb + kblk;
         blk = blk < kb1 ? blk : kb1 - 1;  // stay inside the window: stages past its end re-read its last block
@@ -447,7 +489,8 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
         case 1: wait_vmcnt<T::vm_behind(1)>(); break;
         case 2: wait_vmcnt<T::vm_behind(2)>(); break;
         case 3: wait_vmcnt<T::vm_behind(3)>(); break;
-        default: wait_vmcnt<T::vm_behind(D - 1)>(); break;
+        case 4: wait_vmcnt<T::vm_behind(4)>(); break;
+        default: wait_vmcnt<T::vm_behind(D - 1)>(); break;  // k = 5 = DEPTH - 1 at the deepest ring (DEPTH <= 6)
       }
       step(t, std::false_type{});
     }
@@ -459,10 +502,22 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
     if (acc[0][0] == 12345.678f) a.output[0] = acc[0][0];  // keep the accumulators live
     return;
   }
-  const int orow0 = w * kBlkH + 4 * (lane >> 4);
-  const int ocol0 = fs0 + (lane & 15);
   // powers of two: exact (barring overflow / underflow of the result itself)
   const float oscale = (EB == 2 ? kAScaleInv : 1.0f) * (a.out_scale ? *a.out_scale : 1.0f);
+  const int ocol0 = fs0 + (lane & 15);
+  if (slot >= 0) {  // a cut window's partial tile: [16][F] fp32, summed in unit order by combine_partials_kernel
+    float* const tile = a.partials + (long long)slot * (kBlkH * (long long)F) + (long long)(4 * (lane >> 4)) * F;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      const int col = ocol0 + 16 * s;
+      if (col < F) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[(long long)j * F + col] = acc[s][j] * oscale;
+      }
+    }
+    return;
+  }
+  const int orow0 = w * kBlkH + 4 * (lane >> 4);
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     const int col = ocol0 + 16 * s;
@@ -470,7 +525,13 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = orow0 + j;
-        if (row < a.num_nodes) a.output[(long long)row * F + col] = acc[s][j] * oscale;
+        if (row < a.num_nodes) {
+          float* const dst = a.output + ((long long)row * F + col);
+          if (a.atomic_out)
+            unsafeAtomicAdd(dst, acc[s][j] * oscale);  // global_atomic_add_f32, no return; two addends per element
+          else
+            *dst = acc[s][j] * oscale;
+        }
       }
     }
   }
@@ -482,7 +543,9 @@ template <class T>
 inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed, const int* hind, int num_nodes,
                             int embedding_dim, const void* input /* SpmmArgs<T>::in_t[rows][embedding_dim] */,
                             float* output, hipStream_t stream, const int* window_order = nullptr,
-                            const float* out_scale = nullptr) {
+                            const float* out_scale = nullptr, int atomic_out = 0,
+                            const int* units = nullptr /* int32[U][4] */, const int* unit_ptr = nullptr /* int32[9] */,
+                            int max_units_per_xcd = 0, float* partials = nullptr) {
   if (num_nodes < 0 || embedding_dim < 0) return kErrBadShape;
   if (num_nodes == 0 || embedding_dim == 0) return kOk;
   if (embedding_dim % (16 / T::EB) != 0) return kErrBadShape;  // 16-byte row chunks
@@ -500,18 +563,68 @@ inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed,
   a.windows_per_xcd = (a.num_windows + kNumXcd - 1) / kNumXcd;
   a.window_order = window_order;
   a.out_scale = out_scale;
+  a.atomic_out = atomic_out;
+  a.units = reinterpret_cast<const int4*>(units);
+  a.unit_ptr = unit_ptr;
+  a.partials = partials;
+  if (units != nullptr) {
+    if (unit_ptr == nullptr || max_units_per_xcd < 0 || ((uintptr_t)units & 15)) return kErrBadShape;
+    if (max_units_per_xcd == 0) return kOk;
+    a.windows_per_xcd = max_units_per_xcd;  // sizes the grid below; the kernel reads its range from unit_ptr
+  }
   const long long blocks_per_xcd = ((long long)a.windows_per_xcd * a.num_slabs + T::WAVES - 1) / T::WAVES;
   const long long grid = blocks_per_xcd * kNumXcd;
-  if (grid > 0x7FFFFFFFll) return kErrBadShape;
-  static bool attr_done = false;  // per instantiation
-  if (!attr_done) {
-    if (T::BLOCK_LDS > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_tc16_kernel<T>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, T::BLOCK_LDS) != hipSuccess)
-      return kErrBadConfig;
-    attr_done = true;
-  }
+  if (grid > 0x7FFFFFFFll || (long long)a.windows_per_xcd * a.num_slabs > 0x3FFFFFFFll) return kErrBadShape;  // int unit counters
+  const int lds_rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&spmm_tc16_kernel<T>), T::BLOCK_LDS);
+  if (lds_rc != kOk) return lds_rc;
   hipLaunchKernelGGL(spmm_tc16_kernel<T>, dim3((unsigned)grid), dim3(T::THREADS), T::BLOCK_LDS, stream, a);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Cut windows (unit table, slot >= 0): the units of one window leave their partial [16][F] tiles in consecutive slots
+// of `partials`; this pass sums them IN UNIT ORDER (a fixed order: the result does not depend on which unit finished
+// first) and stores the sum to C -- or adds it onto C when `accumulate` (two-level format: C then holds the panel
+// kernel's part, complete, because this pass runs after the join).  cuts: int32[num_cuts][4] = {window, first slot,
+// units, 0}.  One workgroup per cut window; F % 4 == 0.
+static __global__ __launch_bounds__(256) void combine_partials_kernel(const int4* __restrict__ cuts,
+                                                                     const float* __restrict__ partials,
+                                                                     float* __restrict__ output, const int num_nodes,
+                                                                     const int F, const int accumulate) {
+  const int4 c = cuts[blockIdx.x];
+  const int f4 = F / 4;
+  const long long tile4 = (long long)kBlkH * f4;
+  const float4* src = reinterpret_cast<const float4*>(partials) + (long long)c.y * tile4;
+  for (int i = threadIdx.x; i < (int)tile4; i += 256) {
+    const int row = c.x * kBlkH + i / f4;
+    if (row >= num_nodes) break;  // tail window: rows in ascending order per thread
+    float4 sum = src[i];
+    for (int u = 1; u < c.z; ++u) {
+      const float4 p = src[u * tile4 + i];
+      sum.x += p.x;
+      sum.y += p.y;
+      sum.z += p.z;
+      sum.w += p.w;
+    }
+    float4* const dst = reinterpret_cast<float4*>(output + (long long)row * F) + (i % f4);
+    if (accumulate) {
+      const float4 d = *dst;
+      sum.x += d.x;
+      sum.y += d.y;
+      sum.z += d.z;
+      sum.w += d.w;
+    }
+    *dst = sum;
+  }
+}
+
+inline int combine_partials(const int* cuts, int num_cuts, const float* partials, float* output, int num_nodes,
+                            int embedding_dim, int accumulate, hipStream_t stream) {
+  if (num_cuts < 0 || num_nodes < 0 || embedding_dim < 0 || (embedding_dim % 4) != 0) return kErrBadShape;
+  if (num_cuts == 0 || num_nodes == 0 || embedding_dim == 0) return kOk;
+  if (((uintptr_t)cuts & 15) || ((uintptr_t)partials & 15) || ((uintptr_t)output & 15)) return kErrBadShape;
+  hipLaunchKernelGGL(combine_partials_kernel, dim3((unsigned)num_cuts), dim3(256), 0, stream,
+                     reinterpret_cast<const int4*>(cuts), partials, output, num_nodes, embedding_dim, accumulate);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

@@ -268,14 +268,8 @@ inline int launch_spmm_list(const uint32_t* hspa_packed, const int* hind, int nu
   if (num_nodes == 0 || embedding_dim == 0 || num_waves == 0) return kOk;
   if (embedding_dim % 8 != 0) return kErrBadShape;
   if (((uintptr_t)input & 15) || ((uintptr_t)hspa_packed & 15) || ((uintptr_t)entries & 15)) return kErrBadShape;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (T::BLOCK_LDS > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_list_kernel<LT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, T::BLOCK_LDS) != hipSuccess)
-      return kErrBadConfig;
-    attr_done = true;
-  }
+  const int lds_rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&spmm_list_kernel<LT>), T::BLOCK_LDS);
+  if (lds_rc != kOk) return lds_rc;
   SpmmListArgs a;
   a.hspa_packed = hspa_packed;
   a.hind = hind;

@@ -113,7 +113,9 @@ struct PanelArgs {
   int num_panels;
   int panels_per_xcd;
   int F;
-  int accumulate;              // 1: C += A_shared * B (C holds the window kernel's part); 0: C = A_shared * B
+  int accumulate;              // 0: C = A_shared * B;  1: C += A_shared * B (C holds the window kernel's part, read-add-store);
+                               // 2: C += A_shared * B by float atomics (C pre-zeroed, the window kernel adds its part the
+                               //    same way, in any order: two addends per element, so the sum does not depend on it)
 };
 
 template <class T>
@@ -274,6 +276,20 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
   const float oscale = kAScaleInv * (a.out_scale ? *a.out_scale : 1.0f);
   const int prow0 = panel * T::PANEL_ROWS + wave * (RB * 16) + 4 * (lane >> 4);
   const int ocol0 = fs0 + (lane & 15);
+  if (a.accumulate == 2) {
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = prow0 + 16 * j + i, col = ocol0 + 16 * s;
+          if (col < F && row < a.num_nodes) unsafeAtomicAdd(a.output + ((long long)row * F + col), acc[j][s][i] * oscale);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < RB; ++j) {
     // accumulate mode: all of a row block's loads first (one round trip, not one per element), then add and store
@@ -320,14 +336,8 @@ inline int launch_spmm_panel(const int* panel_ptr, const int* panel_cols, const 
   a.F = embedding_dim;
   a.accumulate = accumulate;
   const int slabs = (embedding_dim + T::FS - 1) / T::FS;
-  static bool attr_done = false;  // per instantiation
-  if (!attr_done) {
-    if (T::BLOCK_LDS > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_panel_kernel<T>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, T::BLOCK_LDS) != hipSuccess)
-      return kErrBadConfig;
-    attr_done = true;
-  }
+  const int lds_rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&spmm_panel_kernel<T>), T::BLOCK_LDS);
+  if (lds_rc != kOk) return lds_rc;
   hipLaunchKernelGGL(spmm_panel_kernel<T>, dim3((unsigned)(a.panels_per_xcd * kNumXcd), (unsigned)slabs),
                      dim3(T::THREADS), T::BLOCK_LDS, stream, a);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;

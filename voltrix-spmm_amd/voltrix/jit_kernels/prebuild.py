@@ -15,10 +15,7 @@ from . import bmat_swizzle, hmat_gem, preprocess, spmm
 
 
 def _spmm_arg_defs(dtype):
-    return (("blk_offsets", torch.int32), ("hspa_packed", torch.uint32), ("hind", torch.int32), ("num_nodes", int),
-            ("num_edges", int), ("embedding_dim", int), ("input", dtype), ("output", torch.float),
-            ("win_order_a", torch.int32), ("win_order_b", torch.int32), ("win_order_c", torch.int32),
-            ("out_scale", torch.float32), ("stream", torch.cuda.Stream))
+    return spmm.arg_defs_for(dtype)
 
 
 def jobs(feature_widths=(32, 64, 128), modes=("default", "none")):

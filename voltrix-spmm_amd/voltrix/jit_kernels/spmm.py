@@ -19,13 +19,21 @@ template = """
 __return_code = voltrix::launch_spmm_tc16<voltrix::SpmmTile<{FS}, {DEPTH}, {WAVES}, {EB}, {BF16} != 0>>(
     blk_offsets, hspa_packed, hind,
     num_nodes, embedding_dim, input, output, stream,
-    {SCHED} == 0 ? nullptr : ({SCHED} == 1 ? win_order_a : ({SCHED} == 2 ? win_order_b : win_order_c)), out_scale);
+    ({SCHED} == 0 || {SCHED} == 4) ? nullptr : ({SCHED} == 1 ? win_order_a : ({SCHED} == 2 ? win_order_b : win_order_c)),
+    out_scale, atomic_out,
+    {SCHED} == 4 ? units : nullptr, unit_ptr, max_units_per_xcd, partials);
+if (__return_code == 0 && {SCHED} == 4 && combine_now != 0)
+  __return_code = voltrix::combine_partials(cuts, num_cuts, partials, output, num_nodes, embedding_dim, atomic_out, stream);
 """
 
 # windows per length-sorted chunk of the "balance" schedule (spmm_kernels.hpp::launch_window_order) for SCHED 1/2/3.
 # Small chunks keep row neighbours together (banded graphs, wide features), wide chunks equalise more (uniform columns).
 # Measured optimum on MI355X: reddit-like F=128 -> 512, F=512 -> 128, uniform columns -> 2048 (DESIGN.md section 5).
 ORDER_CHUNKS = {1: 128, 2: 512, 3: 2048}
+# SCHED 4: unit table (voltrix/schedule.py::unit_table) -- windows longer than 1.5 x the median cut into interleaved units,
+# units listed longest first per XCD range; the partial tiles of cut windows are summed in unit order by
+# combine_partials.  Measured on the reddit-like graph: window format 2.19 -> 1.94 ms, two-level residual 1.41 -> 1.04 ms.
+SCHED_UNITS = 4
 
 
 def feature_hash(feature: torch.Tensor) -> str:
@@ -64,10 +72,11 @@ def _tile_space(embedding_dim: int, elem_bytes: int):
     mode = os.getenv(TUNE_SPACE_FLAG, "default")
     fs_max = 128
     fs_fit = 32 if embedding_dim <= 32 else (64 if embedding_dim <= 64 else fs_max)
-    if mode == "none":  # the ahead-of-time library's default tile (csrc/capi_common.hpp::default_tile) + balance schedule
-        fs = 32 if embedding_dim <= 32 else 64
-        depth = (4 if fs == 32 else 3) if elem_bytes == 2 else 3
-        return ({"FS": fs, "DEPTH": depth, "WAVES": 4 if elem_bytes == 2 else 1, "EB": elem_bytes, "SCHED": 2},)
+    if mode == "none":  # the ahead-of-time library's default tile (csrc/capi_common.hpp::default_tile) + unit table
+        fs = 32 if embedding_dim <= 32 else (64 if embedding_dim <= 64 else 128)
+        if elem_bytes == 4:
+            return ({"FS": min(fs, 64), "DEPTH": 3, "WAVES": 1, "EB": 4, "SCHED": 2},)
+        return ({"FS": fs, "DEPTH": 4 if fs == 32 else 3, "WAVES": 4, "EB": 2, "SCHED": SCHED_UNITS},)
     if mode == "full":
         fs_list = sorted({fs_fit, max(32, fs_fit // 2), min(256, fs_fit * 2) if embedding_dim > 128 else fs_fit})
         depths, waves = (2, 3, 4), (1, 2, 4)
@@ -80,7 +89,8 @@ def _tile_space(embedding_dim: int, elem_bytes: int):
             for w in waves:
                 ndma = 32 * fs * elem_bytes // 1024
                 if _lds_bytes(fs, d, w, elem_bytes) <= 160 * 1024 and (1 + ndma) * (d - 1) <= 63:
-                    for sched in (0,) + tuple(ORDER_CHUNKS):  # natural window order / balance schedule per chunk size
+                    # natural window order / balance schedule per chunk size / unit table (16-bit operands)
+                    for sched in (0,) + tuple(ORDER_CHUNKS) + ((SCHED_UNITS,) if elem_bytes == 2 else ()):
                         space.append({"FS": fs, "DEPTH": d, "WAVES": w, "EB": elem_bytes, "SCHED": sched})
     return tuple(space)
 
@@ -106,6 +116,51 @@ def window_order(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, num_nodes
     return order
 
 
+def arg_defs_for(dtype):
+    """Argument list of the generated ``launch`` for a dense operand of ``dtype`` (the reference's ten arguments,
+    jit_kernels/spmm.py:78-88, then the schedule / output extensions)."""
+    return (
+        ("blk_offsets", torch.int32),
+        ("hspa_packed", torch.uint32),
+        ("hind", torch.int32),
+        ("num_nodes", int),
+        ("num_edges", int),
+        ("embedding_dim", int),
+        ("input", dtype),
+        ("output", torch.float32),
+        ("win_order_a", torch.int32),
+        ("win_order_b", torch.int32),
+        ("win_order_c", torch.int32),
+        ("out_scale", torch.float32),
+        ("atomic_out", int),
+        ("units", torch.int32),
+        ("unit_ptr", torch.int32),
+        ("max_units_per_xcd", int),
+        ("cuts", torch.int32),
+        ("num_cuts", int),
+        ("partials", torch.float32),
+        ("combine_now", int),
+        ("stream", torch.cuda.Stream),
+    )
+
+
+def handle_unit_table(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, num_nodes: int):
+    """The handle's unit table (voltrix.schedule.unit_table, default length bound), built once on the GPU and cached on
+    the ``hspa_packed`` tensor object."""
+    cache = getattr(hspa_packed, "_voltrix_unit_table", None)
+    key = (blk_offsets.data_ptr(), num_nodes)
+    if isinstance(cache, tuple) and cache[0] == key:
+        return cache[1]
+    from ..schedule import unit_table
+
+    table = unit_table(blk_offsets, num_nodes)
+    try:
+        hspa_packed._voltrix_unit_table = (key, table)
+    except AttributeError:
+        pass
+    return table
+
+
 _UNIT_SCALE = {}
 
 
@@ -117,9 +172,34 @@ def unit_scale(device) -> torch.Tensor:
     return _UNIT_SCALE[key]
 
 
-def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, output, out_scale=None):
-    """``out_scale`` (extension): float32 device tensor whose first element multiplies every output element (the
-    power-of-two written by ``capi.launch_cast_f32_f16_scaled``); default 1."""
+class PendingCombine:
+    """Partial tiles of cut windows that still have to be summed into the output (``spmm_kernel(..., defer_combine=True)``:
+    the two-level step runs the pass after the join with the panel kernel, when the output holds that kernel's part)."""
+
+    def __init__(self, table, partials, output, num_nodes, embedding_dim, accumulate):
+        self.table, self.partials, self.output = table, partials, output
+        self.num_nodes, self.embedding_dim, self.accumulate = num_nodes, embedding_dim, accumulate
+
+    def run(self, stream=None):
+        from .. import capi
+
+        stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        rc = capi.launch_combine_partials(self.table, self.partials.data_ptr(), self.output.data_ptr(), self.num_nodes,
+                                          self.embedding_dim, self.accumulate, stream)
+        capi.check(rc, "voltrix_launch_combine_partials")
+
+
+def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, output, out_scale=None,
+                atomic_out=False, beside_panel=False, defer_combine=False):
+    """Extensions over the reference wrapper (all default to its behaviour):
+    ``out_scale``      float32 device tensor whose first element multiplies every output element (the power-of-two
+                       written by ``capi.launch_cast_f32_f16_scaled``); default 1.
+    ``atomic_out``     add the product onto ``output`` with float atomics instead of storing it (two-level format: the
+                       caller zero-fills ``output`` and the panel kernel adds its part the same way).
+    ``beside_panel``   the launch runs beside a panel-kernel workgroup: only tiles that leave it room on the CU.
+    ``defer_combine``  with a unit-table schedule, do not sum the cut windows' partial tiles now: return a
+                       ``PendingCombine`` (or None when nothing is pending) for the caller to ``run()`` later.
+    """
     assert blk_offsets.is_cuda and blk_offsets.dtype == torch.int32
     assert hspa_packed.is_cuda and hspa_packed.dtype == torch.uint32
     assert hind.is_cuda and hind.dtype == torch.int32
@@ -133,40 +213,49 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
         out_scale = unit_scale(input.device)
     assert out_scale.is_cuda and out_scale.dtype == torch.float32 and out_scale.numel() >= 1
 
-    args = (blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, output,
-            window_order(blk_offsets, hspa_packed, num_nodes, 1), window_order(blk_offsets, hspa_packed, num_nodes, 2),
-            window_order(blk_offsets, hspa_packed, num_nodes, 3), out_scale, torch.cuda.current_stream())
+    space = tile_space(embedding_dim, elem_bytes, input.dtype == torch.bfloat16,
+                       TWO_LEVEL_LDS_BUDGET if beside_panel else None)
+    if any(p["SCHED"] == SCHED_UNITS for p in space):
+        table = handle_unit_table(blk_offsets, hspa_packed, num_nodes)
+        partials = torch.empty(max(1, table.num_slots) * 16 * embedding_dim, dtype=torch.float32, device=input.device)
+        units, unit_ptr, cuts = table.units, table.unit_ptr, table.cuts
+        max_units, num_cuts = table.max_units_per_xcd, table.num_cuts
+    else:
+        table, partials = None, out_scale
+        units = unit_ptr = cuts = blk_offsets   # never dereferenced (no SCHED 4 point in the space)
+        max_units = num_cuts = 0
+
+    def make_args(out):
+        return (blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, out,
+                window_order(blk_offsets, hspa_packed, num_nodes, 1), window_order(blk_offsets, hspa_packed, num_nodes, 2),
+                window_order(blk_offsets, hspa_packed, num_nodes, 3), out_scale, int(bool(atomic_out)), units, unit_ptr,
+                max_units, cuts, num_cuts, partials, int(not defer_combine), torch.cuda.current_stream())
+
+    args = make_args(output)
+    keys = {
+        "feature_hash": feature_hash(hspa_packed),
+        "embedding_dim": embedding_dim,
+        "dtype": str(input.dtype),
+        "device": torch.cuda.get_device_name(input.device),
+        "two_level": bool(beside_panel),
+    }
+    # tuning runs must not add onto the caller's output: they get a scratch one (only built when a sweep will happen)
+    tune_args = args
+    if atomic_out and len(space) > 1 and not jit_tuner.is_tuned("spmm_kernel", keys):
+        tune_args = make_args(torch.zeros_like(output))
     runtime = jit_tuner.compile_and_tune(
         name="spmm_kernel",
-        keys={
-            "feature_hash": feature_hash(hspa_packed),
-            "embedding_dim": embedding_dim,
-            "dtype": str(input.dtype),
-            "device": torch.cuda.get_device_name(input.device),
-            "two_level": getattr(hspa_packed, "panel_plan", None) is not None,
-        },
-        # handles of the two-level format run beside the panel kernel: only tiles that leave it room on the CU
-        space=tile_space(embedding_dim, elem_bytes, input.dtype == torch.bfloat16,
-                         TWO_LEVEL_LDS_BUDGET if getattr(hspa_packed, "panel_plan", None) is not None else None),
+        keys=keys,
+        space=space,
         includes=includes,
-        arg_defs=(
-            ("blk_offsets", blk_offsets.dtype),
-            ("hspa_packed", hspa_packed.dtype),
-            ("hind", hind.dtype),
-            ("num_nodes", int),
-            ("num_edges", int),
-            ("embedding_dim", int),
-            ("input", input.dtype),
-            ("output", output.dtype),
-            ("win_order_a", torch.int32),
-            ("win_order_b", torch.int32),
-            ("win_order_c", torch.int32),
-            ("out_scale", torch.float32),
-            ("stream", torch.cuda.Stream),
-        ),
+        arg_defs=arg_defs_for(input.dtype),
         template=template,
-        args=args,
+        args=tune_args,
         kernel_tag="spmm",
     )
     rc = runtime(*args)
     assert rc == 0, f"spmm_kernel failed with return code {rc}"
+    if (defer_combine and table is not None and table.num_cuts > 0
+            and jit_tuner.tuned_point("spmm_kernel", keys).get("SCHED") == SCHED_UNITS):
+        return PendingCombine(table, partials, output, num_nodes, embedding_dim, bool(atomic_out))
+    return None

@@ -62,6 +62,19 @@ class JITTuner:
         except OSError:
             pass
 
+    @staticmethod
+    def _signature(name: str, keys: Dict[str, Any]):
+        keys = {k: keys[k] for k in sorted(keys.keys())}
+        return (name, f"{keys}")
+
+    def is_tuned(self, name: str, keys: Dict[str, Any]) -> bool:
+        """True when ``compile_and_tune(name, keys, ...)`` will not run a sweep (memoised in this process)."""
+        return self._signature(name, keys) in self.tuned
+
+    def tuned_point(self, name: str, keys: Dict[str, Any]) -> Dict:
+        """The point of the space chosen for ``(name, keys)`` (after ``compile_and_tune``)."""
+        return self.tuned_keys.get(self._signature(name, keys), {})
+
     # ---- main entry --------------------------------------------------------------------------------------
     def compile_and_tune(self, name: str, keys: Dict[str, Any], space: tuple, includes: tuple, arg_defs: tuple,
                          template: str, args: tuple, kernel_tag: Optional[str] = None,

@@ -161,3 +161,86 @@ def build_stage_list(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind:
     entries[pad_dst.reshape(-1), 0] = last_block[:, None].expand(num_waves, pad).reshape(-1).to(torch.int32)
     entries[pad_dst.reshape(-1), 1] = 1 << 17   # padding: count 0, tail path (rows = a valid row, nothing multiplied)
     return StageList(entries.contiguous(), wave_ptr.to(torch.int32), num_waves, groups, depth, mode, rounds, num_stages)
+
+
+
+@dataclass
+class UnitTable:
+    """Schedule of the window kernel in units of bounded length (spmm_kernels.hpp, SpmmArgs::units)."""
+    units: torch.Tensor       # int32 [U, 4]: window, phase, stride, slot -- XCD ranges back to back, longest unit first
+    unit_ptr: torch.Tensor    # int32 [9]
+    cuts: torch.Tensor        # int32 [C, 4]: window, first slot, units, 0 -- one row per cut window
+    max_units_per_xcd: int
+    num_units: int
+    num_cuts: int             # windows cut into more than one unit
+    num_slots: int            # partial tiles ([16][F] fp32 each) the cut windows need
+    max_stages: int
+
+
+def length_order(blk_offsets: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    """int32 [W]: position -> window, every XCD's window range sorted by TC-block count, longest first (ties by
+    index)."""
+    dev = blk_offsets.device
+    num_windows = (num_nodes + 15) // 16
+    idx = torch.arange(num_windows, dtype=torch.int64, device=dev)
+    if num_windows == 0:
+        return idx.to(torch.int32)
+    nblk = (blk_offsets[1:num_windows + 1] - blk_offsets[:num_windows]).to(torch.int64)
+    wpx = (num_windows + NUM_XCD - 1) // NUM_XCD
+    top = int(nblk.max())
+    return torch.argsort((idx // wpx) * (top + 1) + (top - nblk), stable=True).to(torch.int32)
+
+
+def default_max_stages(blk_offsets: torch.Tensor, num_nodes: int) -> int:
+    """1.5 x the median window length (in stages of 4 TC blocks): the measured optimum on the reddit-like graph, both for
+    the window format and for the residual of the two-level format."""
+    num_windows = (num_nodes + 15) // 16
+    if num_windows == 0:
+        return 1
+    nst = ((blk_offsets[1:num_windows + 1] - blk_offsets[:num_windows]) + 3) // 4
+    return max(8, int(1.5 * float(nst.float().median())))
+
+
+def unit_table(blk_offsets: torch.Tensor, num_nodes: int, max_stages: int = None, chunk: int = None) -> UnitTable:
+    """Cut every window of more than ``max_stages`` stages (a stage = 4 TC blocks = one MFMA K step) into
+    ``k = ceil(stages / max_stages)`` interleaved units -- unit j runs the stages j, j + k, j + 2k, ... -- so that every
+    unit sweeps the window's whole (sorted) column range with at most ``max_stages`` stages.  Units of one XCD's window
+    range (optionally: of every chunk of ``chunk`` consecutive windows, which keeps row neighbours together) are listed
+    longest first.  No wave is left with a window several times the usual length (the tail of the launch), and units of
+    equal length that start together keep pace, so co-resident waves want the same rows of B at the same time and share
+    them through L2.  Cut windows leave partial tiles that ``combine_partials`` sums in unit order (deterministic).
+    Built with torch tensor ops on the handle's device (plumbing, once per handle)."""
+    dev = blk_offsets.device
+    num_windows = (num_nodes + 15) // 16
+    if max_stages is None:
+        max_stages = default_max_stages(blk_offsets, num_nodes)
+    assert max_stages >= 1
+    if num_windows == 0:
+        z = torch.zeros((0, 4), dtype=torch.int32, device=dev)
+        return UnitTable(z, torch.zeros(9, dtype=torch.int32, device=dev), z, 0, 0, 0, 0, max_stages)
+    nblk = (blk_offsets[1:num_windows + 1] - blk_offsets[:num_windows]).to(torch.int64)
+    nst = (nblk + 3) // 4
+    k = torch.clamp((nst + max_stages - 1) // max_stages, min=1)
+    w = torch.repeat_interleave(torch.arange(num_windows, dtype=torch.int64, device=dev), k)
+    first = torch.cumsum(k, 0) - k
+    j = torch.arange(w.numel(), dtype=torch.int64, device=dev) - first[w]
+    kk = k[w]
+    length = (nst[w] - j + kk - 1) // kk
+    # partial-tile slots: the units of a cut window take consecutive slots, in unit order
+    cut = k > 1
+    k_cut = torch.where(cut, k, torch.zeros_like(k))
+    slot_first = torch.cumsum(k_cut, 0) - k_cut
+    slot = torch.where(cut[w], slot_first[w] + j, torch.full_like(w, -1))
+    wpx = (num_windows + NUM_XCD - 1) // NUM_XCD
+    xcd = w // wpx
+    group = xcd if chunk is None else xcd * (wpx // max(1, chunk) + 2) + (w - xcd * wpx) // max(1, chunk)
+    top = int(length.max())
+    order = torch.argsort(group * (top + 1) + (top - length), stable=True)
+    units = torch.stack([w[order], j[order], kk[order], slot[order]], dim=1).to(torch.int32).contiguous()
+    counts = torch.bincount(xcd, minlength=NUM_XCD)
+    unit_ptr = torch.zeros(NUM_XCD + 1, dtype=torch.int64, device=dev)
+    unit_ptr[1:] = torch.cumsum(counts, 0)
+    cw = torch.nonzero(cut).flatten()
+    cuts = torch.stack([cw, slot_first[cw], k[cw], torch.zeros_like(cw)], dim=1).to(torch.int32).contiguous()
+    return UnitTable(units, unit_ptr.to(torch.int32), cuts, int(counts.max()), int(w.numel()), int(cw.numel()),
+                     int(k_cut.sum()), max_stages)

@@ -24,24 +24,27 @@ BLK_W = 8
 
 def csr_preprocess(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None):
     """CSR (CPU int32, as in the reference :21-22) -> ``(blk_offsets int32 [W+1], hspa_packed uint32 [4T],
-    hind int32 [8T])`` on the current CUDA device.  ``num_cols`` (extension, default ``num_nodes``): the column
-    universe when the ids index something else than the ``num_nodes`` rows (row shards over a gathered B).
+    hind int32 [8T])`` on the current CUDA device: the reference's handle of the WHOLE matrix, byte for byte, whatever
+    the environment says.  ``num_cols`` (extension, default ``num_nodes``): the column universe when the ids index
+    something else than the ``num_nodes`` rows (row shards over a gathered B).
 
     Default: one H2D copy of the CSR and the fused GPU preprocess.  ``VOLTRIX_PREPROCESS=reference`` runs the
     reference's own three-stage pipeline (host ``preprocess_kernel``, ``hmat_gen_kernel``,
     ``hmat_packed_swizzle_kernel``, with the transient fp32 ``hspa``); both give identical bytes.
     Duplicate (row, col) entries count once (bitmap), whereas ``torch.sparse.mm`` sums them (quirk 5).
+
+    Acceleration side-car (``VOLTRIX_HYBRID``, default ``auto``; voltrix/hybrid.py): when enough of the edges sit in
+    columns that several rows of a 512-row panel share, the two-level form of the same matrix is built as well and
+    attached to the ``hspa_packed`` tensor object.  ``voltrix.spmm`` uses it when it finds it; it is a hint, never
+    part of the contract -- a copy of the tensor, ``spmm_kernel``, the C-ABI launches all compute the same product from
+    the three tensors alone.
     """
     assert indptr.is_cpu and indptr.dtype == torch.int32
     assert indices.is_cpu and indices.dtype == torch.int32
     assert indptr.numel() == num_nodes + 1
 
-    if hybrid.hybrid_enabled():  # VOLTRIX_HYBRID=1: two-level format (voltrix/hybrid.py); the handle is the residual's
-        return csr_preprocess_hybrid(indptr, indices, num_nodes, num_cols)
     if os.getenv(PREPROCESS_FLAG, "fused") != "reference":
-        pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(
-            indptr.contiguous().cuda(), indices.contiguous().cuda(), num_nodes, num_cols)
-        return pointer1, hspa_packed, hind
+        return csr_preprocess_device(indptr.contiguous().cuda(), indices.contiguous().cuda(), num_nodes, num_cols)
 
     num_edges = indices.numel()
     num_row_windows = math.ceil(num_nodes / BLK_H)
@@ -67,29 +70,81 @@ def csr_preprocess(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, 
     return pointer1, hspa_packed, hind
 
 
+def csr_preprocess_device(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None):
+    """``csr_preprocess`` for a CSR that already lives on the GPU (extension: the reference takes CPU tensors only; graph
+    pipelines and the row-sharded operator build their shards on the device).  Same handle, same side-car policy."""
+    assert indptr.is_cuda and indptr.dtype == torch.int32 and indices.is_cuda and indices.dtype == torch.int32
+    assert indptr.numel() == num_nodes + 1
+    indptr, indices = indptr.contiguous(), indices.contiguous()
+    pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(indptr, indices, num_nodes, num_cols)
+    mode = hybrid.hybrid_mode()
+    big_enough = (indices.numel() >= hybrid.AUTO_MIN_EDGES
+                  and indices.numel() >= hybrid.AUTO_MIN_MEAN_DEGREE * max(1, num_nodes))
+    if mode == "on" or (mode == "auto" and big_enough):
+        two = _build_two_level(indptr, indices, num_nodes, num_cols)
+        if two is not None:
+            hspa_packed._voltrix_two_level = (two, hspa_packed.data_ptr())
+    return pointer1, hspa_packed, hind
+
+
+def two_level_of(hspa_packed: torch.Tensor):
+    """The ``TwoLevelHandle`` that ``csr_preprocess`` attached to this tensor object, or None."""
+    hint = getattr(hspa_packed, "_voltrix_two_level", None)
+    return hint[0] if hint is not None and hint[1] == hspa_packed.data_ptr() else None
+
+
+def _build_two_level(indptr_d, indices_d, num_nodes, num_cols, waves=hybrid.DEFAULT_WAVES,
+                     row_blocks=hybrid.DEFAULT_ROW_BLOCKS, tau=hybrid.DEFAULT_TAU, min_share=None):
+    """Device CSR -> TwoLevelHandle, or None when fewer than ``min_share`` (VOLTRIX_HYBRID_MIN_SHARE, default 0.2) of
+    the edges land on the panel side: too few for the panel kernel to pay for itself (uniform-random graphs, low
+    degrees) -- the window format of the whole matrix is the better form then."""
+    resid_indptr, resid_indices, plan = hybrid.build_panel_plan(indptr_d, indices_d, num_nodes, num_cols, waves, row_blocks,
+                                                                tau)
+    min_share = hybrid.min_shared_fraction() if min_share is None else min_share
+    if plan.num_ksteps == 0 or plan.num_shared_edges < min_share * max(1, indices_d.numel()):
+        return None
+    pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(resid_indptr, resid_indices, num_nodes, num_cols)
+    return hybrid.TwoLevelHandle(pointer1, hspa_packed, hind, plan, num_nodes, int(indices_d.numel()))
+
+
 def csr_preprocess_hybrid(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
                           waves: int = hybrid.DEFAULT_WAVES, row_blocks: int = hybrid.DEFAULT_ROW_BLOCKS,
-                          tau: int = hybrid.DEFAULT_TAU):
-    """Extension (no reference counterpart): two-level condensed format.  Columns referenced by >= ``tau`` rows of a
-    ``waves * row_blocks * 16``-row panel go to a panel plan (gathered once per panel, ``spmm_panel_kernel``); the
-    remaining edges go through the ordinary ``csr_preprocess``.  Returns the reference-format handle of the RESIDUAL
-    matrix with the plan attached as ``hspa_packed.panel_plan`` -- ``spmm`` adds both parts.  When fewer than
-    ``VOLTRIX_HYBRID_MIN_SHARE`` (default 0.2) of the edges land on the panel side the plan is dropped and the handle is
-    the plain window format of the whole matrix.  The same arguments and assertions as ``csr_preprocess``."""
+                          tau: int = hybrid.DEFAULT_TAU) -> "hybrid.TwoLevelHandle":
+    """Extension (no reference counterpart): the two-level condensed format as an explicit ``TwoLevelHandle`` for
+    ``spmm_two_level``.  Columns referenced by >= ``tau`` rows of a ``waves * row_blocks * 16``-row panel go to a panel
+    plan (gathered once per panel, ``spmm_panel_kernel``); the remaining edges keep the reference's window format (the
+    handle's three tensors describe that RESIDUAL matrix only, which is why this is not a tuple).  The plan may be empty
+    (no column reaches ``tau``, or the universe is beyond the builder's limits): then the residual is the whole matrix.
+    Same argument checks as ``csr_preprocess``."""
     assert indptr.is_cpu and indptr.dtype == torch.int32
     assert indices.is_cpu and indices.dtype == torch.int32
     assert indptr.numel() == num_nodes + 1
     indptr_d, indices_d = indptr.contiguous().cuda(), indices.contiguous().cuda()
     resid_indptr, resid_indices, plan = hybrid.build_panel_plan(indptr_d, indices_d, num_nodes, num_cols, waves, row_blocks,
                                                                 tau)
-    if plan.num_shared_edges < hybrid.min_shared_fraction() * max(1, indices.numel()):
-        # too few edges sit in shared columns for the panel kernel to pay for itself (uniform-random graphs, low degrees):
-        # keep the whole matrix in the window format; the empty plan makes spmm skip the panel kernel
-        resid_indptr, resid_indices = indptr_d, indices_d
-        plan = hybrid.empty_plan(num_nodes, waves, row_blocks, tau, indptr_d.device, indices.numel())
     pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(resid_indptr, resid_indices, num_nodes, num_cols)
-    hspa_packed.panel_plan = plan
-    return pointer1, hspa_packed, hind
+    return hybrid.TwoLevelHandle(pointer1, hspa_packed, hind, plan, num_nodes, int(indices.numel()))
+
+
+def _operand(feat: torch.Tensor):
+    """``feat`` -> (operand for the kernels, out_scale or None, padded width, exact-fp32 flag)."""
+    assert feat.is_cuda and feat.dim() == 2
+    feat = feat.contiguous()
+    num_feats = feat.shape[1]
+    assert feat.dtype in (torch.float32, torch.float16, torch.bfloat16), f"unsupported feature dtype {feat.dtype}"
+    exact = feat.dtype == torch.float32 and os.getenv(FP32_MODE_FLAG, "fp16") == "exact"
+    align = 4 if exact else 8
+    padded = (num_feats + align - 1) // align * align
+    if padded != num_feats:  # keep gathered rows 16-byte aligned
+        feat = torch.nn.functional.pad(feat, (0, padded - num_feats))
+    if exact or feat.dtype in (torch.float16, torch.bfloat16):
+        return feat, None, padded, exact
+    # fp32 -> fp16 with one power-of-two scale per call (undone in the kernel's epilogue): keeps fp32's range, which
+    # the reference's TF32 multiply has and a plain fp16 cast has not; on the stream, no host sync.
+    operand = torch.empty(feat.shape, dtype=torch.float16, device=feat.device)
+    out_scale = torch.empty(2, dtype=torch.float32, device=feat.device)
+    capi.launch_cast_f32_f16_scaled(feat, operand, out_scale, torch.cuda.current_stream().cuda_stream)
+    return operand, out_scale, padded, exact
 
 
 def spmm(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tensor, num_nodes: int, num_edges: int,
@@ -99,39 +154,49 @@ def spmm(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tenso
     ``feat``: CUDA, 2-D, contiguous; float32 (the reference's only dtype, jit_kernels/spmm.py:53), float16
     (BASELINE.json's headline) or bfloat16.  float32 is rounded to fp16 for the MFMA -- the same 10-bit mantissa as the
     reference's TF32 rounding (spmm_kernels.cuh:1671), after a per-call power-of-two rescale that keeps fp32's range --
-    unless ``VOLTRIX_FP32_MODE=exact``, which keeps exact fp32 products.  Every output row is written, including the ``num_nodes % 16`` tail the reference skips.
+    unless ``VOLTRIX_FP32_MODE=exact``, which keeps exact fp32 products.  Every output row is written, including the
+    ``num_nodes % 16`` tail the reference skips.  When ``csr_preprocess`` attached the two-level side-car to this very
+    ``hspa_packed`` tensor, the 16-bit-operand product runs in that form (same result up to fp32 summation order).
     """
-    assert feat.is_cuda and feat.dim() == 2
-    feat = feat.contiguous()
     num_feats = feat.shape[1]
-    assert feat.dtype in (torch.float32, torch.float16, torch.bfloat16), f"unsupported feature dtype {feat.dtype}"
-
-    exact = feat.dtype == torch.float32 and os.getenv(FP32_MODE_FLAG, "fp16") == "exact"
-    align = 4 if exact else 8
-    padded = (num_feats + align - 1) // align * align
-    if padded != num_feats:  # keep gathered rows 16-byte aligned
-        feat = torch.nn.functional.pad(feat, (0, padded - num_feats))
-    out_scale = None
-    if exact or feat.dtype in (torch.float16, torch.bfloat16):
-        operand = feat
-    else:
-        # fp32 -> fp16 with one power-of-two scale per call (undone in the kernel's epilogue): keeps fp32's range, which
-        # the reference's TF32 multiply has and a plain fp16 cast has not; on the stream, no host sync.
-        operand = torch.empty(feat.shape, dtype=torch.float16, device=feat.device)
-        out_scale = torch.empty(2, dtype=torch.float32, device=feat.device)
-        capi.launch_cast_f32_f16_scaled(feat, operand, out_scale, torch.cuda.current_stream().cuda_stream)
+    operand, out_scale, padded, exact = _operand(feat)
     output = torch.empty((num_nodes, padded), dtype=torch.float32, device=feat.device)
-
-    def run_window():
+    hint = getattr(hspa_packed, "_voltrix_two_level", None)
+    if (hint is not None and not exact and hint[1] == hspa_packed.data_ptr() and hint[0].num_nodes == num_nodes
+            and hybrid.hybrid_mode() != "off"):
+        _run_two_level(hint[0], operand, output, out_scale, tag_source=hspa_packed)
+    else:
         spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes=num_nodes, num_edges=num_edges, embedding_dim=padded,
                     input=operand, output=output, out_scale=out_scale)
+    return output if padded == num_feats else output[:, :num_feats].contiguous()
 
-    plan = getattr(hspa_packed, "panel_plan", None)
-    if plan is None:
-        run_window()
-    else:
-        # two-level format: the handle covers the residual edges, the panel kernel adds the shared-column part
-        assert not exact, "the panel kernel takes a 16-bit operand (unset VOLTRIX_FP32_MODE=exact or use csr_preprocess)"
-        assert plan.num_nodes == num_nodes
-        hybrid.spmm_two_level(plan, operand, output, run_window, out_scale=out_scale)
+
+def _run_two_level(two, operand, output, out_scale, tag_source=None):
+    resid = two.hspa_packed
+    if getattr(resid, "hash_tag", None) is None:   # tuner key of the residual launches: the caller's tag + a suffix
+        tag = two.hash_tag or getattr(tag_source, "hash_tag", None)
+        if isinstance(tag, str):
+            resid.hash_tag = tag + "/residual"
+
+    def run_window(atomic):
+        return spmm_kernel(two.blk_offsets, resid, two.hind, num_nodes=two.num_nodes,
+                           num_edges=two.plan.num_resid_edges, embedding_dim=operand.shape[1], input=operand,
+                           output=output, out_scale=out_scale, atomic_out=atomic,
+                           beside_panel=two.plan.num_ksteps > 0, defer_combine=True)
+
+    hybrid.run_two_level(two.plan, operand, output, run_window, out_scale=out_scale)
+
+
+def spmm_two_level(handle: "hybrid.TwoLevelHandle", feat: torch.Tensor):
+    """``csr(ones) @ feat`` for a ``TwoLevelHandle`` (``csr_preprocess_hybrid``): float32 ``[num_nodes, F]``, on the
+    current stream (the panel kernel runs beside the window kernel on a side stream, joined through events).  ``feat``
+    as for ``spmm``; the panel kernel takes a 16-bit operand, so ``VOLTRIX_FP32_MODE=exact`` is refused unless the plan
+    is empty."""
+    assert isinstance(handle, hybrid.TwoLevelHandle)
+    num_feats = feat.shape[1]
+    operand, out_scale, padded, exact = _operand(feat)
+    assert not (exact and handle.plan.num_ksteps > 0), \
+        "the panel kernel takes a 16-bit operand (unset VOLTRIX_FP32_MODE=exact or use csr_preprocess)"
+    output = torch.empty((handle.num_nodes, padded), dtype=torch.float32, device=feat.device)
+    _run_two_level(handle, operand, output, out_scale)
     return output if padded == num_feats else output[:, :num_feats].contiguous()
