@@ -308,6 +308,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         kernel_ms = float(t)
 
+    # ---- per-kernel durations of a step (outside the timed region): every launch of the operator bracketed by its own
+    # ---- HIP event pair on its own stream (voltrix.utils.KernelTimer); the panel kernel runs beside the window kernel
+    from voltrix.utils import KernelTimer
+
+    with KernelTimer() as timer:
+        for _ in range(10):
+            step()
+    kernels_ms = {k: round(v[1], 4) for k, v in timer.summary().items()}
+
     # ---- what the operator ran (the tuner's choice), for the record -----------------------------------------------------
     def tuned(hspa_packed, beside_panel):
         from voltrix.jit_kernels.spmm import feature_hash
@@ -429,7 +438,7 @@ def main():
                 "counters_from": counters.get("source") if counters else
                 f"none for this exact configuration ({counter_key}): PMC passes are separate runs (profiles/)",
                 "kernel": kernels + " (HIP events on the launch stream around the operator call)",
-                "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
+                "kernel_ms": kernel_ms, "kernels_ms": kernels_ms, "algorithmic_bytes": alg_bytes,
                 "gather_bytes": gather_bytes, "gather_gbs": gather_bytes / (kernel_ms * 1e-3) / 1e9,
                 "note": "gather-bound: B rows are served by L2 / Infinity Cache (~8.6-19 TB/s row-gather ceilings), "
                         "see DESIGN.md Roofline",

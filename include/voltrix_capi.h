@@ -100,6 +100,19 @@ void voltrix_launch_spmm_f16_tile(void* blk_offsets, void* hspa_packed, void* hi
                                   int embedding_dim, void* input, void* output, int fs, int depth, int waves,
                                   void* window_order, void* out_scale, void* stream, int* return_code);
 
+/* fp32 features on the 16-bit matrix-core path -- the fast replacement of voltrix_launch_spmm for hosts that keep the
+ * reference's fp32 contract (jit_kernels/spmm.py:53: input float32): `input` float32 [input_rows, embedding_dim] is rounded
+ * to fp16 after ONE power-of-two rescale per call (voltrix_launch_cast_f32_f16_scaled below: the reference's TF32 rounding
+ * keeps the same 10 mantissa bits; fp32's exponent range is preserved) into `workspace`, the product runs on
+ * v_mfma_f32_16x16x32_f16 with the default tile and the epilogue undoes the scale (exact).  What voltrix.spmm does for a
+ * float32 `feat`.  workspace: voltrix_spmm_f32_workspace_bytes(input_rows, embedding_dim) bytes, device, 16-byte aligned,
+ * owned by the caller (input_rows = rows of `input`: num_nodes for a square adjacency).  embedding_dim % 8 == 0.
+ * voltrix_launch_spmm itself keeps exact fp32 products (3.6x slower on the reddit-like headline graph). */
+int64_t voltrix_spmm_f32_workspace_bytes(int64_t input_rows, int embedding_dim);
+void voltrix_launch_spmm_f32_as_f16(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
+                                    int embedding_dim, void* input, int64_t input_rows, void* output, void* workspace,
+                                    void* stream, int* return_code);
+
 /* bfloat16 dense operand (extension; 8-bit mantissa, fp32's exponent range): input bfloat16 [*, embedding_dim], output
  * float32, v_mfma_f32_16x16x32_bf16.  Same tiles, shapes and arguments as the fp16 entry points. */
 void voltrix_launch_spmm_bf16(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,

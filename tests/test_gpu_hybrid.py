@@ -218,12 +218,15 @@ def test_hybrid_quarter_size_properties(cuda_device, monkeypatch):
     a = voltrix.spmm_two_level(two, ints)
     b = voltrix.spmm(*ref_handle, num_nodes=n, num_edges=indices.numel(), feat=ints)
     assert torch.equal(a, b)
-    monkeypatch.setenv("VOLTRIX_HYBRID", "auto")     # 28 M edges, mean degree 490: the side-car is built
+    monkeypatch.setenv("VOLTRIX_HYBRID", "auto")     # 58 k rows = 114 panels: too few to fill 256 CUs, no side-car in auto mode
     auto = voltrix.csr_preprocess(indptr_c, indices_c, n)
-    auto[1].hash_tag = "auto_quarter"
-    assert hasattr(auto[1], "_voltrix_two_level")
-    assert all(torch.equal(x.view(torch.int32), y.view(torch.int32)) for x, y in zip(auto, ref_handle))
-    assert torch.equal(voltrix.spmm(*auto, num_nodes=n, num_edges=indices.numel(), feat=ints), b)
+    assert not hasattr(auto[1], "_voltrix_two_level")
+    monkeypatch.setenv("VOLTRIX_HYBRID", "1")        # forced: built whenever enough edges sit in shared columns
+    forced = voltrix.csr_preprocess(indptr_c, indices_c, n)
+    forced[1].hash_tag = "forced_quarter"
+    assert voltrix.two_level_of(forced[1]) is not None
+    assert all(torch.equal(x.view(torch.int32), y.view(torch.int32)) for x, y in zip(forced, ref_handle))
+    assert torch.equal(voltrix.spmm(*forced, num_nodes=n, num_edges=indices.numel(), feat=ints), b)
 
 
 def test_hybrid_operator_is_graph_capturable(cuda_device, monkeypatch):
@@ -270,7 +273,7 @@ def test_hybrid_degenerate_plans(cuda_device, monkeypatch):
     monkeypatch.delenv("VOLTRIX_FP32_MODE")
     # below VOLTRIX_HYBRID_MIN_SHARE csr_preprocess attaches no side-car
     monkeypatch.setenv("VOLTRIX_HYBRID", "1")
-    monkeypatch.setenv("VOLTRIX_HYBRID_MIN_SHARE", "0.99")
+    monkeypatch.setenv("VOLTRIX_HYBRID_MIN_SHARE", "1.5")   # out of reach
     dropped = voltrix.csr_preprocess(torch.from_numpy(indptr), torch.from_numpy(indices), 777)
     assert not hasattr(dropped[1], "_voltrix_two_level")
     # universe above 2^22 columns: the plan is empty by design, everything stays in the window format

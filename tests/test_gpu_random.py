@@ -54,7 +54,7 @@ def test_random_graphs_operator_api(cuda_device, seed, monkeypatch):
     for dtype, mode, u in ((torch.float16, "fp16", 2.0 ** -11), (torch.float32, "fp16", 2.0 ** -11),
                            (torch.float32, "exact", 0.0)):
         monkeypatch.setenv("VOLTRIX_FP32_MODE", "exact" if mode == "exact" else "fp16")
-        out = voltrix.spmm_two_level(handle, feat.to(dtype).cuda())
+        out = voltrix.spmm(*handle, num_nodes=n, num_edges=len(indices), feat=feat.to(dtype).cuda())
         assert out.shape == (n, num_feats) and out.dtype == torch.float32
         got = out.cpu().numpy().astype(np.float64)
         assert not np.isnan(got).any()

@@ -322,3 +322,45 @@ def test_full_size_properties(cuda_device, name, scale, num_feats):
     assert torch.equal(oxy, ox + oy)
     col_deg = torch.bincount(indices.long(), minlength=n).double()
     assert torch.equal(ox.double().sum(dim=0), (col_deg[:, None] * x.double()).sum(dim=0))
+
+
+def test_route_b_fp32_entry_on_the_fp16_path(cuda_device):
+    """voltrix_launch_spmm_f32_as_f16: the reference's fp32 launch arguments + a caller-owned workspace; magnitudes far
+    outside fp16's range survive (one power-of-two rescale per call), the mantissa is the reference's TF32 one."""
+    g = load_csr_fixture("skewed_1005")
+    n, e = int(g["num_nodes"]), len(g["indices"])
+    handle = voltrix.csr_fused_preprocess_kernel(torch.from_numpy(g["indptr"]).cuda(), torch.from_numpy(g["indices"]).cuda(), n)[:3]
+    for scale in (1.0, 3e7, 2e-9):
+        feat32 = torch.randn(n, 64) * scale
+        feat = feat32.cuda()
+        ws = torch.empty(capi.spmm_f32_workspace_bytes(n, 64), dtype=torch.uint8, device="cuda")
+        assert ws.numel() == 16 + n * 64 * 2
+        out = torch.full((n, 64), float("nan"), device="cuda")
+        rc = capi.launch_spmm_f32_as_f16(handle[0], handle[1], handle[2], n, e, 64, feat, out, ws,
+                                         torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        _assert_close(out, g["indptr"], g["indices"], feat32, n, "fp16-scaled")
+    rc = capi.launch_spmm_f32_as_f16(handle[0], handle[1], handle[2], n, e, 60, feat, out, ws,
+                                     torch.cuda.current_stream().cuda_stream)
+    assert rc == 1   # embedding_dim % 8 != 0
+
+
+def test_kernel_isolated_timing_hook(cuda_device, monkeypatch):
+    """utils.bench_kineto (reference utils.py:232-321): the launches of one multi-kernel operator call timed separately --
+    cast, window kernel (JIT runtime), panel kernel on its side stream, zero fill."""
+    from voltrix.utils import KernelTimer, bench_kineto
+
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    indptr, indices, _ = synth_graphs.generate("reddit_like", scale=0.02)
+    n = indptr.numel() - 1
+    two = voltrix.csr_preprocess_hybrid(indptr, indices, n, tau=130)
+    two.hash_tag = "timing_hook"
+    feat = torch.randn(n, 128, device="cuda")          # fp32: cast + scaled fp16 path
+    t_spmm, t_panel = bench_kineto(lambda: voltrix.spmm_two_level(two, feat), ("spmm_kernel", "spmm_panel"), num_tests=5)
+    assert 0 < t_spmm < 1e-2 and 0 < t_panel < 1e-2    # seconds, like the reference
+    with KernelTimer() as timer:
+        voltrix.spmm_two_level(two, feat)
+    names = set(timer.summary())
+    assert {"spmm_kernel", "spmm_panel", "cast_f32_f16_scaled", "zero_fill"} <= names, names
+    with pytest.raises(AssertionError):
+        bench_kineto(lambda: voltrix.spmm_two_level(two, feat), "no_such_kernel", num_tests=1)

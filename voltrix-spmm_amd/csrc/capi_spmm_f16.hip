@@ -47,6 +47,32 @@ void voltrix_launch_spmm_f16(void* blk_offsets, void* hspa_packed, void* hind, i
                                t.depth, t.waves, nullptr, nullptr, stream, return_code);
 }
 
+// The reference's launch() arguments for fp32 features (jit_kernels/spmm.py:78-88) on the 16-bit matrix-core path: the
+// operand is rounded to fp16 after one power-of-two rescale (cast_f32_to_f16_scaled: same 10-bit mantissa as the
+// reference's TF32 rounding, fp32's range) into the caller's workspace, the epilogue undoes the scale.
+int64_t voltrix_spmm_f32_workspace_bytes(int64_t input_rows, int embedding_dim) {
+  if (input_rows < 0 || embedding_dim < 0) return -1;
+  return 16 + input_rows * (int64_t)embedding_dim * 2;
+}
+
+void voltrix_launch_spmm_f32_as_f16(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
+                                    int embedding_dim, void* input, int64_t input_rows, void* output, void* workspace,
+                                    void* stream, int* return_code) {
+  if (input_rows < 0 || workspace == nullptr || ((uintptr_t)workspace & 15) || embedding_dim % 8 != 0) {
+    *return_code = voltrix::kErrBadShape;
+    return;
+  }
+  float* const scale = static_cast<float*>(workspace);
+  _Float16* const operand = reinterpret_cast<_Float16*>(static_cast<char*>(workspace) + 16);
+  *return_code = voltrix::cast_f32_to_f16_scaled(static_cast<const float*>(input), operand,
+                                                 input_rows * (int64_t)embedding_dim, scale,
+                                                 static_cast<hipStream_t>(stream));
+  if (*return_code != voltrix::kOk) return;
+  const TileId t = default_tile(embedding_dim, true);
+  voltrix_launch_spmm_f16_tile(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, operand, output, t.fs,
+                               t.depth, t.waves, nullptr, scale, stream, return_code);
+}
+
 void voltrix_launch_window_order(void* blk_offsets, int num_nodes, int chunk, void* order_out, void* stream,
                                  int* return_code) {
   *return_code = voltrix::launch_window_order(static_cast<const int*>(blk_offsets), num_nodes, chunk,

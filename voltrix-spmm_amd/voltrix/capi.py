@@ -27,6 +27,8 @@ SYMBOLS = (
     "voltrix_launch_spmm_f32_tile",
     "voltrix_launch_spmm_f16",
     "voltrix_launch_spmm_f16_tile",
+    "voltrix_spmm_f32_workspace_bytes",
+    "voltrix_launch_spmm_f32_as_f16",
     "voltrix_launch_spmm_f16_sched",
     "voltrix_launch_spmm_bf16_sched",
     "voltrix_launch_combine_partials",
@@ -70,6 +72,7 @@ def lib() -> ctypes.CDLL:
         _lib.voltrix_spmm_num_tiles.restype = ctypes.c_int
         _lib.voltrix_csr_preprocess_workspace_bytes.restype = ctypes.c_int64
         _lib.voltrix_panel_plan_workspace_bytes.restype = ctypes.c_int64
+        _lib.voltrix_spmm_f32_workspace_bytes.restype = ctypes.c_int64
         for name in SYMBOLS:
             if name.startswith("voltrix_launch_") or name in ("voltrix_spmm_default_tile", "voltrix_spmm_tile_at"):
                 getattr(_lib, name).restype = None
@@ -178,6 +181,22 @@ def launch_combine_partials(table, partials_ptr, output_ptr, num_nodes, embeddin
     return rc.value
 
 
+def spmm_f32_workspace_bytes(input_rows: int, embedding_dim: int) -> int:
+    return int(lib().voltrix_spmm_f32_workspace_bytes(ctypes.c_int64(input_rows), ctypes.c_int(embedding_dim)))
+
+
+def launch_spmm_f32_as_f16(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, feat, output, workspace,
+                           stream) -> int:
+    """Route B for fp32 features: the reference's launch() arguments + a caller-owned workspace; scaled-fp16 operand on the
+    default tile (include/voltrix_capi.h).  Tensors in, return code out."""
+    rc = ctypes.c_int(-1)
+    lib().voltrix_launch_spmm_f32_as_f16(_ptr(blk_offsets), _ptr(hspa_packed), _ptr(hind), ctypes.c_int(num_nodes),
+                                         ctypes.c_int(num_edges), ctypes.c_int(embedding_dim), _ptr(feat),
+                                         ctypes.c_int64(feat.shape[0]), _ptr(output), _ptr(workspace),
+                                         ctypes.c_void_p(stream), ctypes.byref(rc))
+    return rc.value
+
+
 def launch_spmm_list(hspa_packed, hind, num_nodes, embedding_dim, input_ptr, output_ptr, entries, wave_ptr, num_waves,
                      tile, stream) -> int:
     """Stage-list executor; ``tile`` = (fs, depth, groups).  Returns the return code."""
@@ -257,3 +276,36 @@ def launch_cast_f32_f16_scaled(src, dst, scale, stream) -> None:
     lib().voltrix_launch_cast_f32_f16_scaled(_ptr(src), _ptr(dst), ctypes.c_int64(src.numel()), _ptr(scale),
                                              ctypes.c_void_p(stream), ctypes.byref(rc))
     check(rc.value, "voltrix_launch_cast_f32_f16_scaled")
+
+
+# ---- kernel-isolated timing hook (utils.KernelTimer / bench_kineto): every launch wrapper above that takes a stream is
+# ---- bracketed by an event pair on that stream while a timer is active; free otherwise.
+def _timed(fn, name, stream_index=None, stream_kw="stream"):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        from .utils import KernelTimer
+
+        if KernelTimer.active is None:
+            return fn(*args, **kwargs)
+        stream = kwargs.get(stream_kw)
+        if stream is None and stream_index is not None and len(args) > stream_index:
+            stream = args[stream_index]
+        with KernelTimer.active.bracket(name, stream):
+            return fn(*args, **kwargs)
+
+    return wrapper
+
+
+launch_spmm = _timed(launch_spmm, "spmm", 10)
+launch_spmm_sched = _timed(launch_spmm_sched, "spmm", 9)
+launch_spmm_panel = _timed(launch_spmm_panel, "spmm_panel", 8)
+launch_combine_partials = _timed(launch_combine_partials, "combine_partials", 6)
+launch_add_inplace_f32 = _timed(launch_add_inplace_f32, "add_inplace_f32", 2)
+launch_cast_f32_f16_scaled = _timed(launch_cast_f32_f16_scaled, "cast_f32_f16_scaled", 3)
+launch_cast_f32_f16 = _timed(launch_cast_f32_f16, "cast_f32_f16", 2)
+launch_spmm_f32_as_f16 = _timed(launch_spmm_f32_as_f16, "spmm_f32_as_f16", 9)
+launch_window_order = _timed(launch_window_order, "window_order", 3)
+launch_csr_window_count = _timed(launch_csr_window_count, "csr_window_count", 8)
+launch_csr_fill = _timed(launch_csr_fill, "csr_fill", 8)

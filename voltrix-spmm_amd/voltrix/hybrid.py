@@ -133,6 +133,22 @@ def empty_plan(num_nodes, waves, row_blocks, tau, device, num_edges):
                      num_shared_edges=0, num_resid_edges=num_edges)
 
 
+def longest_first_order(panel_ptr: torch.Tensor) -> torch.Tensor:
+    """Launch order of the panel kernel: int32 [NP], position -> panel; inside every XCD's contiguous range of positions
+    (spmm_panel_kernel: blockIdx % 8 picks the range) the panels with the most k-steps first.  455 workgroups on 256 CUs is
+    1.8 rounds: started in natural order, the last round's long panels finish alone; longest first leaves the short ones
+    for the end.  Measured on the reddit-like graph (tau 3): the two-level step 1.59 -> 1.42 ms
+    (profiles/r02/experiment_tau_reddit.log).  Speed only."""
+    nks = (panel_ptr[1:] - panel_ptr[:-1]).to(torch.int64)
+    num_panels = nks.numel()
+    if num_panels == 0:
+        return torch.zeros(0, dtype=torch.int32, device=panel_ptr.device)
+    per_xcd = (num_panels + 7) // 8
+    top = int(nks.max())
+    key = (torch.arange(num_panels, device=panel_ptr.device) // per_xcd) * (top + 1) + (top - nks)
+    return torch.argsort(key, stable=True).to(torch.int32)
+
+
 def build_panel_plan(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
                      waves: int = DEFAULT_WAVES, row_blocks: int = DEFAULT_ROW_BLOCKS, tau: int = DEFAULT_TAU):
     """CSR on the GPU -> ``(resid_indptr, resid_indices, PanelPlan)`` with the HIP builder (panel_plan.hpp; two launches
@@ -171,7 +187,8 @@ def build_panel_plan(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int
     panel_bits = torch.empty((total_ksteps + 1) * waves * 64, dtype=torch.int32, device=device).view(torch.uint32)
     capi.launch_panel_plan_fill(indptr, indices, num_nodes, num_cols, waves, row_blocks, tau, workspace, panel_ptr,
                                 resid_indptr, total_ksteps, resid_indices, panel_cols, panel_bits, stream)
-    plan = PanelPlan(panel_ptr=panel_ptr, panel_cols=panel_cols, panel_bits=panel_bits, panel_order=None,
+    plan = PanelPlan(panel_ptr=panel_ptr, panel_cols=panel_cols, panel_bits=panel_bits,
+                     panel_order=longest_first_order(panel_ptr) if total_ksteps > 0 else None,
                      num_nodes=num_nodes, waves=waves, row_blocks=row_blocks, tau=tau, num_ksteps=total_ksteps,
                      num_shared_edges=indices.numel() - num_resid, num_resid_edges=num_resid)
     return resid_indptr, resid_indices, plan
@@ -291,7 +308,10 @@ def run_two_level(plan: PanelPlan, operand: torch.Tensor, output: torch.Tensor, 
     side = side_stream(operand.device)
     atomic = join_mode() == "atomic"
     if atomic:
-        output.zero_()
+        from .utils import timed_launch
+
+        with timed_launch("zero_fill", main):
+            output.zero_()
         target = output
     else:
         target = torch.empty_like(output)        # allocated on `main`; its last use (the add) is on `main` too
@@ -346,3 +366,6 @@ def hybrid_mode() -> str:
 # panel kernel needs columns that several rows of a 512-row panel share)
 AUTO_MIN_EDGES = 1 << 22
 AUTO_MIN_MEAN_DEGREE = 64
+# ... and one panel workgroup (512 rows) per CU at the very least: below that the panel kernel cannot fill the chip
+# (measured on a 46 k-row banded graph: 0.29 ms with the side-car, 0.24 ms in the window format)
+AUTO_MIN_ROWS = 256 * DEFAULT_WAVES * DEFAULT_ROW_BLOCKS * 16

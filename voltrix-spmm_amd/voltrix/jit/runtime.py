@@ -48,8 +48,22 @@ class Runtime:
                 assert isinstance(arg, dtype), f"Expected built-in type `{dtype}` for `{name}`, got `{type(arg)}`"
             cargs.append(map_ctype(arg))
         return_code = ctypes.c_int(-1)
-        self._launch(*cargs, ctypes.byref(return_code))
+        from ..utils import KernelTimer   # kernel-isolated timing hook (utils.bench_kineto)
+
+        if KernelTimer.active is None:
+            self._launch(*cargs, ctypes.byref(return_code))
+        else:
+            stream = next((a for a in args if isinstance(a, torch.cuda.Stream)), None)
+            with KernelTimer.active.bracket(self.kernel_name, stream):
+                self._launch(*cargs, ctypes.byref(return_code))
         return return_code.value
+
+    @property
+    def kernel_name(self) -> str:
+        """``spmm_kernel`` for .../kernel.spmm_kernel.<hash>."""
+        base = os.path.basename(os.path.normpath(self.path))
+        parts = base.split(".")
+        return parts[1] if len(parts) >= 3 else base
 
 
 class RuntimeCache:

@@ -78,7 +78,7 @@ def csr_preprocess_device(indptr: torch.Tensor, indices: torch.Tensor, num_nodes
     indptr, indices = indptr.contiguous(), indices.contiguous()
     pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(indptr, indices, num_nodes, num_cols)
     mode = hybrid.hybrid_mode()
-    big_enough = (indices.numel() >= hybrid.AUTO_MIN_EDGES
+    big_enough = (indices.numel() >= hybrid.AUTO_MIN_EDGES and num_nodes >= hybrid.AUTO_MIN_ROWS
                   and indices.numel() >= hybrid.AUTO_MIN_MEAN_DEGREE * max(1, num_nodes))
     if mode == "on" or (mode == "auto" and big_enough):
         two = _build_two_level(indptr, indices, num_nodes, num_cols)
