@@ -328,7 +328,15 @@ def main():
             keys["dtype"] = str(torch.float16)   # fp32 features run as scaled fp16
         return jit_tuner.tuned_point("spmm_kernel", keys)
 
-    used_two = two is not None and os.getenv("VOLTRIX_HYBRID", "auto") not in ("0", "off")
+    padded_width = (num_feats + 7) // 8 * 8
+    operand_dtype = str(torch.float16) if (is_f16 or os.getenv("VOLTRIX_FP32_MODE", "fp16") != "exact") else str(torch.float32)
+    hybrid_env = os.getenv("VOLTRIX_HYBRID", "auto")
+    if two is None or hybrid_env in ("0", "off"):
+        used_two = False
+    elif hybrid_env in ("1", "on"):
+        used_two = True
+    else:   # auto: the operator timed both forms on its first call and kept the faster
+        used_two = two.format_choice.get((padded_width, operand_dtype)) == "two-level"
     point = tuned(two.hspa_packed if used_two else handle[1], used_two)
 
     def sched_name(p):
@@ -350,13 +358,14 @@ def main():
             e.synchronize()
             return s.elapsed_time(e) / iters
 
-        if used_two:
+        if two is not None:
             os.environ["VOLTRIX_HYBRID"] = "0"
             wh = tuple(t for t in handle)   # same tensors; the side-car is ignored with VOLTRIX_HYBRID=0
             extras["window_format_ms"] = time_ms(lambda: voltrix.spmm(*wh, num_nodes=local_rows, num_edges=local_nnz,
                                                                       feat=gathered))
             extras["window_format_choice"] = dict(tuned(handle[1], False))
-            os.environ["VOLTRIX_HYBRID"] = "auto" if args.format == "auto" else "1"
+            os.environ["VOLTRIX_HYBRID"] = hybrid_env
+            extras["format_choice"] = {f"F={k[0]} {k[1]}": v for k, v in two.format_choice.items()}
         # cold caches: 512 MB written between steps (more than L2 + the 256 MB Infinity Cache), as the reference's
         # bench_kineto does with 256 MB for a 50 MB L2 (utils.py:277-281); the headline number is the warm-cache one
         flush = torch.empty(512 << 20, dtype=torch.uint8, device=device)

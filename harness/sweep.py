@@ -4,9 +4,12 @@ feat_dim in {32,128,512} reported at 1 GPU ... alongside the CPU torch.sparse.mm
 
     python harness/sweep.py [--workloads reddit_like,products_like] [--feats 32,128,512] [--cpu] [--vendor] > out.jsonl
 
-One JSON line per (workload, F): best tile of the tuned space (with / without the balance schedule), kernel ms (HIP
-events around batches of 5 back-to-back launches, median of 7 batches after 3 warm-ups), GFLOP/s = 2 nnz F / t, algorithmic GB/s and its fraction of 8 TB/s, gathered-row
-TB/s, optional CPU (torch.sparse.mm, all host threads, fp32) and GPU-vendor (hipSPARSE through torch.sparse.mm, fp32)
+One JSON line per (workload, F), all through the OPERATOR (``voltrix.spmm`` on a ``csr_preprocess_device`` handle; the
+JIT tuner picks tile and schedule on the first call): the window format (VOLTRIX_HYBRID=0), the two-level side-car where
+``csr_preprocess`` would attach one (VOLTRIX_HYBRID=1 with the default share threshold), and for reference the round-1
+launch (tile (128|64|32, 3, 4), balance schedule chunk 512, no unit table).  ms = median over 7 batches of 5 back-to-back
+calls after 3 warm-ups (HIP events); GFLOP/s = 2 nnz F / t; algorithmic GB/s and its fraction of 8 TB/s; gathered-row
+TB/s; optional CPU (torch.sparse.mm, all host threads, fp32) and GPU-vendor (hipSPARSE through torch.sparse.mm, fp32)
 baselines.  Bench infrastructure; the headline line the driver consumes is bench.py's.
 """
 import argparse
@@ -25,7 +28,8 @@ import torch  # noqa: E402
 import synth_graphs  # noqa: E402
 import voltrix  # noqa: E402
 from voltrix import capi  # noqa: E402
-from voltrix.jit_kernels.spmm import tile_space  # noqa: E402
+from voltrix.jit_kernels import jit_tuner  # noqa: E402
+from voltrix.jit_kernels.spmm import feature_hash  # noqa: E402
 
 
 def median_ms(fn, iters=7, warm=3, batch=5):
@@ -46,49 +50,10 @@ def median_ms(fn, iters=7, warm=3, batch=5):
     return sorted(times)[len(times) // 2]
 
 
-def two_level_best(indptr, indices, n, nnz, f, feat, out, dev):
-    """Best of a few two-level configurations: 512-row panels, tau 3 / 4, window tile (fs, 3, 4) on the residual with
-    each balance chunk, panel kernel on a side stream into a second buffer, add pass.  Returns a dict."""
-    from voltrix import hybrid
-    from voltrix.jit_kernels.spmm import ORDER_CHUNKS
-
-    main_s, side = torch.cuda.current_stream(), torch.cuda.Stream()
-    fs = 32 if f <= 32 else (64 if f <= 64 else 128)
-    shared = torch.empty_like(out)
-    best = None
-    for tau in (3, 4):
-        t0 = time.perf_counter()
-        ri, rx, plan = hybrid.build_panel_plan(indptr, indices, n, None, 8, 4, tau)
-        h = voltrix.csr_fused_preprocess_kernel(ri, rx, n)
-        torch.cuda.synchronize()
-        build_ms = (time.perf_counter() - t0) * 1e3
-        if plan.num_ksteps == 0:
-            continue
-        for sched, chunk in ORDER_CHUNKS.items():
-            order = torch.empty((n + 15) // 16, dtype=torch.int32, device=dev)
-            capi.launch_window_order(h[0], n, order, main_s.cuda_stream, chunk)
-
-            def run(plan=plan, h=h, rx=rx, order=order):
-                fork = torch.cuda.Event()
-                fork.record(main_s)
-                side.wait_event(fork)
-                hybrid.launch_panel(plan, feat, shared, accumulate=False, stream=side.cuda_stream)
-                join = torch.cuda.Event()
-                join.record(side)
-                rc = capi.launch_spmm(h[0].data_ptr(), h[1].data_ptr(), h[2].data_ptr(), n, rx.numel(), f, feat.data_ptr(),
-                                      out.data_ptr(), True, (fs, 3, 4), main_s.cuda_stream, order.data_ptr())
-                assert rc == 0
-                main_s.wait_event(join)
-                capi.launch_add_inplace_f32(out, shared, main_s.cuda_stream)
-            ms = median_ms(run, iters=3, warm=1)
-            if best is None or ms < best[0]:
-                best = (ms, run, {"panel_rows": plan.panel_rows, "tau": tau, "balance_chunk": chunk,
-                                  "shared_edge_fraction": plan.num_shared_edges / max(1, nnz),
-                                  "panel_ksteps": plan.num_ksteps, "preprocess_two_level_ms": build_ms}, (plan, h, rx, order))
-    if best is None:
-        return {"ms": None, "note": "no shared columns"}
-    ms = median_ms(best[1])
-    return dict(best[2], ms=ms, gflops=2.0 * nnz * f / ms / 1e6)
+def tuned_point(hspa_packed, f, beside_panel, dev):
+    keys = {"feature_hash": feature_hash(hspa_packed), "embedding_dim": f, "dtype": str(torch.float16),
+            "device": torch.cuda.get_device_name(dev), "two_level": bool(beside_panel)}
+    return dict(jit_tuner.tuned_point("spmm_kernel", keys))
 
 
 def main():
@@ -98,60 +63,64 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--vendor", action="store_true")
-    ap.add_argument("--two-level", action="store_true",
-                    help="also time the two-level format (panel kernel beside the window kernel, voltrix/hybrid.py)")
+    ap.add_argument("--tune", default="default", choices=["default", "full", "none"])
     args = ap.parse_args()
+    os.environ["VOLTRIX_TUNE_SPACE"] = args.tune
     dev = torch.device("cuda", 0)
     stream = torch.cuda.current_stream().cuda_stream
     for name in args.workloads.split(","):
         indptr, indices, cfg = synth_graphs.generate(name, device=dev, scale=args.scale)
         n, nnz = indptr.numel() - 1, indices.numel()
+        os.environ["VOLTRIX_HYBRID"] = "1"
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        p1, packed, hind, _ = voltrix.csr_fused_preprocess_kernel(indptr, indices, n)
+        handle = voltrix.csr_preprocess_device(indptr, indices, n)
         torch.cuda.synchronize()
         prep_ms = (time.perf_counter() - t0) * 1e3
-        total_blocks = int(p1[-1])
-        from voltrix.jit_kernels.spmm import ORDER_CHUNKS
-
-        orders, keep = {0: 0}, []
-        for sched, chunk in ORDER_CHUNKS.items():
-            o = torch.empty((n + 15) // 16, dtype=torch.int32, device=dev)
-            capi.launch_window_order(p1, n, o, stream, chunk)
-            keep.append(o)
-            orders[sched] = o.data_ptr()
+        handle[1].hash_tag = f"sweep/{name}/{args.scale}"
+        two = voltrix.two_level_of(handle[1])
+        total_blocks = int(handle[0][-1])
+        order = torch.empty((n + 15) // 16, dtype=torch.int32, device=dev)
+        capi.launch_window_order(handle[0], n, order, stream, 512)
         for f in [int(x) for x in args.feats.split(",")]:
             feat = torch.randn(n, f, device=dev).half()
             out = torch.empty(n, f, device=dev)
-            aot = set(capi.tiles(True))
-            best = None
-            for p in tile_space(f, 2):
-                tile = (p["FS"], p["DEPTH"], p["WAVES"])
-                if tile not in aot:
-                    continue
-                ordp = orders[p["SCHED"]]
-
-                def run(tile=tile, ordp=ordp):  # bind now: the best candidate is re-timed after the loop
-                    rc = capi.launch_spmm(p1.data_ptr(), packed.data_ptr(), hind.data_ptr(), n, nnz, f,
-                                          feat.data_ptr(), out.data_ptr(), True, tile, stream, ordp)
-                    assert rc == 0
-                ms = median_ms(run, iters=3, warm=1)
-                if best is None or ms < best[0]:
-                    best = (ms, tile, p["SCHED"], run)
-            ms = median_ms(best[3])
+            os.environ["VOLTRIX_HYBRID"] = "0"
+            ms = median_ms(lambda: voltrix.spmm(*handle, num_nodes=n, num_edges=nnz, feat=feat))
             alg = synth_graphs.algorithmic_bytes(n, nnz, f, 2)
             line = {"workload": name, "scale": args.scale, "num_nodes": n, "nnz": nnz, "feat": f, "dtype": "f16",
-                    "tc_blocks": total_blocks, "preprocess_ms": prep_ms,
-                    "tile": {"fs": best[1][0], "depth": best[1][1], "waves": best[1][2], "balance_chunk": ORDER_CHUNKS.get(best[2], 0)},
-                    "kernel_ms": ms, "gflops": 2.0 * nnz * f / ms / 1e6, "algorithmic_gbs": alg / ms / 1e6,
-                    "hbm_roofline_frac": alg / ms / 1e6 / 8000.0,
-                    "gather_tbs": 8.0 * total_blocks * f * 2 / ms / 1e9}
-            if args.two_level:
-                line["two_level"] = two_level_best(indptr, indices, n, nnz, f, feat, out, dev)
+                    "tc_blocks": total_blocks, "preprocess_ms_with_side_car_attempt": prep_ms,
+                    "window_format": {"ms": ms, "choice": tuned_point(handle[1], f, False, dev),
+                                      "gflops": 2.0 * nnz * f / ms / 1e6, "algorithmic_gbs": alg / ms / 1e6,
+                                      "hbm_roofline_frac": alg / ms / 1e6 / 8000.0,
+                                      "gather_tbs": 8.0 * total_blocks * f * 2 / ms / 1e9}}
+            fs = 32 if f <= 32 else (64 if f <= 64 else 128)
+
+            def round1():
+                rc = capi.launch_spmm(handle[0].data_ptr(), handle[1].data_ptr(), handle[2].data_ptr(), n, nnz, f,
+                                      feat.data_ptr(), out.data_ptr(), True, (fs, 4 if fs == 32 else 3, 4), stream,
+                                      order.data_ptr())
+                assert rc == 0
+
+            line["round1_launch_ms"] = median_ms(round1)
+            if two is not None:
+                os.environ["VOLTRIX_HYBRID"] = "1"
+                ms2 = median_ms(lambda: voltrix.spmm(*handle, num_nodes=n, num_edges=nnz, feat=feat))
+                line["two_level"] = {"ms": ms2, "choice": tuned_point(two.hspa_packed, f, True, dev),
+                                     "gflops": 2.0 * nnz * f / ms2 / 1e6, "algorithmic_gbs": alg / ms2 / 1e6,
+                                     "hbm_roofline_frac": alg / ms2 / 1e6 / 8000.0,
+                                     "shared_edge_fraction": two.plan.num_shared_edges / max(1, nnz),
+                                     "panel_ksteps": two.plan.num_ksteps, "tau": two.plan.tau}
+            else:
+                line["two_level"] = None   # fewer than VOLTRIX_HYBRID_MIN_SHARE of the edges in shared columns
+            best = min(ms, line["two_level"]["ms"]) if line["two_level"] else ms
+            line["best_ms"] = best
+            line["best_hbm_roofline_frac"] = alg / best / 1e6 / 8000.0
             if args.vendor:
                 try:
                     a = torch.sparse_csr_tensor(indptr, indices, torch.ones(nnz, device=dev), size=(n, n))
                     f32 = feat.float()
-                    line["vendor_hipsparse_f32_ms"] = median_ms(lambda: a @ f32, iters=3, warm=1)
+                    line["vendor_hipsparse_f32_ms"] = median_ms(lambda: a @ f32, iters=3, warm=1, batch=1)
                     del a, f32
                 except Exception as exc:
                     line["vendor_hipsparse_error"] = str(exc)[:120]
@@ -171,6 +140,8 @@ def main():
                 line["cpu_threads"] = os.cpu_count()
             print(json.dumps(line), flush=True)
             del feat, out
+        del handle, two, indptr, indices
+        torch.cuda.empty_cache()
 
 
 if __name__ == "__main__":

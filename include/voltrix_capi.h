@@ -135,20 +135,28 @@ void voltrix_launch_spmm_bf16_tile(void* blk_offsets, void* hspa_packed, void* h
  *               tile goes to partials + slot * 16 * embedding_dim, and voltrix_launch_combine_partials sums the tiles
  *               of each cut window in unit order (deterministic) into output.  unit_ptr int32[9]: XCD x owns units
  *               [unit_ptr[x], unit_ptr[x+1]); max_units_per_xcd = the largest of those eight counts.  Every stage of
- *               every window must belong to exactly one unit. */
+ *               every window must belong to exactly one unit.
+ *   row_map     NULL, or int32[16 W]: row i of the handle is row row_map[i] of output (-1: a padding row, never
+ *               written).  For handles built from a row-permuted CSR (locality reorder: rows that share columns grouped
+ *               into the same 16-row windows -- the reference takes externally reordered graphs, bench/graph_gen.py:42-45):
+ *               the product is written through the permutation, there is no un-permute pass, and because column ids are
+ *               not relabelled `input` is the caller's B as it is. */
 void voltrix_launch_spmm_f16_sched(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
                                    int embedding_dim, void* input, void* output, int fs, int depth, int waves,
                                    void* window_order, void* out_scale, int atomic_out, void* units, void* unit_ptr,
-                                   int max_units_per_xcd, void* partials, void* stream, int* return_code);
+                                   int max_units_per_xcd, void* partials, void* row_map, void* stream,
+                                   int* return_code);
 void voltrix_launch_spmm_bf16_sched(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
                                     int embedding_dim, void* input, void* output, int fs, int depth, int waves,
                                     void* window_order, void* out_scale, int atomic_out, void* units, void* unit_ptr,
-                                    int max_units_per_xcd, void* partials, void* stream, int* return_code);
+                                    int max_units_per_xcd, void* partials, void* row_map, void* stream,
+                                    int* return_code);
 /* cuts int32[num_cuts][4] = {window, first slot, units, 0} (16-byte aligned): output rows of `window` = (accumulate ?
  * output : 0) + partials[first slot] + partials[first slot + 1] + ... in that order.  Run it on the stream of the
- * launch that wrote the partials, after the join with the panel kernel when accumulate != 0.  embedding_dim % 4 == 0. */
+ * launch that wrote the partials, after the join with the panel kernel when accumulate != 0.  embedding_dim % 4 == 0.
+ * row_map as for the launch that wrote the partials (NULL: identity). */
 void voltrix_launch_combine_partials(void* cuts, int num_cuts, void* partials, void* output, int num_nodes,
-                                     int embedding_dim, int accumulate, void* stream, int* return_code);
+                                     int embedding_dim, int accumulate, void* row_map, void* stream, int* return_code);
 
 /* "Balance" schedule for a handle: order_out int32[W] (device) lists the windows of every XCD range, inside chunks of
  * `chunk` (1..4096) consecutive windows, by descending TC-block count, so that co-resident waves sweep their sorted

@@ -70,3 +70,60 @@ def test_reordered_graph_runs_faster_and_matches(cuda_device, monkeypatch):
     t2 = GPU_bench(lambda: voltrix.spmm(*h2, n, ix2.numel(), feat2), iters=10, warmup=3)
     print(f"shuffled {t1:.3f} ms (T={int(h[0][-1])}) -> rcm {t2:.3f} ms (T={int(h2[0][-1])})")
     assert t2 < 1.15 * t1   # 46 k rows run in ~0.1 ms: launch-bound, the gain shows in the gathered rows (T), asserted above
+
+
+# ---- round 2: reorder on the device, permutation carried by the handle ----------------------------------------------------
+def test_device_bfs_order_regroups_rows_without_relabelling_columns():
+    """Labels shuffled (P A P^T): the breadth-first row order (torch ops, runs on the CPU here) brings the TC-block count
+    of A[perm, :] -- rows regrouped, column ids untouched -- back to the natural order's; the degree order does not."""
+    indptr0, indices0, ip, ix, n = _shuffled_band_graph()
+    perm = reorder.bfs_permutation(ip, ix, n)
+    assert sorted(perm.tolist()) == list(range(n))
+    pip, pix = reorder.permute_rows_csr(ip, ix, n, perm)
+    for k in (0, 7, n // 2, n - 1):
+        r = int(perm[k])
+        assert torch.equal(pix[pip[k]:pip[k + 1]], ix[ip[r]:ip[r + 1]])
+    blocks = lambda a, b: int(oracle_c.preprocess(a.numpy(), b.numpy(), n)[3][-1])  # noqa: E731
+    t_natural, t_shuffled, t_bfs = blocks(indptr0, indices0), blocks(ip, ix), blocks(pip, pix)
+    assert t_shuffled > 1.3 * t_natural and t_bfs < 1.05 * t_natural
+    dip, dix = reorder.permute_rows_csr(ip, ix, n, reorder.degree_permutation_device(ip, n))
+    assert blocks(dip, dix) > 1.3 * t_natural
+    # several components + isolated rows: still a permutation
+    ip2 = torch.cat([ip, ip[-1] + ip[1:4] * 0])            # three empty rows appended
+    perm2 = reorder.bfs_permutation(ip2, ix, n + 3)
+    assert sorted(perm2.tolist()) == list(range(n + 3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["bfs", "degree", "given"])
+def test_reordered_handle_writes_c_through_the_permutation(cuda_device, method, monkeypatch):
+    """csr_preprocess_reordered / spmm_reordered against the oracle on the ORIGINAL graph: the handle describes A[perm, :],
+    the kernel's epilogue writes row i to C[row_map[i]] (no un-permute pass), B is gathered as the caller has it."""
+    import voltrix
+    from oracle import torch_ref
+
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    _, _, ip, ix, n = _shuffled_band_graph(seed=5)
+    n_odd = n - 5                                              # a partial last window: padding rows map to -1
+    ip, ix = ip[: n_odd + 1].contiguous(), ix[: int(ip[n_odd])].contiguous()
+    keep = ix < n_odd
+    counts = torch.zeros(n_odd, dtype=torch.int64).index_add_(
+        0, torch.repeat_interleave(torch.arange(n_odd), (ip[1:] - ip[:-1]).long()), keep.long())
+    ip = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(counts, 0)]).to(torch.int32)
+    ix = ix[keep].contiguous()
+    how = torch.from_numpy(np.random.default_rng(2).permutation(n_odd)) if method == "given" else method
+    h = voltrix.csr_preprocess_reordered(ip, ix, n_odd, method=how)
+    assert isinstance(h, voltrix.ReorderedHandle) and h.row_map.numel() == 16 * ((n_odd + 15) // 16)
+    assert sorted(h.row_map[:n_odd].tolist()) == list(range(n_odd)) and (h.row_map[n_odd:] == -1).all()
+    plain = voltrix.csr_preprocess(ip, ix, n_odd)
+    if method == "bfs":
+        assert int(h.blk_offsets[-1]) < 0.8 * int(plain[0][-1])     # fewer TC blocks = fewer gathered rows of B
+    for dtype, width in ((torch.float16, 128), (torch.float32, 40)):
+        feat32 = torch.randn(n_odd, width)
+        feat32 = feat32.half().float() if dtype == torch.float16 else feat32
+        out = voltrix.spmm_reordered(h, feat32.to(dtype).cuda(), hash_tag=f"reordered_{method}")
+        assert out.shape == (n_odd, width)
+        ref = torch_ref.spmm(ip, ix, feat32, n_odd)
+        assert float((out.cpu() - ref).norm() / ref.norm()) < (1e-6 if dtype == torch.float16 else 1e-3)
+        again = voltrix.spmm_reordered(h, feat32.to(dtype).cuda())
+        assert torch.equal(out, again)

@@ -11,6 +11,7 @@ from .spmm import *  # noqa: F401,F403
 from .spmm import (BLK_H, BLK_W, csr_preprocess, csr_preprocess_device, csr_preprocess_hybrid, spmm, spmm_two_level,
                    two_level_of)
 from .hybrid import TwoLevelHandle
-from . import hybrid, jit, utils
+from .reorder import ReorderedHandle, csr_preprocess_reordered, spmm_reordered
+from . import autograd, hybrid, jit, utils
 
 __version__ = "0.1.0"

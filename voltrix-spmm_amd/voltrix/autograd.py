@@ -1,0 +1,72 @@
+"""Backward pass of the SpMM: ``dB = A^T @ dC`` through a transposed handle.
+
+No reference counterpart -- the reference is forward-only (voltrix/jit_kernels/spmm.py:53-54 asserts a plain float
+input and nothing registers a gradient), which is what keeps it out of GCN *training* loops.  ``A`` is binary, so the
+gradient with respect to the dense operand of ``C = A @ B`` is the SpMM of the transposed adjacency with the incoming
+gradient; the same kernels run it on a second handle built from the transposed CSR (one device-side sort by column).
+
+    op = voltrix.autograd.SpMM(indptr, indices, num_nodes)        # CPU or CUDA int32 CSR; builds A and A^T handles
+    out = op(feat)                                                # float32 [num_nodes, F]; feat.requires_grad honoured
+    out.sum().backward()                                          # feat.grad = A^T @ 1
+
+The forward keeps ``voltrix.spmm``'s numerics (fp16 / bf16 operand or scaled-fp16 rounding of an fp32 operand, fp32
+accumulate); the backward treats the incoming gradient the same way, i.e. the pair is the exact adjoint up to the
+operand rounding the forward applies too.
+"""
+from __future__ import annotations
+
+import torch
+
+from .spmm.spmm import csr_preprocess_device, spmm
+
+
+def csr_transpose_device(indptr: torch.Tensor, indices: torch.Tensor, num_rows: int, num_cols: int):
+    """CSR of ``A^T`` ([num_cols, num_rows]) for a device CSR of ``A`` ([num_rows, num_cols]): int32, rows sorted,
+    duplicates kept (they count once in the block format, like everywhere else)."""
+    assert indptr.is_cuda and indices.is_cuda and indptr.dtype == torch.int32 and indices.dtype == torch.int32
+    dev = indptr.device
+    deg = (indptr[1:] - indptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(num_rows, device=dev, dtype=torch.int64), deg)
+    key = torch.sort(indices.long() * num_rows + rows).values      # by (col, row)
+    t_rows = torch.div(key, num_rows, rounding_mode="floor")
+    t_indices = (key - t_rows * num_rows).to(torch.int32)
+    t_indptr = torch.zeros(num_cols + 1, dtype=torch.int64, device=dev)
+    t_indptr[1:] = torch.cumsum(torch.bincount(t_rows, minlength=num_cols), 0)
+    return t_indptr.to(torch.int32), t_indices
+
+
+class _SpMMFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, op):
+        ctx.op = op
+        ctx.in_dtype = feat.dtype
+        return spmm(*op.handle, num_nodes=op.num_rows, num_edges=op.num_edges, feat=feat)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        op = ctx.op
+        grad = spmm(*op.handle_t, num_nodes=op.num_cols, num_edges=op.num_edges, feat=grad_out.contiguous())
+        return grad.to(ctx.in_dtype), None
+
+
+class SpMM:
+    """``C = A @ B`` with a gradient for ``B``.  ``A``: binary CSR [num_rows, num_cols] (``num_cols`` defaults to
+    ``num_rows``).  Builds two reference-format handles on the current device (A and A^T); both go through
+    ``voltrix.spmm`` -- tuner, schedules and the two-level side-car included."""
+
+    def __init__(self, indptr: torch.Tensor, indices: torch.Tensor, num_rows: int, num_cols: int = None, hash_tag: str = None):
+        assert indptr.dtype == torch.int32 and indices.dtype == torch.int32 and indptr.numel() == num_rows + 1
+        self.num_rows = num_rows
+        self.num_cols = num_rows if num_cols is None else int(num_cols)
+        self.num_edges = int(indices.numel())
+        indptr_d, indices_d = indptr.contiguous().cuda(), indices.contiguous().cuda()
+        self.handle = csr_preprocess_device(indptr_d, indices_d, num_rows, num_cols=self.num_cols)
+        t_indptr, t_indices = csr_transpose_device(indptr_d, indices_d, num_rows, self.num_cols)
+        self.handle_t = csr_preprocess_device(t_indptr, t_indices, self.num_cols, num_cols=num_rows)
+        if hash_tag is not None:
+            self.handle[1].hash_tag = hash_tag
+            self.handle_t[1].hash_tag = hash_tag + "/transposed"
+
+    def __call__(self, feat: torch.Tensor) -> torch.Tensor:
+        assert feat.shape[0] == self.num_cols
+        return _SpMMFunction.apply(feat, self)

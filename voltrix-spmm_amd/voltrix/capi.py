@@ -153,7 +153,8 @@ def launch_spmm(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
 
 
 def launch_spmm_sched(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input_ptr, output_ptr, tile,
-                      stream, window_order=0, out_scale=0, atomic_out=False, bf16=False, table=None, partials=0) -> int:
+                      stream, window_order=0, out_scale=0, atomic_out=False, bf16=False, table=None, partials=0,
+                      row_map=0) -> int:
     """16-bit operand launch with the schedule / output extensions (include/voltrix_capi.h): ``atomic_out`` = add the
     result onto a pre-zeroed output with float atomics (two-level format without a join pass); ``table`` = a
     ``voltrix.schedule.UnitTable`` (replaces ``window_order``), ``partials`` = device pointer of its partial tiles.
@@ -167,17 +168,19 @@ def launch_spmm_sched(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embe
        ctypes.c_void_p(table.units.data_ptr() if table is not None else 0),
        ctypes.c_void_p(table.unit_ptr.data_ptr() if table is not None else 0),
        ctypes.c_int(table.max_units_per_xcd if table is not None else 0), ctypes.c_void_p(partials),
-       ctypes.c_void_p(stream), ctypes.byref(rc))
+       ctypes.c_void_p(row_map), ctypes.c_void_p(stream), ctypes.byref(rc))
     return rc.value
 
 
-def launch_combine_partials(table, partials_ptr, output_ptr, num_nodes, embedding_dim, accumulate, stream) -> int:
+def launch_combine_partials(table, partials_ptr, output_ptr, num_nodes, embedding_dim, accumulate, stream,
+                            row_map=0) -> int:
     """Sum the partial tiles of the cut windows of ``table`` (a ``voltrix.schedule.UnitTable``) into the output."""
     rc = ctypes.c_int(-1)
     lib().voltrix_launch_combine_partials(ctypes.c_void_p(table.cuts.data_ptr()), ctypes.c_int(table.num_cuts),
                                           ctypes.c_void_p(partials_ptr), ctypes.c_void_p(output_ptr),
                                           ctypes.c_int(num_nodes), ctypes.c_int(embedding_dim),
-                                          ctypes.c_int(int(accumulate)), ctypes.c_void_p(stream), ctypes.byref(rc))
+                                          ctypes.c_int(int(accumulate)), ctypes.c_void_p(row_map),
+                                          ctypes.c_void_p(stream), ctypes.byref(rc))
     return rc.value
 
 

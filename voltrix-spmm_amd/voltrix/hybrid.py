@@ -70,6 +70,7 @@ class TwoLevelHandle:
     num_nodes: int
     num_edges: int               # of the whole matrix (shared + residual)
     hash_tag: str = None         # tuner key of the residual launches (like hspa_packed.hash_tag in the reference)
+    format_choice: dict = dataclasses.field(default_factory=dict)   # (width, dtype) -> "two-level" | "window" (voltrix.spmm, auto mode)
 
     @property
     def residual(self):

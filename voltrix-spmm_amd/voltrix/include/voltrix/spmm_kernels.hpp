@@ -185,6 +185,9 @@ struct SpmmArgs {
                                  // result goes to C; slot >= 0: to tile `slot` of `partials` (combine_partials_kernel)
   const int* unit_ptr;           // [9]: XCD x owns units [unit_ptr[x], unit_ptr[x + 1])
   float* partials;               // [num partial tiles][16][F] fp32 (units with slot >= 0)
+  const int* row_map;            // optional [16 W]: row i of the handle is row row_map[i] of C (-1: padding).  A handle built
+                                 // from a row-permuted CSR (locality reorder, voltrix/reorder.py) writes C through it: no
+                                 // un-permute pass.  Column ids are never relabelled, so B is gathered as it is.
   int atomic_out;                // 1: C += result by float atomics (C pre-zeroed; two-level format: no join pass)
 };
 
@@ -518,14 +521,21 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
     return;
   }
   const int orow0 = w * kBlkH + 4 * (lane >> 4);
+  int orow[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    orow[j] = orow0 + j;
+    if (a.row_map) orow[j] = a.row_map[orow[j]];
+    if (orow[j] >= a.num_nodes) orow[j] = -1;
+  }
 #pragma unroll
   for (int s = 0; s < SLOTS; ++s) {
     const int col = ocol0 + 16 * s;
     if (col < F) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int row = orow0 + j;
-        if (row < a.num_nodes) {
+        const int row = orow[j];
+        if (row >= 0) {
           float* const dst = a.output + ((long long)row * F + col);
           if (a.atomic_out)
             unsafeAtomicAdd(dst, acc[s][j] * oscale);  // global_atomic_add_f32, no return; two addends per element
@@ -545,7 +555,7 @@ inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed,
                             float* output, hipStream_t stream, const int* window_order = nullptr,
                             const float* out_scale = nullptr, int atomic_out = 0,
                             const int* units = nullptr /* int32[U][4] */, const int* unit_ptr = nullptr /* int32[9] */,
-                            int max_units_per_xcd = 0, float* partials = nullptr) {
+                            int max_units_per_xcd = 0, float* partials = nullptr, const int* row_map = nullptr) {
   if (num_nodes < 0 || embedding_dim < 0) return kErrBadShape;
   if (num_nodes == 0 || embedding_dim == 0) return kOk;
   if (embedding_dim % (16 / T::EB) != 0) return kErrBadShape;  // 16-byte row chunks
@@ -567,6 +577,7 @@ inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed,
   a.units = reinterpret_cast<const int4*>(units);
   a.unit_ptr = unit_ptr;
   a.partials = partials;
+  a.row_map = row_map;
   if (units != nullptr) {
     if (unit_ptr == nullptr || max_units_per_xcd < 0 || ((uintptr_t)units & 15)) return kErrBadShape;
     if (max_units_per_xcd == 0) return kOk;
@@ -590,14 +601,16 @@ inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed,
 static __global__ __launch_bounds__(256) void combine_partials_kernel(const int4* __restrict__ cuts,
                                                                      const float* __restrict__ partials,
                                                                      float* __restrict__ output, const int num_nodes,
-                                                                     const int F, const int accumulate) {
+                                                                     const int F, const int accumulate,
+                                                                     const int* __restrict__ row_map) {
   const int4 c = cuts[blockIdx.x];
   const int f4 = F / 4;
   const long long tile4 = (long long)kBlkH * f4;
   const float4* src = reinterpret_cast<const float4*>(partials) + (long long)c.y * tile4;
   for (int i = threadIdx.x; i < (int)tile4; i += 256) {
-    const int row = c.x * kBlkH + i / f4;
-    if (row >= num_nodes) break;  // tail window: rows in ascending order per thread
+    int row = c.x * kBlkH + i / f4;
+    if (row_map) row = row_map[row];
+    if (row < 0 || row >= num_nodes) continue;  // tail window / padding rows
     float4 sum = src[i];
     for (int u = 1; u < c.z; ++u) {
       const float4 p = src[u * tile4 + i];
@@ -619,12 +632,12 @@ static __global__ __launch_bounds__(256) void combine_partials_kernel(const int4
 }
 
 inline int combine_partials(const int* cuts, int num_cuts, const float* partials, float* output, int num_nodes,
-                            int embedding_dim, int accumulate, hipStream_t stream) {
+                            int embedding_dim, int accumulate, hipStream_t stream, const int* row_map = nullptr) {
   if (num_cuts < 0 || num_nodes < 0 || embedding_dim < 0 || (embedding_dim % 4) != 0) return kErrBadShape;
   if (num_cuts == 0 || num_nodes == 0 || embedding_dim == 0) return kOk;
   if (((uintptr_t)cuts & 15) || ((uintptr_t)partials & 15) || ((uintptr_t)output & 15)) return kErrBadShape;
   hipLaunchKernelGGL(combine_partials_kernel, dim3((unsigned)num_cuts), dim3(256), 0, stream,
-                     reinterpret_cast<const int4*>(cuts), partials, output, num_nodes, embedding_dim, accumulate);
+                     reinterpret_cast<const int4*>(cuts), partials, output, num_nodes, embedding_dim, accumulate, row_map);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

@@ -21,9 +21,10 @@ __return_code = voltrix::launch_spmm_tc16<voltrix::SpmmTile<{FS}, {DEPTH}, {WAVE
     num_nodes, embedding_dim, input, output, stream,
     ({SCHED} == 0 || {SCHED} == 4) ? nullptr : ({SCHED} == 1 ? win_order_a : ({SCHED} == 2 ? win_order_b : win_order_c)),
     out_scale, atomic_out,
-    {SCHED} == 4 ? units : nullptr, unit_ptr, max_units_per_xcd, partials);
+    {SCHED} == 4 ? units : nullptr, unit_ptr, max_units_per_xcd, partials, has_row_map != 0 ? row_map : nullptr);
 if (__return_code == 0 && {SCHED} == 4 && combine_now != 0)
-  __return_code = voltrix::combine_partials(cuts, num_cuts, partials, output, num_nodes, embedding_dim, atomic_out, stream);
+  __return_code = voltrix::combine_partials(cuts, num_cuts, partials, output, num_nodes, embedding_dim, atomic_out, stream,
+                                            has_row_map != 0 ? row_map : nullptr);
 """
 
 # windows per length-sorted chunk of the "balance" schedule (spmm_kernels.hpp::launch_window_order) for SCHED 1/2/3.
@@ -140,6 +141,8 @@ def arg_defs_for(dtype):
         ("num_cuts", int),
         ("partials", torch.float32),
         ("combine_now", int),
+        ("row_map", torch.int32),
+        ("has_row_map", int),
         ("stream", torch.cuda.Stream),
     )
 
@@ -176,8 +179,8 @@ class PendingCombine:
     """Partial tiles of cut windows that still have to be summed into the output (``spmm_kernel(..., defer_combine=True)``:
     the two-level step runs the pass after the join with the panel kernel, when the output holds that kernel's part)."""
 
-    def __init__(self, table, partials, output, num_nodes, embedding_dim, accumulate):
-        self.table, self.partials, self.output = table, partials, output
+    def __init__(self, table, partials, output, num_nodes, embedding_dim, accumulate, row_map=None):
+        self.table, self.partials, self.output, self.row_map = table, partials, output, row_map
         self.num_nodes, self.embedding_dim, self.accumulate = num_nodes, embedding_dim, accumulate
 
     def run(self, stream=None):
@@ -185,12 +188,13 @@ class PendingCombine:
 
         stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
         rc = capi.launch_combine_partials(self.table, self.partials.data_ptr(), self.output.data_ptr(), self.num_nodes,
-                                          self.embedding_dim, self.accumulate, stream)
+                                          self.embedding_dim, self.accumulate, stream,
+                                          self.row_map.data_ptr() if self.row_map is not None else 0)
         capi.check(rc, "voltrix_launch_combine_partials")
 
 
 def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, output, out_scale=None,
-                atomic_out=False, beside_panel=False, defer_combine=False):
+                atomic_out=False, beside_panel=False, defer_combine=False, row_map=None):
     """Extensions over the reference wrapper (all default to its behaviour):
     ``out_scale``      float32 device tensor whose first element multiplies every output element (the power-of-two
                        written by ``capi.launch_cast_f32_f16_scaled``); default 1.
@@ -199,6 +203,8 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
     ``beside_panel``   the launch runs beside a panel-kernel workgroup: only tiles that leave it room on the CU.
     ``defer_combine``  with a unit-table schedule, do not sum the cut windows' partial tiles now: return a
                        ``PendingCombine`` (or None when nothing is pending) for the caller to ``run()`` later.
+    ``row_map``        int32 [16 W] device tensor: row i of the handle is row ``row_map[i]`` of ``output`` (-1 = padding);
+                       handles of a row-permuted CSR (voltrix/reorder.py) write the product through it.
     """
     assert blk_offsets.is_cuda and blk_offsets.dtype == torch.int32
     assert hspa_packed.is_cuda and hspa_packed.dtype == torch.uint32
@@ -212,6 +218,8 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
     if out_scale is None:
         out_scale = unit_scale(input.device)
     assert out_scale.is_cuda and out_scale.dtype == torch.float32 and out_scale.numel() >= 1
+    if row_map is not None:
+        assert row_map.is_cuda and row_map.dtype == torch.int32 and row_map.numel() == 16 * ((num_nodes + 15) // 16)
 
     space = tile_space(embedding_dim, elem_bytes, input.dtype == torch.bfloat16,
                        TWO_LEVEL_LDS_BUDGET if beside_panel else None)
@@ -229,7 +237,8 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
         return (blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, out,
                 window_order(blk_offsets, hspa_packed, num_nodes, 1), window_order(blk_offsets, hspa_packed, num_nodes, 2),
                 window_order(blk_offsets, hspa_packed, num_nodes, 3), out_scale, int(bool(atomic_out)), units, unit_ptr,
-                max_units, cuts, num_cuts, partials, int(not defer_combine), torch.cuda.current_stream())
+                max_units, cuts, num_cuts, partials, int(not defer_combine),
+                row_map if row_map is not None else blk_offsets, int(row_map is not None), torch.cuda.current_stream())
 
     args = make_args(output)
     keys = {
@@ -257,5 +266,5 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
     assert rc == 0, f"spmm_kernel failed with return code {rc}"
     if (defer_combine and table is not None and table.num_cuts > 0
             and jit_tuner.tuned_point("spmm_kernel", keys).get("SCHED") == SCHED_UNITS):
-        return PendingCombine(table, partials, output, num_nodes, embedding_dim, bool(atomic_out))
+        return PendingCombine(table, partials, output, num_nodes, embedding_dim, bool(atomic_out), row_map)
     return None

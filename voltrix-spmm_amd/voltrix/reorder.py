@@ -1,4 +1,15 @@
-"""Locality reorder of a graph before ``csr_preprocess`` (the "reorder" half).
+"""Locality reorder of a graph (the "reorder" half).
+
+Two layers.  (1) Host utilities from round 1 (scipy RCM, symmetric permutation ``P A P^T``; the caller permutes B and
+un-permutes C).  (2) Round 2, the product form: ``csr_preprocess_reordered`` / ``spmm_reordered`` -- everything on the GPU
+and carried by the handle.  Only the ROWS of A are regrouped (which 16 rows share a window decides the TC-block fill;
+column ids are not relabelled), so B is gathered as the caller has it, and the SpMM writes row i of the handle to row
+``row_map[i]`` of C through the kernel's epilogue: no permute pass before, no un-permute pass after.  The row order comes
+from a level-synchronous breadth-first search of the symmetrised pattern on the device (Cuthill-McKee levels from a
+pseudo-peripheral start, torch tensor ops -- plumbing), from the degrees, or from the caller.
+
+--- round 1 docstring ---
+Locality reorder of a graph before ``csr_preprocess``.
 
 The reference has no reordering code: its benchmark reads externally reordered ``<name>.reorder.npz`` files
 (bench/graph_gen.py:42-45, bench/bench_all.py:120-129).  A symmetric permutation ``P A P^T`` that pulls the non-zeros
@@ -63,3 +74,172 @@ def bandwidth(indptr, indices, num_nodes: int) -> int:
     indptr = np.asarray(indptr, dtype=np.int64)
     rows = np.repeat(np.arange(num_nodes, dtype=np.int64), np.diff(indptr)[:num_nodes])
     return int(np.abs(rows - np.asarray(indices, dtype=np.int64)).max()) if rows.size else 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 2: reorder on the GPU, permutation carried by the handle (no reference counterpart: the reference reads
+# externally reordered <name>.reorder.npz files, bench/graph_gen.py:42-45).
+import dataclasses  # noqa: E402
+
+
+def _symmetrised(indptr: torch.Tensor, indices: torch.Tensor, n: int, num_cols: int):
+    """CSR of the pattern of A + A^T restricted to the first min(n, num_cols) ids (square part), on the input's device."""
+    dev = indptr.device
+    deg = (indptr[1:] - indptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), deg)
+    cols = indices.long()
+    keep = cols < n
+    rows, cols = rows[keep], cols[keep]
+    key = torch.unique(torch.cat([rows * n + cols, cols * n + rows]))
+    su = torch.div(key, n, rounding_mode="floor")
+    sv = key - su * n
+    sptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    sptr[1:] = torch.cumsum(torch.bincount(su, minlength=n), 0)
+    return sptr, sv
+
+
+def _bfs_levels(sptr, sv, start: int, level, rank, next_rank: int, d0: int):
+    """Level-synchronous BFS from ``start`` over the unvisited part; fills ``level`` and ``rank`` (Cuthill-McKee order:
+    level by level, inside a level by the rank of the earliest-ranked parent, then by degree).  Returns
+    (next_rank, last frontier)."""
+    dev = sptr.device
+    sdeg = sptr[1:] - sptr[:-1]
+    frontier = torch.tensor([start], device=dev, dtype=torch.int64)
+    level[start] = d0
+    rank[start] = next_rank
+    next_rank += 1
+    d = d0
+    last = frontier
+    while frontier.numel():
+        counts = sdeg[frontier]
+        total = int(counts.sum())
+        if total == 0:
+            break
+        base = torch.repeat_interleave(sptr[frontier] - (torch.cumsum(counts, 0) - counts), counts)
+        nb = sv[base + torch.arange(total, device=dev)]
+        parent_rank = torch.repeat_interleave(rank[frontier], counts)
+        fresh = level[nb] < 0
+        nb, parent_rank = nb[fresh], parent_rank[fresh]
+        if nb.numel() == 0:
+            break
+        uniq, inv = torch.unique(nb, return_inverse=True)
+        best_parent = torch.full((uniq.numel(),), 1 << 62, dtype=torch.int64, device=dev)
+        best_parent.scatter_reduce_(0, inv, parent_rank, reduce="amin")
+        order = torch.argsort(best_parent * (int(sdeg.max()) + 1) + sdeg[uniq], stable=True)
+        uniq = uniq[order]
+        d += 1
+        level[uniq] = d
+        rank[uniq] = next_rank + torch.arange(uniq.numel(), device=dev)
+        next_rank += int(uniq.numel())
+        last = frontier = uniq
+    return next_rank, last
+
+
+def bfs_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
+                    max_components: int = 64) -> torch.Tensor:
+    """Cuthill-McKee-style row order on the device: int64 [N], position k holds row ``perm[k]``.  Breadth-first levels
+    of the symmetrised pattern from a pseudo-peripheral start (two sweeps), component by component (the largest
+    ``max_components`` ones; what is left -- isolated rows, tiny components -- follows by degree).  Rows that are close
+    in the graph end up in the same 16-row windows and share gathered columns."""
+    n = num_nodes
+    dev = indptr.device
+    num_cols = n if num_cols is None else num_cols
+    sptr, sv = _symmetrised(indptr, indices, n, num_cols)
+    sdeg = sptr[1:] - sptr[:-1]
+    level = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    rank = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    next_rank = 0
+    big = int(sdeg.max()) + 1 if n else 1
+    for _ in range(max_components):
+        cand = torch.where((level < 0) & (sdeg > 0), sdeg, torch.full_like(sdeg, big))
+        start = int(torch.argmin(cand))
+        if n == 0 or int(cand[start]) >= big:
+            break
+        # pseudo-peripheral start: BFS once, restart from a min-degree node of the last level
+        probe_level = level.clone()
+        probe_rank = rank.clone()
+        _, last = _bfs_levels(sptr, sv, start, probe_level, probe_rank, next_rank, 0)
+        start = int(last[torch.argmin(sdeg[last])])
+        next_rank, _ = _bfs_levels(sptr, sv, start, level, rank, next_rank, 0)
+    rest = torch.nonzero(rank < 0).flatten()
+    if rest.numel():
+        rest = rest[torch.argsort(-sdeg[rest], stable=True)]
+        rank[rest] = next_rank + torch.arange(rest.numel(), device=dev)
+    perm = torch.empty(n, dtype=torch.int64, device=dev)
+    perm[rank] = torch.arange(n, device=dev)
+    return perm
+
+
+def degree_permutation_device(indptr: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    """Rows by descending degree (stable), on the input's device: equal-length windows, no locality."""
+    deg = (indptr[1:] - indptr[:-1]).long()
+    return torch.argsort(-deg, stable=True)
+
+
+def permute_rows_csr(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, perm: torch.Tensor):
+    """CSR of ``A[perm, :]`` (rows regrouped, column ids untouched), int32, on the input's device."""
+    dev = indptr.device
+    deg = (indptr[1:] - indptr[:-1]).long()
+    pdeg = deg[perm]
+    new_indptr = torch.zeros(num_nodes + 1, dtype=torch.int64, device=dev)
+    new_indptr[1:] = torch.cumsum(pdeg, 0)
+    shift = torch.repeat_interleave(indptr[:-1].long()[perm] - new_indptr[:-1], pdeg)
+    new_indices = indices[shift + torch.arange(int(new_indptr[-1]), device=dev)]
+    return new_indptr.to(torch.int32), new_indices.contiguous()
+
+
+@dataclasses.dataclass(eq=False)
+class ReorderedHandle:
+    """Reference-format handle of ``A[perm, :]`` + the map that sends its rows back: not a tuple, because the three
+    tensors alone describe the row-permuted matrix."""
+    blk_offsets: torch.Tensor
+    hspa_packed: torch.Tensor
+    hind: torch.Tensor
+    row_map: torch.Tensor        # int32 [16 W]: handle row -> row of C, -1 for the padding rows of the last window
+    perm: torch.Tensor           # int64 [N]
+    num_nodes: int
+    num_edges: int
+    method: str
+
+
+def csr_preprocess_reordered(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
+                             method="bfs") -> ReorderedHandle:
+    """CSR (CPU or CUDA int32) -> handle of the row-reordered matrix for ``spmm_reordered``.  ``method``: "bfs"
+    (Cuthill-McKee levels, default), "degree", or an explicit permutation tensor (position k holds row perm[k])."""
+    from .jit_kernels import csr_fused_preprocess_kernel
+
+    assert indptr.dtype == torch.int32 and indices.dtype == torch.int32 and indptr.numel() == num_nodes + 1
+    indptr_d, indices_d = indptr.contiguous().cuda(), indices.contiguous().cuda()
+    if isinstance(method, torch.Tensor):
+        perm, name = method.to(indptr_d.device, torch.int64), "given"
+        assert perm.numel() == num_nodes and int(torch.sort(perm).values.ne(torch.arange(num_nodes, device=perm.device)).sum()) == 0
+    elif method == "bfs":
+        perm, name = bfs_permutation(indptr_d, indices_d, num_nodes, num_cols), "bfs"
+    elif method == "degree":
+        perm, name = degree_permutation_device(indptr_d, num_nodes), "degree"
+    else:
+        raise ValueError(f"unknown reorder method {method!r}")
+    p_indptr, p_indices = permute_rows_csr(indptr_d, indices_d, num_nodes, perm)
+    pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(p_indptr, p_indices, num_nodes, num_cols)
+    padded = 16 * ((num_nodes + 15) // 16)
+    row_map = torch.full((padded,), -1, dtype=torch.int32, device=indptr_d.device)
+    row_map[:num_nodes] = perm.to(torch.int32)
+    return ReorderedHandle(pointer1, hspa_packed, hind, row_map, perm, num_nodes, int(indices.numel()), name)
+
+
+def spmm_reordered(handle: ReorderedHandle, feat: torch.Tensor, hash_tag: str = None) -> torch.Tensor:
+    """``csr(ones) @ feat`` in the ORIGINAL row order for a ``ReorderedHandle``: float32 [num_nodes, F] on the current
+    stream; ``feat`` as for ``voltrix.spmm`` (it is gathered as it is: column ids were never relabelled)."""
+    from .jit_kernels import spmm_kernel
+    from .spmm.spmm import _operand
+
+    assert isinstance(handle, ReorderedHandle)
+    if hash_tag is not None and getattr(handle.hspa_packed, "hash_tag", None) is None:
+        handle.hspa_packed.hash_tag = hash_tag
+    num_feats = feat.shape[1]
+    operand, out_scale, padded, _ = _operand(feat)
+    output = torch.empty((handle.num_nodes, padded), dtype=torch.float32, device=feat.device)
+    spmm_kernel(handle.blk_offsets, handle.hspa_packed, handle.hind, num_nodes=handle.num_nodes,
+                num_edges=handle.num_edges, embedding_dim=padded, input=operand, output=output, out_scale=out_scale,
+                row_map=handle.row_map)
+    return output if padded == num_feats else output[:, :num_feats].contiguous()

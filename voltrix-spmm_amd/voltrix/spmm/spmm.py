@@ -161,14 +161,55 @@ def spmm(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tenso
     num_feats = feat.shape[1]
     operand, out_scale, padded, exact = _operand(feat)
     output = torch.empty((num_nodes, padded), dtype=torch.float32, device=feat.device)
-    hint = getattr(hspa_packed, "_voltrix_two_level", None)
-    if (hint is not None and not exact and hint[1] == hspa_packed.data_ptr() and hint[0].num_nodes == num_nodes
-            and hybrid.hybrid_mode() != "off"):
-        _run_two_level(hint[0], operand, output, out_scale, tag_source=hspa_packed)
-    else:
+    two = two_level_of(hspa_packed)
+    mode = hybrid.hybrid_mode()
+
+    def window():
         spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes=num_nodes, num_edges=num_edges, embedding_dim=padded,
                     input=operand, output=output, out_scale=out_scale)
+
+    def two_level():
+        _run_two_level(two, operand, output, out_scale, tag_source=hspa_packed)
+
+    if two is None or exact or two.num_nodes != num_nodes or mode == "off":
+        window()
+    elif mode == "on":
+        two_level()
+    else:   # auto: the side-car is a hint -- the first call for this (width, dtype) times both forms and keeps the faster
+        key = (padded, str(operand.dtype))
+        if key not in two.format_choice:
+            two.format_choice[key] = _choose_format(hspa_packed, key, window, two_level)
+        (two_level if two.format_choice[key] == "two-level" else window)()
     return output if padded == num_feats else output[:, :num_feats].contiguous()
+
+
+def _choose_format(hspa_packed, key, window, two_level) -> str:
+    """Time ``window()`` and ``two_level()`` (both write the caller's output: the last one run is the chosen one's, run
+    again by the caller) and return the faster form's name.  The choice is persisted next to the tile choices
+    (``tuned.json``) under the matrix tag, so that a later process skips the comparison."""
+    from ..jit_kernels import jit_tuner
+    from ..jit_kernels.spmm import feature_hash
+
+    signature = ("spmm_format", f"{{'dtype': '{key[1]}', 'embedding_dim': {key[0]}, 'feature_hash': '{feature_hash(hspa_packed)}'}}")
+    stored = jit_tuner._load_store().get(f"{signature[0]}|{signature[1]}")
+    if stored in ("two-level", "window") and hasattr(hspa_packed, "hash_tag"):
+        return stored
+    times = {}
+    for name, fn in (("window", window), ("two-level", two_level)):
+        fn()   # tile / schedule sweep of the first call
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        for _ in range(3):
+            fn()
+        end.record()
+        end.synchronize()
+        times[name] = start.elapsed_time(end)
+    best = min(times, key=times.get)
+    if os.getenv("VOLTRIX_PRINT_AUTO_TUNE") or os.getenv("VOLTRIX_JIT_DEBUG"):
+        print(f"voltrix.spmm format for width {key[0]} {key[1]}: {times} -> {best}")
+    if hasattr(hspa_packed, "hash_tag"):
+        jit_tuner._save_choice(signature, best)
+    return best
 
 
 def _run_two_level(two, operand, output, out_scale, tag_source=None):
