@@ -323,7 +323,7 @@ def main():
 
         keys = {"feature_hash": feature_hash(hspa_packed), "embedding_dim": num_feats,
                 "dtype": str(torch.float16 if is_f16 else torch.float32),
-                "device": torch.cuda.get_device_name(device), "two_level": bool(beside_panel)}
+                "device": torch.cuda.get_device_name(device), "two_level": bool(beside_panel), "weighted": False}
         if not is_f16 and os.getenv("VOLTRIX_FP32_MODE", "fp16") != "exact":
             keys["dtype"] = str(torch.float16)   # fp32 features run as scaled fp16
         return jit_tuner.tuned_point("spmm_kernel", keys)

@@ -52,7 +52,7 @@ def median_ms(fn, iters=7, warm=3, batch=5):
 
 def tuned_point(hspa_packed, f, beside_panel, dev):
     keys = {"feature_hash": feature_hash(hspa_packed), "embedding_dim": f, "dtype": str(torch.float16),
-            "device": torch.cuda.get_device_name(dev), "two_level": bool(beside_panel)}
+            "device": torch.cuda.get_device_name(dev), "two_level": bool(beside_panel), "weighted": False}
     return dict(jit_tuner.tuned_point("spmm_kernel", keys))
 
 

@@ -39,10 +39,11 @@ def test_tile_space_is_valid_and_bounded(monkeypatch):
                     assert p["EB"] == eb and p["FS"] in (32, 64, 128, 256) and p["SCHED"] in ((0, 1, 2, 3, 4) if eb == 2 else (0, 1, 2, 3))
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
     # the single default point = the ahead-of-time library's default tile + the unit-table schedule
-    assert spmm_mod.tile_space(128, 2) == ({"FS": 128, "DEPTH": 3, "WAVES": 4, "EB": 2, "SCHED": 4, "BF16": 0},)
-    assert spmm_mod.tile_space(128, 2, bf16=True) == ({"FS": 128, "DEPTH": 3, "WAVES": 4, "EB": 2, "SCHED": 4, "BF16": 1},)
-    assert spmm_mod.tile_space(64, 2) == ({"FS": 64, "DEPTH": 3, "WAVES": 4, "EB": 2, "SCHED": 4, "BF16": 0},)
-    assert spmm_mod.tile_space(16, 4) == ({"FS": 32, "DEPTH": 3, "WAVES": 1, "EB": 4, "SCHED": 2, "BF16": 0},)
+    assert spmm_mod.tile_space(128, 2) == ({"FS": 128, "DEPTH": 3, "WAVES": 4, "EB": 2, "SCHED": 4, "BF16": 0, "WEIGHTED": 0},)
+    assert spmm_mod.tile_space(128, 2, bf16=True) == ({"FS": 128, "DEPTH": 3, "WAVES": 4, "EB": 2, "SCHED": 4, "BF16": 1, "WEIGHTED": 0},)
+    assert spmm_mod.tile_space(64, 2) == ({"FS": 64, "DEPTH": 3, "WAVES": 4, "EB": 2, "SCHED": 4, "BF16": 0, "WEIGHTED": 0},)
+    assert spmm_mod.tile_space(128, 2, weighted=True) == ({"FS": 128, "DEPTH": 3, "WAVES": 4, "EB": 2, "SCHED": 4, "BF16": 0, "WEIGHTED": 1},)
+    assert spmm_mod.tile_space(16, 4) == ({"FS": 32, "DEPTH": 3, "WAVES": 1, "EB": 4, "SCHED": 2, "BF16": 0, "WEIGHTED": 0},)
 
 
 def test_feature_hash_uses_tag_then_address():

@@ -91,6 +91,11 @@ __device__ __forceinline__ uint2_t lds_read_b64(unsigned addr) {
   asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory");
   return v;
 }
+__device__ __forceinline__ uint4_t lds_read_b128(unsigned addr) {
+  uint4_t v;  // every component is consumed by the caller (a dead component of an asynchronous asm read is a hazard)
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
 template <int OFF>
 __device__ __forceinline__ uint2_t lds_read_tr16_b64(unsigned addr) {
   uint2_t v;  // EXEC must be all ones here (T10): every caller is wave-uniform control flow
@@ -185,6 +190,7 @@ struct SpmmArgs {
                                  // result goes to C; slot >= 0: to tile `slot` of `partials` (combine_partials_kernel)
   const int* unit_ptr;           // [9]: XCD x owns units [unit_ptr[x], unit_ptr[x + 1])
   float* partials;               // [num partial tiles][16][F] fp32 (units with slot >= 0)
+  const in_t* values;            // WEIGHTED tiles: [T][16][8] values of the operand's type (zeros where no edge); else unused
   const int* row_map;            // optional [16 W]: row i of the handle is row row_map[i] of C (-1: padding).  A handle built
                                  // from a row-permuted CSR (locality reorder, voltrix/reorder.py) writes C through it: no
                                  // un-permute pass.  Column ids are never relabelled, so B is gathered as it is.
@@ -284,6 +290,14 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
         src = a.hspa_packed + (4ll * blk + (mj & 3));
       }
       dma_b32(src, meta0 + mslot * T::META_BYTES);
+      if constexpr (T::WEIGHTED) {
+        // values of the stage's four TC blocks: lane 16 g + R fetches row R of block g (8 values = 16 bytes; the wave's
+        // 1 KiB is contiguous inside the window); blocks past the window's end re-read its last block and are zeroed below
+        int vblk = sb + (lane >> 4);
+        vblk = vblk < kb1 ? vblk : kb1 - 1;
+        dma_b128((const char*)a.values + ((long long)vblk * 128 + (lane & 15) * 8) * 2,
+                 meta0 + mslot * T::META_BYTES + 256);
+      }
     };
 
     // hv: lane L holds the (sanitised) row of B for condensed column L & 31 of the stage
@@ -397,8 +411,14 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
         }
       } else if constexpr (EB == 2) {
         // A: lane -> row R of TC block g; its 8 bits are nibble R&7 of words t = R>>3 (cols 0-3), 2 + R>>3 (cols 4-7)
-        const unsigned wlo = lds_read_b32(mt + 128 + 4 * (4 * g + (R >> 3)));
-        const unsigned whi = lds_read_b32(mt + 128 + 4 * (4 * g + 2 + (R >> 3)));
+        unsigned wlo = 0u, whi = 0u;
+        uint4_t avals = {0u, 0u, 0u, 0u};
+        if constexpr (T::WEIGHTED) {
+          avals = lds_read_b128(mt + 256 + 16 * lane);  // A[row R][8 g .. 8 g + 7] as stored: the MFMA A fragment
+        } else {
+          wlo = lds_read_b32(mt + 128 + 4 * (4 * g + (R >> 3)));
+          whi = lds_read_b32(mt + 128 + 4 * (4 * g + 2 + (R >> 3)));
+        }
         // B: lane 16g+4q+p supplies LDS row 8g+q (+4), bytes 8p.. of logical slot s; receives column R
         const int q = (lane >> 2) & 3, p = lane & 3;
         const int trow = 8 * g + q;
@@ -420,9 +440,16 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
           issue_data(dslot, hr);
         }
 
-        unsigned nl = (wlo >> a_shift) & 0xFu, nh = (whi >> a_shift) & 0xFu;
-        if (stage_block(t) + g >= kb1) nl = nh = 0u;  // TC blocks past the window's end contribute zero
-        const half8_t afrag = nibbles_to_half8_x2(nl, nh);
+        half8_t afrag;
+        if constexpr (T::WEIGHTED) {
+          uint4_t av = avals;
+          if (stage_block(t) + g >= kb1) av = uint4_t{0u, 0u, 0u, 0u};  // TC blocks past the window's end contribute zero
+          afrag = __builtin_bit_cast(half8_t, av);
+        } else {
+          unsigned nl = (wlo >> a_shift) & 0xFu, nh = (whi >> a_shift) & 0xFu;
+          if (stage_block(t) + g >= kb1) nl = nh = 0u;  // TC blocks past the window's end contribute zero
+          afrag = nibbles_to_half8_x2(nl, nh);
+        }
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
           const uint4_t bq = {blo[s][0], blo[s][1], bhi[s][0], bhi[s][1]};
@@ -506,7 +533,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
     return;
   }
   // powers of two: exact (barring overflow / underflow of the result itself)
-  const float oscale = (EB == 2 ? kAScaleInv : 1.0f) * (a.out_scale ? *a.out_scale : 1.0f);
+  const float oscale = ((EB == 2 && !T::WEIGHTED) ? kAScaleInv : 1.0f) * (a.out_scale ? *a.out_scale : 1.0f);
   const int ocol0 = fs0 + (lane & 15);
   if (slot >= 0) {  // a cut window's partial tile: [16][F] fp32, summed in unit order by combine_partials_kernel
     float* const tile = a.partials + (long long)slot * (kBlkH * (long long)F) + (long long)(4 * (lane >> 4)) * F;
@@ -555,7 +582,8 @@ inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed,
                             float* output, hipStream_t stream, const int* window_order = nullptr,
                             const float* out_scale = nullptr, int atomic_out = 0,
                             const int* units = nullptr /* int32[U][4] */, const int* unit_ptr = nullptr /* int32[9] */,
-                            int max_units_per_xcd = 0, float* partials = nullptr, const int* row_map = nullptr) {
+                            int max_units_per_xcd = 0, float* partials = nullptr, const int* row_map = nullptr,
+                            const void* values = nullptr /* WEIGHTED tiles: in_t[T][16][8] */) {
   if (num_nodes < 0 || embedding_dim < 0) return kErrBadShape;
   if (num_nodes == 0 || embedding_dim == 0) return kOk;
   if (embedding_dim % (16 / T::EB) != 0) return kErrBadShape;  // 16-byte row chunks
@@ -578,6 +606,8 @@ inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed,
   a.unit_ptr = unit_ptr;
   a.partials = partials;
   a.row_map = row_map;
+  a.values = static_cast<const typename SpmmArgs<T>::in_t*>(values);
+  if (T::WEIGHTED && (values == nullptr || ((uintptr_t)values & 15))) return kErrBadShape;
   if (units != nullptr) {
     if (unit_ptr == nullptr || max_units_per_xcd < 0 || ((uintptr_t)units & 15)) return kErrBadShape;
     if (max_units_per_xcd == 0) return kOk;

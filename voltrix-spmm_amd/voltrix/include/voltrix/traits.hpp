@@ -39,14 +39,19 @@ enum ReturnCode : int {
 //   EB     bytes per element of the dense operand in LDS: 2 (fp16, v_mfma_f32_16x16x32_f16) or
 //          4 (fp32, exact v_mfma_f32_16x16x4_f32)
 //   BF16   EB == 2 only: the 16-bit operand is bfloat16 (v_mfma_f32_16x16x32_bf16) instead of fp16
-template <int FS_, int DEPTH_, int WAVES_, int EB_ = 2, bool BF16_ = false>
+//   WEIGHTED  EB == 2 only: the A operand is a value plane (16 x 8 values of the operand's 16-bit type per TC block,
+//          row-major, zeros where there is no edge) instead of the expansion of the bitmaps -- weighted SpMM, no reference
+//          counterpart (the reference multiplies a binary A only, bmat_kernels.cuh:100-103)
+template <int FS_, int DEPTH_, int WAVES_, int EB_ = 2, bool BF16_ = false, bool WEIGHTED_ = false>
 struct SpmmTile {
   static constexpr int FS = FS_;
   static constexpr int DEPTH = DEPTH_;
   static constexpr int WAVES = WAVES_;
   static constexpr int EB = EB_;
   static constexpr bool BF16 = BF16_;
+  static constexpr bool WEIGHTED = WEIGHTED_;
   static_assert(!BF16 || EB == 2, "bfloat16 is a 2-byte operand");
+  static_assert(!WEIGHTED || EB == 2, "the value plane holds 16-bit values");
   static_assert(FS == 32 || FS == 64 || FS == 128 || FS == 256, "feature slab");
   static_assert(EB == 2 || EB == 4, "element bytes");
   static_assert(DEPTH >= 2 && DEPTH <= 6, "ring depth");
@@ -57,16 +62,20 @@ struct SpmmTile {
   static constexpr int LANES_PER_ROW = ROW_BYTES / 16;
   static constexpr int SLOTS = FS / 16;                           // 16-column slots (one MFMA N) per row
   static constexpr int META_SLOTS = 2 * DEPTH + 1;                // metadata ring (hind + bitmaps)
-  static constexpr int META_BYTES = 256;                          // 32 hind + 16 bitmap words + pad
+  // 32 hind + 16 bitmap words + pad; weighted: + the stage's 4 x 128 values (1 KiB, lane L's row of 8 at 256 + 16 L)
+  static constexpr int META_BYTES = WEIGHTED ? 256 + 1024 : 256;
+  static constexpr int META_DMAS = WEIGHTED ? 2 : 1;              // LDS-DMAs per metadata slot
   static constexpr int WAVE_LDS = DEPTH * STAGE_BYTES + META_SLOTS * META_BYTES;
   static constexpr int BLOCK_LDS = WAVES * WAVE_LDS;
   static constexpr int THREADS = WAVES * kWave;
-  // ops a wave issues per pipeline step: 1 metadata DMA + DMA_PER_STAGE row-gather DMAs
-  static constexpr int VM_PER_STEP = 1 + DMA_PER_STAGE;
+  // ops a wave issues per pipeline step: META_DMAS metadata DMAs + DMA_PER_STAGE row-gather DMAs
+  static constexpr int VM_PER_STEP = META_DMAS + DMA_PER_STAGE;
   static_assert(VM_PER_STEP * (DEPTH - 1) <= 63, "vmcnt is a 6-bit counter on gfx9");
   // s_waitcnt vmcnt immediate that retires the row stage being consumed while `k` younger row stages (k <= DEPTH-1)
   // and the DEPTH-1 metadata DMAs issued between them stay in flight
-  static constexpr int vm_behind(int k) { return (DEPTH - 1) + (k < DEPTH - 1 ? k : DEPTH - 1) * DMA_PER_STAGE; }
+  static constexpr int vm_behind(int k) {
+    return (DEPTH - 1) * META_DMAS + (k < DEPTH - 1 ? k : DEPTH - 1) * DMA_PER_STAGE;
+  }
   static_assert(BLOCK_LDS <= 160 * 1024, "LDS per CU");
 };
 

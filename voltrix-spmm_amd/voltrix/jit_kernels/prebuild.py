@@ -37,8 +37,15 @@ def jobs(feature_widths=(32, 64, 128), modes=("default", "none")):
                 os.environ.pop("VOLTRIX_TUNE_SPACE", None)
             else:
                 os.environ["VOLTRIX_TUNE_SPACE"] = saved
+            if eb == 2:   # weighted SpMM (voltrix/weighted.py): the default tile of every width; other points build on demand
+                os.environ["VOLTRIX_TUNE_SPACE"] = "none"
+                points += list(spmm.tile_space(width, eb, dtype == torch.bfloat16, weighted=True))
+                if saved is None:
+                    os.environ.pop("VOLTRIX_TUNE_SPACE", None)
+                else:
+                    os.environ["VOLTRIX_TUNE_SPACE"] = saved
             for point in points:
-                key = (eb, point["BF16"], point["FS"], point["DEPTH"], point["WAVES"], point["SCHED"])
+                key = (eb, point["BF16"], point["FS"], point["DEPTH"], point["WAVES"], point["SCHED"], point["WEIGHTED"])
                 if key in seen:
                     continue
                 seen.add(key)

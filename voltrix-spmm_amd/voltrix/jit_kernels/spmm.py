@@ -16,12 +16,13 @@ from .tuner import jit_tuner
 
 includes = ('"voltrix/spmm_kernels.hpp"',)
 template = """
-__return_code = voltrix::launch_spmm_tc16<voltrix::SpmmTile<{FS}, {DEPTH}, {WAVES}, {EB}, {BF16} != 0>>(
+__return_code = voltrix::launch_spmm_tc16<voltrix::SpmmTile<{FS}, {DEPTH}, {WAVES}, {EB}, {BF16} != 0, {WEIGHTED} != 0>>(
     blk_offsets, hspa_packed, hind,
     num_nodes, embedding_dim, input, output, stream,
     ({SCHED} == 0 || {SCHED} == 4) ? nullptr : ({SCHED} == 1 ? win_order_a : ({SCHED} == 2 ? win_order_b : win_order_c)),
     out_scale, atomic_out,
-    {SCHED} == 4 ? units : nullptr, unit_ptr, max_units_per_xcd, partials, has_row_map != 0 ? row_map : nullptr);
+    {SCHED} == 4 ? units : nullptr, unit_ptr, max_units_per_xcd, partials, has_row_map != 0 ? row_map : nullptr,
+    {WEIGHTED} != 0 ? (const void*)values : nullptr);
 if (__return_code == 0 && {SCHED} == 4 && combine_now != 0)
   __return_code = voltrix::combine_partials(cuts, num_cuts, partials, output, num_nodes, embedding_dim, atomic_out, stream,
                                             has_row_map != 0 ? row_map : nullptr);
@@ -50,8 +51,8 @@ def feature_hash(feature: torch.Tensor) -> str:
     return hash_to_hex(str(feature.data_ptr()))
 
 
-def _lds_bytes(fs, depth, waves, eb):
-    return waves * (depth * 32 * fs * eb + (2 * depth + 1) * 256)
+def _lds_bytes(fs, depth, waves, eb, weighted=False):
+    return waves * (depth * 32 * fs * eb + (2 * depth + 1) * (1280 if weighted else 256))
 
 
 # LDS a window-kernel workgroup may take when a panel-kernel workgroup (two-level format, 44 KB at FS = 128 / DEPTH 3)
@@ -59,12 +60,18 @@ def _lds_bytes(fs, depth, waves, eb):
 TWO_LEVEL_LDS_BUDGET = 160 * 1024 - 44 * 1024
 
 
-def tile_space(embedding_dim: int, elem_bytes: int, bf16: bool = False, max_lds: int = None):
+def tile_space(embedding_dim: int, elem_bytes: int, bf16: bool = False, max_lds: int = None, weighted: bool = False):
     """Points of the tile space worth trying for this feature width (``bf16``: the 2-byte operand is bfloat16;
-    ``max_lds``: keep only tiles whose workgroup fits that many bytes of LDS)."""
-    points = tuple(dict(point, BF16=int(bf16)) for point in _tile_space(embedding_dim, elem_bytes))
+    ``max_lds``: keep only tiles whose workgroup fits that many bytes of LDS; ``weighted``: the A operand is a value
+    plane, 1 KiB more per metadata slot)."""
+    points = tuple(dict(point, BF16=int(bf16), WEIGHTED=int(weighted)) for point in _tile_space(embedding_dim, elem_bytes))
+    if weighted:
+        assert elem_bytes == 2
+        points = tuple(p for p in points if _lds_bytes(p["FS"], p["DEPTH"], p["WAVES"], 2, True) <= 160 * 1024
+                       and (2 + 32 * p["FS"] * 2 // 1024) * (p["DEPTH"] - 1) <= 63)
     if max_lds is not None:
-        fit = tuple(p for p in points if _lds_bytes(p["FS"], p["DEPTH"], p["WAVES"], p["EB"]) <= max_lds and p["WAVES"] >= 4)
+        fit = tuple(p for p in points if _lds_bytes(p["FS"], p["DEPTH"], p["WAVES"], p["EB"], weighted) <= max_lds
+                    and p["WAVES"] >= 4)
         points = fit or points
     return points
 
@@ -143,6 +150,7 @@ def arg_defs_for(dtype):
         ("combine_now", int),
         ("row_map", torch.int32),
         ("has_row_map", int),
+        ("values", dtype),
         ("stream", torch.cuda.Stream),
     )
 
@@ -194,7 +202,7 @@ class PendingCombine:
 
 
 def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, output, out_scale=None,
-                atomic_out=False, beside_panel=False, defer_combine=False, row_map=None):
+                atomic_out=False, beside_panel=False, defer_combine=False, row_map=None, values=None):
     """Extensions over the reference wrapper (all default to its behaviour):
     ``out_scale``      float32 device tensor whose first element multiplies every output element (the power-of-two
                        written by ``capi.launch_cast_f32_f16_scaled``); default 1.
@@ -205,6 +213,8 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
                        ``PendingCombine`` (or None when nothing is pending) for the caller to ``run()`` later.
     ``row_map``        int32 [16 W] device tensor: row i of the handle is row ``row_map[i]`` of ``output`` (-1 = padding);
                        handles of a row-permuted CSR (voltrix/reorder.py) write the product through it.
+    ``values``         weighted SpMM (voltrix/weighted.py): the value plane [T, 16, 8] of ``input``'s 16-bit dtype that
+                       replaces the bitmaps as the A operand.
     """
     assert blk_offsets.is_cuda and blk_offsets.dtype == torch.int32
     assert hspa_packed.is_cuda and hspa_packed.dtype == torch.uint32
@@ -221,8 +231,11 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
     if row_map is not None:
         assert row_map.is_cuda and row_map.dtype == torch.int32 and row_map.numel() == 16 * ((num_nodes + 15) // 16)
 
+    if values is not None:
+        assert values.is_cuda and values.dtype == input.dtype and elem_bytes == 2 and values.is_contiguous()
+        assert values.numel() * 4 == hspa_packed.numel() * 128, "value plane: 128 values per TC block"
     space = tile_space(embedding_dim, elem_bytes, input.dtype == torch.bfloat16,
-                       TWO_LEVEL_LDS_BUDGET if beside_panel else None)
+                       TWO_LEVEL_LDS_BUDGET if beside_panel else None, weighted=values is not None)
     if any(p["SCHED"] == SCHED_UNITS for p in space):
         table = handle_unit_table(blk_offsets, hspa_packed, num_nodes)
         partials = torch.empty(max(1, table.num_slots) * 16 * embedding_dim, dtype=torch.float32, device=input.device)
@@ -238,7 +251,8 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
                 window_order(blk_offsets, hspa_packed, num_nodes, 1), window_order(blk_offsets, hspa_packed, num_nodes, 2),
                 window_order(blk_offsets, hspa_packed, num_nodes, 3), out_scale, int(bool(atomic_out)), units, unit_ptr,
                 max_units, cuts, num_cuts, partials, int(not defer_combine),
-                row_map if row_map is not None else blk_offsets, int(row_map is not None), torch.cuda.current_stream())
+                row_map if row_map is not None else blk_offsets, int(row_map is not None),
+                values if values is not None else input, torch.cuda.current_stream())
 
     args = make_args(output)
     keys = {
@@ -247,6 +261,7 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
         "dtype": str(input.dtype),
         "device": torch.cuda.get_device_name(input.device),
         "two_level": bool(beside_panel),
+        "weighted": values is not None,
     }
     # tuning runs must not add onto the caller's output: they get a scratch one (only built when a sweep will happen)
     tune_args = args
