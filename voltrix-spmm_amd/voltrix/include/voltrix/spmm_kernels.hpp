@@ -220,6 +220,12 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
     w_begin = a.unit_ptr[xcd];
     w_count = a.unit_ptr[xcd + 1] - w_begin;
   }
+  // Issue priority over whatever else shares the SIMD.  Beside a panel-kernel workgroup (two-level format) this wave is
+  // the YOUNGER one -- panel workgroups live 4-5 times longer -- and instruction issue is arbitrated by priority, then
+  // age: the panel's two issue-dense waves per SIMD took nearly every slot and this gather-bound wave, which only needs a
+  // few slots at the right time to keep its DMAs in flight, ran at half speed.  Measured on the reddit-like pair: 1.48 ->
+  // 1.34 ms, both kernels finishing together (profiles/r02/experiment_corun_diag_setprio.log).  Alone it changes nothing.
+  __builtin_amdgcn_s_setprio(3);
   const int lu = (int)(blockIdx.x / kNumXcd) * T::WAVES + wave;      // unit of this wave inside the XCD's range
   if (w_count <= 0 || lu >= w_count * a.num_slabs) return;           // wave-uniform; the kernel has no barriers (<= 2^30 units: launcher)
   const int wpos = w_begin + lu / a.num_slabs;

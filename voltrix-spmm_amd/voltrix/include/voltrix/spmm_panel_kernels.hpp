@@ -170,15 +170,20 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
       hr_off[d] = KS * 256 + 4 * r;
     }
     // metadata DMAs of k-step group s (clamped to the panel's last group: the pipeline issues a static number of DMAs)
-    const uint32_t* const bits_base = a.panel_bits + ((long long)ks0 * T::WAVES + wave) * kWave + lane;
-    const int* const cols_base = a.panel_cols + (long long)ks0 * kStageK + lane;
+    // wave-uniform bases (scalar registers); the lane offset is added at each DMA from an opaque copy of the lane id, so
+    // that no 64-bit per-lane pointer stays live across the k-step loop (4 VGPRs fewer: 179 of the 184 that fit beside a
+    // window-kernel workgroup)
+    const uint32_t* const bits_base = a.panel_bits + ((long long)ks0 * T::WAVES + wave) * kWave;
+    const int* const cols_base = a.panel_cols + (long long)ks0 * kStageK;
     auto issue_meta = [&](int s) {
       const int sc = s < ngroups ? s : ngroups - 1;
       const unsigned dst = meta0 + (unsigned)(s % MS) * T::META_BYTES;
+      int ml = lane;
+      asm volatile("" : "+v"(ml));
 #pragma unroll
       for (int k = 0; k < KS; ++k)
-        dma_b32(bits_base + (long long)(sc * KS + k) * (T::WAVES * kWave), dst + 256 * k);
-      dma_b32(cols_base + (long long)sc * (KS * kStageK), dst + 256 * KS);
+        dma_b32(bits_base + (long long)(sc * KS + k) * (T::WAVES * kWave) + ml, dst + 256 * k);
+      dma_b32(cols_base + (long long)sc * (KS * kStageK) + ml, dst + 256 * KS);
     };
     auto issue_rows = [&](int s) {
       const unsigned mslot = meta0 + (unsigned)(s % MS) * T::META_BYTES;
