@@ -15,7 +15,7 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 PKG = os.path.join(REPO, "voltrix-spmm_amd")
 sys.path[:0] = [REPO, PKG]
 os.environ.setdefault("VOLTRIX_CACHE_DIR", os.path.join(PKG, ".jit_cache"))
-VARIANTS = {"full": 0, "no_mfma": 1, "no_row_gathers": 2, "no_mfma_no_row_gathers": 3}
+VARIANTS = {"full": 0, "no_mfma": 1, "no_mfma_no_rows": 3, "only_loop_control": 31}
 
 
 def so(name):
@@ -107,7 +107,7 @@ def run():
             w_pairs.append((ws, we)); p_pairs.append((ps, pe)); tot.append((t0, t1))
         torch.cuda.synchronize()
         avg = lambda pairs: sum(a.elapsed_time(b) for a, b in pairs[2:]) / len(pairs[2:])   # noqa: E731
-        print(f"panel [{name:24s}] window setprio {'3' if prio == 3 else '-'} | panel alone {alone:.3f} ms | side by side: panel {avg(p_pairs):.3f}, window {avg(w_pairs):.3f}, "
+        print(f"panel [{name:24s}] panel alone {alone:.3f} ms | side by side: panel {avg(p_pairs):.3f}, window {avg(w_pairs):.3f}, "
               f"pair {avg(tot):.3f} ms", flush=True)
 
 

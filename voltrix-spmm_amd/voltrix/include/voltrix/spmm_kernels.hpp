@@ -108,6 +108,10 @@ __device__ __forceinline__ void dma_b128(const void* src, unsigned lds_byte_addr
 __device__ __forceinline__ void dma_b32(const void* src, unsigned lds_byte_addr) {
   __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(uintptr_t)lds_byte_addr, 4, 0, 0);
 }
+// non-temporal form (aux = 2) for streams that are read once (metadata): they should not push gathered rows of B out of L2
+__device__ __forceinline__ void dma_b32_nt(const void* src, unsigned lds_byte_addr) {
+  __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(uintptr_t)lds_byte_addr, 4, 0, 2);
+}
 
 // Slot swizzle: LDS row r keeps logical 32-byte slot s at physical slot s ^ slot_swizzle(r).  One transposed read
 // touches, per 32-lane half, rows {8g+q, 8g'+q : q<4} (+4 for the second read); this makes their 8 x 32 B land on
@@ -194,6 +198,9 @@ struct SpmmArgs {
   const int* row_map;            // optional [16 W]: row i of the handle is row row_map[i] of C (-1: padding).  A handle built
                                  // from a row-permuted CSR (locality reorder, voltrix/reorder.py) writes C through it: no
                                  // un-permute pass.  Column ids are never relabelled, so B is gathered as it is.
+  int slab_major;                // unit order inside an XCD's range when F spans several slabs (launcher, see slab_major_order)
+  int meta_nt;                   // 1: bitmap / hind DMAs are non-temporal (set by the launcher when one slab covers F, i.e.
+                                 // every metadata byte is read exactly once and should not displace rows of B in L2)
   int atomic_out;                // 1: C += result by float atomics (C pre-zeroed; two-level format: no join pass)
 };
 
@@ -210,9 +217,9 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
 
   // XCD x = blockIdx.x % 8 owns the contiguous window range [x * windows_per_xcd, ...) (blocks b, b+8, ... share an
-  // XCD: speed only, any placement is correct); its workgroups walk that range window by window, the slabs of a window
-  // side by side, so co-resident waves of one L2 gather overlapping row neighbourhoods and share the metadata.
-  // (Measured alternatives that lost: slab-major order, non-temporal loads for far rows -- DESIGN.md section 5.)
+  // XCD: speed only, any placement is correct); its workgroups walk that range window by window (the slabs of a window
+  // side by side, or slab by slab: slab_major_order below), so co-resident waves of one L2 gather overlapping row
+  // neighbourhoods.  (Measured alternative that lost: non-temporal loads for far rows -- DESIGN.md section 5.)
   const int xcd = blockIdx.x % kNumXcd;
   int w_begin = xcd * a.windows_per_xcd;
   int w_count = (a.num_windows - w_begin) < a.windows_per_xcd ? (a.num_windows - w_begin) : a.windows_per_xcd;
@@ -228,7 +235,9 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
   __builtin_amdgcn_s_setprio(3);
   const int lu = (int)(blockIdx.x / kNumXcd) * T::WAVES + wave;      // unit of this wave inside the XCD's range
   if (w_count <= 0 || lu >= w_count * a.num_slabs) return;           // wave-uniform; the kernel has no barriers (<= 2^30 units: launcher)
-  const int wpos = w_begin + lu / a.num_slabs;
+  // window-major (the slabs of a window side by side: shared metadata, overlapping row neighbourhoods) or slab-major (the
+  // whole range for slab 0, then slab 1, ...: one FS-wide column slab of B is the cache working set at a time)
+  const int wpos = w_begin + (a.slab_major ? lu % w_count : lu / a.num_slabs);
   int w, st0 = 0, st_step = 1, slot = -1;   // the unit runs stages st0, st0 + st_step, ... of window w
   if (a.units) {
     const int4 u = a.units[wpos];
@@ -239,7 +248,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
   } else {
     w = a.window_order ? a.window_order[wpos] : wpos;
   }
-  const int fs0 = (int)(lu % a.num_slabs) * FS;
+  const int fs0 = (int)(a.slab_major ? lu / w_count : lu % a.num_slabs) * FS;
 
   const int kb0 = a.blk_offsets[w];
   const int kb1 = a.blk_offsets[w + 1];
@@ -275,6 +284,20 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
     const int g = lane >> 4, R = lane & 15;  // MFMA lane group / row (A) or column (B, D)
     const unsigned a_shift = 4 * (R & 7);
     const int mj = (lane - 32) & 15;         // metadata DMA: lanes 32-63 fetch bitmap words (48-63 duplicate)
+    // transposed B reads (EB == 2): lane 16g+4q+p supplies LDS row 8g+q (+4), bytes 8p.. of logical slot s
+    unsigned tr_base = 0;
+    int tr_delta[4] = {0, 0, 0, 0};
+    if constexpr (EB == 2) {
+      const int trow = 8 * g + ((lane >> 2) & 3);
+      const int tr_z = slot_swizzle<SLOTS>(trow);
+      tr_base = lds0 + trow * ROW_BYTES + 8 * (lane & 3) + (tr_z << 5);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        tr_delta[b] = ((tr_z >> b) & 1) ? -(32 << b) : (32 << b);
+        asm volatile("" : "+v"(tr_delta[b]));   // keep the chain: no re-derivation from tr_z in the loop
+      }
+      asm volatile("" : "+v"(tr_base));
+    }
 
     // metadata of a stage that lies fully inside the window: lane address = base + tau * stride (one 64-bit mad);
     // lanes 0-31 fetch hind[8 * block + k32] (32 ints / stage), lanes 32-63 the 16 bitmap words of the stage
@@ -295,7 +318,10 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
         blk = blk < kb1 ? blk : kb1 - 1;
         src = a.hspa_packed + (4ll * blk + (mj & 3));
       }
-      dma_b32(src, meta0 + mslot * T::META_BYTES);
+      if (a.meta_nt)   // workgroup-uniform
+        dma_b32_nt(src, meta0 + mslot * T::META_BYTES);
+      else
+        dma_b32(src, meta0 + mslot * T::META_BYTES);
       if constexpr (T::WEIGHTED) {
         // values of the stage's four TC blocks: lane 16 g + R fetches row R of block g (8 values = 16 bytes; the wave's
         // 1 KiB is contiguous inside the window); blocks past the window's end re-read its last block and are zeroed below
@@ -399,12 +425,13 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
       uint2_t vw = {0u, 0u};
       int hr[NDMA];
       if (more) {
+        // the DMA rows' hind words are read unconditionally (a tail stage overwrites them below): a conditional read makes
+        // the compiler zero-fill hr[] every step (8 v_mov in the steady loop)
         const unsigned md = meta0 + mslot_d * T::META_BYTES;
+        read_rows(md, hr);
         if (tail_stage) {
           hraw = lds_read_b32(md + 4 * k32);
           vw = lds_read_b64(md + vword_off);
-        } else {
-          read_rows(md, hr);
         }
       }
 
@@ -426,16 +453,19 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
           whi = lds_read_b32(mt + 128 + 4 * (4 * g + 2 + (R >> 3)));
         }
         // B: lane 16g+4q+p supplies LDS row 8g+q (+4), bytes 8p.. of logical slot s; receives column R
-        const int q = (lane >> 2) & 3, p = lane & 3;
-        const int trow = 8 * g + q;
-        const unsigned dbase = lds0 + dslot * STAGE_BYTES + trow * ROW_BYTES + 8 * p;
-        const int tr_z = slot_swizzle<SLOTS>(trow);
+        // physical slot of logical slot s = s ^ tr_z: address(s) = address(0) +- 32, +- 64, ... per set bit of s, the sign
+        // being the lane's (tr_delta): SLOTS - 1 adds per stage instead of an xor + add per slot
+        unsigned taddr[SLOTS];
+        taddr[0] = tr_base + dslot * STAGE_BYTES;
+#pragma unroll
+        for (int b = 0; (1 << b) < SLOTS; ++b)
+#pragma unroll
+          for (int s = (1 << b); s < (2 << b) && s < SLOTS; ++s) taddr[s] = taddr[s - (1 << b)] + tr_delta[b];
         uint2_t blo[SLOTS], bhi[SLOTS];
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-          const unsigned addr = dbase + ((s ^ tr_z) << 5);
-          blo[s] = lds_read_tr16_b64<0>(addr);
-          bhi[s] = lds_read_tr16_b64<4 * ROW_BYTES>(addr);
+          blo[s] = lds_read_tr16_b64<0>(taddr[s]);
+          bhi[s] = lds_read_tr16_b64<4 * ROW_BYTES>(taddr[s]);
         }
         wait_lgkmcnt0();
 
@@ -580,6 +610,22 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
   }
 }
 
+// Unit order for F > FS (SpmmArgs::slab_major): slab-major as soon as a slab's piece of a row of B is a whole 128-byte
+// cache line.  One FS-wide column slab of B is then the working set of L2 / Infinity Cache at a time instead of all of
+// them (reddit-like F=512: 12.4 -> 9.2 ms for the window format, products-like F=512 FS=64: 17.5 -> 14.5 ms, reddit-like
+// F=128 FS=64: 2.53 -> 2.06 ms); with 64-byte pieces two neighbouring slabs share every line and window-major wins
+// (F=64 FS=32: 1.55 vs 2.30 ms) -- profiles/r02/experiment_slab_order.log.  The panel kernel's grid (slab = blockIdx.y)
+// is slab-major by construction, so the two kernels of the two-level format walk the slabs in step.
+// VOLTRIX_SLAB_ORDER=major|minor overrides the rule (experiments).
+inline int slab_major_order(int num_slabs, int slab_row_bytes) {
+  if (num_slabs <= 1) return 0;
+  if (const char* e = std::getenv("VOLTRIX_SLAB_ORDER")) {
+    if (e[0] == 'm' && e[1] == 'a') return 1;
+    if (e[0] == 'm' && e[1] == 'i') return 0;
+  }
+  return slab_row_bytes >= 128;
+}
+
 // ----------------------------------------------------------------------------------------------
 // Host launcher for one tile configuration.
 template <class T>
@@ -608,6 +654,8 @@ inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed,
   a.window_order = window_order;
   a.out_scale = out_scale;
   a.atomic_out = atomic_out;
+  a.meta_nt = a.num_slabs == 1;
+  a.slab_major = slab_major_order(a.num_slabs, T::FS * T::EB);
   a.units = reinterpret_cast<const int4*>(units);
   a.unit_ptr = unit_ptr;
   a.partials = partials;

@@ -40,8 +40,8 @@
 
 #include "voltrix/spmm_kernels.hpp"
 
-// Diagnostic builds only (harness/experiments/panel_diag.py): bit 0 skips the MFMAs, bit 1 the row DMAs, bit 2 the
-// barrier.  Results are wrong by design; shipped kernels use 0.
+// Diagnostic builds only (harness/experiments/panel_diag.py, exp_corun_diag.py): bit 0 skips the MFMAs, bit 1 the row DMAs,
+// bit 2 the barrier, bit 3 the fragment reads, bit 4 the metadata DMAs of the loop.  Results are wrong by design; shipped kernels use 0.
 #ifndef VOLTRIX_PANEL_DIAG
 #define VOLTRIX_PANEL_DIAG 0
 #endif
@@ -113,6 +113,7 @@ struct PanelArgs {
   int num_panels;
   int panels_per_xcd;
   int F;
+  int meta_nt;                 // 1: bitmap / column DMAs are non-temporal (launcher: one slab covers F, every byte read once)
   int accumulate;              // 0: C = A_shared * B;  1: C += A_shared * B (C holds the window kernel's part, read-add-store);
                                // 2: C += A_shared * B by float atomics (C pre-zeroed, the window kernel adds its part the
                                //    same way, in any order: two addends per element, so the sum does not depend on it)
@@ -125,7 +126,6 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
   constexpr int RPD = T::ROWS_PER_DMA, LPR = T::LANES_PER_ROW, SLOTS = T::SLOTS;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
 
   // XCD x = blockIdx.x % 8 owns a contiguous range of launch positions: neighbouring panels share most of their
@@ -137,6 +137,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
   const int panel = a.panel_order ? a.panel_order[pos] : pos;
   const int fs0 = blockIdx.y * FS;
   const int F = a.F;
+  const int lane = threadIdx.x & (kWave - 1);
 
   const int ks0 = a.panel_ptr[panel];
   const int nks = a.panel_ptr[panel + 1] - ks0;
@@ -175,19 +176,28 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
     // window-kernel workgroup)
     const uint32_t* const bits_base = a.panel_bits + ((long long)ks0 * T::WAVES + wave) * kWave;
     const int* const cols_base = a.panel_cols + (long long)ks0 * kStageK;
-    auto issue_meta = [&](int s) {
+    // ring positions are carried counters (ms = group % MS, ds = group % D), never a division: the k-step loop issued
+    // 66 scalar instructions per step when they were computed with %
+    auto issue_meta = [&](int s, int ms) {
       const int sc = s < ngroups ? s : ngroups - 1;
-      const unsigned dst = meta0 + (unsigned)(s % MS) * T::META_BYTES;
+      const unsigned dst = meta0 + (unsigned)ms * T::META_BYTES;
       int ml = lane;
       asm volatile("" : "+v"(ml));
+      if (a.meta_nt) {   // workgroup-uniform
 #pragma unroll
-      for (int k = 0; k < KS; ++k)
-        dma_b32(bits_base + (long long)(sc * KS + k) * (T::WAVES * kWave) + ml, dst + 256 * k);
-      dma_b32(cols_base + (long long)sc * (KS * kStageK) + ml, dst + 256 * KS);
+        for (int k = 0; k < KS; ++k)
+          dma_b32_nt(bits_base + (long long)(sc * KS + k) * (T::WAVES * kWave) + ml, dst + 256 * k);
+        dma_b32_nt(cols_base + (long long)sc * (KS * kStageK) + ml, dst + 256 * KS);
+      } else {
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+          dma_b32(bits_base + (long long)(sc * KS + k) * (T::WAVES * kWave) + ml, dst + 256 * k);
+        dma_b32(cols_base + (long long)sc * (KS * kStageK) + ml, dst + 256 * KS);
+      }
     };
-    auto issue_rows = [&](int s) {
-      const unsigned mslot = meta0 + (unsigned)(s % MS) * T::META_BYTES;
-      const unsigned dst = data0 + (unsigned)(s % D) * STAGE_BYTES + (unsigned)dma0 * 1024u;
+    auto issue_rows = [&](int ms, int ds) {
+      const unsigned mslot = meta0 + (unsigned)ms * T::META_BYTES;
+      const unsigned dst = data0 + (unsigned)ds * STAGE_BYTES + (unsigned)dma0 * 1024u;
       unsigned hrow[DPW];
 #pragma unroll
       for (int d = 0; d < DPW; ++d) hrow[d] = lds_read_b32(mslot + hr_off[d]);
@@ -199,21 +209,33 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
 
     // ---- prologue: metadata of groups 0 .. D-2, then the virtual steps -(D-1) .. -1 ------------------------------
 #pragma unroll
-    for (int s = 0; s < D - 1; ++s) issue_meta(s);
+    for (int s = 0; s < D - 1; ++s) issue_meta(s, s % MS);
     wait_vmcnt<0>();
 #pragma unroll
     for (int s = 0; s < D - 1; ++s) {
-      issue_rows(s);            // groups past the panel's end re-gather its last group (static DMA count)
-      issue_meta(s + D - 1);
+      issue_rows(s % MS, s % D);            // groups past the panel's end re-gather its last group (static DMA count)
+      issue_meta(s + D - 1, (s + D - 1) % MS);
     }
 
-    // MFMA lane roles (as in spmm_tc16_kernel): A row R of block g's 8 columns; B column R, rows 8g+q (+4)
+    // MFMA lane roles (as in spmm_tc16_kernel): A row R of block g's 8 columns; B column R, rows 8g+q (+4).  Physical
+    // slot of logical slot s = s ^ tr_z: address(s) = address(0) +- 32, +- 64, +- 128 per set bit of s, the sign being the
+    // lane's -- SLOTS - 1 adds per k-step instead of an xor + add per slot
     const int g = lane >> 4;
     const int q = (lane >> 2) & 3, p = lane & 3;
     const int trow = 8 * g + q;
-    const unsigned rd_off = trow * ROW_BYTES + 8 * p;
     const int tr_z = slot_swizzle<SLOTS>(trow);
+    unsigned rd_off = trow * ROW_BYTES + 8 * p + (tr_z << 5);
+    int tr_delta[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      tr_delta[b] = ((tr_z >> b) & 1) ? -(32 << b) : (32 << b);
+      asm volatile("" : "+v"(tr_delta[b]));
+    }
+    asm volatile("" : "+v"(rd_off));
 
+    int ds_t = 0, ms_t = 0;                              // group t
+    int ds_r = (D - 1) % D, ms_r = (D - 1) % MS;         // group t + D - 1 (rows issued this step)
+    int ms_m = (2 * D - 2) % MS;                         // group t + 2D - 2 (metadata issued this step)
     for (int t = 0; t < ngroups; ++t) {
       // rows of group t (issued D-1 steps ago) and the metadata of group t+D-1 must have landed; the D-2 younger
       // steps may stay in flight.  Steps past ngroups-D+1 issue nothing.
@@ -235,22 +257,37 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
       __builtin_amdgcn_sched_barrier(0);
 
       if (t + D - 1 < ngroups) {     // workgroup-uniform
-        issue_rows(t + D - 1);       // into the slot group t-1 has just left
-        issue_meta(t + 2 * D - 2);
+        issue_rows(ms_r, ds_r);      // into the slot group t-1 has just left
+        if (!(VOLTRIX_PANEL_DIAG & 16)) issue_meta(t + 2 * D - 2, ms_m);   // diagnostic bit 16: no metadata DMAs in the loop
       }
 
-      const unsigned mt = meta0 + (unsigned)(t % MS) * T::META_BYTES;
-      const unsigned dt = data0 + (unsigned)(t % D) * STAGE_BYTES + rd_off;
+      const unsigned mt = meta0 + (unsigned)ms_t * T::META_BYTES;
+      const unsigned dt = data0 + (unsigned)ds_t * STAGE_BYTES + rd_off;
+      ds_t = ds_t + 1 == D ? 0 : ds_t + 1;
+      ds_r = ds_r + 1 == D ? 0 : ds_r + 1;
+      ms_t = ms_t + 1 == MS ? 0 : ms_t + 1;
+      ms_r = ms_r + 1 == MS ? 0 : ms_r + 1;
+      ms_m = ms_m + 1 == MS ? 0 : ms_m + 1;
 #pragma unroll
       for (int k = 0; k < KS; ++k) {
         if (t * KS + k < nks) {      // workgroup-uniform
           const unsigned aw = lds_read_b32(mt + 256 * k + 4 * lane);
+          unsigned taddr[SLOTS];
+          taddr[0] = dt + k * T::KSTEP_BYTES;
+#pragma unroll
+          for (int b = 0; (1 << b) < SLOTS; ++b)
+#pragma unroll
+            for (int s = (1 << b); s < (2 << b) && s < SLOTS; ++s) taddr[s] = taddr[s - (1 << b)] + tr_delta[b];
           uint2_t blo[SLOTS], bhi[SLOTS];
 #pragma unroll
           for (int s = 0; s < SLOTS; ++s) {
-            const unsigned addr = dt + k * T::KSTEP_BYTES + ((s ^ tr_z) << 5);
-            blo[s] = lds_read_tr16_b64<0>(addr);
-            bhi[s] = lds_read_tr16_b64<4 * ROW_BYTES>(addr);
+            if (VOLTRIX_PANEL_DIAG & 8) {   // diagnostic: no fragment reads
+              blo[s] = uint2_t{taddr[s], 1u};
+              bhi[s] = uint2_t{taddr[s], 2u};
+              continue;
+            }
+            blo[s] = lds_read_tr16_b64<0>(taddr[s]);
+            bhi[s] = lds_read_tr16_b64<4 * ROW_BYTES>(taddr[s]);
           }
           wait_lgkmcnt0();
 #pragma unroll
@@ -341,6 +378,7 @@ inline int launch_spmm_panel(const int* panel_ptr, const int* panel_cols, const 
   a.F = embedding_dim;
   a.accumulate = accumulate;
   const int slabs = (embedding_dim + T::FS - 1) / T::FS;
+  a.meta_nt = slabs == 1;
   const int lds_rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&spmm_panel_kernel<T>), T::BLOCK_LDS);
   if (lds_rc != kOk) return lds_rc;
   hipLaunchKernelGGL(spmm_panel_kernel<T>, dim3((unsigned)(a.panels_per_xcd * kNumXcd), (unsigned)slabs),

@@ -70,8 +70,12 @@ def tile_space(embedding_dim: int, elem_bytes: int, bf16: bool = False, max_lds:
         points = tuple(p for p in points if _lds_bytes(p["FS"], p["DEPTH"], p["WAVES"], 2, True) <= 160 * 1024
                        and (2 + 32 * p["FS"] * 2 // 1024) * (p["DEPTH"] - 1) <= 63)
     if max_lds is not None:
+        # beside a panel workgroup: the panel tile's slab width only (the two kernels then walk the column slabs in step;
+        # the tuner times this kernel ALONE, where a half-width slab-major tile can look as good -- reddit-like F=128:
+        # FS=64 picked once, 1.61 ms for the pair against 1.38 ms with FS=128, profiles/r02/bench_fs64_beside_panel.json)
+        fs_top = max(p["FS"] for p in points)
         fit = tuple(p for p in points if _lds_bytes(p["FS"], p["DEPTH"], p["WAVES"], p["EB"], weighted) <= max_lds
-                    and p["WAVES"] >= 4)
+                    and p["WAVES"] >= 4 and p["FS"] == fs_top)
         points = fit or points
     return points
 
