@@ -23,13 +23,15 @@
 
 namespace voltrix {
 
-constexpr int kPlanThreads = 512;
+constexpr int kPlanThreads = 1024;               // 16 waves: the row loops are round-trip-bound, LDS allows one workgroup per CU anyway
 constexpr int kPlanWaves = kPlanThreads / kWave;
 constexpr int kPlanRange = 1 << 16;                 // columns per counter range
 constexpr int kPlanFlagWords = kPlanRange / 32;     // 2048
 constexpr int kPlanMaxPanelRows = 512;
 constexpr int kPlanMaxRanges = 64;                  // universes up to 2^22 columns
 constexpr int kPlanBatch = 8;                       // independent global loads in flight per thread
+constexpr int kPlanVecBatch = 8;                    // 16-byte loads in flight per thread in the panel's edge sweep
+constexpr int kPlanRowBatch = 8;                    // ... per lane in the per-row loops (8 x 64 edges of a row per round trip)
 
 struct PlanLds {
   unsigned counters[kPlanRange / 2];   // two 16-bit counters per word
@@ -46,16 +48,35 @@ __device__ __forceinline__ void plan_count_range(PlanLds& s, const int* __restri
                                                  const long long hi, const int c0) {
   for (int i = threadIdx.x; i < kPlanRange / 2; i += kPlanThreads) s.counters[i] = 0u;
   __syncthreads();
-  for (long long base = lo + threadIdx.x; base < hi; base += (long long)kPlanThreads * kPlanBatch) {
-    int c[kPlanBatch];
+  // the panel's edge list is one contiguous stream: scalar head up to the first 16-byte boundary, then 16 bytes per lane
+  // and load (kPlanVecBatch loads = 64 KiB per workgroup in flight; 4-byte loads left this pass latency-bound: 61 round
+  // trips for a 250 k-edge panel), scalar tail
+  auto bump = [&](const int c) {
+    if ((unsigned)c < (unsigned)kPlanRange) atomicAdd(&s.counters[c >> 1], 1u << (16 * (c & 1)));
+  };
+  const long long head_end = lo + ((4 - (int)(((uintptr_t)(indices + lo) & 15) >> 2)) & 3);
+  const long long vec_lo = head_end < hi ? head_end : hi;
+  const long long vec_hi = vec_lo + ((hi - vec_lo) & ~3ll);
+  for (long long e = lo + threadIdx.x; e < vec_lo; e += kPlanThreads) bump(indices[e] - c0);
+  for (long long e = vec_hi + threadIdx.x; e < hi; e += kPlanThreads) bump(indices[e] - c0);
+  const int4* const vec = reinterpret_cast<const int4*>(indices + vec_lo);
+  const long long nvec = (vec_hi - vec_lo) >> 2;
+  for (long long base = threadIdx.x; base < nvec; base += (long long)kPlanThreads * kPlanVecBatch) {
+    int4 c[kPlanVecBatch];
 #pragma unroll
-    for (int b = 0; b < kPlanBatch; ++b) {
-      const long long e = base + (long long)b * kPlanThreads;
-      c[b] = e < hi ? indices[e] - c0 : -1;
+    for (int b = 0; b < kPlanVecBatch; ++b) {
+      const long long i = base + (long long)b * kPlanThreads;
+      c[b] = i < nvec ? vec[i] : make_int4(-1, -1, -1, -1);
     }
 #pragma unroll
-    for (int b = 0; b < kPlanBatch; ++b)
-      if ((unsigned)c[b] < (unsigned)kPlanRange) atomicAdd(&s.counters[c[b] >> 1], 1u << (16 * (c[b] & 1)));
+    for (int b = 0; b < kPlanVecBatch; ++b) {
+      if (base + (long long)b * kPlanThreads < nvec) {
+        bump(c[b].x - c0);
+        bump(c[b].y - c0);
+        bump(c[b].z - c0);
+        bump(c[b].w - c0);
+      }
+    }
   }
   __syncthreads();
 }
@@ -100,21 +121,37 @@ static __global__ __launch_bounds__(kPlanThreads) void panel_plan_count_kernel(
 
   // residual edges per row: one wave per row; range 0 also checks the input (sorted, duplicate-free, ids in the universe)
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  for (int row = r0 + wave; row < r1; row += kPlanWaves) {
-    const long long a = indptr[row], b = indptr[row + 1];
+  // row bounds of this wave's rows (row r0 + wave + 16 i in lane i), one round trip for all of them
+  static_assert(kPlanMaxPanelRows <= kPlanWaves * kWave, "one lane per row of the wave");
+  const int my_row = r0 + wave + kPlanWaves * lane;
+  const int my_a = my_row < r1 ? indptr[my_row] : 0, my_b = my_row < r1 ? indptr[my_row + 1] : 0;
+  for (int row = r0 + wave, ri = 0; row < r1; row += kPlanWaves, ++ri) {
+    const long long a = __shfl(my_a, ri, kWave), b = __shfl(my_b, ri, kWave);
     int cnt = 0, bad = 0, prev_last = -1;
-    for (long long e0 = a; e0 < b; e0 += kWave) {
-      const long long e = e0 + lane;
-      const int c = e < b ? indices[e] : 0x7FFFFFFF;
-      if (rho == 0) {
-        int prev = __shfl_up(c, 1, kWave);
-        if (lane == 0) prev = prev_last;
-        bad += (e < b && (c <= prev || c < 0 || c >= num_cols)) ? 1 : 0;
-        prev_last = __shfl(c, kWave - 1, kWave);
+    // kPlanRowBatch x 64 edges of the row per round trip (one load per iteration left the wave waiting on memory for the
+    // whole row loop: 64 rows x 8 iterations x ~1.5 us per workgroup and range)
+    for (long long e0 = a; e0 < b; e0 += kWave * kPlanRowBatch) {
+      int cs[kPlanRowBatch];
+#pragma unroll
+      for (int k = 0; k < kPlanRowBatch; ++k) {
+        const long long e = e0 + k * kWave + lane;
+        cs[k] = e < b ? indices[e] : 0x7FFFFFFF;
       }
-      const int cr = c - c0;
-      const bool resid = e < b && (unsigned)cr < (unsigned)kPlanRange && plan_counter(s, cr) < tau;
-      cnt += __popcll(__ballot(resid));
+#pragma unroll
+      for (int k = 0; k < kPlanRowBatch; ++k) {
+        if (e0 + k * kWave >= b) break;  // wave-uniform
+        const long long e = e0 + k * kWave + lane;
+        const int c = cs[k];
+        if (rho == 0) {
+          int prev = __shfl_up(c, 1, kWave);
+          if (lane == 0) prev = prev_last;
+          bad += (e < b && (c <= prev || c < 0 || c >= num_cols)) ? 1 : 0;
+          prev_last = __shfl(c, kWave - 1, kWave);
+        }
+        const int cr = c - c0;
+        const bool resid = e < b && (unsigned)cr < (unsigned)kPlanRange && plan_counter(s, cr) < tau;
+        cnt += __popcll(__ballot(resid));
+      }
     }
     if (lane == 0 && cnt) atomicAdd(&resid_count[row], cnt);
     if (rho == 0) {
@@ -167,6 +204,9 @@ static __global__ __launch_bounds__(kPlanThreads) void panel_plan_fill_kernel(
   for (int i = threadIdx.x; i < r1 - r0; i += kPlanThreads) s.rpos[i] = resid_indptr[r0 + i];
   if (threadIdx.x == 0) s.first_col = 0;
   int rank_base = 0;  // shared columns of the panel in the ranges before this one (workgroup-uniform)
+  // row bounds of this wave's rows (row r0 + wave + 16 i in lane i), loaded once for all ranges
+  const int my_row = r0 + wave + kPlanWaves * lane;
+  const int my_a = my_row < r1 ? indptr[my_row] : 0, my_b = my_row < r1 ? indptr[my_row + 1] : 0;
 
   for (int rho = 0; rho < nranges; ++rho) {
     const int c0 = rho * kPlanRange;
@@ -220,27 +260,37 @@ static __global__ __launch_bounds__(kPlanThreads) void panel_plan_fill_kernel(
     __syncthreads();
 
     // rows: residual edges keep their order in the residual CSR, shared edges become adjacency bits
-    for (int row = r0 + wave; row < r1; row += kPlanWaves) {
+    for (int row = r0 + wave, ri = 0; row < r1; row += kPlanWaves, ++ri) {
       const int rp = row - r0;
       const int v = rp / (16 * row_blocks), j = (rp % (16 * row_blocks)) / 16, r16 = rp % 16;
-      const long long a = indptr[row], b = indptr[row + 1];
+      const long long a = __shfl(my_a, ri, kWave), b = __shfl(my_b, ri, kWave);
       int pos = s.rpos[rp];
-      for (long long e0 = a; e0 < b; e0 += kWave) {
-        const long long e = e0 + lane;
-        const int c = e < b ? indices[e] : 0x7FFFFFFF;
-        const int cr = c - c0;
-        const bool in_range = e < b && (unsigned)cr < (unsigned)kPlanRange;
-        const bool shared = in_range && ((s.flags[cr >> 5] >> (cr & 31)) & 1u);
-        const bool resid = in_range && !shared;
-        const unsigned long long rmask = __ballot(resid);
-        if (resid) resid_indices[pos + __popcll(rmask & ((1ull << lane) - 1ull))] = c;
-        pos += __popcll(rmask);
-        if (shared) {
-          const int rank = rank_base + s.prefix[cr >> 5] + __popc(s.flags[cr >> 5] & ((1u << (cr & 31)) - 1u));
-          const long long ks = ks0 + (rank >> 5);
-          const int k = rank & 31;
-          atomicOr(&panel_bits[(ks * waves + v) * kWave + (k >> 3) * 16 + r16],
-                   1u << (16 * (k & 1) + 4 * j + ((k & 7) >> 1)));
+      for (long long e0 = a; e0 < b; e0 += kWave * kPlanRowBatch) {   // batched as in the count kernel
+        int cs[kPlanRowBatch];
+#pragma unroll
+        for (int q = 0; q < kPlanRowBatch; ++q) {
+          const long long e = e0 + q * kWave + lane;
+          cs[q] = e < b ? indices[e] : 0x7FFFFFFF;
+        }
+#pragma unroll
+        for (int q = 0; q < kPlanRowBatch; ++q) {
+          if (e0 + q * kWave >= b) break;  // wave-uniform
+          const long long e = e0 + q * kWave + lane;
+          const int c = cs[q];
+          const int cr = c - c0;
+          const bool in_range = e < b && (unsigned)cr < (unsigned)kPlanRange;
+          const bool shared = in_range && ((s.flags[cr >> 5] >> (cr & 31)) & 1u);
+          const bool resid = in_range && !shared;
+          const unsigned long long rmask = __ballot(resid);
+          if (resid) resid_indices[pos + __popcll(rmask & ((1ull << lane) - 1ull))] = c;
+          pos += __popcll(rmask);
+          if (shared) {
+            const int rank = rank_base + s.prefix[cr >> 5] + __popc(s.flags[cr >> 5] & ((1u << (cr & 31)) - 1u));
+            const long long ks = ks0 + (rank >> 5);
+            const int k = rank & 31;
+            atomicOr(&panel_bits[(ks * waves + v) * kWave + (k >> 3) * 16 + r16],
+                     1u << (16 * (k & 1) + 4 * j + ((k & 7) >> 1)));
+          }
         }
       }
       if (lane == 0) s.rpos[rp] = pos;

@@ -54,9 +54,20 @@ def jobs(feature_widths=(32, 64, 128), modes=("default", "none")):
     return out
 
 
-def prebuild(feature_widths=(32, 64, 128), workers=None) -> int:
+def prebuild(feature_widths=(32, 64, 128), workers=None, prune=False) -> int:
+    """``prune``: afterwards remove every other ``kernel.*`` directory of the cache (entries of older header versions --
+    the cache key hashes the include tree -- which would only travel to the GPU box as dead weight)."""
     todo = jobs(feature_widths)
     workers = workers or max(1, min(len(todo), os.cpu_count() or 1))
     with ThreadPoolExecutor(max_workers=workers) as pool:
-        list(pool.map(lambda j: build(*j), todo))
+        runtimes = list(pool.map(lambda j: build(*j), todo))
+    if prune and runtimes:
+        import shutil
+
+        keep = {os.path.realpath(r.path) for r in runtimes}
+        root = os.path.dirname(next(iter(keep)))
+        for entry in os.listdir(root):
+            full = os.path.realpath(os.path.join(root, entry))
+            if entry.startswith("kernel.") and os.path.isdir(full) and full not in keep:
+                shutil.rmtree(full, ignore_errors=True)
     return len(todo)
