@@ -248,10 +248,11 @@ void voltrix_launch_cast_f32_f16_scaled(void* src, void* dst, int64_t count, voi
  * num_cols = the column universe: every id in edge_list lies in [0, num_cols) (square adjacency: num_nodes; a row shard
  * whose ids index a gathered B: the rows of that buffer).  num_cols <= 0 = unknown.  The condensed-column ranks come
  * from an LDS bitmap + popcounts when the universe fits LDS (num_cols <= 2^19) and is small next to a window's edge
- * list, otherwise from a per-window sort (needs the 4-byte-per-edge key workspace); VOLTRIX_CSR_PATH=sort|bitmap in
- * the environment overrides the choice.  status[0] = number of edges with an id outside [0, num_cols) (outside
+ * list, otherwise from a per-window sort (needs the 4-byte-per-edge key workspace); universes of 2 .. 16 bitmap ranges
+ * (up to 2^23 columns) sort the windows up to 8192 edges and send only the bigger ones through the bitmap kernels, one
+ * sweep per range ("mixed"); VOLTRIX_CSR_PATH=sort|bitmap|mixed in the environment overrides the choice.  status[0] = number of edges with an id outside [0, num_cols) (outside
  * [0, 2^28) when num_cols <= 0): the handle is valid only if it is 0 (callers retry with num_cols = 0 or reject).
- * Output is bit-identical to preprocess + hmat_gen + hmat_packed_swizzle on both paths. */
+ * Output is bit-identical to preprocess + hmat_gen + hmat_packed_swizzle on every path. */
 int64_t voltrix_csr_preprocess_workspace_bytes(int num_nodes, int num_cols, int64_t num_edges);
 void voltrix_launch_csr_window_count(void* node_pointer, void* edge_list, int num_nodes, int num_cols, int64_t num_edges,
                                      void* workspace, void* block_partition, void* pointer1, void* status, void* stream,

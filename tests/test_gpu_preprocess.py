@@ -51,14 +51,15 @@ def _check(handle, indptr, indices, n):
     assert np.array_equal(packed.cpu().numpy(), opacked)
 
 
-ROUTES = ["fused-sort", "fused-bitmap", "fused-auto", "reference"]
+ROUTES = ["fused-sort", "fused-bitmap", "fused-mixed", "fused-auto", "reference"]
 
 
 def _set_route(monkeypatch, route):
-    """fused-sort / fused-bitmap force one of the two rank algorithms of the fused preprocess (VOLTRIX_CSR_PATH)."""
+    """fused-sort / fused-bitmap / fused-mixed force one of the rank algorithms of the fused preprocess
+    (VOLTRIX_CSR_PATH; mixed = windows up to 8192 edges sorted, bigger ones through the bitmap kernels)."""
     monkeypatch.setenv("VOLTRIX_PREPROCESS", route.split("-")[0])
     monkeypatch.delenv("VOLTRIX_CSR_PATH", raising=False)
-    if route in ("fused-sort", "fused-bitmap"):
+    if route in ("fused-sort", "fused-bitmap", "fused-mixed"):
         monkeypatch.setenv("VOLTRIX_CSR_PATH", route.split("-")[1])
 
 
@@ -83,7 +84,7 @@ def test_edge_cases_bit_exact(cuda_device, name, route, monkeypatch):
     _check(handle, indptr, indices, n)
 
 
-@pytest.mark.parametrize("path", ["sort", "bitmap"])
+@pytest.mark.parametrize("path", ["sort", "bitmap", "mixed"])
 def test_non_square_universe_and_unstaged_window(cuda_device, path, monkeypatch):
     """96 rows x 12000 columns: with the universe declared, the bitmap path takes its global-atomics branch for the
     1125-block window; without it (default universe = num_nodes) out-of-universe ids are detected and the sort path
@@ -121,7 +122,11 @@ def test_bitmap_path_with_several_column_ranges(cuda_device, monkeypatch):
     ix = torch.as_tensor(indices, dtype=torch.int32).cuda()
     handle = voltrix.csr_fused_preprocess_kernel(ip, ix, nrows, num_cols=ncols)[:3]
     _check(handle, indptr, indices, nrows)
-    monkeypatch.setenv("VOLTRIX_CSR_PATH", "sort")
+    for path in ("sort", "mixed"):   # mixed: window 0 (11200 edges) through the bitmap kernels, the others sorted
+        monkeypatch.setenv("VOLTRIX_CSR_PATH", path)
+        handle = voltrix.csr_fused_preprocess_kernel(ip, ix, nrows, num_cols=ncols)[:3]
+        _check(handle, indptr, indices, nrows)
+    monkeypatch.delenv("VOLTRIX_CSR_PATH")   # 3 ranges: the default choice is the mixed path
     handle = voltrix.csr_fused_preprocess_kernel(ip, ix, nrows, num_cols=ncols)[:3]
     _check(handle, indptr, indices, nrows)
 
@@ -155,7 +160,7 @@ def test_low_level_kernel_wrappers_like_reference_test(cuda_device):
     assert np.array_equal(packed.cpu().numpy(), oracle_c.hmat_packed_swizzle(op1, ohspa))
 
 
-@pytest.mark.parametrize("path", ["sort", "bitmap"])
+@pytest.mark.parametrize("path", ["sort", "bitmap", "mixed"])
 def test_fused_preprocess_mid_size_with_large_windows(cuda_device, path, monkeypatch):
     monkeypatch.setenv("VOLTRIX_CSR_PATH", path)
     indptr, indices, _ = synth_graphs.generate("reddit_like", device="cuda", scale=0.02)
@@ -164,3 +169,25 @@ def test_fused_preprocess_mid_size_with_large_windows(cuda_device, path, monkeyp
     p1, packed, hind, bp = voltrix.csr_fused_preprocess_kernel(indptr, indices, n)
     _check((p1, packed, hind), indptr.cpu().numpy(), indices.cpu().numpy(), n)
     assert np.array_equal(bp.cpu().numpy(), np.diff(p1.cpu().numpy()))
+
+
+def test_mixed_path_power_law_windows(cuda_device, monkeypatch):
+    """Power-law stand-in at 1/64 size with its full-size density (62.5 k rows, Zipf degrees: windows from a few hundred to
+    tens of thousands of edges) over a 1.2 M-column universe (3 bitmap ranges): the default choice is the mixed path --
+    wave sort, workgroup LDS sort and bitmap kernels all take windows -- and must give the oracle's bytes."""
+    monkeypatch.delenv("VOLTRIX_CSR_PATH", raising=False)
+    n, ncols = 62_500, 1_200_000
+    g = torch.Generator(device="cuda").manual_seed(12)
+    deg = synth_graphs.zipf_degrees(n, 400.0, 2.0, ncols // 4, g, torch.device("cuda"))
+    total = int(deg.sum())
+    rows = torch.repeat_interleave(torch.arange(n, device="cuda"), deg)
+    cols = torch.randint(0, ncols, (total,), device="cuda", generator=g)
+    key = torch.unique(rows * ncols + cols)            # sorted, duplicate-free per row
+    rows, cols = key // ncols, key % ncols
+    indptr = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    indptr[1:] = torch.bincount(rows, minlength=n).cumsum(0)
+    ip, ix = indptr.to(torch.int32), cols.to(torch.int32)
+    per_window = ip[16::16] - ip[:-16:16]
+    assert int(per_window.max()) > 8192 and int(per_window.min()) < 2048 and int(((per_window > 2048) & (per_window <= 8192)).sum()) > 0
+    p1, packed, hind, _ = voltrix.csr_fused_preprocess_kernel(ip, ix, n, num_cols=ncols)
+    _check((p1, packed, hind), ip.cpu().numpy(), ix.cpu().numpy(), n)

@@ -7,7 +7,8 @@
 //   * the O(TC blocks x window edges) rescan in hmat_cuda_kernel (:66,:94),
 //   * the transient fp32 `hspa` (512 bytes per TC block).
 //
-// Two rank algorithms, chosen per call by csr_use_bitmap() (one workgroup per 16-row window, grid-strided, both):
+// Two rank algorithms (one workgroup or wave per 16-row window, grid-strided), chosen per call by csr_path(): bitmap,
+// sort, or mixed = sort for the windows up to kSortLdsKeys edges and bitmap for the bigger ones:
 //  bitmap (column universe <= 2^19 and not much larger than a window's edge list; e.g. reddit):
 //   1. csr_bitmap_count_kernel  every edge sets bit `column` of an LDS bitmap; distinct columns = popcount.
 //   2. scan_* kernels           pointer1 = exclusive prefix sum (wave shuffles + LDS, three small launches).
@@ -309,8 +310,10 @@ static __global__ __launch_bounds__(kSortThreads) void csr_window_sort_kernel(co
                                                                        uint32_t* __restrict__ keys_ws,
                                                                        int* __restrict__ block_partition,
                                                                        int* __restrict__ status,
-                                                                       const int* __restrict__ counts,
-                                                                       const int* __restrict__ queue) {
+                                                                       int* __restrict__ counts,
+                                                                       const int* __restrict__ queue,
+                                                                       const int big_limit,
+                                                                       int* __restrict__ queue2) {
   __shared__ uint32_t lkeys[kSortLdsKeys];
   __shared__ int rowptr[kBlkH + 1];
   __shared__ int wave_cnt[kSortThreads / kWave];
@@ -324,6 +327,11 @@ static __global__ __launch_bounds__(kSortThreads) void csr_window_sort_kernel(co
     }
     __syncthreads();
     const int lo = rowptr[0], n = rowptr[kBlkH] - lo;
+    if (big_limit > 0 && n > big_limit) {  // mixed path: this window goes to the bitmap kernels (workgroup-uniform)
+      if (tid == 0) queue2[atomicAdd(&counts[1], 1)] = w;
+      __syncthreads();  // rowptr is rewritten by the next iteration
+      continue;
+    }
     uint32_t* const dst = keys_ws + lo;
     const bool in_lds = n <= kSortLdsKeys;  // workgroup-uniform
     for (int i = tid; i < n; i += kSortThreads) {
@@ -458,7 +466,8 @@ static __global__ __launch_bounds__(kSortThreads) void csr_window_fill_kernel(co
                                                                        uint32_t* __restrict__ hspa_packed,
                                                                        int* __restrict__ hind,
                                                                        const int* __restrict__ counts,
-                                                                       const int* __restrict__ queue) {
+                                                                       const int* __restrict__ queue,
+                                                                       const int big_limit) {
   __shared__ int wave_tot[kSortThreads / kWave];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
   const int num_big = *counts;
@@ -467,6 +476,7 @@ static __global__ __launch_bounds__(kSortThreads) void csr_window_fill_kernel(co
     const long long r0 = (long long)w * kBlkH, r1 = r0 + kBlkH;
     const int lo = indptr[r0 < num_nodes ? r0 : num_nodes];
     const int n = indptr[r1 < num_nodes ? r1 : num_nodes] - lo;
+    if (big_limit > 0 && n > big_limit) continue;  // mixed path: csr_bitmap_fill_kernel's share (workgroup-uniform)
     const long long p0 = pointer1[w];
     {  // zero this window's part of the handle; the barrier (stores acknowledged by L2, same CU) orders it before the ORs
       const int nb = pointer1[w + 1] - (int)p0;
@@ -566,7 +576,9 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_count_kernel(con
                                                                       const int num_nodes, const int num_cols,
                                                                       const int num_windows,
                                                                       int* __restrict__ block_partition,
-                                                                      int* __restrict__ status) {
+                                                                      int* __restrict__ status,
+                                                                      const int* __restrict__ list,
+                                                                      const int* __restrict__ list_count) {
   extern __shared__ uint4 bm_lds[];
   __shared__ int wave_cnt[kBmWaves];
   uint4* const bitmap4 = bm_lds;
@@ -576,7 +588,9 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_count_kernel(con
   const int tid = threadIdx.x;
   for (int i = tid; i < ng; i += kBmThreads) bitmap4[i] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
-  for (int w = blockIdx.x; w < num_windows; w += gridDim.x) {
+  const int todo = list ? *list_count : num_windows;  // mixed path: only the listed windows
+  for (int q = blockIdx.x; q < todo; q += gridDim.x) {
+    const int w = list ? list[q] : q;
     const long long r0 = (long long)w * kBlkH, r1 = r0 + kBlkH;
     const long long lo = indptr[r0 < num_nodes ? r0 : num_nodes], hi = indptr[r1 < num_nodes ? r1 : num_nodes];
     int cnt = 0;
@@ -610,7 +624,9 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_fill_kernel(cons
                                                                      const int num_windows,
                                                                      const int* __restrict__ pointer1,
                                                                      uint32_t* __restrict__ hspa_packed,
-                                                                     int* __restrict__ hind) {
+                                                                     int* __restrict__ hind,
+                                                                     const int* __restrict__ list,
+                                                                     const int* __restrict__ list_count) {
   extern __shared__ uint4 bm_lds[];
   __shared__ int wave_tot[kBmSweeps][kBmWaves];
   const int range_cols = bm_range_cols(num_cols);
@@ -626,7 +642,9 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_fill_kernel(cons
   for (int i = tid; i < kBmStageBlocks; i += kBmThreads) stage4[i] = zero4;
   __syncthreads();
 
-  for (int w = blockIdx.x; w < num_windows; w += gridDim.x) {
+  const int todo = list ? *list_count : num_windows;  // mixed path: only the listed windows
+  for (int q = blockIdx.x; q < todo; q += gridDim.x) {
+    const int w = list ? list[q] : q;
     int rp[kBlkH + 1];  // wave-uniform row pointers of the window (scalar loads)
     load_window_rowptr(indptr, w, num_nodes, rp);
     const long long lo = rp[0], hi = rp[kBlkH];
@@ -794,16 +812,27 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_fill_kernel(cons
 }
 
 // Path choice (the same in workspace_bytes / count / fill).  num_cols = the caller's column universe (every id is in
-// [0, num_cols); <= 0: unknown -> sort path).  Bitmap when its sweeps (one per 2^19-column range) cost less than sorting
-// the window's edges.  VOLTRIX_CSR_PATH=sort|bitmap overrides (bitmap is honoured only when 0 < num_cols <= 2^25).
-inline bool csr_use_bitmap(int num_nodes, int num_cols, long long num_edges) {
-  if (num_cols <= 0 || num_nodes <= 0) return false;
+// [0, num_cols); <= 0: unknown -> sort path).
+//   bitmap  one range (universe <= 2^19) whose sweep costs less than sorting the window's edges (reddit);
+//   mixed   2 .. 16 ranges: windows up to kSortLdsKeys edges are sorted (a wave in registers / a workgroup in LDS: cost
+//           ~ their edges), only the bigger ones pay the per-range sweeps of the bitmap kernels (cost ~ universe).  On
+//           the power-law stand-in (4 M columns = 8 ranges; median window 3.2 k edges, 13 % of the windows above 8 k
+//           with 55 % of the edges) every window through the bitmap kernels cost ~100 us of sweeps and barriers;
+//   sort    unknown universes; more ranges than that: bitmap or sort for every window by the same cost estimate.
+// VOLTRIX_CSR_PATH=sort|bitmap|mixed overrides (bitmap / mixed are honoured only when 0 < num_cols <= 2^25).
+enum CsrPath { kCsrSort = 0, kCsrBitmap = 1, kCsrMixed = 2 };
+constexpr int kMixedMaxPasses = 16;
+
+inline CsrPath csr_path(int num_nodes, int num_cols, long long num_edges) {
+  if (num_cols <= 0 || num_nodes <= 0) return kCsrSort;
   const long long passes = ((long long)num_cols + kBmMaxCols - 1) / kBmMaxCols;  // column ranges per window
-  if (passes > 64) return false;
+  if (passes > 64) return kCsrSort;
   if (const char* e = std::getenv("VOLTRIX_CSR_PATH")) {
-    if (e[0] == 's') return false;
-    if (e[0] == 'b') return true;
+    if (e[0] == 's') return kCsrSort;
+    if (e[0] == 'b') return kCsrBitmap;
+    if (e[0] == 'm') return kCsrMixed;
   }
+  if (passes > 1 && passes <= kMixedMaxPasses) return kCsrMixed;
   const long long W = ((long long)num_nodes + kBlkH - 1) / kBlkH;
   const double per_window = (double)num_edges / (double)W;       // mean edges per window
   // rough per-window costs in LDS word operations: a bitmap pass sweeps its range's 128-column groups and touches every
@@ -813,7 +842,10 @@ inline bool csr_use_bitmap(int num_nodes, int num_cols, long long num_edges) {
   double lg = 1.0;
   for (double x = 2.0; x < per_window; x *= 2.0) lg += 1.0;      // ~ log2
   const double sort_cost = per_window <= (double)kWsKeys ? 2.0 * per_window : per_window * lg * (lg + 1.0) / 8.0;
-  return bitmap_cost <= sort_cost;
+  return bitmap_cost <= sort_cost ? kCsrBitmap : kCsrSort;
+}
+inline bool csr_use_bitmap(int num_nodes, int num_cols, long long num_edges) {
+  return csr_path(num_nodes, num_cols, num_edges) == kCsrBitmap;
 }
 
 template <class K>
@@ -827,28 +859,32 @@ inline int bm_set_lds(K kernel, size_t bytes) {
 // ---- host side -------------------------------------------------------------------------------------------------
 inline long long align16(long long x) { return (x + 15) & ~15ll; }
 
-// workspace: [sort path: keys uint32[E]] [scan scratch int[nchunks]] [sort path: queue count (16 B), queue int[W]]
+// workspace: [sort / mixed: keys uint32[E]] [scan scratch int[nchunks]] [queue counts (16 B)] [sort / mixed: queue int[W]]
+// [mixed: queue2 int[W]]
 struct CsrWorkspace {
   uint32_t* keys;
   int* chunk_sums;
-  int* counts;
+  int* counts;   // [0] windows above kWsKeys edges (queue), [1] mixed path: of those, the windows above kSortLdsKeys (queue2)
   int* queue;
+  int* queue2;
   long long bytes;
 };
 inline CsrWorkspace csr_workspace(void* base, int num_nodes, int num_cols, long long num_edges) {
   const long long W = ((long long)num_nodes + kBlkH - 1) / kBlkH;
   const long long nchunks = (W + kScanChunk - 1) / kScanChunk + 1;
-  const bool bitmap = csr_use_bitmap(num_nodes, num_cols, num_edges);
+  const CsrPath path = csr_path(num_nodes, num_cols, num_edges);
   char* p = static_cast<char*>(base);
   CsrWorkspace ws;
   ws.keys = reinterpret_cast<uint32_t*>(p);
-  p += bitmap ? 0 : align16(num_edges * 4);
+  p += path == kCsrBitmap ? 0 : align16(num_edges * 4);
   ws.chunk_sums = reinterpret_cast<int*>(p);
   p += align16(nchunks * 4);
   ws.counts = reinterpret_cast<int*>(p);
   p += 16;
   ws.queue = reinterpret_cast<int*>(p);
-  p += bitmap ? 0 : align16(W * 4);
+  p += path == kCsrBitmap ? 0 : align16(W * 4);
+  ws.queue2 = reinterpret_cast<int*>(p);
+  p += path == kCsrMixed ? align16(W * 4) : 0;
   ws.bytes = p - static_cast<char*>(base);
   return ws;
 }
@@ -875,26 +911,30 @@ inline int csr_window_count(const int* indptr, const int* indices, int num_nodes
   if (W == 0) {
     return hipMemsetAsync(pointer1, 0, sizeof(int), stream) == hipSuccess ? kOk : kErrLaunch;
   }
-  const bool bitmap = csr_use_bitmap(num_nodes, num_cols, num_edges);
+  const CsrPath path = csr_path(num_nodes, num_cols, num_edges);
   const CsrWorkspace ws = csr_workspace(workspace, num_nodes, num_cols, num_edges);
   uint32_t* const keys = ws.keys;
   int* const chunk_sums = ws.chunk_sums;
   const int nchunks = (W + kScanChunk - 1) / kScanChunk;
-  if (bitmap) {
-    const size_t lds = bm_count_lds(num_cols);
-    if (int rc = bm_set_lds(csr_bitmap_count_kernel, lds)) return rc;
-    const int grid = W < kBmGrid ? W : kBmGrid;
-    hipLaunchKernelGGL(csr_bitmap_count_kernel, dim3(grid), dim3(kBmThreads), lds, stream, indptr, indices, num_nodes,
-                       num_cols, W, block_partition, status);
-  } else {
+  if (path != kCsrBitmap) {
     const unsigned col_limit = num_cols > 0 ? (unsigned)num_cols : (1u << 28);
     const int wgs = (W + kWsWaves - 1) / kWsWaves;  // small windows: one wave each
-    if (hipMemsetAsync(ws.counts, 0, sizeof(int), stream) != hipSuccess) return kErrLaunch;
+    if (hipMemsetAsync(ws.counts, 0, 2 * sizeof(int), stream) != hipSuccess) return kErrLaunch;
     hipLaunchKernelGGL(csr_wave_sort_kernel, dim3(wgs < kWsGrid ? wgs : kWsGrid), dim3(kWsWaves * kWave), 0, stream,
                        indptr, indices, num_nodes, W, col_limit, keys, block_partition, status, ws.counts, ws.queue);
     const int grid = W < 256 * 8 ? W : 256 * 8;  // windows above kWsKeys edges (queued above): one workgroup each
     hipLaunchKernelGGL(csr_window_sort_kernel, dim3(grid), dim3(kSortThreads), 0, stream, indptr, indices, num_nodes,
-                       W, col_limit, keys, block_partition, status, ws.counts, ws.queue);
+                       W, col_limit, keys, block_partition, status, ws.counts, ws.queue,
+                       path == kCsrMixed ? kSortLdsKeys : 0, ws.queue2);
+  }
+  if (path != kCsrSort) {  // bitmap: every window; mixed: the windows csr_window_sort_kernel listed in queue2
+    const size_t lds = bm_count_lds(num_cols);
+    if (int rc = bm_set_lds(csr_bitmap_count_kernel, lds)) return rc;
+    const int grid = W < kBmGrid ? W : kBmGrid;
+    const bool listed = path == kCsrMixed;
+    hipLaunchKernelGGL(csr_bitmap_count_kernel, dim3(grid), dim3(kBmThreads), lds, stream, indptr, indices, num_nodes,
+                       num_cols, W, block_partition, status, listed ? ws.queue2 : nullptr,
+                       listed ? ws.counts + 1 : nullptr);
   }
   hipLaunchKernelGGL(scan_chunk_sums_kernel, dim3(nchunks), dim3(256), 0, stream, block_partition, W, chunk_sums);
   hipLaunchKernelGGL(scan_chunk_offsets_kernel, dim3(1), dim3(256), 0, stream, chunk_sums, nchunks);
@@ -908,22 +948,26 @@ inline int csr_fill(const int* indptr, const int* indices, int num_nodes, int nu
   if (((uintptr_t)workspace & 15) || ((uintptr_t)hspa_packed & 15) || ((uintptr_t)hind & 15)) return kErrBadShape;
   const int W = (num_nodes + kBlkH - 1) / kBlkH;
   if (W == 0) return kOk;
-  if (csr_use_bitmap(num_nodes, num_cols, num_edges)) {
+  const CsrPath path = csr_path(num_nodes, num_cols, num_edges);
+  const CsrWorkspace ws = csr_workspace(workspace, num_nodes, num_cols, num_edges);
+  if (path != kCsrSort) {  // bitmap: every window; mixed: the windows of queue2 (the big ones go first: longest jobs)
     const size_t lds = bm_fill_lds(num_cols);
     if (int rc = bm_set_lds(csr_bitmap_fill_kernel, lds)) return rc;
     const int grid = W < kBmGrid ? W : kBmGrid;
+    const bool listed = path == kCsrMixed;
     hipLaunchKernelGGL(csr_bitmap_fill_kernel, dim3(grid), dim3(kBmThreads), lds, stream, indptr, indices, num_nodes,
-                       num_cols, W, pointer1, hspa_packed, hind);
-    return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+                       num_cols, W, pointer1, hspa_packed, hind, listed ? ws.queue2 : nullptr,
+                       listed ? ws.counts + 1 : nullptr);
   }
-  const CsrWorkspace ws = csr_workspace(workspace, num_nodes, num_cols, num_edges);
-  const uint32_t* const keys = ws.keys;
-  const int wgs = (W + kWsWaves - 1) / kWsWaves;
-  hipLaunchKernelGGL(csr_wave_fill_kernel, dim3(wgs < kWsGrid ? wgs : kWsGrid), dim3(kWsWaves * kWave), 0, stream, indptr,
-                     num_nodes, W, keys, pointer1, hspa_packed, hind);
-  const int grid = W < 256 * 8 ? W : 256 * 8;
-  hipLaunchKernelGGL(csr_window_fill_kernel, dim3(grid), dim3(kSortThreads), 0, stream, indptr, num_nodes, W, keys,
-                     pointer1, hspa_packed, hind, ws.counts, ws.queue);
+  if (path != kCsrBitmap) {
+    const uint32_t* const keys = ws.keys;
+    const int wgs = (W + kWsWaves - 1) / kWsWaves;
+    hipLaunchKernelGGL(csr_wave_fill_kernel, dim3(wgs < kWsGrid ? wgs : kWsGrid), dim3(kWsWaves * kWave), 0, stream,
+                       indptr, num_nodes, W, keys, pointer1, hspa_packed, hind);
+    const int grid = W < 256 * 8 ? W : 256 * 8;
+    hipLaunchKernelGGL(csr_window_fill_kernel, dim3(grid), dim3(kSortThreads), 0, stream, indptr, num_nodes, W, keys,
+                       pointer1, hspa_packed, hind, ws.counts, ws.queue, path == kCsrMixed ? kSortLdsKeys : 0);
+  }
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

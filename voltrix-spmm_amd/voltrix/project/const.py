@@ -21,6 +21,6 @@ HIPCC_COMPILER_FLAG = "VOLTRIX_HIPCC_COMPILER"        # path of hipcc (default /
 OFFLOAD_ARCH_FLAG = "VOLTRIX_OFFLOAD_ARCH"            # default gfx950
 FP32_MODE_FLAG = "VOLTRIX_FP32_MODE"                  # "fp16" (default: cast, fp16 MFMA) | "exact" (fp32 MFMA)
 PREPROCESS_FLAG = "VOLTRIX_PREPROCESS"                # "fused" (default, GPU) | "reference" (CPU + 2 kernels)
-CSR_PATH_FLAG = "VOLTRIX_CSR_PATH"                    # fused preprocess rank algorithm: unset = auto | "sort" | "bitmap" (read in libvoltrix_hip.so)
+CSR_PATH_FLAG = "VOLTRIX_CSR_PATH"                    # fused preprocess rank algorithm: unset = auto | "sort" | "bitmap" | "mixed" (read in libvoltrix_hip.so)
 TUNE_SPACE_FLAG = "VOLTRIX_TUNE_SPACE"                # "default" | "full" | "none"
 DISABLE_JIT_FLAG = "VOLTRIX_DISABLE_JIT"              # 1: use the ahead-of-time libvoltrix_hip.so only
