@@ -22,12 +22,13 @@ for name in sys.argv[1:] or ["reddit_like", "products_like", "powerlaw_4m"]:
     per_window = (indptr[16::16] - indptr[:-16:16]).float()
     print(f"{name}: N={n} nnz={e} edges per window: median {int(per_window.median())} max {int(per_window.max())}", flush=True)
     ref = None
-    for path in ("auto", "sort", "bitmap", "mixed"):
+    paths = os.environ.get("EXP_PATHS", "auto,sort,bitmap,mixed").split(",")
+    for path in paths:
         if path == "auto":
             os.environ.pop("VOLTRIX_CSR_PATH", None)
         else:
             os.environ["VOLTRIX_CSR_PATH"] = path
-        if name == "powerlaw_4m" and path == "sort":
+        if name in ("powerlaw_4m", "papers_like") and path in ("sort", "bitmap") and path != "auto" and len(paths) > 1:
             print("  sort  : skipped (global-memory bitonic sort of 100 k-edge windows)", flush=True)
             continue
         times = []

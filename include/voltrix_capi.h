@@ -158,6 +158,26 @@ void voltrix_launch_spmm_bf16_sched(void* blk_offsets, void* hspa_packed, void* 
 void voltrix_launch_combine_partials(void* cuts, int num_cuts, void* partials, void* output, int num_nodes,
                                      int embedding_dim, int accumulate, void* row_map, void* stream, int* return_code);
 
+/* Unit table of a handle (the `units` / `unit_ptr` / `cuts` arguments above), built on the device from blk_offsets alone,
+ * in two phases around the one host read that sizes the outputs (no reference counterpart -- its equal-work scheduler,
+ * spmm_kernels.cuh:499-540, is dead code; layout and rules: voltrix/unit_table.hpp):
+ *   phase 1  voltrix_launch_unit_table_count: header int32[8] (device) = {num_units U, num_cuts C, num_slots, max units per
+ *            XCD, max_stages L, top (longest unit), 0, 0}.  max_stages <= 0: L = max(8, floor(1.5 x median stages per window)).
+ *            workspace: voltrix_unit_table_workspace_bytes(num_nodes) bytes, device, 16-byte aligned.
+ *   (caller reads the header; allocates units int32[U][4], unit_ptr int32[9], cuts int32[C][4], partials
+ *    float[num_slots * 16 * embedding_dim] and voltrix_unit_table_fill_workspace_bytes(U) bytes of fill workspace)
+ *   phase 2  voltrix_launch_unit_table_fill: writes units, unit_ptr, cuts (every element); same workspace, untouched since
+ *            phase 1; num_units / num_cuts / top as read from the header.
+ * The table depends on blk_offsets only (ties between units of equal length are broken by window, then unit index), so a
+ * handle always gets the same table and the SpMM the same bits. */
+int64_t voltrix_unit_table_workspace_bytes(int num_nodes);
+int64_t voltrix_unit_table_fill_workspace_bytes(int64_t num_units);
+void voltrix_launch_unit_table_count(void* blk_offsets, int num_nodes, int max_stages, void* workspace, void* header,
+                                     void* stream, int* return_code);
+void voltrix_launch_unit_table_fill(void* blk_offsets, int num_nodes, void* workspace, void* fill_workspace, int num_units,
+                                    int num_cuts, int top, void* units, void* unit_ptr, void* cuts, void* stream,
+                                    int* return_code);
+
 /* "Balance" schedule for a handle: order_out int32[W] (device) lists the windows of every XCD range, inside chunks of
  * `chunk` (1..4096) consecutive windows, by descending TC-block count, so that co-resident waves sweep their sorted
  * columns at a similar pace and share gathered rows through L2.  Depends on blk_offsets only; results of the SpMM are
@@ -215,6 +235,11 @@ void voltrix_launch_panel_plan_fill(void* node_pointer, void* edge_list, int num
                                     int waves, int row_blocks, int tau, void* workspace, void* panel_ptr,
                                     void* resid_node_pointer, int64_t total_ksteps, void* resid_edge_list,
                                     void* panel_cols, void* panel_bits, void* stream, int* return_code);
+
+/* `panel_order` of the panel launches: order_out int32[num_panels] (device), position -> panel; inside every XCD's range of
+ * ceil(num_panels / 8) positions the panels with the most k-steps first (ties by panel index).  Speed only: the launch
+ * then ends on its short panels instead of its long ones. */
+void voltrix_launch_panel_order(void* panel_ptr, int num_panels, void* order_out, void* stream, int* return_code);
 
 /* dst[i] += src[i], float32, count % 4 == 0, both 16-byte aligned: joins the two halves of the two-level format when
  * the window kernel (-> dst) and the panel kernel (accumulate = 0 -> src) ran side by side on two streams. */

@@ -289,6 +289,54 @@ def test_window_order_schedule_is_a_sorted_permutation_and_changes_no_bit(cuda_d
     assert torch.equal(out0, out1) and not torch.isnan(out0).any()
 
 
+@pytest.mark.parametrize("kind,num_feats,tile", [("f16", 264, (128, 3, 4)), ("f16", 512, (64, 3, 4)), ("bf16", 320, (128, 3, 4)),
+                                                 ("f16", 96, (32, 4, 4)), ("f32", 200, (64, 3, 1))])
+def test_slab_order_changes_no_bit(cuda_device, kind, num_feats, tile, monkeypatch):
+    """F > FS: window-major and slab-major unit orders (spmm_kernels.hpp::slab_major_order; rule: slab-major from 128-byte
+    row pieces on) give the same bits -- every output element has the same addends in the same order -- with the natural
+    window order and with a unit table; last slab partially filled in every case."""
+    from voltrix.schedule import unit_table
+
+    indptr, indices, _ = synth_graphs.generate("reddit_like", device="cuda", scale=0.05)
+    n, e = indptr.numel() - 1, indices.numel()
+    handle = voltrix.csr_fused_preprocess_kernel(indptr, indices, n)[:3]
+    tb = unit_table(handle[0], n)
+    assert tb.num_cuts > 0
+    dtype = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[kind]
+    feat = torch.randn(n, num_feats, device="cuda").to(dtype)
+    s = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    for order in ("minor", "major", None):
+        if order is None:
+            monkeypatch.delenv("VOLTRIX_SLAB_ORDER")
+        else:
+            monkeypatch.setenv("VOLTRIX_SLAB_ORDER", order)
+        out = torch.full((n, num_feats), float("nan"), device="cuda")
+        if kind == "f32":
+            rc = capi.launch_spmm(handle[0].data_ptr(), handle[1].data_ptr(), handle[2].data_ptr(), n, e, num_feats,
+                                  feat.data_ptr(), out.data_ptr(), False, tile, s)
+            assert rc == 0
+        else:
+            rc = capi.launch_spmm_sched(handle[0].data_ptr(), handle[1].data_ptr(), handle[2].data_ptr(), n, e, num_feats,
+                                        feat.data_ptr(), out.data_ptr(), tile, s, bf16=kind == "bf16")
+            assert rc == 0
+            out_t = torch.full((n, num_feats), float("nan"), device="cuda")
+            buf = torch.empty(max(1, tb.num_slots) * 16 * num_feats, dtype=torch.float32, device="cuda")
+            assert capi.launch_spmm_sched(handle[0].data_ptr(), handle[1].data_ptr(), handle[2].data_ptr(), n, e, num_feats,
+                                          feat.data_ptr(), out_t.data_ptr(), tile, s, 0, 0, False, kind == "bf16", tb,
+                                          buf.data_ptr()) == 0
+            assert capi.launch_combine_partials(tb, buf.data_ptr(), out_t.data_ptr(), n, num_feats, False, s) == 0
+            outs[(order, "table")] = out_t
+        outs[(order, "natural")] = out
+    torch.cuda.synchronize()
+    for key, out in outs.items():
+        assert not torch.isnan(out).any(), key
+        assert torch.equal(out, outs[("minor", key[1])]), key
+    ref = torch_ref.spmm(indptr.cpu().numpy(), indices.cpu().numpy(), feat.float().cpu(), n)
+    got = outs[("major", "natural")].cpu()
+    assert torch.linalg.norm(got - ref) / torch.linalg.norm(ref) <= 1e-3
+
+
 def test_cast_entry_point(cuda_device):
     x = torch.randn(1000, 64, device="cuda") * 300
     y = torch.empty(1000, 64, dtype=torch.float16, device="cuda")

@@ -56,6 +56,11 @@ void voltrix_launch_spmm_panel_bf16(void* panel_ptr, void* panel_cols, void* pan
                                 static_cast<hipStream_t>(stream));
 }
 
+void voltrix_launch_panel_order(void* panel_ptr, int num_panels, void* order_out, void* stream, int* return_code) {
+  *return_code = voltrix::panel_order(static_cast<const int*>(panel_ptr), num_panels, static_cast<int*>(order_out),
+                                      static_cast<hipStream_t>(stream));
+}
+
 void voltrix_launch_add_inplace_f32(void* dst, void* src, int64_t count, void* stream, int* return_code) {
   *return_code = voltrix::add_inplace_f32(static_cast<float*>(dst), static_cast<const float*>(src), count,
                                           static_cast<hipStream_t>(stream));

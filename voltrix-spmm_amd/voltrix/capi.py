@@ -39,6 +39,7 @@ SYMBOLS = (
     "voltrix_panel_plan_workspace_bytes",
     "voltrix_launch_panel_plan_count",
     "voltrix_launch_panel_plan_fill",
+    "voltrix_launch_panel_order",
     "voltrix_spmm_default_tile",
     "voltrix_spmm_num_tiles",
     "voltrix_spmm_tile_at",
@@ -50,6 +51,10 @@ SYMBOLS = (
     "voltrix_csr_preprocess_workspace_bytes",
     "voltrix_launch_csr_window_count",
     "voltrix_launch_csr_fill",
+    "voltrix_unit_table_workspace_bytes",
+    "voltrix_unit_table_fill_workspace_bytes",
+    "voltrix_launch_unit_table_count",
+    "voltrix_launch_unit_table_fill",
 )
 
 
@@ -73,6 +78,8 @@ def lib() -> ctypes.CDLL:
         _lib.voltrix_csr_preprocess_workspace_bytes.restype = ctypes.c_int64
         _lib.voltrix_panel_plan_workspace_bytes.restype = ctypes.c_int64
         _lib.voltrix_spmm_f32_workspace_bytes.restype = ctypes.c_int64
+        _lib.voltrix_unit_table_workspace_bytes.restype = ctypes.c_int64
+        _lib.voltrix_unit_table_fill_workspace_bytes.restype = ctypes.c_int64
         for name in SYMBOLS:
             if name.startswith("voltrix_launch_") or name in ("voltrix_spmm_default_tile", "voltrix_spmm_tile_at"):
                 getattr(_lib, name).restype = None
@@ -184,6 +191,35 @@ def launch_combine_partials(table, partials_ptr, output_ptr, num_nodes, embeddin
     return rc.value
 
 
+def build_unit_table(blk_offsets, num_nodes: int, max_stages: int = 0, stream=None):
+    """The handle's unit table through the library's two-phase builder (voltrix/unit_table.hpp): returns
+    ``(units int32 [U, 4], unit_ptr int32 [9], cuts int32 [C, 4], header)`` with ``header`` = the eight ints of phase 1
+    as a Python list (num_units, num_cuts, num_slots, max_units_per_xcd, max_stages, top, 0, 0).  One host sync."""
+    import torch
+
+    dev = blk_offsets.device
+    stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    workspace = torch.empty(max(16, int(lib().voltrix_unit_table_workspace_bytes(ctypes.c_int(num_nodes)))),
+                            dtype=torch.uint8, device=dev)
+    header = torch.empty(8, dtype=torch.int32, device=dev)
+    rc = ctypes.c_int(-1)
+    lib().voltrix_launch_unit_table_count(_ptr(blk_offsets), ctypes.c_int(num_nodes), ctypes.c_int(int(max_stages)),
+                                          _ptr(workspace), _ptr(header), ctypes.c_void_p(stream), ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_unit_table_count")
+    head = [int(v) for v in header.tolist()]   # the sync
+    num_units, num_cuts, top = head[0], head[1], head[5]
+    units = torch.empty((num_units, 4), dtype=torch.int32, device=dev)
+    cuts = torch.empty((num_cuts, 4), dtype=torch.int32, device=dev)
+    unit_ptr = torch.empty(9, dtype=torch.int32, device=dev)
+    fill_ws = torch.empty(max(16, int(lib().voltrix_unit_table_fill_workspace_bytes(ctypes.c_int64(num_units)))),
+                          dtype=torch.uint8, device=dev)
+    lib().voltrix_launch_unit_table_fill(_ptr(blk_offsets), ctypes.c_int(num_nodes), _ptr(workspace), _ptr(fill_ws),
+                                         ctypes.c_int(num_units), ctypes.c_int(num_cuts), ctypes.c_int(top), _ptr(units),
+                                         _ptr(unit_ptr), _ptr(cuts), ctypes.c_void_p(stream), ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_unit_table_fill")
+    return units, unit_ptr, cuts, head
+
+
 def spmm_f32_workspace_bytes(input_rows: int, embedding_dim: int) -> int:
     return int(lib().voltrix_spmm_f32_workspace_bytes(ctypes.c_int64(input_rows), ctypes.c_int(embedding_dim)))
 
@@ -224,6 +260,13 @@ def launch_spmm_panel(plan, input_ptr, output_ptr, embedding_dim, accumulate, bf
        ctypes.c_int(plan.row_blocks), ctypes.c_int(tile[2]), ctypes.c_void_p(out_scale), ctypes.c_void_p(stream),
        ctypes.byref(rc))
     return rc.value
+
+
+def launch_panel_order(panel_ptr, num_panels: int, order_out, stream) -> None:
+    rc = ctypes.c_int(-1)
+    lib().voltrix_launch_panel_order(_ptr(panel_ptr), ctypes.c_int(num_panels), _ptr(order_out), ctypes.c_void_p(stream),
+                                     ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_panel_order")
 
 
 def panel_plan_workspace_bytes(num_nodes: int, waves: int, row_blocks: int) -> int:

@@ -140,10 +140,14 @@ def longest_first_order(panel_ptr: torch.Tensor) -> torch.Tensor:
     1.8 rounds: started in natural order, the last round's long panels finish alone; longest first leaves the short ones
     for the end.  Measured on the reddit-like graph (tau 3): the two-level step 1.59 -> 1.42 ms
     (profiles/r02/experiment_tau_reddit.log).  Speed only."""
-    nks = (panel_ptr[1:] - panel_ptr[:-1]).to(torch.int64)
-    num_panels = nks.numel()
-    if num_panels == 0:
+    num_panels = panel_ptr.numel() - 1
+    if num_panels <= 0:
         return torch.zeros(0, dtype=torch.int32, device=panel_ptr.device)
+    if panel_ptr.is_cuda:   # the library's kernel (panel_plan.hpp::panel_order_kernel; same order, checked by the tests)
+        order = torch.empty(num_panels, dtype=torch.int32, device=panel_ptr.device)
+        capi.launch_panel_order(panel_ptr, num_panels, order, torch.cuda.current_stream().cuda_stream)
+        return order
+    nks = (panel_ptr[1:] - panel_ptr[:-1]).to(torch.int64)
     per_xcd = (num_panels + 7) // 8
     top = int(nks.max())
     key = (torch.arange(num_panels, device=panel_ptr.device) // per_xcd) * (top + 1) + (top - nks)

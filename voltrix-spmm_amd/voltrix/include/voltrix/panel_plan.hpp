@@ -305,6 +305,33 @@ static __global__ __launch_bounds__(kPlanThreads) void panel_plan_fill_kernel(
   if ((int)threadIdx.x < padded - cnt) panel_cols[ks0 * kStageK + cnt + threadIdx.x] = s.first_col;
 }
 
+// Launch order of the panel kernel (spmm_panel_kernels.hpp, PanelArgs::panel_order): order_out[position] = panel; inside
+// every XCD's contiguous range of positions (ceil(NP / 8) each) the panels with the most k-steps first, ties by panel
+// index -- a stable order, so a plan always gets the same one.  Rank by counting inside the range (NP is small: N / 512).
+static __global__ __launch_bounds__(256) void panel_order_kernel(const int* __restrict__ panel_ptr, const int num_panels,
+                                                                 const int per_xcd, int* __restrict__ order_out) {
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < num_panels; p += gridDim.x * 256) {
+    const int lo = (p / per_xcd) * per_xcd;
+    const int hi = lo + per_xcd < num_panels ? lo + per_xcd : num_panels;
+    const int mine = panel_ptr[p + 1] - panel_ptr[p];
+    int rank = 0;
+    for (int q = lo; q < hi; ++q) {
+      const int other = panel_ptr[q + 1] - panel_ptr[q];
+      rank += (other > mine || (other == mine && q < p)) ? 1 : 0;
+    }
+    order_out[lo + rank] = p;
+  }
+}
+
+inline int panel_order(const int* panel_ptr, int num_panels, int* order_out, hipStream_t stream) {
+  if (num_panels < 0) return kErrBadShape;
+  if (num_panels == 0) return kOk;
+  const int per_xcd = (num_panels + kNumXcd - 1) / kNumXcd;
+  hipLaunchKernelGGL(panel_order_kernel, dim3((num_panels + 255) / 256), dim3(256), 0, stream, panel_ptr, num_panels,
+                     per_xcd, order_out);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
 struct PlanWorkspace {
   int* shared_count;  // [NP]
   int* resid_count;   // [N]

@@ -202,6 +202,20 @@ def default_max_stages(blk_offsets: torch.Tensor, num_nodes: int) -> int:
 
 
 def unit_table(blk_offsets: torch.Tensor, num_nodes: int, max_stages: int = None, chunk: int = None) -> UnitTable:
+    """The handle's unit table (layout and rules: :func:`unit_table_torch`).  Built by the library's two-phase device
+    builder (``voltrix/unit_table.hpp`` through ``capi.build_unit_table`` -- the same entry points a C host binds);
+    the chunked listing (experiments) and CPU tensors go through the torch-tensor restatement, which the tests also use
+    to check the native table element by element."""
+    if chunk is not None or not blk_offsets.is_cuda:
+        return unit_table_torch(blk_offsets, num_nodes, max_stages, chunk)
+    from . import capi
+
+    units, unit_ptr, cuts, head = capi.build_unit_table(blk_offsets, num_nodes, 0 if max_stages is None else max_stages)
+    return UnitTable(units, unit_ptr, cuts, head[3], head[0], head[1], head[2], head[4] if num_nodes > 0 else
+                     (1 if max_stages is None else max_stages))
+
+
+def unit_table_torch(blk_offsets: torch.Tensor, num_nodes: int, max_stages: int = None, chunk: int = None) -> UnitTable:
     """Cut every window of more than ``max_stages`` stages (a stage = 4 TC blocks = one MFMA K step) into
     ``k = ceil(stages / max_stages)`` interleaved units -- unit j runs the stages j, j + k, j + 2k, ... -- so that every
     unit sweeps the window's whole (sorted) column range with at most ``max_stages`` stages.  Units of one XCD's window
