@@ -524,8 +524,11 @@ static __global__ __launch_bounds__(kSortThreads) void csr_window_fill_kernel(co
 // O(edges + num_nodes / 32) LDS operations, no sort, no key workspace, and the handle is written exactly once
 // (bitmap words of a window are staged in LDS, hind comes out of the bitmap scan in rank order).  Same output, bit
 // for bit, as the sort path and as the reference pipeline.
-constexpr int kBmThreads = 512;
-constexpr int kBmWaves = kBmThreads / kWave;
+// threads per workgroup: 512 when every window goes through these kernels (single range: 1024 costs 45 % on the
+// reddit-like graph, barriers), 1024 for the listed big windows of the mixed path (their sweeps are round-trip-bound:
+// power-law 4 M 84 -> 73 ms)
+constexpr int kBmThreadsAll = 512;
+constexpr int kBmThreadsListed = 1024;
 constexpr int kBmStageWords = 4096;      // 16 KiB: the packed words of kBmStageBlocks TC blocks / one sweep of hind
 constexpr int kBmStageBlocks = kBmStageWords / 4;
 constexpr int kBmGrid = 4096;            // grid-strided; ~5 rounds of workgroups even out the window sizes (measured)
@@ -540,15 +543,13 @@ inline size_t bm_fill_lds(int num_cols) {
 __device__ __forceinline__ int popc4(const uint4 v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
 
 constexpr int kBmBatch = 8;  // independent global loads in flight per thread (the loops are latency-bound otherwise)
-constexpr int kBmSweeps = kBmMaxCols / 128 / kBmThreads;  // 128-column groups per thread in a full range
-static_assert(kBmSweeps * kBmThreads * 128 == kBmMaxCols, "range = whole sweeps");
 
 // Universes above kBmMaxCols are covered in column RANGES of kBmMaxCols: one bitmap pass per range, the distinct-column
 // count carried from range to range (the window's edges are re-read from L2 by every pass).
 __host__ __device__ inline int bm_range_cols(int num_cols) { return num_cols < kBmMaxCols ? num_cols : kBmMaxCols; }
 
 // marks bit (c - c0) for every edge of the window with c in [c0, c0 + range)
-template <bool COUNT_INVALID>
+template <int kBmThreads, bool COUNT_INVALID>
 __device__ __forceinline__ void bm_mark_window(uint32_t* bitmap, const int* __restrict__ indices, const long long lo,
                                                const long long hi, const int c0, const int range, const int num_cols,
                                                int* status) {
@@ -571,6 +572,7 @@ __device__ __forceinline__ void bm_mark_window(uint32_t* bitmap, const int* __re
   }
 }
 
+template <int kBmThreads>
 static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_count_kernel(const int* __restrict__ indptr,
                                                                       const int* __restrict__ indices,
                                                                       const int num_nodes, const int num_cols,
@@ -579,6 +581,7 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_count_kernel(con
                                                                       int* __restrict__ status,
                                                                       const int* __restrict__ list,
                                                                       const int* __restrict__ list_count) {
+  constexpr int kBmWaves = kBmThreads / kWave;
   extern __shared__ uint4 bm_lds[];
   __shared__ int wave_cnt[kBmWaves];
   uint4* const bitmap4 = bm_lds;
@@ -596,7 +599,7 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_count_kernel(con
     int cnt = 0;
     for (int c0 = 0; c0 < num_cols; c0 += range_cols) {
       const int range = num_cols - c0 < range_cols ? num_cols - c0 : range_cols;
-      bm_mark_window<true>(bitmap, indices, lo, hi, c0, range, num_cols, status);
+      bm_mark_window<kBmThreads, true>(bitmap, indices, lo, hi, c0, range, num_cols, status);
       __syncthreads();
       for (int i = tid; i < ng; i += kBmThreads) {  // count and clear in one sweep
         cnt += popc4(bitmap4[i]);
@@ -618,6 +621,7 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_count_kernel(con
   }
 }
 
+template <int kBmThreads>
 static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_fill_kernel(const int* __restrict__ indptr,
                                                                      const int* __restrict__ indices,
                                                                      const int num_nodes, const int num_cols,
@@ -627,6 +631,9 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_fill_kernel(cons
                                                                      int* __restrict__ hind,
                                                                      const int* __restrict__ list,
                                                                      const int* __restrict__ list_count) {
+  constexpr int kBmWaves = kBmThreads / kWave;
+  constexpr int kBmSweeps = kBmMaxCols / 128 / kBmThreads;  // 128-column groups per thread in a full range
+  static_assert(kBmSweeps * kBmThreads * 128 == kBmMaxCols, "range = whole sweeps");
   extern __shared__ uint4 bm_lds[];
   __shared__ int wave_tot[kBmSweeps][kBmWaves];
   const int range_cols = bm_range_cols(num_cols);
@@ -659,7 +666,7 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_fill_kernel(cons
       const int range = num_cols - c0 < range_cols ? num_cols - c0 : range_cols;
       const bool last_range = c0 + range_cols >= num_cols;
       const int ngr = bm_groups(range);
-      bm_mark_window<false>(bitmap, indices, lo, hi, c0, range, num_cols, nullptr);
+      bm_mark_window<kBmThreads, false>(bitmap, indices, lo, hi, c0, range, num_cols, nullptr);
       __syncthreads();
 
       // scan the bitmap: group prefixes for the rank lookups, and hind = the set bits in ascending (= rank) order.
@@ -929,12 +936,16 @@ inline int csr_window_count(const int* indptr, const int* indices, int num_nodes
   }
   if (path != kCsrSort) {  // bitmap: every window; mixed: the windows csr_window_sort_kernel listed in queue2
     const size_t lds = bm_count_lds(num_cols);
-    if (int rc = bm_set_lds(csr_bitmap_count_kernel, lds)) return rc;
     const int grid = W < kBmGrid ? W : kBmGrid;
-    const bool listed = path == kCsrMixed;
-    hipLaunchKernelGGL(csr_bitmap_count_kernel, dim3(grid), dim3(kBmThreads), lds, stream, indptr, indices, num_nodes,
-                       num_cols, W, block_partition, status, listed ? ws.queue2 : nullptr,
-                       listed ? ws.counts + 1 : nullptr);
+    if (path == kCsrMixed) {
+      if (int rc = bm_set_lds(csr_bitmap_count_kernel<kBmThreadsListed>, lds)) return rc;
+      hipLaunchKernelGGL(csr_bitmap_count_kernel<kBmThreadsListed>, dim3(grid), dim3(kBmThreadsListed), lds, stream, indptr,
+                         indices, num_nodes, num_cols, W, block_partition, status, ws.queue2, ws.counts + 1);
+    } else {
+      if (int rc = bm_set_lds(csr_bitmap_count_kernel<kBmThreadsAll>, lds)) return rc;
+      hipLaunchKernelGGL(csr_bitmap_count_kernel<kBmThreadsAll>, dim3(grid), dim3(kBmThreadsAll), lds, stream, indptr,
+                         indices, num_nodes, num_cols, W, block_partition, status, nullptr, nullptr);
+    }
   }
   hipLaunchKernelGGL(scan_chunk_sums_kernel, dim3(nchunks), dim3(256), 0, stream, block_partition, W, chunk_sums);
   hipLaunchKernelGGL(scan_chunk_offsets_kernel, dim3(1), dim3(256), 0, stream, chunk_sums, nchunks);
@@ -952,12 +963,16 @@ inline int csr_fill(const int* indptr, const int* indices, int num_nodes, int nu
   const CsrWorkspace ws = csr_workspace(workspace, num_nodes, num_cols, num_edges);
   if (path != kCsrSort) {  // bitmap: every window; mixed: the windows of queue2 (the big ones go first: longest jobs)
     const size_t lds = bm_fill_lds(num_cols);
-    if (int rc = bm_set_lds(csr_bitmap_fill_kernel, lds)) return rc;
     const int grid = W < kBmGrid ? W : kBmGrid;
-    const bool listed = path == kCsrMixed;
-    hipLaunchKernelGGL(csr_bitmap_fill_kernel, dim3(grid), dim3(kBmThreads), lds, stream, indptr, indices, num_nodes,
-                       num_cols, W, pointer1, hspa_packed, hind, listed ? ws.queue2 : nullptr,
-                       listed ? ws.counts + 1 : nullptr);
+    if (path == kCsrMixed) {
+      if (int rc = bm_set_lds(csr_bitmap_fill_kernel<kBmThreadsListed>, lds)) return rc;
+      hipLaunchKernelGGL(csr_bitmap_fill_kernel<kBmThreadsListed>, dim3(grid), dim3(kBmThreadsListed), lds, stream, indptr,
+                         indices, num_nodes, num_cols, W, pointer1, hspa_packed, hind, ws.queue2, ws.counts + 1);
+    } else {
+      if (int rc = bm_set_lds(csr_bitmap_fill_kernel<kBmThreadsAll>, lds)) return rc;
+      hipLaunchKernelGGL(csr_bitmap_fill_kernel<kBmThreadsAll>, dim3(grid), dim3(kBmThreadsAll), lds, stream, indptr,
+                         indices, num_nodes, num_cols, W, pointer1, hspa_packed, hind, nullptr, nullptr);
+    }
   }
   if (path != kCsrBitmap) {
     const uint32_t* const keys = ws.keys;
