@@ -191,3 +191,34 @@ def test_mixed_path_power_law_windows(cuda_device, monkeypatch):
     assert int(per_window.max()) > 8192 and int(per_window.min()) < 2048 and int(((per_window > 2048) & (per_window <= 8192)).sum()) > 0
     p1, packed, hind, _ = voltrix.csr_fused_preprocess_kernel(ip, ix, n, num_cols=ncols)
     _check((p1, packed, hind), ip.cpu().numpy(), ix.cpu().numpy(), n)
+
+
+@pytest.mark.parametrize("path", ["sort", "mixed"])
+def test_bucket_ranking_mid_size_windows_and_clustered_columns(cuda_device, path, monkeypatch):
+    """Windows of 2049 .. 8192 edges take the bucket-ranking kernels (csr_bucket_count / _fill_kernel).  Six windows over
+    a 2 M-column universe: uniform columns; a tight band; 3000 edges on one column + singletons; exactly 8192 edges;
+    exactly 2049 edges; and a window whose 6000 edges sit on 900 neighbouring columns (the clustering test hands it on to
+    the workgroup sort / the bitmap kernels).  Oracle bytes on every route."""
+    monkeypatch.setenv("VOLTRIX_CSR_PATH", path)
+    rng = np.random.default_rng(77)
+    ncols = 2_000_000
+
+    def window(row_cols):
+        return [np.sort(np.asarray(c, np.int64)) for c in row_cols]
+
+    rows = []
+    rows += window([rng.choice(ncols, 300, replace=False) for _ in range(16)])                       # 4800 uniform
+    rows += window([700_000 + rng.choice(5000, 250, replace=False) for _ in range(16)])              # 4000 in a band
+    rows += window([np.concatenate([[123_456], rng.choice(ncols, 187, replace=False)]) for _ in range(16)])  # one hot column
+    rows += window([rng.choice(ncols, 512, replace=False) for _ in range(16)])                       # 8192 exactly
+    rows += window([rng.choice(ncols, 129 if r == 0 else 128, replace=False) for r in range(16)])    # 2049 exactly
+    rows += window([1_500_000 + rng.choice(900, 375, replace=False) for _ in range(16)])             # 6000 on 900 columns
+    rows = [np.unique(r) for r in rows]
+    indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    indices = np.concatenate(rows).astype(np.int32)
+    n = len(rows)
+    per_window = np.diff(indptr[::16])
+    assert per_window[3] == 8192 and per_window[4] == 2049 and (per_window > 2048).all()
+    ip, ix = torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda()
+    p1, packed, hind, _ = voltrix.csr_fused_preprocess_kernel(ip, ix, n, num_cols=ncols)
+    _check((p1, packed, hind), indptr, indices, n)

@@ -25,6 +25,8 @@
 //   3. csr_window_fill_kernel   zero the window's part of the handle; per sorted key: "first of its column" flags -> ballot/popcount prefix sum = condensed
 //                               column rank; hind[8*pointer1[w] + rank] = column; bit (row, rank) OR-ed into the
 //                               reference's swizzled word/bit position.
+//   Windows of kWsKeys .. kSortLdsKeys edges take csr_bucket_count / _fill_kernel instead (ids below 2^27): an O(n) bucket
+//   ranking in LDS, no sort (section "mid-size windows" below).
 //   Windows with <= kWsKeys edges take the csr_wave_* twins of steps 1 and 3: one WAVE per window -- the sort is a
 //   register-resident bitonic network (cross-lane shuffles, no LDS, no barriers), the fill stages the packed words in a
 //   wave-private LDS slice and writes them once.
@@ -310,10 +312,8 @@ static __global__ __launch_bounds__(kSortThreads) void csr_window_sort_kernel(co
                                                                        uint32_t* __restrict__ keys_ws,
                                                                        int* __restrict__ block_partition,
                                                                        int* __restrict__ status,
-                                                                       int* __restrict__ counts,
-                                                                       const int* __restrict__ queue,
-                                                                       const int big_limit,
-                                                                       int* __restrict__ queue2) {
+                                                                       const int* __restrict__ counts,
+                                                                       const int* __restrict__ queue) {
   __shared__ uint32_t lkeys[kSortLdsKeys];
   __shared__ int rowptr[kBlkH + 1];
   __shared__ int wave_cnt[kSortThreads / kWave];
@@ -327,11 +327,6 @@ static __global__ __launch_bounds__(kSortThreads) void csr_window_sort_kernel(co
     }
     __syncthreads();
     const int lo = rowptr[0], n = rowptr[kBlkH] - lo;
-    if (big_limit > 0 && n > big_limit) {  // mixed path: this window goes to the bitmap kernels (workgroup-uniform)
-      if (tid == 0) queue2[atomicAdd(&counts[1], 1)] = w;
-      __syncthreads();  // rowptr is rewritten by the next iteration
-      continue;
-    }
     uint32_t* const dst = keys_ws + lo;
     const bool in_lds = n <= kSortLdsKeys;  // workgroup-uniform
     for (int i = tid; i < n; i += kSortThreads) {
@@ -466,8 +461,7 @@ static __global__ __launch_bounds__(kSortThreads) void csr_window_fill_kernel(co
                                                                        uint32_t* __restrict__ hspa_packed,
                                                                        int* __restrict__ hind,
                                                                        const int* __restrict__ counts,
-                                                                       const int* __restrict__ queue,
-                                                                       const int big_limit) {
+                                                                       const int* __restrict__ queue) {
   __shared__ int wave_tot[kSortThreads / kWave];
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
   const int num_big = *counts;
@@ -476,7 +470,6 @@ static __global__ __launch_bounds__(kSortThreads) void csr_window_fill_kernel(co
     const long long r0 = (long long)w * kBlkH, r1 = r0 + kBlkH;
     const int lo = indptr[r0 < num_nodes ? r0 : num_nodes];
     const int n = indptr[r1 < num_nodes ? r1 : num_nodes] - lo;
-    if (big_limit > 0 && n > big_limit) continue;  // mixed path: csr_bitmap_fill_kernel's share (workgroup-uniform)
     const long long p0 = pointer1[w];
     {  // zero this window's part of the handle; the barrier (stores acknowledged by L2, same CU) orders it before the ORs
       const int nb = pointer1[w + 1] - (int)p0;
@@ -514,6 +507,270 @@ static __global__ __launch_bounds__(kSortThreads) void csr_window_fill_kernel(co
       carry += tot;
       __syncthreads();
     }
+  }
+}
+
+// ---- mid-size windows (kWsKeys < n <= kSortLdsKeys edges): bucket ranking, O(n) ------------------------------------
+// The bitonic network costs n lg^2 n / 2 compare-exchanges (a 4 k-edge window: ~120 us of a 256-thread workgroup).  Ranks
+// do not need a sort: spread the keys over NB = 4096 column buckets of equal width (range [cmin, cmax] of the window,
+// width a power of two: bucket order = column order), one LDS counter per bucket -- the returning atomic add is the key's
+// slot inside its bucket -- an exclusive scan of the counters, and the keys land bucket by bucket.  Inside a bucket (a few
+// keys) "first key of its column" and "distinct columns below mine" are pair comparisons.  Count kernel: distinct columns
+// = number of first flags; the bucket-ordered keys, first flag in bit 31, go to the key workspace.  Fill kernel: prefix
+// sum of the flags = rank of every bucket's first column, + the smaller first columns of the own bucket.
+// Windows whose columns cluster (sum of squared bucket sizes above kBkPairsPerKey x n: the pair loops would cost more
+// than the sort -- band graphs put half a window's edges into a handful of buckets) go on to the workgroup sort through
+// one queue, windows above kSortLdsKeys edges to the next kernels through another.
+// Needs column ids below 2^27 (bit 31 of the key is the flag).
+constexpr int kBkThreads = 256;
+constexpr int kBkBuckets = 4096;
+constexpr int kBkItems = kSortLdsKeys / kBkThreads;   // 32 keys per thread
+constexpr int kBkPairsPerKey = 8;    // clustering test: sum of squared bucket sizes <= 8 n (uniform columns: 1-3 n)
+constexpr unsigned kBkMaxCols = 1u << 27;
+constexpr uint32_t kBkFirst = 0x80000000u;
+
+struct BkLds {
+  uint32_t keys[kSortLdsKeys];
+  int start[kBkBuckets + 16];   // counters, then exclusive offsets; start[kBkBuckets] = n
+  int rowptr[kBlkH + 1];
+  int wsum[kBkThreads / kWave];
+  long long wsq[kBkThreads / kWave];
+  unsigned wmin[kBkThreads / kWave], wmax[kBkThreads / kWave];
+};
+
+// smallest shift with ((cmax - cmin) >> shift) < kBkBuckets
+__device__ __forceinline__ int bk_shift(const unsigned span) {
+  int shift = 0;
+  while ((span >> shift) >= (unsigned)kBkBuckets) ++shift;
+  return shift;
+}
+
+// workgroup min / max of the window's columns (every thread gets them)
+template <class Lds>
+__device__ __forceinline__ void bk_min_max(Lds& s, unsigned lo, unsigned hi, unsigned& cmin, unsigned& cmax) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    const unsigned a = (unsigned)__shfl_xor((int)lo, off, kWave), b = (unsigned)__shfl_xor((int)hi, off, kWave);
+    lo = a < lo ? a : lo;
+    hi = b > hi ? b : hi;
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+    s.wmin[threadIdx.x / kWave] = lo;
+    s.wmax[threadIdx.x / kWave] = hi;
+  }
+  __syncthreads();
+  cmin = s.wmin[0];
+  cmax = s.wmax[0];
+#pragma unroll
+  for (int k = 1; k < kBkThreads / kWave; ++k) {
+    cmin = s.wmin[k] < cmin ? s.wmin[k] : cmin;
+    cmax = s.wmax[k] > cmax ? s.wmax[k] : cmax;
+  }
+}
+
+static __global__ __launch_bounds__(kBkThreads) void csr_bucket_count_kernel(
+    const int* __restrict__ indptr, const int* __restrict__ indices, const int num_nodes, const unsigned col_limit,
+    uint32_t* __restrict__ keys_ws, int* __restrict__ block_partition, int* __restrict__ status,
+    int* __restrict__ counts /* [0] in, [1] too big, [2] done, [3] clustered */, const int* __restrict__ queue,
+    int* __restrict__ queue_big, int* __restrict__ queue_done, int* __restrict__ queue_clustered) {
+  __shared__ BkLds s;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  const int todo = counts[0];
+  for (int q = blockIdx.x; q < todo; q += gridDim.x) {
+    const int w = queue[q];
+    if (tid <= kBlkH) {
+      const long long r = (long long)w * kBlkH + tid;
+      s.rowptr[tid] = indptr[r < num_nodes ? r : num_nodes];
+    }
+    for (int i = tid; i < kBkBuckets / 4; i += kBkThreads) reinterpret_cast<uint4*>(s.start)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    const int lo = s.rowptr[0], n = s.rowptr[kBlkH] - lo;
+    if (n > kSortLdsKeys) {  // workgroup-uniform: the next kernels' share
+      if (tid == 0) queue_big[atomicAdd(&counts[1], 1)] = w;
+      __syncthreads();
+      continue;
+    }
+    // three sweeps over the window's edges (the first from HBM, the others out of L2): range, histogram, scatter --
+    // nothing per edge is kept in registers between them.  fn(i, column) for every edge i < n, 8 loads in flight.
+    auto for_each_edge = [&](auto fn) {
+      for (int base = tid; base < n; base += 8 * kBkThreads) {
+        uint32_t c[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c[k] = base + k * kBkThreads < n ? (uint32_t)indices[lo + base + k * kBkThreads] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (base + k * kBkThreads < n) fn(base + k * kBkThreads, c[k]);
+      }
+    };
+    unsigned mn = 0xFFFFFFFFu, mx = 0u;
+    int bad = 0;
+    for_each_edge([&](const int, const uint32_t col) {
+      bad += col >= col_limit ? 1 : 0;
+      const uint32_t m = col & (kBkMaxCols - 1u);  // ids outside the universe are reported (status); arithmetic stays in range
+      mn = m < mn ? m : mn;
+      mx = m > mx ? m : mx;
+    });
+    unsigned cmin, cmax;
+    bk_min_max(s, mn, mx, cmin, cmax);
+    const int shift = bk_shift(cmax - cmin);
+    for_each_edge([&](const int, const uint32_t col) { atomicAdd(&s.start[((col & (kBkMaxCols - 1u)) - cmin) >> shift], 1); });
+    __syncthreads();
+    // exclusive scan of the counters (16 per thread), sum of squares for the clustering test
+    int c[16];
+    int tot = 0;
+    long long sq = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      c[k] = s.start[16 * tid + k];
+      sq += (long long)c[k] * c[k];
+      tot += c[k];
+    }
+    const int inc = wave_inclusive_scan(tot);
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) sq += __shfl_xor(sq, off, kWave);
+    if (lane == kWave - 1) s.wsum[wv] = inc;
+    if (lane == 0) s.wsq[wv] = sq;
+    __syncthreads();
+    int run = inc - tot;
+    long long pairs = 0;
+#pragma unroll
+    for (int k = 0; k < kBkThreads / kWave; ++k) {
+      run += k < wv ? s.wsum[k] : 0;
+      pairs += s.wsq[k];
+    }
+    if (pairs > (long long)kBkPairsPerKey * n) {  // workgroup-uniform: clustered columns -> workgroup sort
+      if (tid == 0) queue_clustered[atomicAdd(&counts[3], 1)] = w;
+      __syncthreads();
+      continue;
+    }
+    if (bad) atomicAdd(status, bad);   // this kernel keeps the window: its out-of-universe ids are reported here, once
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      s.start[16 * tid + k] = run;
+      run += c[k];
+    }
+    __syncthreads();
+    // scatter: the returning add hands out the positions of a bucket; afterwards start[b] = END of bucket b (= start of b + 1)
+    for_each_edge([&](const int i, const uint32_t col) {
+      const uint32_t m = col & (kBkMaxCols - 1u);
+      int rl = 0;
+#pragma unroll
+      for (int k = 1; k < kBlkH; ++k) rl += (s.rowptr[k] <= lo + i) ? 1 : 0;
+      s.keys[atomicAdd(&s.start[(m - cmin) >> shift], 1)] = (m << 4) | (uint32_t)rl;
+    });
+    __syncthreads();
+    // first key of its column inside the bucket = no equal column at a lower position of the bucket.  Readers mask the
+    // flag bit, so the owner of a position may set it while others still compare against that key.
+    int firsts = 0;
+    for (int p = tid; p < n; p += kBkThreads) {
+      const uint32_t k = s.keys[p];
+      const uint32_t col = k >> 4;
+      const int bkt = (col - cmin) >> shift;
+      bool first = true;
+      for (int t = bkt ? s.start[bkt - 1] : 0; t < p; ++t) first = first && (((s.keys[t] & ~kBkFirst) >> 4) != col);
+      firsts += first ? 1 : 0;
+      if (first) s.keys[p] = k | kBkFirst;
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) firsts += __shfl_xor(firsts, off, kWave);
+    if (lane == 0) s.wsum[wv] = firsts;
+    __syncthreads();
+    uint32_t* const dst = keys_ws + lo;
+    for (int i = tid; i < n; i += kBkThreads) dst[i] = s.keys[i];
+    if (tid == 0) {
+      int u = 0;
+#pragma unroll
+      for (int k = 0; k < kBkThreads / kWave; ++k) u += s.wsum[k];
+      block_partition[w] = (u + kBlkW - 1) / kBlkW;   // n > kWsKeys here: never the empty-window case
+      queue_done[atomicAdd(&counts[2], 1)] = w;
+    }
+    __syncthreads();
+  }
+}
+
+struct BkFillLds {
+  uint32_t keys[kSortLdsKeys];
+  uint16_t pref[kSortLdsKeys + 2];   // first flags below the position
+  uint4 stage[kSortLdsKeys / kBlkW]; // packed words of up to 1024 TC blocks
+  int wsum[kBkThreads / kWave];
+  unsigned wmin[kBkThreads / kWave], wmax[kBkThreads / kWave];
+};
+
+static __global__ __launch_bounds__(kBkThreads) void csr_bucket_fill_kernel(
+    const int* __restrict__ indptr, const int num_nodes, const uint32_t* __restrict__ keys_ws,
+    const int* __restrict__ pointer1, uint32_t* __restrict__ hspa_packed, int* __restrict__ hind,
+    const int* __restrict__ counts /* [2] = windows in queue_done */, const int* __restrict__ queue_done) {
+  extern __shared__ __attribute__((aligned(16))) char bk_smem[];
+  BkFillLds& s = *reinterpret_cast<BkFillLds*>(bk_smem);
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wv = tid / kWave;
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = tid; i < kSortLdsKeys / kBlkW; i += kBkThreads) s.stage[i] = zero4;
+  __syncthreads();
+  const int todo = counts[2];
+  for (int q = blockIdx.x; q < todo; q += gridDim.x) {
+    const int w = queue_done[q];
+    const long long r0 = (long long)w * kBlkH, r1 = r0 + kBlkH;
+    const int lo = indptr[r0 < num_nodes ? r0 : num_nodes];
+    const int n = indptr[r1 < num_nodes ? r1 : num_nodes] - lo;
+    const long long p0 = pointer1[w];
+    const int nb = pointer1[w + 1] - (int)p0;
+    unsigned mn = 0xFFFFFFFFu, mx = 0u;
+    for (int i = tid; i < n; i += kBkThreads) {
+      const uint32_t k = keys_ws[lo + i];
+      s.keys[i] = k;
+      const unsigned col = (k & ~kBkFirst) >> 4;
+      mn = col < mn ? col : mn;
+      mx = col > mx ? col : mx;
+    }
+    unsigned cmin, cmax;
+    bk_min_max(s, mn, mx, cmin, cmax);
+    const int shift = bk_shift(cmax - cmin);
+    // exclusive prefix of the first flags: thread tid owns positions [tid * per, (tid + 1) * per)
+    const int per = (n + kBkThreads - 1) / kBkThreads;
+    const int a = tid * per < n ? tid * per : n, b = a + per < n ? a + per : n;
+    int mine = 0;
+    for (int p = a; p < b; ++p) mine += (s.keys[p] & kBkFirst) ? 1 : 0;
+    const int inc = wave_inclusive_scan(mine);
+    if (lane == kWave - 1) s.wsum[wv] = inc;
+    __syncthreads();
+    int run = inc - mine;
+#pragma unroll
+    for (int k = 0; k < kBkThreads / kWave; ++k) run += k < wv ? s.wsum[k] : 0;
+    for (int p = a; p < b; ++p) {
+      s.pref[p] = (uint16_t)run;
+      run += (s.keys[p] & kBkFirst) ? 1 : 0;
+    }
+    __syncthreads();
+    int* const hind_w = hind + 8 * p0;
+    uint32_t* const stage = reinterpret_cast<uint32_t*>(s.stage);
+    for (int p = tid; p < n; p += kBkThreads) {
+      const uint32_t k = s.keys[p];
+      const unsigned col = (k & ~kBkFirst) >> 4;
+      const unsigned bkt = (col - cmin) >> shift;
+      int lo_p = p;  // first position of the bucket
+      while (lo_p > 0 && ((((s.keys[lo_p - 1] & ~kBkFirst) >> 4) - cmin) >> shift) == bkt) --lo_p;
+      int rank = s.pref[lo_p];
+      for (int t = lo_p; t < n; ++t) {
+        const uint32_t kt = s.keys[t];
+        const unsigned ct = (kt & ~kBkFirst) >> 4;
+        if (((ct - cmin) >> shift) != bkt) break;
+        rank += ((kt & kBkFirst) && ct < col) ? 1 : 0;
+      }
+      if (k & kBkFirst) hind_w[rank] = (int)col;
+      const int rl = k & 15, c = rank & 7;
+      // reference bit order (bmat_kernels.cuh:180-188): word t = (r>>3) + 2*(c>>2), bit 4*(r&7) + (c&3)
+      atomicOr(&stage[4 * (rank >> 3) + (rl >> 3) + 2 * (c >> 2)], 1u << (4 * (rl & 7) + (c & 3)));
+    }
+    __syncthreads();
+    uint4* const out4 = reinterpret_cast<uint4*>(hspa_packed) + p0;
+    for (int i = tid; i < nb; i += kBkThreads) {
+      out4[i] = s.stage[i];
+      s.stage[i] = zero4;
+    }
+    // distinct columns = first flags in total = prefix at the last position + its flag
+    const int u = n > 0 ? (int)s.pref[n - 1] + ((s.keys[n - 1] & kBkFirst) ? 1 : 0) : 0;
+    for (int k = u + tid; k < 8 * nb; k += kBkThreads) hind_w[k] = 0;  // unused slots of the last block
+    __syncthreads();
   }
 }
 
@@ -867,19 +1124,26 @@ inline int bm_set_lds(K kernel, size_t bytes) {
 inline long long align16(long long x) { return (x + 15) & ~15ll; }
 
 // workspace: [sort / mixed: keys uint32[E]] [scan scratch int[nchunks]] [queue counts (16 B)] [sort / mixed: queue int[W]]
-// [mixed: queue2 int[W]]
+// [bucket kernels in use: queue_big int[W], queue_done int[W], queue_clustered int[W]]
 struct CsrWorkspace {
   uint32_t* keys;
   int* chunk_sums;
-  int* counts;   // [0] windows above kWsKeys edges (queue), [1] mixed path: of those, the windows above kSortLdsKeys (queue2)
+  int* counts;          // [0] windows above kWsKeys edges (queue); bucket kernels: of those, [1] the windows above kSortLdsKeys
+                        // edges (queue_big), [2] the ones they ranked (queue_done), [3] clustered columns (queue_clustered)
   int* queue;
-  int* queue2;
+  int* queue_big;
+  int* queue_done;
+  int* queue_clustered;
   long long bytes;
 };
+// the bucket kernels flag keys in bit 31: column ids below 2^27 (num_cols <= 0: unknown universe -> not used)
+inline bool csr_use_buckets(int num_cols) { return num_cols > 0 && (unsigned)num_cols <= kBkMaxCols; }
+
 inline CsrWorkspace csr_workspace(void* base, int num_nodes, int num_cols, long long num_edges) {
   const long long W = ((long long)num_nodes + kBlkH - 1) / kBlkH;
   const long long nchunks = (W + kScanChunk - 1) / kScanChunk + 1;
   const CsrPath path = csr_path(num_nodes, num_cols, num_edges);
+  const bool buckets = path != kCsrBitmap && csr_use_buckets(num_cols);
   char* p = static_cast<char*>(base);
   CsrWorkspace ws;
   ws.keys = reinterpret_cast<uint32_t*>(p);
@@ -890,8 +1154,12 @@ inline CsrWorkspace csr_workspace(void* base, int num_nodes, int num_cols, long 
   p += 16;
   ws.queue = reinterpret_cast<int*>(p);
   p += path == kCsrBitmap ? 0 : align16(W * 4);
-  ws.queue2 = reinterpret_cast<int*>(p);
-  p += path == kCsrMixed ? align16(W * 4) : 0;
+  ws.queue_big = reinterpret_cast<int*>(p);
+  p += buckets ? align16(W * 4) : 0;
+  ws.queue_done = reinterpret_cast<int*>(p);
+  p += buckets ? align16(W * 4) : 0;
+  ws.queue_clustered = reinterpret_cast<int*>(p);
+  p += buckets ? align16(W * 4) : 0;
   ws.bytes = p - static_cast<char*>(base);
   return ws;
 }
@@ -923,24 +1191,38 @@ inline int csr_window_count(const int* indptr, const int* indices, int num_nodes
   uint32_t* const keys = ws.keys;
   int* const chunk_sums = ws.chunk_sums;
   const int nchunks = (W + kScanChunk - 1) / kScanChunk;
+  // Windows up to kWsKeys edges: one wave each (sort in registers).  The rest is queued: bucket ranking for the windows
+  // up to kSortLdsKeys edges when the ids fit its key format (clustered ones: workgroup sort in LDS); the bigger windows
+  // -- or everything queued, without the bucket kernels -- go to the bitmap kernels (mixed path) or to the workgroup sort
+  // (sort path).
+  const bool buckets = path != kCsrBitmap && csr_use_buckets(num_cols);
+  const int* big_count = buckets ? ws.counts + 1 : ws.counts;
+  const int* big_queue = buckets ? ws.queue_big : ws.queue;
   if (path != kCsrBitmap) {
     const unsigned col_limit = num_cols > 0 ? (unsigned)num_cols : (1u << 28);
     const int wgs = (W + kWsWaves - 1) / kWsWaves;  // small windows: one wave each
-    if (hipMemsetAsync(ws.counts, 0, 2 * sizeof(int), stream) != hipSuccess) return kErrLaunch;
+    if (hipMemsetAsync(ws.counts, 0, 4 * sizeof(int), stream) != hipSuccess) return kErrLaunch;
     hipLaunchKernelGGL(csr_wave_sort_kernel, dim3(wgs < kWsGrid ? wgs : kWsGrid), dim3(kWsWaves * kWave), 0, stream,
                        indptr, indices, num_nodes, W, col_limit, keys, block_partition, status, ws.counts, ws.queue);
-    const int grid = W < 256 * 8 ? W : 256 * 8;  // windows above kWsKeys edges (queued above): one workgroup each
-    hipLaunchKernelGGL(csr_window_sort_kernel, dim3(grid), dim3(kSortThreads), 0, stream, indptr, indices, num_nodes,
-                       W, col_limit, keys, block_partition, status, ws.counts, ws.queue,
-                       path == kCsrMixed ? kSortLdsKeys : 0, ws.queue2);
+    const int grid = W < 256 * 8 ? W : 256 * 8;  // queued windows: one workgroup each
+    if (buckets) {
+      hipLaunchKernelGGL(csr_bucket_count_kernel, dim3(grid), dim3(kBkThreads), 0, stream, indptr, indices, num_nodes,
+                         col_limit, keys, block_partition, status, ws.counts, ws.queue, ws.queue_big, ws.queue_done,
+                         ws.queue_clustered);
+      hipLaunchKernelGGL(csr_window_sort_kernel, dim3(grid), dim3(kSortThreads), 0, stream, indptr, indices, num_nodes,
+                         W, col_limit, keys, block_partition, status, ws.counts + 3, ws.queue_clustered);
+    }
+    if (path == kCsrSort)
+      hipLaunchKernelGGL(csr_window_sort_kernel, dim3(grid), dim3(kSortThreads), 0, stream, indptr, indices, num_nodes,
+                         W, col_limit, keys, block_partition, status, big_count, big_queue);
   }
-  if (path != kCsrSort) {  // bitmap: every window; mixed: the windows csr_window_sort_kernel listed in queue2
+  if (path != kCsrSort) {  // bitmap: every window; mixed: the listed windows
     const size_t lds = bm_count_lds(num_cols);
     const int grid = W < kBmGrid ? W : kBmGrid;
     if (path == kCsrMixed) {
       if (int rc = bm_set_lds(csr_bitmap_count_kernel<kBmThreadsListed>, lds)) return rc;
       hipLaunchKernelGGL(csr_bitmap_count_kernel<kBmThreadsListed>, dim3(grid), dim3(kBmThreadsListed), lds, stream, indptr,
-                         indices, num_nodes, num_cols, W, block_partition, status, ws.queue2, ws.counts + 1);
+                         indices, num_nodes, num_cols, W, block_partition, status, big_queue, big_count);
     } else {
       if (int rc = bm_set_lds(csr_bitmap_count_kernel<kBmThreadsAll>, lds)) return rc;
       hipLaunchKernelGGL(csr_bitmap_count_kernel<kBmThreadsAll>, dim3(grid), dim3(kBmThreadsAll), lds, stream, indptr,
@@ -961,13 +1243,16 @@ inline int csr_fill(const int* indptr, const int* indices, int num_nodes, int nu
   if (W == 0) return kOk;
   const CsrPath path = csr_path(num_nodes, num_cols, num_edges);
   const CsrWorkspace ws = csr_workspace(workspace, num_nodes, num_cols, num_edges);
-  if (path != kCsrSort) {  // bitmap: every window; mixed: the windows of queue2 (the big ones go first: longest jobs)
+  const bool buckets = path != kCsrBitmap && csr_use_buckets(num_cols);
+  const int* big_count = buckets ? ws.counts + 1 : ws.counts;
+  const int* big_queue = buckets ? ws.queue_big : ws.queue;
+  if (path != kCsrSort) {  // bitmap: every window; mixed: the listed windows (the big ones go first: longest jobs)
     const size_t lds = bm_fill_lds(num_cols);
     const int grid = W < kBmGrid ? W : kBmGrid;
     if (path == kCsrMixed) {
       if (int rc = bm_set_lds(csr_bitmap_fill_kernel<kBmThreadsListed>, lds)) return rc;
       hipLaunchKernelGGL(csr_bitmap_fill_kernel<kBmThreadsListed>, dim3(grid), dim3(kBmThreadsListed), lds, stream, indptr,
-                         indices, num_nodes, num_cols, W, pointer1, hspa_packed, hind, ws.queue2, ws.counts + 1);
+                         indices, num_nodes, num_cols, W, pointer1, hspa_packed, hind, big_queue, big_count);
     } else {
       if (int rc = bm_set_lds(csr_bitmap_fill_kernel<kBmThreadsAll>, lds)) return rc;
       hipLaunchKernelGGL(csr_bitmap_fill_kernel<kBmThreadsAll>, dim3(grid), dim3(kBmThreadsAll), lds, stream, indptr,
@@ -980,8 +1265,16 @@ inline int csr_fill(const int* indptr, const int* indices, int num_nodes, int nu
     hipLaunchKernelGGL(csr_wave_fill_kernel, dim3(wgs < kWsGrid ? wgs : kWsGrid), dim3(kWsWaves * kWave), 0, stream,
                        indptr, num_nodes, W, keys, pointer1, hspa_packed, hind);
     const int grid = W < 256 * 8 ? W : 256 * 8;
-    hipLaunchKernelGGL(csr_window_fill_kernel, dim3(grid), dim3(kSortThreads), 0, stream, indptr, num_nodes, W, keys,
-                       pointer1, hspa_packed, hind, ws.counts, ws.queue, path == kCsrMixed ? kSortLdsKeys : 0);
+    if (buckets) {
+      if (int rc = bm_set_lds(csr_bucket_fill_kernel, sizeof(BkFillLds))) return rc;
+      hipLaunchKernelGGL(csr_bucket_fill_kernel, dim3(grid), dim3(kBkThreads), sizeof(BkFillLds), stream, indptr, num_nodes,
+                         keys, pointer1, hspa_packed, hind, ws.counts, ws.queue_done);
+      hipLaunchKernelGGL(csr_window_fill_kernel, dim3(grid), dim3(kSortThreads), 0, stream, indptr, num_nodes, W, keys,
+                         pointer1, hspa_packed, hind, ws.counts + 3, ws.queue_clustered);
+    }
+    if (path == kCsrSort)
+      hipLaunchKernelGGL(csr_window_fill_kernel, dim3(grid), dim3(kSortThreads), 0, stream, indptr, num_nodes, W, keys,
+                         pointer1, hspa_packed, hind, big_count, big_queue);
   }
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
