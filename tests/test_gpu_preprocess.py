@@ -193,12 +193,13 @@ def test_mixed_path_power_law_windows(cuda_device, monkeypatch):
     _check((p1, packed, hind), ip.cpu().numpy(), ix.cpu().numpy(), n)
 
 
+@pytest.mark.parametrize("shuffle", [False, True])
 @pytest.mark.parametrize("path", ["sort", "mixed"])
-def test_bucket_ranking_mid_size_windows_and_clustered_columns(cuda_device, path, monkeypatch):
-    """Windows of 2049 .. 8192 edges take the bucket-ranking kernels (csr_bucket_count / _fill_kernel).  Six windows over
+def test_bucket_ranking_mid_size_windows_and_clustered_columns(cuda_device, path, shuffle, monkeypatch):
+    """Windows of 2049 .. 8192 edges take the bucket-ranking kernels (csr_bucket_count / _fill_kernel).  Seven windows over
     a 2 M-column universe: uniform columns; a tight band; 3000 edges on one column + singletons; exactly 8192 edges;
-    exactly 2049 edges; and a window whose 6000 edges sit on 900 neighbouring columns (the clustering test hands it on to
-    the workgroup sort / the bitmap kernels).  Oracle bytes on every route."""
+    exactly 2049 edges; a window whose 6000 edges sit on 900 neighbouring columns (the clustering test hands it on to
+    the workgroup sort); and one of 11200 edges (global-memory sort, or the bitmap kernels on range-grouped keys).  Oracle bytes on every route."""
     monkeypatch.setenv("VOLTRIX_CSR_PATH", path)
     rng = np.random.default_rng(77)
     ncols = 2_000_000
@@ -213,12 +214,15 @@ def test_bucket_ranking_mid_size_windows_and_clustered_columns(cuda_device, path
     rows += window([rng.choice(ncols, 512, replace=False) for _ in range(16)])                       # 8192 exactly
     rows += window([rng.choice(ncols, 129 if r == 0 else 128, replace=False) for r in range(16)])    # 2049 exactly
     rows += window([1_500_000 + rng.choice(900, 375, replace=False) for _ in range(16)])             # 6000 on 900 columns
+    rows += window([rng.choice(ncols, 700, replace=False) for _ in range(16)])                       # 11200: above the LDS keys
     rows = [np.unique(r) for r in rows]
+    if shuffle:   # rows need not be sorted (the reference condenses through a std::map)
+        rows = [rng.permutation(r) for r in rows]
     indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
     indices = np.concatenate(rows).astype(np.int32)
     n = len(rows)
     per_window = np.diff(indptr[::16])
-    assert per_window[3] == 8192 and per_window[4] == 2049 and (per_window > 2048).all()
+    assert per_window[3] == 8192 and per_window[4] == 2049 and per_window[6] > 8192 and (per_window > 2048).all()
     ip, ix = torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda()
     p1, packed, hind, _ = voltrix.csr_fused_preprocess_kernel(ip, ix, n, num_cols=ncols)
     _check((p1, packed, hind), indptr, indices, n)

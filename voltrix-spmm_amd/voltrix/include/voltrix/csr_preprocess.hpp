@@ -829,6 +829,90 @@ __device__ __forceinline__ void bm_mark_window(uint32_t* bitmap, const int* __re
   }
 }
 
+// ---- listed (big) windows of the mixed path: the window's edges grouped by column range, once --------------------
+// Every range pass of the plain kernels sweeps ALL edges of the window (count 1 + fill 2 sweeps per range: 24 n edge reads
+// for 8 ranges).  For the listed windows the count kernel first writes the keys (column << 4 | local row) into the key
+// workspace grouped by range -- per-wave LDS counters, two sweeps -- and group_ptr[q][0 .. R] (q = position in the list);
+// afterwards every pass reads only its own group (count: 3 n edge reads, fill: 2 n).  Rows need not be sorted.
+constexpr int kBmMaxGroups = 16;   // = kMixedMaxPasses: the mixed path takes universes of up to 16 ranges
+
+// marks bit (column - c0) for the keys of one group
+template <int kBmThreads>
+__device__ __forceinline__ void bm_mark_keys(uint32_t* bitmap, const uint32_t* __restrict__ keys, const int count,
+                                             const int c0) {
+  for (int base = threadIdx.x; base < count; base += kBmBatch * kBmThreads) {
+    uint32_t k[kBmBatch];
+#pragma unroll
+    for (int u = 0; u < kBmBatch; ++u) k[u] = base + u * kBmThreads < count ? keys[base + u * kBmThreads] : 0u;
+#pragma unroll
+    for (int u = 0; u < kBmBatch; ++u) {
+      if (base + u * kBmThreads < count) {
+        const unsigned rel = (k[u] >> 4) - (unsigned)c0;
+        atomicOr(&bitmap[rel >> 5], 1u << (rel & 31));
+      }
+    }
+  }
+}
+
+// keys_out[0 .. valid) <- the window's edges grouped by column range (range = column / range_cols); gptr[0 .. R] <- group
+// boundaries; ids outside [0, num_cols) are dropped and counted.  cnt = LDS int[waves][kBmMaxGroups] scratch.
+template <int kBmThreads>
+__device__ __forceinline__ void bm_group_by_range(const int* __restrict__ indices, const int (&rp)[kBlkH + 1],
+                                                  const int num_cols, const int range_shift, const int nranges,
+                                                  uint32_t* __restrict__ keys_out, int* __restrict__ gptr,
+                                                  int* __restrict__ status, int* cnt /* LDS */) {
+  constexpr int kWaves = kBmThreads / kWave;
+  const int tid = threadIdx.x, wv = tid / kWave;
+  const int lo = rp[0], hi = rp[kBlkH];
+  for (int i = tid; i < kWaves * kBmMaxGroups; i += kBmThreads) cnt[i] = 0;
+  __syncthreads();
+  int bad = 0;
+  // sweep 1: edges per (wave, range); the same thread handles the same edges in both sweeps
+  for (int base = lo + tid; base < hi; base += kBmBatch * kBmThreads) {
+    int c[kBmBatch];
+#pragma unroll
+    for (int u = 0; u < kBmBatch; ++u) c[u] = base + u * kBmThreads < hi ? indices[base + u * kBmThreads] : -1;
+#pragma unroll
+    for (int u = 0; u < kBmBatch; ++u) {
+      if (base + u * kBmThreads < hi) {
+        if ((unsigned)c[u] < (unsigned)num_cols) atomicAdd(&cnt[wv * kBmMaxGroups + (c[u] >> range_shift)], 1);
+        else ++bad;
+      }
+    }
+  }
+  if (bad) atomicAdd(status, bad);
+  __syncthreads();
+  // exclusive scan, range-major / wave-minor (one thread: waves x ranges <= 256 values)
+  if (tid == 0) {
+    int run = 0;
+    for (int r = 0; r < nranges; ++r) {
+      gptr[r] = run;
+      for (int v = 0; v < kWaves; ++v) {
+        const int t = cnt[v * kBmMaxGroups + r];
+        cnt[v * kBmMaxGroups + r] = run;
+        run += t;
+      }
+    }
+    gptr[nranges] = run;
+  }
+  __syncthreads();
+  // sweep 2: scatter
+  for (int base = lo + tid; base < hi; base += kBmBatch * kBmThreads) {
+    int c[kBmBatch];
+#pragma unroll
+    for (int u = 0; u < kBmBatch; ++u) c[u] = base + u * kBmThreads < hi ? indices[base + u * kBmThreads] : -1;
+#pragma unroll
+    for (int u = 0; u < kBmBatch; ++u) {
+      const int e = base + u * kBmThreads;
+      if (e < hi && (unsigned)c[u] < (unsigned)num_cols) {
+        const int pos = atomicAdd(&cnt[wv * kBmMaxGroups + (c[u] >> range_shift)], 1);
+        keys_out[pos] = ((uint32_t)c[u] << 4) | (uint32_t)local_row(rp, e);
+      }
+    }
+  }
+  __syncthreads();
+}
+
 template <int kBmThreads>
 static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_count_kernel(const int* __restrict__ indptr,
                                                                       const int* __restrict__ indices,
@@ -837,10 +921,14 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_count_kernel(con
                                                                       int* __restrict__ block_partition,
                                                                       int* __restrict__ status,
                                                                       const int* __restrict__ list,
-                                                                      const int* __restrict__ list_count) {
+                                                                      const int* __restrict__ list_count,
+                                                                      uint32_t* __restrict__ keys_ws,
+                                                                      int* __restrict__ group_ptr) {
   constexpr int kBmWaves = kBmThreads / kWave;
   extern __shared__ uint4 bm_lds[];
   __shared__ int wave_cnt[kBmWaves];
+  __shared__ int group_cnt[kBmWaves * kBmMaxGroups];
+  __shared__ int gptr_s[kBmMaxGroups + 1];
   uint4* const bitmap4 = bm_lds;
   uint32_t* const bitmap = reinterpret_cast<uint32_t*>(bm_lds);
   const int range_cols = bm_range_cols(num_cols);
@@ -853,10 +941,21 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_count_kernel(con
     const int w = list ? list[q] : q;
     const long long r0 = (long long)w * kBlkH, r1 = r0 + kBlkH;
     const long long lo = indptr[r0 < num_nodes ? r0 : num_nodes], hi = indptr[r1 < num_nodes ? r1 : num_nodes];
+    const bool grouped = list != nullptr && group_ptr != nullptr;  // kernel-uniform
+    if (grouped) {
+      int rp[kBlkH + 1];
+      load_window_rowptr(indptr, w, num_nodes, rp);
+      const int nranges = (num_cols + range_cols - 1) / range_cols;
+      // several ranges: range_cols = 2^19; a single range (forced mixed path on a small universe): everything in group 0
+      bm_group_by_range<kBmThreads>(indices, rp, num_cols, nranges > 1 ? 31 - __clz(range_cols) : 31, nranges,
+                                    keys_ws + lo, gptr_s, status, group_cnt);
+      if (tid <= nranges) group_ptr[(long long)q * (kBmMaxGroups + 1) + tid] = gptr_s[tid];
+    }
     int cnt = 0;
-    for (int c0 = 0; c0 < num_cols; c0 += range_cols) {
+    for (int c0 = 0, r = 0; c0 < num_cols; c0 += range_cols, ++r) {
       const int range = num_cols - c0 < range_cols ? num_cols - c0 : range_cols;
-      bm_mark_window<kBmThreads, true>(bitmap, indices, lo, hi, c0, range, num_cols, status);
+      if (grouped) bm_mark_keys<kBmThreads>(bitmap, keys_ws + lo + gptr_s[r], gptr_s[r + 1] - gptr_s[r], c0);
+      else bm_mark_window<kBmThreads, true>(bitmap, indices, lo, hi, c0, range, num_cols, status);
       __syncthreads();
       for (int i = tid; i < ng; i += kBmThreads) {  // count and clear in one sweep
         cnt += popc4(bitmap4[i]);
@@ -887,8 +986,11 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_fill_kernel(cons
                                                                      uint32_t* __restrict__ hspa_packed,
                                                                      int* __restrict__ hind,
                                                                      const int* __restrict__ list,
-                                                                     const int* __restrict__ list_count) {
+                                                                     const int* __restrict__ list_count,
+                                                                     const uint32_t* __restrict__ keys_ws,
+                                                                     const int* __restrict__ group_ptr) {
   constexpr int kBmWaves = kBmThreads / kWave;
+  __shared__ int gptr_s[kBmMaxGroups + 1];
   constexpr int kBmSweeps = kBmMaxCols / 128 / kBmThreads;  // 128-column groups per thread in a full range
   static_assert(kBmSweeps * kBmThreads * 128 == kBmMaxCols, "range = whole sweeps");
   extern __shared__ uint4 bm_lds[];
@@ -917,13 +1019,24 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_fill_kernel(cons
     uint4* const out4 = reinterpret_cast<uint4*>(hspa_packed) + p0;
     int* const hind_w = hind + 8 * p0;
 
+    // listed windows of the mixed path: the count kernel left the keys grouped by range (bm_group_by_range)
+    const bool grouped = list != nullptr && group_ptr != nullptr;  // kernel-uniform
+    if (grouped) {
+      const int nranges = (num_cols + range_cols - 1) / range_cols;
+      if (tid <= nranges) gptr_s[tid] = group_ptr[(long long)q * (kBmMaxGroups + 1) + tid];
+      __syncthreads();
+    }
+
     int carry = 0;    // distinct columns of the ranges before the current one
     int flushed = 0;  // TC blocks of this window already written; block `flushed` starts at stage4[0]
-    for (int c0 = 0; c0 < num_cols; c0 += range_cols) {
+    for (int c0 = 0, rho = 0; c0 < num_cols; c0 += range_cols, ++rho) {
       const int range = num_cols - c0 < range_cols ? num_cols - c0 : range_cols;
       const bool last_range = c0 + range_cols >= num_cols;
       const int ngr = bm_groups(range);
-      bm_mark_window<kBmThreads, false>(bitmap, indices, lo, hi, c0, range, num_cols, nullptr);
+      const uint32_t* const gkeys = grouped ? keys_ws + lo + gptr_s[rho] : nullptr;
+      const int gcount = grouped ? gptr_s[rho + 1] - gptr_s[rho] : 0;
+      if (grouped) bm_mark_keys<kBmThreads>(bitmap, gkeys, gcount, c0);
+      else bm_mark_window<kBmThreads, false>(bitmap, indices, lo, hi, c0, range, num_cols, nullptr);
       __syncthreads();
 
       // scan the bitmap: group prefixes for the rank lookups, and hind = the set bits in ascending (= rank) order.
@@ -1012,18 +1125,21 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_fill_kernel(cons
       if (new_carry > carry) {
         const int last_blk = (new_carry - 1) >> 3;
         for (int pass0 = flushed;;) {
-          for (long long base = lo + tid; base < hi; base += (long long)kBmBatch * kBmThreads) {
+          // the edges of the range: (column, local row) from the window's CSR segment (every edge, filtered) or from the
+          // range's key group
+          const long long sweep_lo = grouped ? 0 : lo, sweep_hi = grouped ? gcount : hi;
+          for (long long base = sweep_lo + tid; base < sweep_hi; base += (long long)kBmBatch * kBmThreads) {
             int cs[kBmBatch];
 #pragma unroll
             for (int k = 0; k < kBmBatch; ++k) {
               const long long e = base + (long long)k * kBmThreads;
-              cs[k] = e < hi ? indices[e] : -1;
+              cs[k] = e < sweep_hi ? (grouped ? (int)gkeys[e] : indices[e]) : -1;
             }
 #pragma unroll
             for (int k = 0; k < kBmBatch; ++k) {
               const long long e = base + (long long)k * kBmThreads;
-              const unsigned rel = (unsigned)(cs[k] - c0);
-              if (e >= hi || rel >= (unsigned)range) continue;
+              const unsigned rel = (grouped ? (unsigned)cs[k] >> 4 : (unsigned)cs[k]) - (unsigned)c0;
+              if (e >= sweep_hi || rel >= (unsigned)range) continue;
               const int g = rel >> 7, wi = (rel >> 5) & 3;
               const uint4 v = bitmap4[g];
               const uint32_t below = (1u << (rel & 31)) - 1u;
@@ -1033,7 +1149,7 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_fill_kernel(cons
                                __popc(v.w & (wi == 3 ? below : 0u));
               const int blk = (rank >> 3) - pass0;
               if ((unsigned)blk >= (unsigned)kBmStageBlocks) continue;  // another pass owns this TC block
-              const int rl = local_row(rp, (int)e);
+              const int rl = grouped ? (cs[k] & 15) : local_row(rp, (int)e);
               const int cc = rank & 7;
               // reference bit order (bmat_kernels.cuh:180-188): word t = (r>>3) + 2*(c>>2), bit 4*(r&7) + (c&3)
               atomicOr(&stage[4 * blk + (rl >> 3) + 2 * (cc >> 2)], 1u << (4 * (rl & 7) + (cc & 3)));
@@ -1085,7 +1201,7 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_fill_kernel(cons
 //   sort    unknown universes; more ranges than that: bitmap or sort for every window by the same cost estimate.
 // VOLTRIX_CSR_PATH=sort|bitmap|mixed overrides (bitmap / mixed are honoured only when 0 < num_cols <= 2^25).
 enum CsrPath { kCsrSort = 0, kCsrBitmap = 1, kCsrMixed = 2 };
-constexpr int kMixedMaxPasses = 16;
+constexpr int kMixedMaxPasses = kBmMaxGroups;
 
 inline CsrPath csr_path(int num_nodes, int num_cols, long long num_edges) {
   if (num_cols <= 0 || num_nodes <= 0) return kCsrSort;
@@ -1134,6 +1250,7 @@ struct CsrWorkspace {
   int* queue_big;
   int* queue_done;
   int* queue_clustered;
+  int* group_ptr;       // mixed path: int[(E / kSortLdsKeys + 1)][kBmMaxGroups + 1], range groups of the listed windows
   long long bytes;
 };
 // the bucket kernels flag keys in bit 31: column ids below 2^27 (num_cols <= 0: unknown universe -> not used)
@@ -1160,6 +1277,8 @@ inline CsrWorkspace csr_workspace(void* base, int num_nodes, int num_cols, long 
   p += buckets ? align16(W * 4) : 0;
   ws.queue_clustered = reinterpret_cast<int*>(p);
   p += buckets ? align16(W * 4) : 0;
+  ws.group_ptr = reinterpret_cast<int*>(p);   // every listed window has more than kSortLdsKeys edges
+  p += path == kCsrMixed ? align16((num_edges / kSortLdsKeys + 1) * (kBmMaxGroups + 1) * 4) : 0;
   ws.bytes = p - static_cast<char*>(base);
   return ws;
 }
@@ -1222,11 +1341,12 @@ inline int csr_window_count(const int* indptr, const int* indices, int num_nodes
     if (path == kCsrMixed) {
       if (int rc = bm_set_lds(csr_bitmap_count_kernel<kBmThreadsListed>, lds)) return rc;
       hipLaunchKernelGGL(csr_bitmap_count_kernel<kBmThreadsListed>, dim3(grid), dim3(kBmThreadsListed), lds, stream, indptr,
-                         indices, num_nodes, num_cols, W, block_partition, status, big_queue, big_count);
+                         indices, num_nodes, num_cols, W, block_partition, status, big_queue, big_count, keys,
+                         buckets ? ws.group_ptr : nullptr);
     } else {
       if (int rc = bm_set_lds(csr_bitmap_count_kernel<kBmThreadsAll>, lds)) return rc;
       hipLaunchKernelGGL(csr_bitmap_count_kernel<kBmThreadsAll>, dim3(grid), dim3(kBmThreadsAll), lds, stream, indptr,
-                         indices, num_nodes, num_cols, W, block_partition, status, nullptr, nullptr);
+                         indices, num_nodes, num_cols, W, block_partition, status, nullptr, nullptr, nullptr, nullptr);
     }
   }
   hipLaunchKernelGGL(scan_chunk_sums_kernel, dim3(nchunks), dim3(256), 0, stream, block_partition, W, chunk_sums);
@@ -1252,11 +1372,12 @@ inline int csr_fill(const int* indptr, const int* indices, int num_nodes, int nu
     if (path == kCsrMixed) {
       if (int rc = bm_set_lds(csr_bitmap_fill_kernel<kBmThreadsListed>, lds)) return rc;
       hipLaunchKernelGGL(csr_bitmap_fill_kernel<kBmThreadsListed>, dim3(grid), dim3(kBmThreadsListed), lds, stream, indptr,
-                         indices, num_nodes, num_cols, W, pointer1, hspa_packed, hind, big_queue, big_count);
+                         indices, num_nodes, num_cols, W, pointer1, hspa_packed, hind, big_queue, big_count, ws.keys,
+                         buckets ? ws.group_ptr : nullptr);
     } else {
       if (int rc = bm_set_lds(csr_bitmap_fill_kernel<kBmThreadsAll>, lds)) return rc;
       hipLaunchKernelGGL(csr_bitmap_fill_kernel<kBmThreadsAll>, dim3(grid), dim3(kBmThreadsAll), lds, stream, indptr,
-                         indices, num_nodes, num_cols, W, pointer1, hspa_packed, hind, nullptr, nullptr);
+                         indices, num_nodes, num_cols, W, pointer1, hspa_packed, hind, nullptr, nullptr, nullptr, nullptr);
     }
   }
   if (path != kCsrBitmap) {
