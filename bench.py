@@ -347,6 +347,21 @@ def main():
 
     # ---- untimed comparison runs (N = 1): the window format alone, and a cold-cache timing --------------------------------
     extras = {}
+    if world > 1:
+        # the two halves of a step on their own ("report all-gather time and SpMM time separately + combined"):
+        # three all-gathers back to back on the communication stream, MAX over ranks; the local SpMM is roofline.kernel_ms
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(comm_stream):
+            for _ in range(3):
+                dist.all_gather_into_tensor(bufs[0], sends[0] if in_place else sends[0].clone())
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0) / 3 * 1e3], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        extras["allgather_ms"] = float(t)
+        extras["allgather_bytes_received_per_rank"] = (world - 1) * rows_padded * num_feats * gathered.element_size()
+        extras["local_spmm_ms"] = kernel_ms
     if world == 1 and not args.no_reference_formats:
         def time_ms(fn, iters=10):
             fn()
