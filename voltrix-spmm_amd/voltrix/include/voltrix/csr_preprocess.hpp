@@ -1199,7 +1199,7 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_fill_kernel(cons
 //           the power-law stand-in (4 M columns = 8 ranges; median window 3.2 k edges, 13 % of the windows above 8 k
 //           with 55 % of the edges) every window through the bitmap kernels cost ~100 us of sweeps and barriers;
 //   sort    unknown universes; more ranges than that: bitmap or sort for every window by the same cost estimate.
-// VOLTRIX_CSR_PATH=sort|bitmap|mixed overrides (bitmap / mixed are honoured only when 0 < num_cols <= 2^25).
+// VOLTRIX_CSR_PATH=sort|bitmap|mixed overrides (bitmap is honoured only when 0 < num_cols <= 2^25, mixed when <= 2^23).
 enum CsrPath { kCsrSort = 0, kCsrBitmap = 1, kCsrMixed = 2 };
 constexpr int kMixedMaxPasses = kBmMaxGroups;
 
@@ -1210,7 +1210,7 @@ inline CsrPath csr_path(int num_nodes, int num_cols, long long num_edges) {
   if (const char* e = std::getenv("VOLTRIX_CSR_PATH")) {
     if (e[0] == 's') return kCsrSort;
     if (e[0] == 'b') return kCsrBitmap;
-    if (e[0] == 'm') return kCsrMixed;
+    if (e[0] == 'm' && passes <= kMixedMaxPasses) return kCsrMixed;   // the range groups of the listed windows: <= 16
   }
   if (passes > 1 && passes <= kMixedMaxPasses) return kCsrMixed;
   const long long W = ((long long)num_nodes + kBlkH - 1) / kBlkH;
