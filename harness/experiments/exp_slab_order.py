@@ -20,6 +20,12 @@ import voltrix  # noqa: E402
 from voltrix import capi  # noqa: E402
 from voltrix.schedule import unit_table  # noqa: E402
 
+WIDE = {   # EXP_WIDE=1: 256-column slabs (512-byte row pieces) for the wide-feature cases
+    "reddit_like": [(512, (128, 3, 4)), (512, (256, 2, 4)), (512, (256, 3, 2)), (512, (256, 3, 1)), (256, (256, 2, 4)), (256, (256, 3, 2))],
+    "products_like": [(512, (64, 3, 4)), (512, (128, 3, 4)), (512, (256, 2, 4)), (512, (256, 3, 2)), (512, (256, 3, 1)), (256, (128, 3, 4)),
+                      (256, (256, 2, 4)), (256, (256, 3, 2)), (256, (256, 3, 1))],
+    "powerlaw_4m": [(256, (128, 3, 4)), (256, (256, 2, 4)), (256, (256, 3, 2)), (256, (256, 3, 1))],
+}
 CASES = {   # workload -> [(F, tile)]
     "reddit_like": [(64, (32, 4, 4)), (128, (64, 3, 4)), (128, (32, 4, 4)), (256, (128, 3, 4)), (256, (64, 3, 4)),
                     (512, (128, 3, 4)), (512, (128, 4, 4))],
@@ -50,7 +56,7 @@ def main():
         del indptr, indices
         tb = unit_table(h[0], n)
         print(f"{name}: N={n} nnz={e} units {tb.num_units} cuts {tb.num_cuts}", flush=True)
-        for F, tile in CASES[name]:
+        for F, tile in (WIDE if os.environ.get("EXP_WIDE") else CASES)[name]:
             feat = torch.randn(n, F, device=dev).half()
             out = torch.empty(n, F, device=dev)
             buf = torch.empty(max(1, tb.num_slots) * 16 * F, dtype=torch.float32, device=dev)
