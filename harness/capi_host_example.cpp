@@ -1,0 +1,238 @@
+// A host WITHOUT torch on libvoltrix_hip.so (include/voltrix_capi.h): plain hipMalloc buffers, the two-phase builders,
+// every launch on one hipStream_t pair -- the whole Route-B chain of INTEGRATION.md in ~250 lines of C++:
+//
+//   CSR (device) -> csr_window_count / csr_fill (the handle) -> unit_table_count / _fill -> spmm_f16_sched + combine_partials
+//                -> panel_plan_count / _fill + residual handle + panel_order -> zero C; panel kernel || window kernel; combine
+//
+// and checks both results against a plain CPU loop over the CSR (fp16-rounded B, double accumulation).
+//   build:  hipcc --offload-arch=gfx950 -O2 -std=c++17 -I include harness/capi_host_example.cpp \
+//                 -L voltrix-spmm_amd/lib -lvoltrix_hip -Wl,-rpath,$PWD/voltrix-spmm_amd/lib -o capi_host_example
+//   run:    ./capi_host_example [num_nodes] [mean_degree] [embedding_dim]      (exit code 0 = both formats agree with the CPU)
+// tests/test_gpu_capi_host.py builds and runs it on the GPU box.
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "voltrix_capi.h"
+
+#define HIP_OK(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      std::fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+      std::exit(2);                                                                        \
+    }                                                                                      \
+  } while (0)
+#define RC_OK(call)                                                         \
+  do {                                                                      \
+    int rc_ = -1;                                                           \
+    call;                                                                   \
+    if (rc_ != 0) {                                                         \
+      std::fprintf(stderr, "%s:%d return code %d\n", __FILE__, __LINE__, rc_); \
+      std::exit(3);                                                         \
+    }                                                                       \
+  } while (0)
+
+template <class T>
+static T* dev_alloc(size_t count) {
+  void* p = nullptr;
+  HIP_OK(hipMalloc(&p, std::max<size_t>(count, 4) * sizeof(T)));
+  return static_cast<T*>(p);
+}
+template <class T>
+static std::vector<T> to_host(const T* d, size_t count) {
+  std::vector<T> h(count);
+  if (count) HIP_OK(hipMemcpy(h.data(), d, count * sizeof(T), hipMemcpyDeviceToHost));
+  return h;
+}
+
+struct Handle {  // the reference's three tensors
+  int* blk_offsets;
+  uint32_t* hspa_packed;
+  int* hind;
+  int total_blocks;
+};
+
+static Handle preprocess(const int* d_indptr, const int* d_indices, int n, int num_cols, int64_t e, hipStream_t s) {
+  const int W = (n + VOLTRIX_BLK_H - 1) / VOLTRIX_BLK_H;
+  void* ws = dev_alloc<char>((size_t)voltrix_csr_preprocess_workspace_bytes(n, num_cols, e));
+  int* block_partition = dev_alloc<int>(W);
+  int* status = dev_alloc<int>(1);
+  Handle h{};
+  h.blk_offsets = dev_alloc<int>(W + 1);
+  RC_OK(voltrix_launch_csr_window_count((void*)d_indptr, (void*)d_indices, n, num_cols, e, ws, block_partition,
+                                        h.blk_offsets, status, s, &rc_));
+  int bad = 0;
+  HIP_OK(hipMemcpyAsync(&h.total_blocks, h.blk_offsets + W, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(&bad, status, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));  // the one host read that sizes the handle
+  if (bad) {
+    std::fprintf(stderr, "column ids outside the universe: %d\n", bad);
+    std::exit(4);
+  }
+  h.hspa_packed = dev_alloc<uint32_t>(4 * (size_t)h.total_blocks);
+  h.hind = dev_alloc<int>(8 * (size_t)h.total_blocks);
+  RC_OK(voltrix_launch_csr_fill((void*)d_indptr, (void*)d_indices, n, num_cols, e, ws, h.blk_offsets, h.hspa_packed,
+                                h.hind, s, &rc_));
+  HIP_OK(hipStreamSynchronize(s));
+  HIP_OK(hipFree(ws));
+  HIP_OK(hipFree(block_partition));
+  HIP_OK(hipFree(status));
+  return h;
+}
+
+struct UnitTable {
+  int *units, *unit_ptr, *cuts;
+  int header[8];
+};
+
+static UnitTable build_unit_table(const Handle& h, int n, hipStream_t s) {
+  UnitTable t{};
+  void* ws = dev_alloc<char>((size_t)voltrix_unit_table_workspace_bytes(n));
+  int* d_header = dev_alloc<int>(8);
+  RC_OK(voltrix_launch_unit_table_count(h.blk_offsets, n, /*max_stages=*/0, ws, d_header, s, &rc_));
+  HIP_OK(hipMemcpyAsync(t.header, d_header, sizeof(t.header), hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  const int num_units = t.header[0], num_cuts = t.header[1], top = t.header[5];
+  t.units = dev_alloc<int>(4 * (size_t)num_units);
+  t.cuts = dev_alloc<int>(4 * (size_t)num_cuts);
+  t.unit_ptr = dev_alloc<int>(9);
+  void* fill_ws = dev_alloc<char>((size_t)voltrix_unit_table_fill_workspace_bytes(num_units));
+  RC_OK(voltrix_launch_unit_table_fill(h.blk_offsets, n, ws, fill_ws, num_units, num_cuts, top, t.units, t.unit_ptr,
+                                       t.cuts, s, &rc_));
+  HIP_OK(hipStreamSynchronize(s));
+  HIP_OK(hipFree(ws));
+  HIP_OK(hipFree(fill_ws));
+  HIP_OK(hipFree(d_header));
+  return t;
+}
+
+static void window_spmm(const Handle& h, const UnitTable& t, int n, int num_edges, int f, const void* d_b, float* d_c,
+                        int atomic_out, float* partials, hipStream_t s) {
+  int fs, depth, waves;
+  voltrix_spmm_default_tile(f, 1, &fs, &depth, &waves);
+  RC_OK(voltrix_launch_spmm_f16_sched(h.blk_offsets, h.hspa_packed, h.hind, n, num_edges, f, (void*)d_b, d_c, fs, depth,
+                                      waves, /*window_order=*/nullptr, /*out_scale=*/nullptr, atomic_out, t.units,
+                                      t.unit_ptr, t.header[3], partials, /*row_map=*/nullptr, s, &rc_));
+}
+
+int main(int argc, char** argv) {
+  const int n = argc > 1 ? std::atoi(argv[1]) : 6000;
+  const int mean_degree = argc > 2 ? std::atoi(argv[2]) : 300;
+  const int f = argc > 3 ? std::atoi(argv[3]) : 128;
+  if (voltrix_abi_version() != VOLTRIX_ABI_VERSION) return 5;
+
+  // CSR: a third of a row's edges inside a band around the diagonal (shared columns for the panels), the rest anywhere;
+  // sorted, duplicate-free rows; a few empty rows and a few hubs (their windows are cut by the unit table)
+  std::mt19937 rng(7);
+  std::vector<int> indptr(n + 1, 0), indices;
+  std::vector<int> row;
+  for (int r = 0; r < n; ++r) {
+    row.clear();
+    const int deg = (r % 97 == 0) ? 0 : (r % 501 == 7 ? 8 * mean_degree : (int)(rng() % (2 * mean_degree)));  // hubs: cut windows
+    for (int k = 0; k < deg; ++k) {
+      const int c = (k % 3) ? (int)(rng() % n) : (int)(((long long)r + (long long)(rng() % 1024) - 512 + n) % n);
+      row.push_back(c);
+    }
+    std::sort(row.begin(), row.end());
+    row.erase(std::unique(row.begin(), row.end()), row.end());
+    indices.insert(indices.end(), row.begin(), row.end());
+    indptr[r + 1] = (int)indices.size();
+  }
+  const int64_t e = (int64_t)indices.size();
+  std::vector<__half> b((size_t)n * f);
+  std::uniform_real_distribution<float> dist(-1.f, 1.f);
+  for (auto& x : b) x = __float2half(dist(rng));
+
+  hipStream_t s_main, s_side;
+  HIP_OK(hipStreamCreate(&s_main));
+  HIP_OK(hipStreamCreate(&s_side));
+  int* d_indptr = dev_alloc<int>(n + 1);
+  int* d_indices = dev_alloc<int>(e);
+  __half* d_b = dev_alloc<__half>((size_t)n * f);
+  float* d_c = dev_alloc<float>((size_t)n * f);
+  HIP_OK(hipMemcpy(d_indptr, indptr.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(d_indices, indices.data(), e * sizeof(int), hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(d_b, b.data(), b.size() * sizeof(__half), hipMemcpyHostToDevice));
+
+  // CPU reference on the same fp16 operand
+  std::vector<double> ref((size_t)n * f, 0.0);
+  for (int r = 0; r < n; ++r)
+    for (int p = indptr[r]; p < indptr[r + 1]; ++p)
+      for (int k = 0; k < f; ++k) ref[(size_t)r * f + k] += (double)__half2float(b[(size_t)indices[p] * f + k]);
+  auto max_rel_err = [&](const std::vector<float>& got) {
+    double num = 0.0, den = 0.0;
+    for (size_t i = 0; i < ref.size(); ++i) {
+      num += (got[i] - ref[i]) * (got[i] - ref[i]);
+      den += ref[i] * ref[i];
+    }
+    return std::sqrt(num / std::max(den, 1e-30));
+  };
+
+  // ---- 1. window format: handle, unit table, SpMM, combine ------------------------------------------------------------------
+  const Handle h = preprocess(d_indptr, d_indices, n, n, e, s_main);
+  const UnitTable t = build_unit_table(h, n, s_main);
+  float* partials = dev_alloc<float>((size_t)std::max(1, t.header[2]) * 16 * f);
+  HIP_OK(hipMemsetAsync(d_c, 0xFF, (size_t)n * f * sizeof(float), s_main));  // NaN pattern: every element must be written
+  window_spmm(h, t, n, (int)e, f, d_b, d_c, /*atomic_out=*/0, partials, s_main);
+  RC_OK(voltrix_launch_combine_partials(t.cuts, t.header[1], partials, d_c, n, f, /*accumulate=*/0, nullptr, s_main, &rc_));
+  HIP_OK(hipStreamSynchronize(s_main));
+  const double err_window = max_rel_err(to_host(d_c, (size_t)n * f));
+
+  // ---- 2. two-level format: plan + residual handle, panel kernel || window kernel onto a zeroed C ----------------------------
+  const int waves = 8, row_blocks = 4, tau = 3, panel_rows = waves * row_blocks * 16;
+  const int num_panels = (n + panel_rows - 1) / panel_rows;
+  void* plan_ws = dev_alloc<char>((size_t)voltrix_panel_plan_workspace_bytes(n, waves, row_blocks));
+  int* panel_ptr = dev_alloc<int>(num_panels + 1);
+  int* resid_indptr = dev_alloc<int>(n + 1);
+  int* status = dev_alloc<int>(1);
+  RC_OK(voltrix_launch_panel_plan_count(d_indptr, d_indices, n, n, e, waves, row_blocks, tau, plan_ws, panel_ptr,
+                                        resid_indptr, status, s_main, &rc_));
+  int ksteps = 0, resid_edges = 0, bad = 0;
+  HIP_OK(hipMemcpyAsync(&ksteps, panel_ptr + num_panels, sizeof(int), hipMemcpyDeviceToHost, s_main));
+  HIP_OK(hipMemcpyAsync(&resid_edges, resid_indptr + n, sizeof(int), hipMemcpyDeviceToHost, s_main));
+  HIP_OK(hipMemcpyAsync(&bad, status, sizeof(int), hipMemcpyDeviceToHost, s_main));
+  HIP_OK(hipStreamSynchronize(s_main));
+  if (bad) return 6;
+  int* resid_indices = dev_alloc<int>(resid_edges);
+  int* panel_cols = dev_alloc<int>(32 * ((size_t)ksteps + 2));
+  uint32_t* panel_bits = dev_alloc<uint32_t>(((size_t)ksteps + 1) * waves * 64);
+  int* panel_order = dev_alloc<int>(num_panels);
+  RC_OK(voltrix_launch_panel_plan_fill(d_indptr, d_indices, n, n, e, waves, row_blocks, tau, plan_ws, panel_ptr,
+                                       resid_indptr, ksteps, resid_indices, panel_cols, panel_bits, s_main, &rc_));
+  RC_OK(voltrix_launch_panel_order(panel_ptr, num_panels, panel_order, s_main, &rc_));
+  const Handle hr = preprocess(resid_indptr, resid_indices, n, n, resid_edges, s_main);
+  const UnitTable tr = build_unit_table(hr, n, s_main);
+  float* partials_r = dev_alloc<float>((size_t)std::max(1, tr.header[2]) * 16 * f);
+
+  hipEvent_t fork, join;
+  HIP_OK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+  HIP_OK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+  HIP_OK(hipMemsetAsync(d_c, 0, (size_t)n * f * sizeof(float), s_main));
+  HIP_OK(hipEventRecord(fork, s_main));
+  HIP_OK(hipStreamWaitEvent(s_side, fork, 0));
+  RC_OK(voltrix_launch_spmm_panel_f16(panel_ptr, panel_cols, panel_bits, panel_order, n, f, d_b, d_c, /*accumulate=*/2,
+                                      /*fs=*/128, /*depth=*/3, waves, row_blocks, /*ksteps=*/1, /*out_scale=*/nullptr,
+                                      s_side, &rc_));
+  HIP_OK(hipEventRecord(join, s_side));
+  window_spmm(hr, tr, n, resid_edges, f, d_b, d_c, /*atomic_out=*/1, partials_r, s_main);
+  HIP_OK(hipStreamWaitEvent(s_main, join, 0));
+  RC_OK(voltrix_launch_combine_partials(tr.cuts, tr.header[1], partials_r, d_c, n, f, /*accumulate=*/1, nullptr, s_main,
+                                        &rc_));
+  HIP_OK(hipStreamSynchronize(s_main));
+  const double err_two_level = max_rel_err(to_host(d_c, (size_t)n * f));
+
+  std::printf("N=%d nnz=%lld F=%d | window format: %d TC blocks, %d units (%d cut windows), rel err %.3e | two-level: %d "
+              "k-steps, %d residual edges (%d units), rel err %.3e\n",
+              n, (long long)e, f, h.total_blocks, t.header[0], t.header[1], err_window, ksteps, resid_edges, tr.header[0],
+              err_two_level);
+  const bool ok = err_window < 1e-5 && err_two_level < 1e-5 && std::isfinite(err_window) && std::isfinite(err_two_level);
+  return ok ? 0 : 1;
+}
