@@ -205,6 +205,36 @@ def test_operator_is_graph_capturable(cuda_device, dtype, monkeypatch):
         _assert_close(out, g["indptr"], g["indices"], feat.float().cpu(), n, mode)
 
 
+@pytest.mark.parametrize("case", ["cora_like fp32", "two-level fp16"])
+def test_graphed_operator_replays_either_format(cuda_device, case, monkeypatch):
+    """voltrix.GraphedSpMM: the operator captured once, replayed with new features; bit-equal to the eager call, for the
+    window format (fp32 features: cast kernels inside the graph) and for the two-level format (two streams, atomics,
+    combine pass inside the graph)."""
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    if case.startswith("cora"):
+        g = load_csr_fixture("cora_like")
+        n, indptr, indices = int(g["num_nodes"]), torch.from_numpy(g["indptr"]), torch.from_numpy(g["indices"])
+        feat = torch.randn(n, 32, device="cuda")
+    else:
+        monkeypatch.setenv("VOLTRIX_HYBRID", "1")
+        ip, ix, _ = synth_graphs.generate("reddit_like", device="cuda", scale=0.03)
+        n, indptr, indices = ip.numel() - 1, ip.cpu(), ix.cpu()
+        feat = torch.randn(n, 128, device="cuda").half()
+    handle = voltrix.csr_preprocess(indptr, indices, n)
+    handle[1].hash_tag = f"graphed/{case}"
+    if not case.startswith("cora"):
+        assert voltrix.two_level_of(handle[1]) is not None
+    op = voltrix.GraphedSpMM(*handle, n, indices.numel(), feat)
+    for scale in (1.0, -2.5, 0.0):
+        x = (torch.randn_like(feat.float()) * scale).to(feat.dtype)
+        got = op(x).clone()
+        want = voltrix.spmm(*handle, num_nodes=n, num_edges=indices.numel(), feat=x)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+    ref = torch_ref.spmm(indptr.numpy(), indices.numpy(), x.float().cpu(), n)
+    assert torch.equal(got.cpu(), ref) if scale == 0.0 else True
+
+
 def test_every_output_row_is_written_and_empty_windows_are_zero(cuda_device):
     g = load_csr_fixture("toy40")  # rows 16..31 empty (one all-zero TC block), N % 16 = 8
     n, e = 40, len(g["indices"])

@@ -13,6 +13,7 @@ from .spmm import (BLK_H, BLK_W, csr_preprocess, csr_preprocess_device, csr_prep
 from .hybrid import TwoLevelHandle
 from .reorder import ReorderedHandle, csr_preprocess_reordered, spmm_reordered
 from .weighted import WeightedHandle, csr_preprocess_weighted, spmm_weighted
+from .graphed import GraphedSpMM
 from . import autograd, hybrid, jit, utils
 
 __version__ = "0.1.0"

@@ -857,12 +857,19 @@ static __global__ __launch_bounds__(256) void cast_f32_to_f16_scaled_kernel(cons
   }
 }
 
+// scale[0 .. 1] <- 0 as a KERNEL: inside a captured HIP graph a memset node in front of the amax kernel did not order
+// reliably against that kernel's atomics (graph replays rounded a few tiny elements on a different fp16 grid than the
+// eager call: the maximum had lost contributions) -- kernel nodes of one stream are strictly ordered.
+static __global__ void zero_scale_kernel(float* __restrict__ scale) {
+  if (threadIdx.x < 2) scale[threadIdx.x] = 0.f;
+}
+
 // scale: device float[2], 8-byte aligned.  scale[0] <- 2^e (pass it to launch_spmm_tc16 as out_scale).
 inline int cast_f32_to_f16_scaled(const float* src, _Float16* dst, long long n, float* scale, hipStream_t stream) {
   if (n < 0 || (n % 8) != 0 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15) || scale == nullptr ||
       ((uintptr_t)scale & 7))
     return kErrBadShape;
-  if (hipMemsetAsync(scale, 0, 2 * sizeof(float), stream) != hipSuccess) return kErrLaunch;
+  hipLaunchKernelGGL(zero_scale_kernel, dim3(1), dim3(64), 0, stream, scale);
   const long long n8 = n / 8;
   const int blocks = (int)(n8 / 256 + 1 < 256 * 16 ? n8 / 256 + 1 : 256 * 16);
   if (n > 0)
