@@ -19,10 +19,15 @@ from voltrix import capi, hybrid  # noqa: E402
 from voltrix.schedule import unit_table  # noqa: E402
 
 TILES = [(128, 3, 4), (128, 4, 4), (128, 2, 4), (128, 2, 8), (128, 3, 2), (128, 3, 1), (128, 2, 2), (128, 2, 1)]
+if os.environ.get("EXP_TILES") == "fs64":   # 64-column slabs (slab-major): eight waves with a three- or four-deep ring fit
+    TILES = [(128, 3, 4), (64, 3, 4), (64, 3, 8), (64, 4, 8), (64, 2, 8), (64, 4, 4)]
 
 
 def lds(fs, d, w):
     return w * (d * 32 * fs * 2 + (2 * d + 1) * 256)
+
+
+os.environ.setdefault("VOLTRIX_SLAB_ORDER", "major")
 
 
 def timeit(fn, iters=10, warm=3):
