@@ -160,7 +160,7 @@ def main():
     import voltrix
     from voltrix import dist as vdist
     from voltrix.jit_kernels import jit_tuner
-    from voltrix.jit_kernels.spmm import ORDER_CHUNKS, SCHED_UNITS
+    from voltrix.jit_kernels.spmm import ORDER_CHUNKS, SCHED_PAIRS, SCHED_UNITS
 
     workload = args.workload or ("reddit_like" if world == 1 else "papers_like")
     config_index = {"cora_like": 0, "reddit_like": 1, "reddit_uniform": 1, "products_like": 2, "powerlaw_4m": 3,
@@ -343,6 +343,9 @@ def main():
         s = p.get("SCHED")
         if s == SCHED_UNITS:
             return "unit table (windows cut at 1.5 x the median length, longest first) + combine pass"
+        if s == SCHED_PAIRS:
+            return ("unit table (windows cut at 1.25 x the median length, longest first), two units per wave "
+                    "(spmm_tc16_pair_kernel) + combine pass")
         return "natural window order" if s == 0 else f"balance schedule, chunk {ORDER_CHUNKS.get(s)}"
 
     # ---- untimed comparison runs (N = 1): the window format alone, and a cold-cache timing --------------------------------
@@ -413,11 +416,14 @@ def main():
                    "panel_rows": two.plan.panel_rows, "tau": two.plan.tau,
                    "shared_edge_fraction_rank0": two.plan.num_shared_edges / max(1, local_nnz),
                    "panel_ksteps_rank0": two.plan.num_ksteps, "residual_tc_blocks_rank0": resid_blocks}
-            kernels = "memset(C) ; spmm_panel_kernel || spmm_tc16_kernel ; combine_partials_kernel"
+            kernels = ("memset(C) ; spmm_panel_kernel || "
+                       + ("spmm_tc16_pair_kernel" if point.get("SCHED") == SCHED_PAIRS else "spmm_tc16_kernel")
+                       + " ; combine_partials_kernel")
         else:
             gather_bytes = 8 * total_blocks * num_feats * in_bytes  # rows gathered from L2 / Infinity Cache / HBM
             fmt = {"format": "window (the reference's block format)"}
-            kernels = "spmm_tc16_kernel" + (" ; combine_partials_kernel" if point.get("SCHED") == SCHED_UNITS else "")
+            kernels = ("spmm_tc16_pair_kernel" if point.get("SCHED") == SCHED_PAIRS else "spmm_tc16_kernel") + (
+                " ; combine_partials_kernel" if point.get("SCHED") in (SCHED_UNITS, SCHED_PAIRS) else "")
         tile_desc = {"fs": point.get("FS"), "depth": point.get("DEPTH"), "waves": point.get("WAVES"),
                      "schedule": sched_name(point)}
         counter_key = (f"{workload}|F{num_feats}|{args.dtype}|{'two-level' if used_two else 'window'}|"

@@ -120,7 +120,7 @@ static void window_spmm(const Handle& h, const UnitTable& t, int n, int num_edge
   voltrix_spmm_default_tile(f, 1, &fs, &depth, &waves);
   RC_OK(voltrix_launch_spmm_f16_sched(h.blk_offsets, h.hspa_packed, h.hind, n, num_edges, f, (void*)d_b, d_c, fs, depth,
                                       waves, /*window_order=*/nullptr, /*out_scale=*/nullptr, atomic_out, t.units,
-                                      t.unit_ptr, t.header[3], partials, /*row_map=*/nullptr, s, &rc_));
+                                      t.unit_ptr, t.header[3], partials, /*row_map=*/nullptr, /*units_per_wave=*/1, s, &rc_));
 }
 
 int main(int argc, char** argv) {

@@ -136,6 +136,11 @@ void voltrix_launch_spmm_bf16_tile(void* blk_offsets, void* hspa_packed, void* h
  *               of each cut window in unit order (deterministic) into output.  unit_ptr int32[9]: XCD x owns units
  *               [unit_ptr[x], unit_ptr[x+1]); max_units_per_xcd = the largest of those eight counts.  Every stage of
  *               every window must belong to exactly one unit.
+ *   units_per_wave  1, or 2 with a unit table and embedding_dim <= fs <= 128: every wave runs two consecutive units of the
+ *               table, their stages alternating through one ring into two accumulator sets (same bits as 1): twice the
+ *               windows sweep their sorted columns in step per CU at the same LDS and bytes in flight.  Measured beside the
+ *               panel kernel on the reddit-like graph with units cut at 1.25 x the median: 1.365 -> 1.293 ms.  Ignored
+ *               (= 1) where it does not apply.
  *   row_map     NULL, or int32[16 W]: row i of the handle is row row_map[i] of output (-1: a padding row, never
  *               written).  For handles built from a row-permuted CSR (locality reorder: rows that share columns grouped
  *               into the same 16-row windows -- the reference takes externally reordered graphs, bench/graph_gen.py:42-45):
@@ -144,12 +149,12 @@ void voltrix_launch_spmm_bf16_tile(void* blk_offsets, void* hspa_packed, void* h
 void voltrix_launch_spmm_f16_sched(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
                                    int embedding_dim, void* input, void* output, int fs, int depth, int waves,
                                    void* window_order, void* out_scale, int atomic_out, void* units, void* unit_ptr,
-                                   int max_units_per_xcd, void* partials, void* row_map, void* stream,
+                                   int max_units_per_xcd, void* partials, void* row_map, int units_per_wave, void* stream,
                                    int* return_code);
 void voltrix_launch_spmm_bf16_sched(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
                                     int embedding_dim, void* input, void* output, int fs, int depth, int waves,
                                     void* window_order, void* out_scale, int atomic_out, void* units, void* unit_ptr,
-                                    int max_units_per_xcd, void* partials, void* row_map, void* stream,
+                                    int max_units_per_xcd, void* partials, void* row_map, int units_per_wave, void* stream,
                                     int* return_code);
 /* cuts int32[num_cuts][4] = {window, first slot, units, 0} (16-byte aligned): output rows of `window` = (accumulate ?
  * output : 0) + partials[first slot] + partials[first slot + 1] + ... in that order.  Run it on the stream of the

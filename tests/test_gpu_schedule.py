@@ -83,3 +83,45 @@ def test_native_panel_order_equals_the_torch_restatement(cuda_device, num_panels
     ref = longest_first_order(panel_ptr)          # CPU tensor -> torch argsort
     assert native.is_cuda and torch.equal(native.cpu(), ref)
     assert torch.equal(torch.sort(native.cpu().long()).values, torch.arange(num_panels))
+
+
+@pytest.mark.parametrize("kind", ["f16", "bf16"])
+@pytest.mark.parametrize("name,scale,num_feats,max_stages", [("reddit_like", 0.05, 128, None), ("reddit_like", 0.05, 104, 13),
+                                                             ("products_like", 0.02, 128, 4), ("powerlaw_4m", 0.004, 72, None)])
+def test_two_units_per_wave_give_the_same_bits(cuda_device, kind, name, scale, num_feats, max_stages):
+    """spmm_tc16_pair_kernel (units_per_wave = 2): every wave runs two consecutive units of the table, stages alternating
+    through one ring into two accumulator sets.  Same bits as one unit per wave -- store mode and atomic mode onto zeros --
+    with odd unit counts per XCD, units of unequal length, empty windows, the N % 16 tail and a partially filled slab."""
+    indptr, indices, _ = synth_graphs.generate(name, device="cuda", scale=scale)
+    n, e = indptr.numel() - 1, indices.numel()
+    indptr = indptr.clone()
+    # a few empty rows -> empty windows (one all-zero TC block each)
+    h = voltrix.csr_fused_preprocess_kernel(indptr, indices, n)[:3]
+    tb = unit_table(h[0], n, max_stages)
+    dtype = torch.float16 if kind == "f16" else torch.bfloat16
+    feat = torch.randn(n, num_feats, device="cuda").to(dtype)
+    feat[0] = float("nan")   # row 0 of B is what padded slots and idle stages must never multiply in
+    s = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    for atomic in (False, True):
+        for nu in (1, 2):
+            out = torch.zeros(n, num_feats, device="cuda") if atomic else torch.full((n, num_feats), 7.0, device="cuda")
+            buf = torch.full((max(1, tb.num_slots) * 16 * num_feats,), float("nan"), device="cuda")
+            assert capi.launch_spmm_sched(h[0].data_ptr(), h[1].data_ptr(), h[2].data_ptr(), n, e, num_feats, feat.data_ptr(),
+                                          out.data_ptr(), (128, 3, 4), s, 0, 0, atomic, kind == "bf16", tb, buf.data_ptr(), 0,
+                                          nu) == 0
+            assert capi.launch_combine_partials(tb, buf.data_ptr(), out.data_ptr(), n, num_feats, atomic, s) == 0
+            outs[(atomic, nu)] = out
+    torch.cuda.synchronize()
+    for atomic in (False, True):   # NaN positions and every other bit
+        a, b = outs[(atomic, 1)], outs[(atomic, 2)]
+        assert torch.equal(torch.isnan(a), torch.isnan(b))
+        assert torch.equal(torch.nan_to_num(a, nan=0.0), torch.nan_to_num(b, nan=0.0))
+    # NaN only where row 0 of B is really referenced
+    deg0 = torch.zeros(n, dtype=torch.bool, device="cuda")
+    rows = torch.repeat_interleave(torch.arange(n, device="cuda"), (indptr[1:] - indptr[:-1]).long())
+    deg0[rows[indices.long() == 0]] = True
+    nan_rows = torch.isnan(outs[(False, 2)]).any(dim=1)
+    windows_with_nan = torch.zeros((n + 15) // 16, dtype=torch.bool, device="cuda")
+    windows_with_nan[(deg0.nonzero().flatten() // 16)] = True
+    assert not nan_rows[~windows_with_nan.repeat_interleave(16)[:n]].any()   # NaN stays inside the windows that gather row 0

@@ -28,7 +28,7 @@ def test_spmm_kernel_asserts_like_reference():
 
 
 def test_tile_space_is_valid_and_bounded(monkeypatch):
-    for mode, lo, hi in (("default", 16, 60), ("full", 36, 200), ("none", 1, 1)):
+    for mode, lo, hi in (("default", 16, 64), ("full", 36, 210), ("none", 1, 1)):
         monkeypatch.setenv("VOLTRIX_TUNE_SPACE", mode)
         for f in (16, 32, 64, 128, 512):
             for eb in (2, 4):
@@ -36,12 +36,16 @@ def test_tile_space_is_valid_and_bounded(monkeypatch):
                 assert lo <= len(space) <= hi, (mode, f, eb, len(space))
                 for p in space:
                     assert spmm_mod._lds_bytes(p["FS"], p["DEPTH"], p["WAVES"], p["EB"]) <= 160 * 1024
-                    assert p["EB"] == eb and p["FS"] in (32, 64, 128, 256) and p["SCHED"] in ((0, 1, 2, 3, 4) if eb == 2 else (0, 1, 2, 3))
+                    assert p["EB"] == eb and p["FS"] in (32, 64, 128, 256) and p["SCHED"] in ((0, 1, 2, 3, 4, 5) if eb == 2 else (0, 1, 2, 3))
+                    assert p["SCHED"] != 5 or (p["FS"] == 128 and f <= 128 and p["WAVES"] == 4)   # paired units: one slab
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
     # the single default point = the ahead-of-time library's default tile + the unit-table schedule
     assert spmm_mod.tile_space(128, 2) == ({"FS": 128, "DEPTH": 3, "WAVES": 4, "EB": 2, "SCHED": 4, "BF16": 0, "WEIGHTED": 0},)
     assert spmm_mod.tile_space(128, 2, bf16=True) == ({"FS": 128, "DEPTH": 3, "WAVES": 4, "EB": 2, "SCHED": 4, "BF16": 1, "WEIGHTED": 0},)
     assert spmm_mod.tile_space(64, 2) == ({"FS": 64, "DEPTH": 3, "WAVES": 4, "EB": 2, "SCHED": 4, "BF16": 0, "WEIGHTED": 0},)
+    # ... beside a panel workgroup (two-level format): two units per wave
+    assert spmm_mod.tile_space(128, 2, max_lds=spmm_mod.TWO_LEVEL_LDS_BUDGET) == (
+        {"FS": 128, "DEPTH": 3, "WAVES": 4, "EB": 2, "SCHED": 5, "BF16": 0, "WEIGHTED": 0},)
     assert spmm_mod.tile_space(128, 2, weighted=True) == ({"FS": 128, "DEPTH": 3, "WAVES": 4, "EB": 2, "SCHED": 4, "BF16": 0, "WEIGHTED": 1},)
     assert spmm_mod.tile_space(16, 4) == ({"FS": 32, "DEPTH": 3, "WAVES": 1, "EB": 4, "SCHED": 2, "BF16": 0, "WEIGHTED": 0},)
 

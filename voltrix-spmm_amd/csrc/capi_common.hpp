@@ -58,12 +58,13 @@ template <int FS, int D, int W, int EB, class In, bool BF16 = false>
 inline int launch_if_ok(const int* blk_offsets, const uint32_t* hspa_packed, const int* hind, int num_nodes,
                         int embedding_dim, const In* input, float* output, hipStream_t stream, const int* order,
                         const float* out_scale, int atomic_out, const int* units, const int* unit_ptr,
-                        int max_units_per_xcd, float* partials, const int* row_map) {
+                        int max_units_per_xcd, float* partials, const int* row_map, int units_per_wave) {
   if constexpr (tile_ok<FS, D, W, EB>()) {
     return voltrix::launch_spmm_tc16<voltrix::SpmmTile<FS, D, W, EB, BF16>>(blk_offsets, hspa_packed, hind, num_nodes,
                                                                        embedding_dim, input, output, stream, order,
                                                                        out_scale, atomic_out, units, unit_ptr,
-                                                                       max_units_per_xcd, partials, row_map);
+                                                                       max_units_per_xcd, partials, row_map, nullptr,
+                                                                       units_per_wave);
   } else {
     return voltrix::kErrBadConfig;
   }
@@ -74,10 +75,11 @@ inline int dispatch_spmm(int fs, int depth, int waves, const int* blk_offsets, c
                          const int* hind, int num_nodes, int embedding_dim, const In* input, float* output,
                          hipStream_t stream, const int* order, const float* out_scale = nullptr,
                          int atomic_out = 0, const int* units = nullptr, const int* unit_ptr = nullptr,
-                         int max_units_per_xcd = 0, float* partials = nullptr, const int* row_map = nullptr) {
+                         int max_units_per_xcd = 0, float* partials = nullptr, const int* row_map = nullptr,
+                         int units_per_wave = 1) {
 #define X(FS, D, W)                                  \
   if (fs == FS && depth == D && waves == W)          \
-    return launch_if_ok<FS, D, W, EB, In, BF16>(blk_offsets, hspa_packed, hind, num_nodes, embedding_dim, input, output, stream, order, out_scale, atomic_out, units, unit_ptr, max_units_per_xcd, partials, row_map);
+    return launch_if_ok<FS, D, W, EB, In, BF16>(blk_offsets, hspa_packed, hind, num_nodes, embedding_dim, input, output, stream, order, out_scale, atomic_out, units, unit_ptr, max_units_per_xcd, partials, row_map, units_per_wave);
   VOLTRIX_TILE_SPACE(X)
 #undef X
   return voltrix::kErrBadConfig;

@@ -20,7 +20,8 @@ void voltrix_launch_spmm_bf16_tile(void* blk_offsets, void* hspa_packed, void* h
 void voltrix_launch_spmm_bf16_sched(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
                                     int embedding_dim, void* input, void* output, int fs, int depth, int waves,
                                     void* window_order, void* out_scale, int atomic_out,
-                                    void* units, void* unit_ptr, int max_units_per_xcd, void* partials, void* row_map, void* stream,
+                                    void* units, void* unit_ptr, int max_units_per_xcd, void* partials, void* row_map,
+                                   int units_per_wave, void* stream,
                                     int* return_code) {
   (void)num_edges;
   *return_code = dispatch_spmm<2, voltrix::bfloat16_bits, true>(
@@ -29,7 +30,8 @@ void voltrix_launch_spmm_bf16_sched(void* blk_offsets, void* hspa_packed, void* 
       static_cast<float*>(output), static_cast<hipStream_t>(stream), static_cast<const int*>(window_order),
       static_cast<const float*>(out_scale), atomic_out,
                                             static_cast<const int*>(units), static_cast<const int*>(unit_ptr),
-                                            max_units_per_xcd, static_cast<float*>(partials), static_cast<const int*>(row_map));
+                                            max_units_per_xcd, static_cast<float*>(partials), static_cast<const int*>(row_map),
+                                            units_per_wave);
 }
 
 void voltrix_launch_spmm_bf16(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,

@@ -20,7 +20,8 @@ void voltrix_launch_spmm_f16_tile(void* blk_offsets, void* hspa_packed, void* hi
 void voltrix_launch_spmm_f16_sched(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int num_edges,
                                    int embedding_dim, void* input, void* output, int fs, int depth, int waves,
                                    void* window_order, void* out_scale, int atomic_out,
-                                   void* units, void* unit_ptr, int max_units_per_xcd, void* partials, void* row_map, void* stream,
+                                   void* units, void* unit_ptr, int max_units_per_xcd, void* partials, void* row_map,
+                                   int units_per_wave, void* stream,
                                    int* return_code) {
   (void)num_edges;
   *return_code = dispatch_spmm<2, _Float16>(fs, depth, waves, static_cast<const int*>(blk_offsets),
@@ -30,7 +31,8 @@ void voltrix_launch_spmm_f16_sched(void* blk_offsets, void* hspa_packed, void* h
                                             static_cast<const int*>(window_order),
                                             static_cast<const float*>(out_scale), atomic_out,
                                             static_cast<const int*>(units), static_cast<const int*>(unit_ptr),
-                                            max_units_per_xcd, static_cast<float*>(partials), static_cast<const int*>(row_map));
+                                            max_units_per_xcd, static_cast<float*>(partials), static_cast<const int*>(row_map),
+                                            units_per_wave);
 }
 
 void voltrix_launch_combine_partials(void* cuts, int num_cuts, void* partials, void* output, int num_nodes,

@@ -161,7 +161,7 @@ def launch_spmm(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
 
 def launch_spmm_sched(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input_ptr, output_ptr, tile,
                       stream, window_order=0, out_scale=0, atomic_out=False, bf16=False, table=None, partials=0,
-                      row_map=0) -> int:
+                      row_map=0, units_per_wave=1) -> int:
     """16-bit operand launch with the schedule / output extensions (include/voltrix_capi.h): ``atomic_out`` = add the
     result onto a pre-zeroed output with float atomics (two-level format without a join pass); ``table`` = a
     ``voltrix.schedule.UnitTable`` (replaces ``window_order``), ``partials`` = device pointer of its partial tiles.
@@ -175,7 +175,7 @@ def launch_spmm_sched(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embe
        ctypes.c_void_p(table.units.data_ptr() if table is not None else 0),
        ctypes.c_void_p(table.unit_ptr.data_ptr() if table is not None else 0),
        ctypes.c_int(table.max_units_per_xcd if table is not None else 0), ctypes.c_void_p(partials),
-       ctypes.c_void_p(row_map), ctypes.c_void_p(stream), ctypes.byref(rc))
+       ctypes.c_void_p(row_map), ctypes.c_int(int(units_per_wave)), ctypes.c_void_p(stream), ctypes.byref(rc))
     return rc.value
 
 

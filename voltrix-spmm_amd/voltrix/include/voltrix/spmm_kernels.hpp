@@ -206,8 +206,20 @@ struct SpmmArgs {
 
 // One wave64 = one (row window, FS-column slab) unit.  EB == 2: fp16 (or bfloat16) operand, v_mfma_f32_16x16x32_f16 (_bf16).
 // EB == 4: fp32 operand, exact products on v_mfma_f32_16x16x4_f32 (k-step m of a stage uses LDS rows 4m + lane/16).
-template <class T>
-static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const SpmmArgs<T> a) {
+template <int I, int N, class Fn>
+__device__ __forceinline__ void static_for(Fn&& fn) {
+  if constexpr (I < N) {
+    fn(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(fn);
+  }
+}
+
+// NU = units per wave (1, or 2 = "paired" launch of a unit table with F <= FS): a wave that runs two units takes their
+// stages alternately through ONE ring (stage t of the wave = stage t / 2 of unit t % 2) into two accumulator sets, so twice
+// as many windows sweep their sorted columns side by side per CU at the same LDS and the same bytes in flight.
+template <class T, int NU>
+__device__ __forceinline__ void spmm_tc16_body(const SpmmArgs<T>& a) {
+  static_assert(NU == 1 || NU == 2, "units per wave");
   constexpr int FS = T::FS, D = T::DEPTH, MS = T::META_SLOTS, EB = T::EB;
   constexpr int ROW_BYTES = T::ROW_BYTES, STAGE_BYTES = T::STAGE_BYTES, NDMA = T::DMA_PER_STAGE;
   constexpr int RPD = T::ROWS_PER_DMA, LPR = T::LANES_PER_ROW, SLOTS = T::SLOTS;
@@ -233,48 +245,63 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
   // few slots at the right time to keep its DMAs in flight, ran at half speed.  Measured on the reddit-like pair: 1.48 ->
   // 1.34 ms, both kernels finishing together (profiles/r02/experiment_corun_diag_setprio.log).  Alone it changes nothing.
   __builtin_amdgcn_s_setprio(3);
-  const int lu = (int)(blockIdx.x / kNumXcd) * T::WAVES + wave;      // unit of this wave inside the XCD's range
+  const int lu = ((int)(blockIdx.x / kNumXcd) * T::WAVES + wave) * NU;   // first unit of this wave inside the XCD's range
   if (w_count <= 0 || lu >= w_count * a.num_slabs) return;           // wave-uniform; the kernel has no barriers (<= 2^30 units: launcher)
   // window-major (the slabs of a window side by side: shared metadata, overlapping row neighbourhoods) or slab-major (the
   // whole range for slab 0, then slab 1, ...: one FS-wide column slab of B is the cache working set at a time)
-  const int wpos = w_begin + (a.slab_major ? lu % w_count : lu / a.num_slabs);
-  int w, st0 = 0, st_step = 1, slot = -1;   // the unit runs stages st0, st0 + st_step, ... of window w
-  if (a.units) {
-    const int4 u = a.units[wpos];
-    w = u.x;
-    st0 = u.y;
-    st_step = u.z;
-    slot = u.w;
-  } else {
-    w = a.window_order ? a.window_order[wpos] : wpos;
-  }
-  const int fs0 = (int)(a.slab_major ? lu / w_count : lu % a.num_slabs) * FS;
-
-  const int kb0 = a.blk_offsets[w];
-  const int kb1 = a.blk_offsets[w + 1];
-  const int nblk = kb1 - kb0;
-  const int nst_window = (nblk + kTcbPerStage - 1) / kTcbPerStage;
-  const int nst = st0 < nst_window ? (nst_window - st0 + st_step - 1) / st_step : 0;
-  const int F = a.F;
-  auto stage_of = [&](int tau) -> int { return st0 + st_step * tau; };                         // stage of the window
-  auto stage_block = [&](int tau) -> int { return kb0 + kTcbPerStage * stage_of(tau); };       // its first TC block
-
-  float4_t acc[SLOTS];
+  // (NU == 2: one slab only -- launcher -- so position = unit)
+  int w[NU], st0[NU], st_step[NU], slot[NU];   // unit p runs stages st0, st0 + st_step, ... of window w
+  int kb0[NU], kb1[NU], nst_u[NU], h_safe[NU];
+  bool present[NU];
+  int nst_max = 0;
 #pragma unroll
-  for (int s = 0; s < SLOTS; ++s) acc[s] = float4_t{0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < NU; ++p) {
+    present[p] = lu + p < w_count * a.num_slabs;
+    const int lup = present[p] ? lu + p : lu;   // an odd unit out: the wave's second unit is a copy that does nothing
+    const int wpos = w_begin + (a.slab_major ? lup % w_count : lup / a.num_slabs);
+    st0[p] = 0;
+    st_step[p] = 1;
+    slot[p] = -1;
+    if (a.units) {
+      const int4 u = a.units[wpos];
+      w[p] = u.x;
+      st0[p] = u.y;
+      st_step[p] = u.z;
+      slot[p] = u.w;
+    } else {
+      w[p] = a.window_order ? a.window_order[wpos] : wpos;
+    }
+    kb0[p] = a.blk_offsets[w[p]];
+    kb1[p] = a.blk_offsets[w[p] + 1];
+    const int nblk = kb1[p] - kb0[p];
+    const int nst_window = (nblk + kTcbPerStage - 1) / kTcbPerStage;
+    nst_u[p] = st0[p] < nst_window ? (nst_window - st0[p] + st_step[p] - 1) / st_step[p] : 0;
+    // a window without edges owns one all-zero TC block (reference quirk, bmat_kernels.cuh:252): nothing to gather
+    if (nblk == 1) {
+      const uint4 w4 = *reinterpret_cast<const uint4*>(a.hspa_packed + 4ll * kb0[p]);
+      if ((w4.x | w4.y | w4.z | w4.w) == 0u) nst_u[p] = 0;
+    }
+    if (!present[p]) nst_u[p] = 0;
+    h_safe[p] = a.hind[8ll * kb0[p]];  // first real column of the window: finite data, gathered anyway
+    nst_max = nst_u[p] > nst_max ? nst_u[p] : nst_max;
+  }
+  const int nst = NU * nst_max;   // stages of the wave: stage t = stage t / NU of unit t % NU (a unit past its end idles)
+  const int fs0 = (int)(a.slab_major ? lu / w_count : lu % a.num_slabs) * FS;
+  const int F = a.F;
+  auto stage_of = [&](int t) -> int { return st0[t % NU] + st_step[t % NU] * (t / NU); };        // stage of its window
+  auto stage_block = [&](int t) -> int { return kb0[t % NU] + kTcbPerStage * stage_of(t); };     // its first TC block
+  auto stage_end = [&](int t) -> int { return kb1[t % NU]; };                                     // end of its window
+
+  float4_t acc[NU][SLOTS];
+#pragma unroll
+  for (int p = 0; p < NU; ++p)
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) acc[p][s] = float4_t{0.f, 0.f, 0.f, 0.f};
 
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem + (unsigned)wave * T::WAVE_LDS;
   const unsigned meta0 = lds0 + D * STAGE_BYTES;
 
-  // a window without edges owns one all-zero TC block (reference quirk, bmat_kernels.cuh:252): nothing to gather
-  bool empty = false;
-  if (nblk == 1) {
-    const uint4 w4 = *reinterpret_cast<const uint4*>(a.hspa_packed + 4ll * kb0);
-    empty = (w4.x | w4.y | w4.z | w4.w) == 0u;
-  }
-
-  if (nst > 0 && !empty) {
-    const int h_safe = a.hind[8ll * kb0];  // first real column of the window: finite data, gathered anyway
+  if (nst > 0) {
 
     // ---- lane constants -------------------------------------------------------------------------------------
     const int k32 = lane & 31;             // condensed column of the stage this lane holds metadata for
@@ -301,14 +328,14 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
 
     // metadata of a stage that lies fully inside the window: lane address = base + tau * stride (one 64-bit mad);
     // lanes 0-31 fetch hind[8 * block + k32] (32 ints / stage), lanes 32-63 the 16 bitmap words of the stage
-    const char* const meta_base = lane < 32 ? (const char*)(a.hind + (8ll * kb0 + k32))
-                                            : (const char*)(a.hspa_packed + (4ll * kb0 + mj));
-    const unsigned meta_stride = lane < 32 ? 4u * 8u * kTcbPerStage : 4u * 4u * kTcbPerStage;
+    const char* const meta_base = lane < 32 ? (const char*)(a.hind + k32) : (const char*)(a.hspa_packed + mj);
+    const unsigned meta_blk_bytes = lane < 32 ? 4u * 8u : 4u * 4u;   // bytes per TC block in hind / hspa_packed
     auto issue_meta = [&](int tau, int mslot) {
       const void* src;
       const int sb = stage_block(tau);
+      const int kb1 = stage_end(tau);
       if (sb + kTcbPerStage <= kb1) {  // wave-uniform
-        src = meta_base + (unsigned long long)(unsigned)stage_of(tau) * meta_stride;
+        src = meta_base + (unsigned long long)(unsigned)sb * meta_blk_bytes;
       } else if (lane < 32) {
         int blk = sb + kblk;
         blk = blk < kb1 ? blk : kb1 - 1;  // stay inside the window: stages past its end re-read its last block
@@ -338,9 +365,13 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
     // address = cbase[i] + hr[i] * row_bytes -- one v_mad_u64_u32 per DMA.  cbase[i] already carries the -K KiB that
     // the instruction's immediate offset (K = i % 4, shared M0) adds back.
     const unsigned row_bytes = (unsigned)F * EB;
-    const char* cbase[NDMA];
+    // DMAs i and i + 4 of a stage (FS = 128, 16-bit operand: 4 rows per DMA) gather the same chunk column with the same
+    // immediate offset: the swizzle of LDS row 4 i + x repeats with period 16 rows -- four base pointers serve eight DMAs
+    constexpr int NBASE = (EB == 2 && NDMA == 8 && RPD == 4) ? 4 : NDMA;
+    static_assert(NBASE == NDMA || slot_swizzle<SLOTS>(4 * RPD + 1) == slot_swizzle<SLOTS>(1), "period of the row swizzle");
+    const char* cbase[NBASE];
 #pragma unroll
-    for (int i = 0; i < NDMA; ++i) {
+    for (int i = 0; i < NBASE; ++i) {
       const int r = i * RPD + lane / LPR;       // LDS row written by this lane
       const int c = lane % LPR;                 // 16-byte chunk inside the row
       int col;                                  // logical column of that chunk (swizzle on the SOURCE)
@@ -361,7 +392,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
           const int i = ib + K;
           unsigned hrow = (unsigned)hr[i];
           if (VOLTRIX_DIAG & 2) hrow &= 1023u;
-          const char* src = cbase[i] + (unsigned long long)hrow * row_bytes;
+          const char* src = cbase[i % NBASE] + (unsigned long long)hrow * row_bytes;
           __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(uintptr_t)(dst + ib * 1024), 16, K * 1024, 0);
         }
       };
@@ -386,9 +417,9 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
     };
 
     auto sanitise = [&](int tau, unsigned hraw, uint2_t vw) -> int {
-      const bool inwin = (stage_block(tau) + kblk) < kb1;
+      const bool inwin = (stage_block(tau) + kblk) < stage_end(tau);
       const bool valid = inwin && (((vw[0] | vw[1]) & colmask) != 0u);
-      return valid ? (int)hraw : h_safe;  // padded hind slots are 0 in the format: never gather B[0] for them
+      return valid ? (int)hraw : h_safe[tau % NU];  // padded hind slots are 0 in the format: never gather B[0] for them
     };
 
     // ---- prologue: metadata of stages 0..D-1, then (metadata D+j, rows of stage j) for j < D -------------------
@@ -414,13 +445,19 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
     int mslot = 0;                  // t % MS
     int mslot_d = D;                // (t + D) % MS
     int mslot_2d = (2 * D) % MS;    // (t + 2D) % MS
+    auto kb1_of = [&](int p) -> int { return kb1[p]; };
     // One step = consume stage t, refill its ring slot with stage t+D.  MORE (= t + D < nst) is static: the steady
     // loop always refills and always waits with the same count, the last D steps only drain.
-    auto step = [&](int t, auto more_c) {
+    auto step = [&](int t, auto more_c, auto unit_c) {
       constexpr bool more = decltype(more_c)::value;
+      constexpr int P = decltype(unit_c)::value;   // = t % NU: the unit whose stage is consumed (accumulator set)
+      const int kb1 = kb1_of(P);
+      // wave-uniform: a unit past its end re-gathers its last block with a zero A fragment (keeps the DMA count static); the
+      // accumulators of a unit that never had a stage (empty window, odd unit out) are not stored at all (epilogue)
+      const bool live = NU == 1 || t / NU < nst_u[P];
       const unsigned mt = meta0 + mslot * T::META_BYTES;
       // padded hind slots exist only in a window's last TC block: every earlier stage takes hind as it is
-      const bool tail_stage = stage_block(t + D) + kTcbPerStage >= kb1;  // wave-uniform
+      const bool tail_stage = stage_block(t + D) + kTcbPerStage >= stage_end(t + D);  // wave-uniform
       unsigned hraw = 0;
       uint2_t vw = {0u, 0u};
       int hr[NDMA];
@@ -461,40 +498,51 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
         for (int b = 0; (1 << b) < SLOTS; ++b)
 #pragma unroll
           for (int s = (1 << b); s < (2 << b) && s < SLOTS; ++s) taddr[s] = taddr[s - (1 << b)] + tr_delta[b];
-        uint2_t blo[SLOTS], bhi[SLOTS];
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-          blo[s] = lds_read_tr16_b64<0>(taddr[s]);
-          bhi[s] = lds_read_tr16_b64<4 * ROW_BYTES>(taddr[s]);
-        }
-        wait_lgkmcnt0();
-
-        // refill: metadata for stage t+2D (always: keeps the vmcnt arithmetic static), rows for stage t+D
-        issue_meta(t + 2 * D, mslot_2d);
-        if (more) {
-          if (tail_stage) rows_from_columns(sanitise(t + D, hraw, vw), hr);
-          issue_data(dslot, hr);
-        }
-
-        half8_t afrag;
-        if constexpr (T::WEIGHTED) {
-          uint4_t av = avals;
-          if (stage_block(t) + g >= kb1) av = uint4_t{0u, 0u, 0u, 0u};  // TC blocks past the window's end contribute zero
-          afrag = __builtin_bit_cast(half8_t, av);
-        } else {
-          unsigned nl = (wlo >> a_shift) & 0xFu, nh = (whi >> a_shift) & 0xFu;
-          if (stage_block(t) + g >= kb1) nl = nh = 0u;  // TC blocks past the window's end contribute zero
-          afrag = nibbles_to_half8_x2(nl, nh);
-        }
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-          const uint4_t bq = {blo[s][0], blo[s][1], bhi[s][0], bhi[s][1]};
+        // A fragment first (its LDS words were requested above); B fragments in one go, or -- two units per wave, where the
+        // second accumulator set has taken the registers -- in two halves, the ring slot being refilled after the last read
+        auto a_fragment = [&]() -> half8_t {
+          if constexpr (T::WEIGHTED) {
+            uint4_t av = avals;
+            if (stage_block(t) + g >= kb1 || !live) av = uint4_t{0u, 0u, 0u, 0u};  // TC blocks past the window's end contribute zero
+            return __builtin_bit_cast(half8_t, av);
+          } else {
+            unsigned nl = (wlo >> a_shift) & 0xFu, nh = (whi >> a_shift) & 0xFu;
+            if (stage_block(t) + g >= kb1 || !live) nl = nh = 0u;  // TC blocks past the window's end contribute zero
+            return nibbles_to_half8_x2(nl, nh);
+          }
+        };
+        auto refill = [&]() {  // metadata for stage t+2D (always: keeps the vmcnt arithmetic static), rows for stage t+D
+          issue_meta(t + 2 * D, mslot_2d);
+          if (more) {
+            if (tail_stage) rows_from_columns(sanitise(t + D, hraw, vw), hr);
+            issue_data(dslot, hr);
+          }
+        };
+        auto mfma = [&](const half8_t afrag, const uint2_t lo, const uint2_t hi, const int s) {
+          const uint4_t bq = {lo[0], lo[1], hi[0], hi[1]};
           // 2.0 is 0x4000 in fp16 AND in bfloat16, so the A fragment is the same bits for both operand types
           if constexpr (T::BF16)
-            acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, afrag),
-                                                             __builtin_bit_cast(bf16x8_t, bq), acc[s], 0, 0, 0);
+            acc[P][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, afrag),
+                                                                __builtin_bit_cast(bf16x8_t, bq), acc[P][s], 0, 0, 0);
           else
-            acc[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, __builtin_bit_cast(half8_t, bq), acc[s], 0, 0, 0);
+            acc[P][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, __builtin_bit_cast(half8_t, bq), acc[P][s], 0, 0, 0);
+        };
+        constexpr int HALVES = (NU == 2 && SLOTS >= 8) ? 2 : 1;
+        constexpr int SPH = SLOTS / HALVES;
+        half8_t afrag;
+#pragma unroll
+        for (int h = 0; h < HALVES; ++h) {
+          uint2_t blo[SPH], bhi[SPH];
+#pragma unroll
+          for (int s = 0; s < SPH; ++s) {
+            blo[s] = lds_read_tr16_b64<0>(taddr[h * SPH + s]);
+            bhi[s] = lds_read_tr16_b64<4 * ROW_BYTES>(taddr[h * SPH + s]);
+          }
+          wait_lgkmcnt0();
+          if (h == 0) afrag = a_fragment();
+          if (h == HALVES - 1) refill();
+#pragma unroll
+          for (int s = 0; s < SPH; ++s) mfma(afrag, blo[s], bhi[s], h * SPH + s);
         }
       } else {
         // A: k-step m covers condensed columns 4m+g: TC block m>>1, column 4(m&1)+g -> word 2(m&1) + R>>3, bit
@@ -530,10 +578,10 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
         for (int m = 0; m < 8; ++m) {
           const int bm = m >> 1;
           unsigned word = (m & 1) ? whi[bm] : wlo[bm];
-          if (stage_block(t) + bm >= kb1) word = 0u;
+          if (stage_block(t) + bm >= kb1 || !live) word = 0u;
           const float av = ((word >> (a_shift + g)) & 1u) ? 1.0f : 0.0f;
 #pragma unroll
-          for (int s = 0; s < SLOTS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[m][s], acc[s], 0, 0, 0);
+          for (int s = 0; s < SLOTS; ++s) acc[P][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[m][s], acc[P][s], 0, 0, 0);
         }
       }
 
@@ -545,69 +593,110 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const Spmm
     // stage t's rows and stage t+D's metadata were issued D steps ago; everything younger may stay in flight:
     // (D-1) metadata DMAs + NDMA per younger row stage (at most D-1 of them)
     int t = 0;
-    for (; t < nst - D; ++t) {
-      wait_vmcnt<T::vm_behind(D - 1)>();
-      step(t, std::true_type{});
-    }
-    for (; t < nst; ++t) {
-      switch (nst - 1 - t) {  // younger row stages still in flight: 0 .. D-1
-        case 0: wait_vmcnt<T::vm_behind(0)>(); break;
-        case 1: wait_vmcnt<T::vm_behind(1)>(); break;
-        case 2: wait_vmcnt<T::vm_behind(2)>(); break;
-        case 3: wait_vmcnt<T::vm_behind(3)>(); break;
-        case 4: wait_vmcnt<T::vm_behind(4)>(); break;
-        default: wait_vmcnt<T::vm_behind(D - 1)>(); break;  // k = 5 = DEPTH - 1 at the deepest ring (DEPTH <= 6)
+    if constexpr (NU == 2) {
+      // nst is even, so the unit of every step is static: the steady loop runs two steps at a time, the drain is unrolled
+      // (step nst - D + i consumes unit (D + i) % 2) -- no branch merges two accumulator sets
+      for (; t + 1 < nst - D; t += 2) {
+        wait_vmcnt<T::vm_behind(D - 1)>();
+        step(t, std::true_type{}, std::integral_constant<int, 0>{});
+        wait_vmcnt<T::vm_behind(D - 1)>();
+        step(t + 1, std::true_type{}, std::integral_constant<int, 1>{});
       }
-      step(t, std::false_type{});
+      if (t < nst - D) {  // t is even
+        wait_vmcnt<T::vm_behind(D - 1)>();
+        step(t, std::true_type{}, std::integral_constant<int, 0>{});
+      }
+      static_for<0, D>([&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        if (nst - D + I >= 0) {  // wave-uniform (nst < D: the first steps do not exist)
+          wait_vmcnt<T::vm_behind(D - 1 - I)>();
+          step(nst - D + I, std::false_type{}, std::integral_constant<int, (D + I) & 1>{});
+        }
+      });
+    } else {
+      for (; t < nst - D; ++t) {
+        wait_vmcnt<T::vm_behind(D - 1)>();
+        step(t, std::true_type{}, std::integral_constant<int, 0>{});
+      }
+      for (; t < nst; ++t) {
+        switch (nst - 1 - t) {  // younger row stages still in flight: 0 .. D-1
+          case 0: wait_vmcnt<T::vm_behind(0)>(); break;
+          case 1: wait_vmcnt<T::vm_behind(1)>(); break;
+          case 2: wait_vmcnt<T::vm_behind(2)>(); break;
+          case 3: wait_vmcnt<T::vm_behind(3)>(); break;
+          case 4: wait_vmcnt<T::vm_behind(4)>(); break;
+          default: wait_vmcnt<T::vm_behind(D - 1)>(); break;  // k = 5 = DEPTH - 1 at the deepest ring (DEPTH <= 6)
+        }
+        step(t, std::false_type{}, std::integral_constant<int, 0>{});
+      }
     }
     wait_vmcnt<0>();  // the trailing metadata DMAs must have landed before the wave's LDS is released
   }
 
   // ---- epilogue: D[row = 4*(lane>>4) + j][col = lane & 15] per 16-column slot ----------------------------------
   if (VOLTRIX_DIAG & 4) {
-    if (acc[0][0] == 12345.678f) a.output[0] = acc[0][0];  // keep the accumulators live
+    if (acc[0][0][0] == 12345.678f) a.output[0] = acc[0][0][0];  // keep the accumulators live
     return;
   }
   // powers of two: exact (barring overflow / underflow of the result itself)
   const float oscale = ((EB == 2 && !T::WEIGHTED) ? kAScaleInv : 1.0f) * (a.out_scale ? *a.out_scale : 1.0f);
   const int ocol0 = fs0 + (lane & 15);
-  if (slot >= 0) {  // a cut window's partial tile: [16][F] fp32, summed in unit order by combine_partials_kernel
-    float* const tile = a.partials + (long long)slot * (kBlkH * (long long)F) + (long long)(4 * (lane >> 4)) * F;
+#pragma unroll
+  for (int p = 0; p < NU; ++p) {
+    if (!present[p]) continue;  // wave-uniform
+    // NU == 2: a unit without stages may have seen MFMAs of zero A fragments on rows that are not its own (0 x NaN)
+    const bool dead = NU > 1 && nst_u[p] == 0;
+    if (slot[p] >= 0) {  // a cut window's partial tile: [16][F] fp32, summed in unit order by combine_partials_kernel
+      float* const tile = a.partials + (long long)slot[p] * (kBlkH * (long long)F) + (long long)(4 * (lane >> 4)) * F;
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s) {
+        const int col = ocol0 + 16 * s;
+        if (col < F) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) tile[(long long)j * F + col] = dead ? 0.f : acc[p][s][j] * oscale;
+        }
+      }
+      continue;
+    }
+    const int orow0 = w[p] * kBlkH + 4 * (lane >> 4);
+    int orow[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      orow[j] = orow0 + j;
+      if (a.row_map) orow[j] = a.row_map[orow[j]];
+      if (orow[j] >= a.num_nodes) orow[j] = -1;
+    }
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
       const int col = ocol0 + 16 * s;
       if (col < F) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) tile[(long long)j * F + col] = acc[s][j] * oscale;
-      }
-    }
-    return;
-  }
-  const int orow0 = w * kBlkH + 4 * (lane >> 4);
-  int orow[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    orow[j] = orow0 + j;
-    if (a.row_map) orow[j] = a.row_map[orow[j]];
-    if (orow[j] >= a.num_nodes) orow[j] = -1;
-  }
-#pragma unroll
-  for (int s = 0; s < SLOTS; ++s) {
-    const int col = ocol0 + 16 * s;
-    if (col < F) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = orow[j];
-        if (row >= 0) {
-          float* const dst = a.output + ((long long)row * F + col);
-          if (a.atomic_out)
-            unsafeAtomicAdd(dst, acc[s][j] * oscale);  // global_atomic_add_f32, no return; two addends per element
-          else
-            *dst = acc[s][j] * oscale;
+        for (int j = 0; j < 4; ++j) {
+          const int row = orow[j];
+          if (row >= 0) {
+            float* const dst = a.output + ((long long)row * F + col);
+            const float v = dead ? 0.f : acc[p][s][j] * oscale;
+            if (a.atomic_out)
+              unsafeAtomicAdd(dst, v);  // global_atomic_add_f32, no return; two addends per element
+            else
+              *dst = v;
+          }
         }
       }
     }
   }
+}
+
+template <class T>
+static __global__ __launch_bounds__(T::THREADS) void spmm_tc16_kernel(const SpmmArgs<T> a) {
+  spmm_tc16_body<T, 1>(a);
+}
+
+// two units per wave: 160 registers at most, so that the wave still fits beside two panel-kernel waves on its SIMD
+template <class T>
+static __global__ __launch_bounds__(T::THREADS) __attribute__((amdgpu_num_vgpr(160)))
+void spmm_tc16_pair_kernel(const SpmmArgs<T> a) {
+  spmm_tc16_body<T, 2>(a);
 }
 
 // Unit order for F > FS (SpmmArgs::slab_major): slab-major as soon as a slab's piece of a row of B is a whole 128-byte
@@ -635,7 +724,8 @@ inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed,
                             const float* out_scale = nullptr, int atomic_out = 0,
                             const int* units = nullptr /* int32[U][4] */, const int* unit_ptr = nullptr /* int32[9] */,
                             int max_units_per_xcd = 0, float* partials = nullptr, const int* row_map = nullptr,
-                            const void* values = nullptr /* WEIGHTED tiles: in_t[T][16][8] */) {
+                            const void* values = nullptr /* WEIGHTED tiles: in_t[T][16][8] */,
+                            int units_per_wave = 1 /* 2: paired units (unit table, 16-bit operand, F <= FS; else ignored) */) {
   if (num_nodes < 0 || embedding_dim < 0) return kErrBadShape;
   if (num_nodes == 0 || embedding_dim == 0) return kOk;
   if (embedding_dim % (16 / T::EB) != 0) return kErrBadShape;  // 16-byte row chunks
@@ -667,9 +757,21 @@ inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed,
     if (max_units_per_xcd == 0) return kOk;
     a.windows_per_xcd = max_units_per_xcd;  // sizes the grid below; the kernel reads its range from unit_ptr
   }
+  if ((long long)a.windows_per_xcd * a.num_slabs > 0x3FFFFFFFll) return kErrBadShape;  // int unit counters
+  if constexpr (T::EB == 2 && !T::WEIGHTED && T::FS <= 128) {
+    if (units_per_wave == 2 && units != nullptr && a.num_slabs == 1) {
+      const long long blocks_per_xcd = ((long long)a.windows_per_xcd + 2 * T::WAVES - 1) / (2 * T::WAVES);
+      const long long grid = blocks_per_xcd * kNumXcd;
+      if (grid > 0x7FFFFFFFll) return kErrBadShape;
+      const int lds_rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&spmm_tc16_pair_kernel<T>), T::BLOCK_LDS);
+      if (lds_rc != kOk) return lds_rc;
+      hipLaunchKernelGGL(spmm_tc16_pair_kernel<T>, dim3((unsigned)grid), dim3(T::THREADS), T::BLOCK_LDS, stream, a);
+      return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+    }
+  }
   const long long blocks_per_xcd = ((long long)a.windows_per_xcd * a.num_slabs + T::WAVES - 1) / T::WAVES;
   const long long grid = blocks_per_xcd * kNumXcd;
-  if (grid > 0x7FFFFFFFll || (long long)a.windows_per_xcd * a.num_slabs > 0x3FFFFFFFll) return kErrBadShape;  // int unit counters
+  if (grid > 0x7FFFFFFFll) return kErrBadShape;
   const int lds_rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&spmm_tc16_kernel<T>), T::BLOCK_LDS);
   if (lds_rc != kOk) return lds_rc;
   hipLaunchKernelGGL(spmm_tc16_kernel<T>, dim3((unsigned)grid), dim3(T::THREADS), T::BLOCK_LDS, stream, a);

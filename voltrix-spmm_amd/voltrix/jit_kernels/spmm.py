@@ -19,13 +19,17 @@ template = """
 __return_code = voltrix::launch_spmm_tc16<voltrix::SpmmTile<{FS}, {DEPTH}, {WAVES}, {EB}, {BF16} != 0, {WEIGHTED} != 0>>(
     blk_offsets, hspa_packed, hind,
     num_nodes, embedding_dim, input, output, stream,
-    ({SCHED} == 0 || {SCHED} == 4) ? nullptr : ({SCHED} == 1 ? win_order_a : ({SCHED} == 2 ? win_order_b : win_order_c)),
+    ({SCHED} == 0 || {SCHED} >= 4) ? nullptr : ({SCHED} == 1 ? win_order_a : ({SCHED} == 2 ? win_order_b : win_order_c)),
     out_scale, atomic_out,
-    {SCHED} == 4 ? units : nullptr, unit_ptr, max_units_per_xcd, partials, has_row_map != 0 ? row_map : nullptr,
-    {WEIGHTED} != 0 ? (const void*)values : nullptr);
+    {SCHED} == 4 ? units : ({SCHED} == 5 ? units_p : nullptr), {SCHED} == 5 ? unit_ptr_p : unit_ptr,
+    {SCHED} == 5 ? max_units_per_xcd_p : max_units_per_xcd, {SCHED} == 5 ? partials_p : partials,
+    has_row_map != 0 ? row_map : nullptr, {WEIGHTED} != 0 ? (const void*)values : nullptr, {SCHED} == 5 ? 2 : 1);
 if (__return_code == 0 && {SCHED} == 4 && combine_now != 0)
   __return_code = voltrix::combine_partials(cuts, num_cuts, partials, output, num_nodes, embedding_dim, atomic_out, stream,
                                             has_row_map != 0 ? row_map : nullptr);
+if (__return_code == 0 && {SCHED} == 5 && combine_now != 0)
+  __return_code = voltrix::combine_partials(cuts_p, num_cuts_p, partials_p, output, num_nodes, embedding_dim, atomic_out,
+                                            stream, has_row_map != 0 ? row_map : nullptr);
 """
 
 # windows per length-sorted chunk of the "balance" schedule (spmm_kernels.hpp::launch_window_order) for SCHED 1/2/3.
@@ -36,6 +40,12 @@ ORDER_CHUNKS = {1: 128, 2: 512, 3: 2048}
 # units listed longest first per XCD range; the partial tiles of cut windows are summed in unit order by
 # combine_partials.  Measured on the reddit-like graph: window format 2.19 -> 1.94 ms, two-level residual 1.41 -> 1.04 ms.
 SCHED_UNITS = 4
+# SCHED 5: the same with TWO units per wave (spmm_tc16_pair_kernel: their stages alternate through one ring into two
+# accumulator sets), units cut at 1.25 x the median.  Twice the rows sweep their sorted columns in step per CU at the same LDS
+# and bytes in flight: reddit-like two-level residual TCC hits 49 -> 58 %, 1.03 -> 0.92 ms alone, the pair with the panel kernel
+# 1.365 -> 1.293 ms (profiles/r02/experiment_pair_units.log).  One column slab only (F <= FS), 16-bit binary operand.
+SCHED_PAIRS = 5
+PAIR_UNIT_FACTOR = 1.25
 
 
 def feature_hash(feature: torch.Tensor) -> str:
@@ -65,10 +75,19 @@ def tile_space(embedding_dim: int, elem_bytes: int, bf16: bool = False, max_lds:
     ``max_lds``: keep only tiles whose workgroup fits that many bytes of LDS; ``weighted``: the A operand is a value
     plane, 1 KiB more per metadata slot)."""
     points = tuple(dict(point, BF16=int(bf16), WEIGHTED=int(weighted)) for point in _tile_space(embedding_dim, elem_bytes))
+    pairs_allowed = os.getenv("VOLTRIX_PAIR_UNITS", "1") != "0"   # 0: never two units per wave (A/B runs)
+    if not pairs_allowed:
+        points = tuple(p for p in points if p["SCHED"] != SCHED_PAIRS)
     if weighted:
         assert elem_bytes == 2
+        points = tuple(p for p in points if p["SCHED"] != SCHED_PAIRS)   # paired units: binary operand only
         points = tuple(p for p in points if _lds_bytes(p["FS"], p["DEPTH"], p["WAVES"], 2, True) <= 160 * 1024
                        and (2 + 32 * p["FS"] * 2 // 1024) * (p["DEPTH"] - 1) <= 63)
+    if (max_lds is not None and not weighted and pairs_allowed and os.getenv(TUNE_SPACE_FLAG, "default") == "none"
+            and len(points) == 1
+            and points[0]["FS"] == 128 and points[0]["EB"] == 2 and embedding_dim <= 128):
+        # the single untuned point beside a panel workgroup: two units per wave (measured: 1.365 -> 1.293 ms for the pair)
+        points = (dict(points[0], SCHED=SCHED_PAIRS),)
     if max_lds is not None:
         # beside a panel workgroup: the panel tile's slab width only (the two kernels then walk the column slabs in step;
         # the tuner times this kernel ALONE, where a half-width slab-major tile can look as good -- reddit-like F=128:
@@ -102,7 +121,10 @@ def _tile_space(embedding_dim: int, elem_bytes: int):
                 ndma = 32 * fs * elem_bytes // 1024
                 if _lds_bytes(fs, d, w, elem_bytes) <= 160 * 1024 and (1 + ndma) * (d - 1) <= 63:
                     # natural window order / balance schedule per chunk size / unit table (16-bit operands)
-                    for sched in (0,) + tuple(ORDER_CHUNKS) + ((SCHED_UNITS,) if elem_bytes == 2 else ()):
+                    scheds = (0,) + tuple(ORDER_CHUNKS) + ((SCHED_UNITS,) if elem_bytes == 2 else ())
+                    if elem_bytes == 2 and fs == 128 and embedding_dim <= fs and w == 4:
+                        scheds += (SCHED_PAIRS,)   # two units per wave: the 128-column tile with one slab
+                    for sched in scheds:
                         space.append({"FS": fs, "DEPTH": d, "WAVES": w, "EB": elem_bytes, "SCHED": sched})
     return tuple(space)
 
@@ -151,6 +173,12 @@ def arg_defs_for(dtype):
         ("cuts", torch.int32),
         ("num_cuts", int),
         ("partials", torch.float32),
+        ("units_p", torch.int32),
+        ("unit_ptr_p", torch.int32),
+        ("max_units_per_xcd_p", int),
+        ("cuts_p", torch.int32),
+        ("num_cuts_p", int),
+        ("partials_p", torch.float32),
         ("combine_now", int),
         ("row_map", torch.int32),
         ("has_row_map", int),
@@ -159,18 +187,23 @@ def arg_defs_for(dtype):
     )
 
 
-def handle_unit_table(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, num_nodes: int):
-    """The handle's unit table (voltrix.schedule.unit_table, default length bound), built once on the GPU and cached on
-    the ``hspa_packed`` tensor object."""
-    cache = getattr(hspa_packed, "_voltrix_unit_table", None)
+def handle_unit_table(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, num_nodes: int, pairs: bool = False):
+    """The handle's unit table (voltrix.schedule.unit_table; default length bound, or 1.25 x the median for the paired
+    launch), built once on the GPU and cached on the ``hspa_packed`` tensor object."""
+    attr = "_voltrix_unit_table_pairs" if pairs else "_voltrix_unit_table"
+    cache = getattr(hspa_packed, attr, None)
     key = (blk_offsets.data_ptr(), num_nodes)
     if isinstance(cache, tuple) and cache[0] == key:
         return cache[1]
-    from ..schedule import unit_table
+    from ..schedule import default_max_stages, unit_table
 
-    table = unit_table(blk_offsets, num_nodes)
+    if pairs:
+        median_x_1_5 = default_max_stages(blk_offsets, num_nodes)
+        table = unit_table(blk_offsets, num_nodes, max(8, int(PAIR_UNIT_FACTOR * median_x_1_5 / 1.5)))
+    else:
+        table = unit_table(blk_offsets, num_nodes)
     try:
-        hspa_packed._voltrix_unit_table = (key, table)
+        setattr(hspa_packed, attr, (key, table))
     except AttributeError:
         pass
     return table
@@ -249,12 +282,20 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
         table, partials = None, out_scale
         units = unit_ptr = cuts = blk_offsets   # never dereferenced (no SCHED 4 point in the space)
         max_units = num_cuts = 0
+    if any(p["SCHED"] == SCHED_PAIRS for p in space):
+        table_p = handle_unit_table(blk_offsets, hspa_packed, num_nodes, pairs=True)
+        partials_p = torch.empty(max(1, table_p.num_slots) * 16 * embedding_dim, dtype=torch.float32, device=input.device)
+    else:
+        table_p, partials_p = None, out_scale
 
     def make_args(out):
         return (blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, out,
                 window_order(blk_offsets, hspa_packed, num_nodes, 1), window_order(blk_offsets, hspa_packed, num_nodes, 2),
                 window_order(blk_offsets, hspa_packed, num_nodes, 3), out_scale, int(bool(atomic_out)), units, unit_ptr,
-                max_units, cuts, num_cuts, partials, int(not defer_combine),
+                max_units, cuts, num_cuts, partials,
+                table_p.units if table_p is not None else blk_offsets, table_p.unit_ptr if table_p is not None else blk_offsets,
+                table_p.max_units_per_xcd if table_p is not None else 0, table_p.cuts if table_p is not None else blk_offsets,
+                table_p.num_cuts if table_p is not None else 0, partials_p, int(not defer_combine),
                 row_map if row_map is not None else blk_offsets, int(row_map is not None),
                 values if values is not None else input, torch.cuda.current_stream())
 
@@ -283,7 +324,10 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
     )
     rc = runtime(*args)
     assert rc == 0, f"spmm_kernel failed with return code {rc}"
-    if (defer_combine and table is not None and table.num_cuts > 0
-            and jit_tuner.tuned_point("spmm_kernel", keys).get("SCHED") == SCHED_UNITS):
-        return PendingCombine(table, partials, output, num_nodes, embedding_dim, bool(atomic_out), row_map)
+    if defer_combine:
+        sched = jit_tuner.tuned_point("spmm_kernel", keys).get("SCHED")
+        if sched == SCHED_UNITS and table is not None and table.num_cuts > 0:
+            return PendingCombine(table, partials, output, num_nodes, embedding_dim, bool(atomic_out), row_map)
+        if sched == SCHED_PAIRS and table_p is not None and table_p.num_cuts > 0:
+            return PendingCombine(table_p, partials_p, output, num_nodes, embedding_dim, bool(atomic_out), row_map)
     return None
