@@ -207,7 +207,7 @@ int main(int argc, char** argv) {
   int* panel_order = dev_alloc<int>(num_panels);
   RC_OK(voltrix_launch_panel_plan_fill(d_indptr, d_indices, n, n, e, waves, row_blocks, tau, plan_ws, panel_ptr,
                                        resid_indptr, ksteps, resid_indices, panel_cols, panel_bits, s_main, &rc_));
-  RC_OK(voltrix_launch_panel_order(panel_ptr, num_panels, panel_order, s_main, &rc_));
+  RC_OK(voltrix_launch_panel_order(panel_ptr, num_panels, /*group=*/1, panel_order, s_main, &rc_));
   const Handle hr = preprocess(resid_indptr, resid_indices, n, n, resid_edges, s_main);
   const UnitTable tr = build_unit_table(hr, n, s_main);
   float* partials_r = dev_alloc<float>((size_t)std::max(1, tr.header[2]) * 16 * f);

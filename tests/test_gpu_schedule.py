@@ -71,16 +71,17 @@ def test_workspace_sizes_and_bad_arguments(cuda_device):
     assert rc.value == 1   # no header
 
 
+@pytest.mark.parametrize("group", [1, 4, 7])
 @pytest.mark.parametrize("num_panels", [1, 5, 8, 9, 455, 4100])
-def test_native_panel_order_equals_the_torch_restatement(cuda_device, num_panels):
+def test_native_panel_order_equals_the_torch_restatement(cuda_device, num_panels, group):
     from voltrix.hybrid import longest_first_order
 
     g = torch.Generator().manual_seed(num_panels)
     nks = torch.randint(0, 7 if num_panels > 100 else 1000, (num_panels,), generator=g)   # many ties in the large cases
     panel_ptr = torch.zeros(num_panels + 1, dtype=torch.int32)
     panel_ptr[1:] = nks.cumsum(0)
-    native = longest_first_order(panel_ptr.cuda())
-    ref = longest_first_order(panel_ptr)          # CPU tensor -> torch argsort
+    native = longest_first_order(panel_ptr.cuda(), group)
+    ref = longest_first_order(panel_ptr, group)   # CPU tensor -> torch argsort
     assert native.is_cuda and torch.equal(native.cpu(), ref)
     assert torch.equal(torch.sort(native.cpu().long()).values, torch.arange(num_panels))
 

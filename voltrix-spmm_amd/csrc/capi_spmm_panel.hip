@@ -56,9 +56,14 @@ void voltrix_launch_spmm_panel_bf16(void* panel_ptr, void* panel_cols, void* pan
                                 static_cast<hipStream_t>(stream));
 }
 
-void voltrix_launch_panel_order(void* panel_ptr, int num_panels, void* order_out, void* stream, int* return_code) {
-  *return_code = voltrix::panel_order(static_cast<const int*>(panel_ptr), num_panels, static_cast<int*>(order_out),
+void voltrix_launch_panel_order(void* panel_ptr, int num_panels, int group, void* order_out, void* stream,
+                                int* return_code) {
+  *return_code = voltrix::panel_order(static_cast<const int*>(panel_ptr), num_panels, group, static_cast<int*>(order_out),
                                       static_cast<hipStream_t>(stream));
+}
+
+void voltrix_launch_zero_f32(void* dst, int64_t count, void* stream, int* return_code) {
+  *return_code = voltrix::zero_f32_nt(static_cast<float*>(dst), count, static_cast<hipStream_t>(stream));
 }
 
 void voltrix_launch_add_inplace_f32(void* dst, void* src, int64_t count, void* stream, int* return_code) {

@@ -36,6 +36,7 @@ SYMBOLS = (
     "voltrix_launch_spmm_panel_f16",
     "voltrix_launch_spmm_panel_bf16",
     "voltrix_launch_add_inplace_f32",
+    "voltrix_launch_zero_f32",
     "voltrix_panel_plan_workspace_bytes",
     "voltrix_launch_panel_plan_count",
     "voltrix_launch_panel_plan_fill",
@@ -262,11 +263,18 @@ def launch_spmm_panel(plan, input_ptr, output_ptr, embedding_dim, accumulate, bf
     return rc.value
 
 
-def launch_panel_order(panel_ptr, num_panels: int, order_out, stream) -> None:
+def launch_panel_order(panel_ptr, num_panels: int, order_out, stream, group: int = 1) -> None:
     rc = ctypes.c_int(-1)
-    lib().voltrix_launch_panel_order(_ptr(panel_ptr), ctypes.c_int(num_panels), _ptr(order_out), ctypes.c_void_p(stream),
-                                     ctypes.byref(rc))
+    lib().voltrix_launch_panel_order(_ptr(panel_ptr), ctypes.c_int(num_panels), ctypes.c_int(group), _ptr(order_out),
+                                     ctypes.c_void_p(stream), ctypes.byref(rc))
     check(rc.value, "voltrix_launch_panel_order")
+
+
+def launch_zero_f32(tensor, stream) -> None:
+    """``tensor`` (float32, contiguous, numel % 4 == 0) <- 0 with non-temporal stores."""
+    rc = ctypes.c_int(-1)
+    lib().voltrix_launch_zero_f32(_ptr(tensor), ctypes.c_int64(tensor.numel()), ctypes.c_void_p(stream), ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_zero_f32")
 
 
 def panel_plan_workspace_bytes(num_nodes: int, waves: int, row_blocks: int) -> int:

@@ -134,23 +134,35 @@ def empty_plan(num_nodes, waves, row_blocks, tau, device, num_edges):
                      num_shared_edges=0, num_resid_edges=num_edges)
 
 
-def longest_first_order(panel_ptr: torch.Tensor) -> torch.Tensor:
+PANEL_ORDER_GROUP = int(os.environ.get("VOLTRIX_PANEL_GROUP", "1"))   # consecutive panels launched side by side (1: plain longest-first)
+
+
+def longest_first_order(panel_ptr: torch.Tensor, group: int = PANEL_ORDER_GROUP) -> torch.Tensor:
     """Launch order of the panel kernel: int32 [NP], position -> panel; inside every XCD's contiguous range of positions
-    (spmm_panel_kernel: blockIdx % 8 picks the range) the panels with the most k-steps first.  455 workgroups on 256 CUs is
-    1.8 rounds: started in natural order, the last round's long panels finish alone; longest first leaves the short ones
-    for the end.  Measured on the reddit-like graph (tau 3): the two-level step 1.59 -> 1.42 ms
-    (profiles/r02/experiment_tau_reddit.log).  Speed only."""
+    (spmm_panel_kernel: blockIdx % 8 picks the range) GROUPS of ``group`` consecutive panels, the groups with the most k-steps
+    first, the panels of a group in their natural order; ``group`` = 1 (shipped): plain longest-first.  455 workgroups on
+    256 CUs is 1.8 rounds: started in natural order, the last round's long panels finish alone (two-level step 1.59 ms),
+    longest-first leaves the short ones for the end (1.42 ms, profiles/r02/experiment_tau_reddit.log).  Groups of neighbours
+    launched side by side share their band columns through L2: 1.323 -> 1.282 ms for the bare kernel pair
+    (experiment_panel_groups.log), but nothing through the operator (1.357 vs 1.360 ms, bench_ab_panel_group.txt: the zero
+    fill of C between the steps costs the window kernel more than the panel kernel gains), so it stays an option
+    (``VOLTRIX_PANEL_GROUP``).  Speed only."""
     num_panels = panel_ptr.numel() - 1
     if num_panels <= 0:
         return torch.zeros(0, dtype=torch.int32, device=panel_ptr.device)
     if panel_ptr.is_cuda:   # the library's kernel (panel_plan.hpp::panel_order_kernel; same order, checked by the tests)
         order = torch.empty(num_panels, dtype=torch.int32, device=panel_ptr.device)
-        capi.launch_panel_order(panel_ptr, num_panels, order, torch.cuda.current_stream().cuda_stream)
+        capi.launch_panel_order(panel_ptr, num_panels, order, torch.cuda.current_stream().cuda_stream, group)
         return order
     nks = (panel_ptr[1:] - panel_ptr[:-1]).to(torch.int64)
     per_xcd = (num_panels + 7) // 8
-    top = int(nks.max())
-    key = (torch.arange(num_panels, device=panel_ptr.device) // per_xcd) * (top + 1) + (top - nks)
+    idx = torch.arange(num_panels, device=panel_ptr.device)
+    xcd = idx // per_xcd
+    gid = xcd * (per_xcd // group + 2) + (idx - xcd * per_xcd) // group
+    gsum = torch.zeros(int(gid.max()) + 1, dtype=torch.int64, device=panel_ptr.device).index_add_(0, gid, nks)
+    top = int(gsum.max())
+    key = ((xcd * (top + 1) + (top - gsum[gid])) * (per_xcd + 1) + (idx - xcd * per_xcd) // group) * (group + 1) + (
+        idx - xcd * per_xcd) % group
     return torch.argsort(key, stable=True).to(torch.int32)
 
 
@@ -316,7 +328,12 @@ def run_two_level(plan: PanelPlan, operand: torch.Tensor, output: torch.Tensor, 
         from .utils import timed_launch
 
         with timed_launch("zero_fill", main):
-            output.zero_()
+            # VOLTRIX_ZERO_FILL=nt: the library's fill with non-temporal stores (so that C does not push B's rows out of the
+            # caches) -- measured: the fill itself 0.021 -> 0.028 ms, the step unchanged (profiles/r02/bench_ab_zero_fill.txt)
+            if os.environ.get("VOLTRIX_ZERO_FILL", "torch") == "nt" and output.is_contiguous() and output.numel() % 4 == 0:
+                capi.launch_zero_f32(output, main.cuda_stream)
+            else:
+                output.zero_()
         target = output
     else:
         target = torch.empty_like(output)        # allocated on `main`; its last use (the add) is on `main` too

@@ -305,30 +305,39 @@ static __global__ __launch_bounds__(kPlanThreads) void panel_plan_fill_kernel(
   if ((int)threadIdx.x < padded - cnt) panel_cols[ks0 * kStageK + cnt + threadIdx.x] = s.first_col;
 }
 
-// Launch order of the panel kernel (spmm_panel_kernels.hpp, PanelArgs::panel_order): order_out[position] = panel; inside
-// every XCD's contiguous range of positions (ceil(NP / 8) each) the panels with the most k-steps first, ties by panel
-// index -- a stable order, so a plan always gets the same one.  Rank by counting inside the range (NP is small: N / 512).
+// Launch order of the panel kernel (spmm_panel_kernels.hpp, PanelArgs::panel_order): order_out[position] = panel.  Inside
+// every XCD's contiguous range of positions (ceil(NP / 8) each) the panels are taken in GROUPS of `group` consecutive
+// panels -- neighbours share most of their band columns, and launched side by side they share the gathered rows through
+// L2 -- the groups with the most k-steps first (ties by index: a stable order, so a plan always gets the same one), the
+// panels of a group in their natural order.  group = 1: plain longest-first.  Rank by counting inside the range (NP is
+// small: N / 512).  Measured on the reddit-like pair with two units per wave on the residual: groups of 4 1.282 ms,
+// plain longest-first 1.323 ms, natural order 1.294 ms (profiles/r02/experiment_panel_groups.log) -- but no gain through
+// the operator (profiles/r02/bench_ab_panel_group.txt), so hosts pass group = 1.
 static __global__ __launch_bounds__(256) void panel_order_kernel(const int* __restrict__ panel_ptr, const int num_panels,
-                                                                 const int per_xcd, int* __restrict__ order_out) {
+                                                                 const int per_xcd, const int group,
+                                                                 int* __restrict__ order_out) {
   for (int p = blockIdx.x * 256 + threadIdx.x; p < num_panels; p += gridDim.x * 256) {
     const int lo = (p / per_xcd) * per_xcd;
     const int hi = lo + per_xcd < num_panels ? lo + per_xcd : num_panels;
-    const int mine = panel_ptr[p + 1] - panel_ptr[p];
-    int rank = 0;
-    for (int q = lo; q < hi; ++q) {
-      const int other = panel_ptr[q + 1] - panel_ptr[q];
-      rank += (other > mine || (other == mine && q < p)) ? 1 : 0;
+    const int my_group = (p - lo) / group;
+    const int g0 = lo + my_group * group, g1 = g0 + group < hi ? g0 + group : hi;
+    const int mine = panel_ptr[g1] - panel_ptr[g0];      // k-steps of my group
+    int before = 0;                                       // panels of the groups launched before mine
+    for (int q0 = lo, gi = 0; q0 < hi; q0 += group, ++gi) {
+      const int q1 = q0 + group < hi ? q0 + group : hi;
+      const int other = panel_ptr[q1] - panel_ptr[q0];
+      if (other > mine || (other == mine && gi < my_group)) before += q1 - q0;
     }
-    order_out[lo + rank] = p;
+    order_out[lo + before + (p - g0)] = p;
   }
 }
 
-inline int panel_order(const int* panel_ptr, int num_panels, int* order_out, hipStream_t stream) {
-  if (num_panels < 0) return kErrBadShape;
+inline int panel_order(const int* panel_ptr, int num_panels, int group, int* order_out, hipStream_t stream) {
+  if (num_panels < 0 || group < 1) return kErrBadShape;
   if (num_panels == 0) return kOk;
   const int per_xcd = (num_panels + kNumXcd - 1) / kNumXcd;
   hipLaunchKernelGGL(panel_order_kernel, dim3((num_panels + 255) / 256), dim3(256), 0, stream, panel_ptr, num_panels,
-                     per_xcd, order_out);
+                     per_xcd, group, order_out);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

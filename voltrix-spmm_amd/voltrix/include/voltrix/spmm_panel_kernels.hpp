@@ -402,6 +402,27 @@ static __global__ __launch_bounds__(256) void add_inplace_f32_kernel(float* __re
   }
 }
 
+// dst <- 0 with NON-TEMPORAL stores (float32, count % 4 == 0, 16-byte aligned): the zero fill of C in front of the two-level
+// step (both kernels add onto it).  C (119 MB on the headline graph) is written once here and touched again only by the
+// kernels' atomics.  (Measured: no gain over an ordinary fill on the headline graph -- 0.028 vs 0.021 ms for the fill, the
+// step unchanged, profiles/r02/bench_ab_zero_fill.txt; the Python host keeps torch's fill.)
+static __global__ __launch_bounds__(256) void zero_f32_nt_kernel(float* __restrict__ dst, const long long n4) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 z = {0.f, 0.f, 0.f, 0.f};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+    __builtin_nontemporal_store(z, reinterpret_cast<f4*>(dst) + i);
+}
+
+inline int zero_f32_nt(float* dst, long long count, hipStream_t stream) {
+  if (count < 0 || (count % 4) != 0 || ((uintptr_t)dst & 15)) return kErrBadShape;
+  if (count == 0) return kOk;
+  const long long n4 = count / 4;
+  const int blocks = (int)(n4 / 256 + 1 < 256 * 16 ? n4 / 256 + 1 : 256 * 16);
+  hipLaunchKernelGGL(zero_f32_nt_kernel, dim3(blocks), dim3(256), 0, stream, dst, n4);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
 inline int add_inplace_f32(float* dst, const float* src, long long count, hipStream_t stream) {
   if (count < 0 || (count % 4) != 0 || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) return kErrBadShape;
   if (count == 0) return kOk;
