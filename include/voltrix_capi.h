@@ -136,7 +136,7 @@ void voltrix_launch_spmm_bf16_tile(void* blk_offsets, void* hspa_packed, void* h
  *               of each cut window in unit order (deterministic) into output.  unit_ptr int32[9]: XCD x owns units
  *               [unit_ptr[x], unit_ptr[x+1]); max_units_per_xcd = the largest of those eight counts.  Every stage of
  *               every window must belong to exactly one unit.
- *   units_per_wave  1, or 2 with a unit table and embedding_dim <= fs <= 128: every wave runs two consecutive units of the
+ *   units_per_wave  1, or 2 with a unit table and fs <= 128 (several column slabs: fs = 128, slab-major order): every wave runs two consecutive units of the
  *               table, their stages alternating through one ring into two accumulator sets (same bits as 1): twice the
  *               windows sweep their sorted columns in step per CU at the same LDS and bytes in flight.  Measured beside the
  *               panel kernel on the reddit-like graph with units cut at 1.25 x the median: 1.365 -> 1.293 ms.  Ignored

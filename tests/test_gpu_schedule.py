@@ -88,11 +88,13 @@ def test_native_panel_order_equals_the_torch_restatement(cuda_device, num_panels
 
 @pytest.mark.parametrize("kind", ["f16", "bf16"])
 @pytest.mark.parametrize("name,scale,num_feats,max_stages", [("reddit_like", 0.05, 128, None), ("reddit_like", 0.05, 104, 13),
-                                                             ("products_like", 0.02, 128, 4), ("powerlaw_4m", 0.004, 72, None)])
+                                                             ("products_like", 0.02, 128, 4), ("powerlaw_4m", 0.004, 72, None),
+                                                             ("reddit_like", 0.03, 264, None), ("products_like", 0.01, 512, 5)])
 def test_two_units_per_wave_give_the_same_bits(cuda_device, kind, name, scale, num_feats, max_stages):
     """spmm_tc16_pair_kernel (units_per_wave = 2): every wave runs two consecutive units of the table, stages alternating
     through one ring into two accumulator sets.  Same bits as one unit per wave -- store mode and atomic mode onto zeros --
-    with odd unit counts per XCD, units of unequal length, empty windows, the N % 16 tail and a partially filled slab."""
+    with odd unit counts per XCD, units of unequal length, empty windows, the N % 16 tail, a partially filled slab, and
+    several column slabs (slab-major: a pair never straddles two slabs)."""
     indptr, indices, _ = synth_graphs.generate(name, device="cuda", scale=scale)
     n, e = indptr.numel() - 1, indices.numel()
     indptr = indptr.clone()

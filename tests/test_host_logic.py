@@ -37,7 +37,7 @@ def test_tile_space_is_valid_and_bounded(monkeypatch):
                 for p in space:
                     assert spmm_mod._lds_bytes(p["FS"], p["DEPTH"], p["WAVES"], p["EB"]) <= 160 * 1024
                     assert p["EB"] == eb and p["FS"] in (32, 64, 128, 256) and p["SCHED"] in ((0, 1, 2, 3, 4, 5) if eb == 2 else (0, 1, 2, 3))
-                    assert p["SCHED"] != 5 or (p["FS"] == 128 and f <= 128 and p["WAVES"] == 4)   # paired units: one slab
+                    assert p["SCHED"] != 5 or (p["FS"] == 128 and p["WAVES"] == 4)   # paired units: the 128-column tile
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
     # the single default point = the ahead-of-time library's default tile + the unit-table schedule
     assert spmm_mod.tile_space(128, 2) == ({"FS": 128, "DEPTH": 3, "WAVES": 4, "EB": 2, "SCHED": 4, "BF16": 0, "WEIGHTED": 0},)

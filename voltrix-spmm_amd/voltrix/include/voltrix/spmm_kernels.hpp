@@ -245,20 +245,23 @@ __device__ __forceinline__ void spmm_tc16_body(const SpmmArgs<T>& a) {
   // few slots at the right time to keep its DMAs in flight, ran at half speed.  Measured on the reddit-like pair: 1.48 ->
   // 1.34 ms, both kernels finishing together (profiles/r02/experiment_corun_diag_setprio.log).  Alone it changes nothing.
   __builtin_amdgcn_s_setprio(3);
-  const int lu = ((int)(blockIdx.x / kNumXcd) * T::WAVES + wave) * NU;   // first unit of this wave inside the XCD's range
-  if (w_count <= 0 || lu >= w_count * a.num_slabs) return;           // wave-uniform; the kernel has no barriers (<= 2^30 units: launcher)
-  // window-major (the slabs of a window side by side: shared metadata, overlapping row neighbourhoods) or slab-major (the
-  // whole range for slab 0, then slab 1, ...: one FS-wide column slab of B is the cache working set at a time)
-  // (NU == 2: one slab only -- launcher -- so position = unit)
+  // Unit(s) of this wave inside the XCD's range.  One unit per wave: position lu of w_count x num_slabs, window-major (the
+  // slabs of a window side by side: shared metadata, overlapping row neighbourhoods) or slab-major (the whole range for slab
+  // 0, then slab 1, ...: one FS-wide column slab of B is the cache working set at a time).  Two units per wave: slab-major
+  // only (launcher), pairs never straddle a slab: pair q of ceil(w_count / 2) per slab = units 2 q, 2 q + 1 of that slab.
+  const int wave_pos = (int)(blockIdx.x / kNumXcd) * T::WAVES + wave;
+  const int pairs_per_slab = (w_count + 1) / 2;
+  if (w_count <= 0 || (NU == 1 ? wave_pos >= w_count * a.num_slabs : wave_pos >= pairs_per_slab * a.num_slabs)) return;  // wave-uniform; no barriers
+  const int lu = NU == 1 ? wave_pos : (wave_pos / pairs_per_slab) * w_count + 2 * (wave_pos % pairs_per_slab);
   int w[NU], st0[NU], st_step[NU], slot[NU];   // unit p runs stages st0, st0 + st_step, ... of window w
   int kb0[NU], kb1[NU], nst_u[NU], h_safe[NU];
   bool present[NU];
   int nst_max = 0;
 #pragma unroll
   for (int p = 0; p < NU; ++p) {
-    present[p] = lu + p < w_count * a.num_slabs;
+    present[p] = NU == 1 || (lu % w_count) + p < w_count;   // NU == 2: the second unit of a slab's last pair may not exist
     const int lup = present[p] ? lu + p : lu;   // an odd unit out: the wave's second unit is a copy that does nothing
-    const int wpos = w_begin + (a.slab_major ? lup % w_count : lup / a.num_slabs);
+    const int wpos = w_begin + ((a.slab_major || NU == 2) ? lup % w_count : lup / a.num_slabs);
     st0[p] = 0;
     st_step[p] = 1;
     slot[p] = -1;
@@ -286,7 +289,7 @@ __device__ __forceinline__ void spmm_tc16_body(const SpmmArgs<T>& a) {
     nst_max = nst_u[p] > nst_max ? nst_u[p] : nst_max;
   }
   const int nst = NU * nst_max;   // stages of the wave: stage t = stage t / NU of unit t % NU (a unit past its end idles)
-  const int fs0 = (int)(a.slab_major ? lu / w_count : lu % a.num_slabs) * FS;
+  const int fs0 = (int)((a.slab_major || NU == 2) ? lu / w_count : lu % a.num_slabs) * FS;
   const int F = a.F;
   auto stage_of = [&](int t) -> int { return st0[t % NU] + st_step[t % NU] * (t / NU); };        // stage of its window
   auto stage_block = [&](int t) -> int { return kb0[t % NU] + kTcbPerStage * stage_of(t); };     // its first TC block
@@ -725,7 +728,7 @@ inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed,
                             const int* units = nullptr /* int32[U][4] */, const int* unit_ptr = nullptr /* int32[9] */,
                             int max_units_per_xcd = 0, float* partials = nullptr, const int* row_map = nullptr,
                             const void* values = nullptr /* WEIGHTED tiles: in_t[T][16][8] */,
-                            int units_per_wave = 1 /* 2: paired units (unit table, 16-bit operand, F <= FS; else ignored) */) {
+                            int units_per_wave = 1 /* 2: paired units (unit table, 16-bit binary operand, FS <= 128, one slab or slab-major order; else ignored) */) {
   if (num_nodes < 0 || embedding_dim < 0) return kErrBadShape;
   if (num_nodes == 0 || embedding_dim == 0) return kOk;
   if (embedding_dim % (16 / T::EB) != 0) return kErrBadShape;  // 16-byte row chunks
@@ -759,8 +762,9 @@ inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed,
   }
   if ((long long)a.windows_per_xcd * a.num_slabs > 0x3FFFFFFFll) return kErrBadShape;  // int unit counters
   if constexpr (T::EB == 2 && !T::WEIGHTED && T::FS <= 128) {
-    if (units_per_wave == 2 && units != nullptr && a.num_slabs == 1) {
-      const long long blocks_per_xcd = ((long long)a.windows_per_xcd + 2 * T::WAVES - 1) / (2 * T::WAVES);
+    if (units_per_wave == 2 && units != nullptr && (a.num_slabs == 1 || a.slab_major)) {
+      const long long pairs = ((long long)a.windows_per_xcd + 1) / 2 * a.num_slabs;   // pairs never straddle a slab
+      const long long blocks_per_xcd = (pairs + T::WAVES - 1) / T::WAVES;
       const long long grid = blocks_per_xcd * kNumXcd;
       if (grid > 0x7FFFFFFFll) return kErrBadShape;
       const int lds_rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&spmm_tc16_pair_kernel<T>), T::BLOCK_LDS);
