@@ -43,8 +43,8 @@ SCHED_UNITS = 4
 # SCHED 5: the same with TWO units per wave (spmm_tc16_pair_kernel: their stages alternate through one ring into two
 # accumulator sets), units cut at 1.25 x the median.  Twice the rows sweep their sorted columns in step per CU at the same LDS
 # and bytes in flight: reddit-like two-level residual TCC hits 49 -> 58 %, 1.03 -> 0.92 ms alone, the pair with the panel kernel
-# 1.365 -> 1.293 ms (profiles/r02/experiment_pair_units.log).  16-bit binary operand, the 128-column tile; with several
-# column slabs the launch is slab-major and a pair never straddles two slabs.
+# 1.365 -> 1.293 ms (profiles/r02/experiment_pair_units.log).  16-bit binary operand, four-wave tiles; with several column
+# slabs the launch is slab-major (slabs of 128 bytes and more) and a pair never straddles two slabs.
 SCHED_PAIRS = 5
 PAIR_UNIT_FACTOR = 1.25
 
@@ -86,7 +86,7 @@ def tile_space(embedding_dim: int, elem_bytes: int, bf16: bool = False, max_lds:
                        and (2 + 32 * p["FS"] * 2 // 1024) * (p["DEPTH"] - 1) <= 63)
     if (max_lds is not None and not weighted and pairs_allowed and os.getenv(TUNE_SPACE_FLAG, "default") == "none"
             and len(points) == 1
-            and points[0]["FS"] == 128 and points[0]["EB"] == 2):
+            and points[0]["EB"] == 2 and (points[0]["FS"] >= 64 or embedding_dim <= points[0]["FS"])):
         # the single untuned point beside a panel workgroup: two units per wave (measured: 1.365 -> 1.293 ms for the pair)
         points = (dict(points[0], SCHED=SCHED_PAIRS),)
     if max_lds is not None:
@@ -123,8 +123,8 @@ def _tile_space(embedding_dim: int, elem_bytes: int):
                 if _lds_bytes(fs, d, w, elem_bytes) <= 160 * 1024 and (1 + ndma) * (d - 1) <= 63:
                     # natural window order / balance schedule per chunk size / unit table (16-bit operands)
                     scheds = (0,) + tuple(ORDER_CHUNKS) + ((SCHED_UNITS,) if elem_bytes == 2 else ())
-                    if elem_bytes == 2 and fs == 128 and w == 4:
-                        scheds += (SCHED_PAIRS,)   # two units per wave: the 128-column tile (several slabs: slab-major order)
+                    if elem_bytes == 2 and w == 4 and (fs >= 64 or embedding_dim <= fs):
+                        scheds += (SCHED_PAIRS,)   # two units per wave (several slabs: slab-major order, i.e. slabs >= 128 bytes)
                     for sched in scheds:
                         space.append({"FS": fs, "DEPTH": d, "WAVES": w, "EB": elem_bytes, "SCHED": sched})
     return tuple(space)
