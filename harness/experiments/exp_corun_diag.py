@@ -16,6 +16,8 @@ PKG = os.path.join(REPO, "voltrix-spmm_amd")
 sys.path[:0] = [REPO, PKG]
 os.environ.setdefault("VOLTRIX_CACHE_DIR", os.path.join(PKG, ".jit_cache"))
 VARIANTS = {"full": 0, "no_mfma": 1, "no_mfma_no_rows": 3, "only_loop_control": 31}
+if os.environ.get("EXP_SLEEP"):   # the panel kernel throttled by s_sleep per k-step (name -> quanta)
+    VARIANTS = {"full": 0, "sleep1": 0, "sleep2": 0, "sleep4": 0, "sleep8": 0}
 
 
 def so(name):
@@ -25,7 +27,8 @@ def so(name):
 def build():
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     procs = [subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                               f"-DVOLTRIX_PANEL_DIAG={bits}", f"-I{PKG}/voltrix/include", f"-I{REPO}/include",
+                               f"-DVOLTRIX_PANEL_DIAG={bits}", f"-DVOLTRIX_PANEL_SLEEP={int(name[5:]) if name.startswith('sleep') else 0}",
+                               f"-I{PKG}/voltrix/include", f"-I{REPO}/include",
                                os.path.join(HERE, "corun_diag.hip"), "-o", so(name)]) for name, bits in VARIANTS.items()]
     assert all(p.wait() == 0 for p in procs)
 
@@ -49,14 +52,16 @@ def run():
     r_indptr, r_indices, plan = hybrid.build_panel_plan(indptr, indices, n, None, 8, 4, 3)
     resid = voltrix.csr_fused_preprocess_kernel(r_indptr, r_indices, n)[:3]
     rn = r_indices.numel()
-    tb = unit_table(resid[0], n)
+    from voltrix.schedule import default_max_stages
+
+    tb = unit_table(resid[0], n, max(8, int(1.25 * default_max_stages(resid[0], n) / 1.5)))   # the shipped residual launch:
     buf = torch.empty(max(1, tb.num_slots) * 16 * F, dtype=torch.float32, device=dev)
 
     flags = [1]   # atomic output (round 2 experiment build: | 2 = s_setprio 3 in the window kernel; shipped: always set)
 
     def window(stream):
         rc = capi.launch_spmm_sched(resid[0].data_ptr(), resid[1].data_ptr(), resid[2].data_ptr(), n, rn, F, feat.data_ptr(),
-                                    out.data_ptr(), (128, 3, 4), stream, 0, 0, flags[0], False, tb, buf.data_ptr())
+                                    out.data_ptr(), (128, 3, 4), stream, 0, 0, flags[0], False, tb, buf.data_ptr(), 0, 2)   # two units per wave
         assert rc == 0
 
     def timed(fn, stream, iters=10):

@@ -45,6 +45,11 @@
 #ifndef VOLTRIX_PANEL_DIAG
 #define VOLTRIX_PANEL_DIAG 0
 #endif
+// Experiment builds only: s_sleep of that many 64-clock quanta at the top of every k-step group (yield issue slots and
+// memory pipes to the window kernel beside it).  Shipped kernels: 0.
+#ifndef VOLTRIX_PANEL_SLEEP
+#define VOLTRIX_PANEL_SLEEP 0
+#endif
 
 namespace voltrix {
 
@@ -113,6 +118,7 @@ struct PanelArgs {
   int num_panels;
   int panels_per_xcd;
   int F;
+  int throttle;                // s_sleep quanta per k-step group (0; VOLTRIX_PANEL_THROTTLE for experiments)
   int meta_nt;                 // 1: bitmap / column DMAs are non-temporal (launcher: one slab covers F, every byte read once)
   int accumulate;              // 0: C = A_shared * B;  1: C += A_shared * B (C holds the window kernel's part, read-add-store);
                                // 2: C += A_shared * B by float atomics (C pre-zeroed, the window kernel adds its part the
@@ -237,6 +243,22 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
     int ds_r = (D - 1) % D, ms_r = (D - 1) % MS;         // group t + D - 1 (rows issued this step)
     int ms_m = (2 * D - 2) % MS;                         // group t + 2D - 2 (metadata issued this step)
     for (int t = 0; t < ngroups; ++t) {
+      if (VOLTRIX_PANEL_SLEEP) __builtin_amdgcn_s_sleep(VOLTRIX_PANEL_SLEEP);
+      // Optional throttle (VOLTRIX_PANEL_THROTTLE, experiments): sleeping a few 64-clock quanta per k-step leaves issue
+      // slots, LDS and memory pipes to the gather-bound window-kernel waves next to this workgroup.  Bare kernel pair, back
+      // to back: 1.341 -> 1.295 ms with 4 quanta (profiles/r02/experiment_corun_diag_sleep.log); through the operator the
+      // panel kernel has no such slack (1.28 vs 1.34 ms) and every setting loses (1.350 / 1.360 / 1.366 / 1.381 ms for 0 / 3 /
+      // 4 / 6 quanta, profiles/r02/bench_ab_panel_throttle.txt).  Shipped: 0.
+      switch (a.throttle) {  // workgroup-uniform; s_sleep takes an immediate
+        case 0: break;
+        case 1: __builtin_amdgcn_s_sleep(1); break;
+        case 2: __builtin_amdgcn_s_sleep(2); break;
+        case 3: __builtin_amdgcn_s_sleep(3); break;
+        case 4: __builtin_amdgcn_s_sleep(4); break;
+        case 5: __builtin_amdgcn_s_sleep(5); break;
+        case 6: __builtin_amdgcn_s_sleep(6); break;
+        default: __builtin_amdgcn_s_sleep(8); break;
+      }
       // rows of group t (issued D-1 steps ago) and the metadata of group t+D-1 must have landed; the D-2 younger
       // steps may stay in flight.  Steps past ngroups-D+1 issue nothing.
       const int young = ngroups - 1 - t;
@@ -379,6 +401,8 @@ inline int launch_spmm_panel(const int* panel_ptr, const int* panel_cols, const 
   a.accumulate = accumulate;
   const int slabs = (embedding_dim + T::FS - 1) / T::FS;
   a.meta_nt = slabs == 1;
+  a.throttle = 0;
+  if (const char* e = std::getenv("VOLTRIX_PANEL_THROTTLE")) a.throttle = std::atoi(e);   // experiments
   const int lds_rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&spmm_panel_kernel<T>), T::BLOCK_LDS);
   if (lds_rc != kOk) return lds_rc;
   hipLaunchKernelGGL(spmm_panel_kernel<T>, dim3((unsigned)(a.panels_per_xcd * kNumXcd), (unsigned)slabs),
