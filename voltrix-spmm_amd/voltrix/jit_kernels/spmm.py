@@ -46,7 +46,7 @@ SCHED_UNITS = 4
 # 1.365 -> 1.293 ms (profiles/r02/experiment_pair_units.log).  16-bit binary operand, four-wave tiles; with several column
 # slabs the launch is slab-major (slabs of 128 bytes and more) and a pair never straddles two slabs.
 SCHED_PAIRS = 5
-PAIR_UNIT_FACTOR = 1.25
+PAIR_UNIT_FACTOR = float(os.getenv("VOLTRIX_PAIR_UNIT_FACTOR", "1.25"))   # x the median window length (experiments: 1.0 .. 1.5)
 
 
 def feature_hash(feature: torch.Tensor) -> str:
