@@ -222,6 +222,26 @@ void voltrix_launch_spmm_panel_bf16(void* panel_ptr, void* panel_cols, void* pan
                                     int depth, int waves, int row_blocks, int ksteps, void* out_scale, void* stream,
                                     int* return_code);
 
+/* The two-level format in ONE launch (spmm_fused_kernels.hpp; round 3).  One 512-thread workgroup per 512-row panel
+ * (waves = 8, row_blocks = 4) computes the whole product for its rows: the shared columns from the panel plan (arrays as for
+ * voltrix_launch_spmm_panel_f16) and the residual edges from per-wave streams of stage records, into the same accumulators;
+ * output [num_nodes, embedding_dim] float32 is written once with plain stores (every row; no zero fill, no atomics, no
+ * second stream, no combine pass; the summation order is fixed, so results are run-to-run identical).
+ *   wave_ptr int32 [8 NP + 1]    first record of (panel p, wave v) at index 8 p + v; wave v owns windows 32 p + 4 v + j, j < 4
+ *   records  uint32 [R + 1][64]  16-byte aligned; one record = one stage (4 TC blocks = 32 condensed columns) of ONE of the
+ *                                wave's windows: words 0..31 rows of `input` (unused columns repeat a real one), 32..47 the
+ *                                stage's 16 bitmap words (hspa_packed order), word 48 = j; a wave's records are sorted by
+ *                                their first column; one record of padding at the end.  Built from the block-format handle of
+ *                                the residual matrix by voltrix_launch_fused_records_* below.
+ * Tile: fs in {32,64,128}, depth = slots of the shared panel ring (3, or 4 below fs 128); VOLTRIX_ERR_BAD_CONFIG otherwise.
+ * input / out_scale as for voltrix_launch_spmm_panel_f16. */
+void voltrix_launch_spmm_fused_f16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order,
+                                   void* wave_ptr, void* records, int num_nodes, int embedding_dim, void* input,
+                                   void* output, int fs, int depth, void* out_scale, void* stream, int* return_code);
+void voltrix_launch_spmm_fused_bf16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order,
+                                    void* wave_ptr, void* records, int num_nodes, int embedding_dim, void* input,
+                                    void* output, int fs, int depth, void* out_scale, void* stream, int* return_code);
+
 /* Builder of the panel plan (panel_plan.hpp): CSR on the DEVICE (rows sorted, duplicate-free, ids in [0, num_cols),
  * num_cols <= 2^22) -> residual CSR + plan, in two phases because the caller owns every buffer:
  *   phase 1  voltrix_launch_panel_plan_count: panel_ptr int32[NP+1], resid_node_pointer int32[num_nodes+1], status[1];

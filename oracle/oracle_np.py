@@ -323,3 +323,75 @@ def panel_to_edges(panel_ptr, panel_cols, panel_bits, num_nodes, waves, row_bloc
                                 assert row < num_nodes
                                 edges.append((row, int(panel_cols[32 * ks + 8 * g + c])))
     return sorted(edges)
+
+
+# ------------------------------------------------------- residual stage records of the one-launch two-level format
+def fused_records(pointer1, hspa_packed, hind, num_nodes, waves=8, row_blocks=4):
+    """Definition (plain loops) of the per-wave stage-record stream that ``spmm_fused_kernel`` consumes
+    (spmm_fused_kernels.hpp; no reference counterpart): the block-format handle of the RESIDUAL matrix, re-packed.
+
+    A *stage* is four consecutive TC blocks of one window (32 condensed columns); wave v of panel p owns windows
+    ``row_blocks * (waves * p + v) + j``, j < row_blocks, and its records are the stages of those windows MERGED by their first
+    column (ties: lower j first).  A window whose only block is all zero (the reference's empty-window quirk,
+    bmat_kernels.cuh:252) has no stage.  Record = 64 uint32: words 0..31 the rows of B of the 32 columns (columns
+    nobody references, and blocks past the window's end, repeat the window's first column: finite data, zero bits), words
+    32..47 the 16 bitmap words (zero past the window's end), word 48 = j, the rest 0.
+    -> ``(wave_ptr int32 [waves * NP + 1], records uint32 [R + 1, 64])`` (one zero record of padding)."""
+    pointer1 = np.asarray(pointer1, dtype=np.int64)
+    packed = np.asarray(hspa_packed, dtype=np.uint32)
+    hind = np.asarray(hind, dtype=np.int64)
+    num_windows = (num_nodes + BLK_H - 1) // BLK_H
+    panel_rows = waves * row_blocks * BLK_H
+    num_panels = (num_nodes + panel_rows - 1) // panel_rows
+    wave_ptr = np.zeros(waves * num_panels + 1, dtype=np.int32)
+    records = []
+    for gw in range(waves * num_panels):
+        stages = []
+        for j in range(row_blocks):
+            w = row_blocks * gw + j
+            if w >= num_windows:
+                continue
+            kb0, kb1 = int(pointer1[w]), int(pointer1[w + 1])
+            if kb1 - kb0 == 1 and not packed[4 * kb0:4 * kb0 + 4].any():
+                continue
+            for sb in range(kb0, kb1, 4):
+                stages.append((int(hind[8 * sb]), j, sb, kb0, kb1))
+        stages.sort(key=lambda s: (s[0], s[1]))
+        for _, j, sb, kb0, kb1 in stages:
+            rec = np.zeros(64, dtype=np.uint32)
+            safe = int(hind[8 * kb0])
+            for k in range(32):
+                blk, c = sb + k // 8, k % 8
+                used = False
+                if blk < kb1:
+                    mask = np.uint32((0x11111111 << (c & 3)) & 0xFFFFFFFF)
+                    used = bool((packed[4 * blk + 2 * (c >> 2)] | packed[4 * blk + 2 * (c >> 2) + 1]) & mask)
+                rec[k] = int(hind[8 * blk + c]) if used else safe
+            for t in range(16):
+                blk = sb + t // 4
+                rec[32 + t] = packed[4 * blk + t % 4] if blk < kb1 else 0
+            rec[48] = j
+            records.append(rec)
+        wave_ptr[gw + 1] = len(records)
+    records.append(np.zeros(64, dtype=np.uint32))
+    return wave_ptr, np.stack(records)
+
+
+def fused_records_to_edges(wave_ptr, records, num_nodes, waves=8, row_blocks=4):
+    """Consumer-side interpreter of the record stream (what spmm_fused_kernel's half-stages multiply): sorted (row, col)."""
+    edges = []
+    for gw in range(len(wave_ptr) - 1):
+        for r in range(int(wave_ptr[gw]), int(wave_ptr[gw + 1])):
+            rec = records[r]
+            j = int(rec[48]) & 3
+            for half in range(2):
+                for lane in range(64):
+                    g, row16 = lane >> 4, lane & 15
+                    word = int(rec[32 + 8 * half + 4 * (g >> 1) + (row16 >> 3) + 2 * (g & 1)])
+                    nib = (word >> (4 * (row16 & 7))) & 0xF
+                    for i in range(4):
+                        if (nib >> i) & 1:
+                            row = BLK_H * (row_blocks * gw + j) + row16
+                            assert row < num_nodes
+                            edges.append((row, int(rec[16 * half + 4 * g + i])))
+    return sorted(edges)

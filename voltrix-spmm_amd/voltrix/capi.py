@@ -35,6 +35,8 @@ SYMBOLS = (
     "voltrix_launch_spmm_f16_list",
     "voltrix_launch_spmm_panel_f16",
     "voltrix_launch_spmm_panel_bf16",
+    "voltrix_launch_spmm_fused_f16",
+    "voltrix_launch_spmm_fused_bf16",
     "voltrix_launch_add_inplace_f32",
     "voltrix_launch_zero_f32",
     "voltrix_panel_plan_workspace_bytes",
@@ -263,6 +265,19 @@ def launch_spmm_panel(plan, input_ptr, output_ptr, embedding_dim, accumulate, bf
     return rc.value
 
 
+def launch_spmm_fused(plan, fused, input_ptr, output_ptr, embedding_dim, bf16, tile, out_scale, stream) -> int:
+    """The two-level product in one launch; ``plan`` = voltrix.hybrid.PanelPlan (8 waves x 4 row blocks), ``fused`` =
+    voltrix.hybrid.FusedRecords, ``tile`` = (fs, depth).  Returns the return code."""
+    rc = ctypes.c_int(-1)
+    fn = lib().voltrix_launch_spmm_fused_bf16 if bf16 else lib().voltrix_launch_spmm_fused_f16
+    order = plan.panel_order.data_ptr() if plan.panel_order is not None else 0
+    fn(_ptr(plan.panel_ptr), _ptr(plan.panel_cols), _ptr(plan.panel_bits), ctypes.c_void_p(order), _ptr(fused.wave_ptr),
+       _ptr(fused.records), ctypes.c_int(plan.num_nodes), ctypes.c_int(embedding_dim), ctypes.c_void_p(input_ptr),
+       ctypes.c_void_p(output_ptr), ctypes.c_int(tile[0]), ctypes.c_int(tile[1]), ctypes.c_void_p(out_scale),
+       ctypes.c_void_p(stream), ctypes.byref(rc))
+    return rc.value
+
+
 def launch_panel_order(panel_ptr, num_panels: int, order_out, stream, group: int = 1) -> None:
     rc = ctypes.c_int(-1)
     lib().voltrix_launch_panel_order(_ptr(panel_ptr), ctypes.c_int(num_panels), ctypes.c_int(group), _ptr(order_out),
@@ -355,6 +370,7 @@ def _timed(fn, name, stream_index=None, stream_kw="stream"):
 launch_spmm = _timed(launch_spmm, "spmm", 10)
 launch_spmm_sched = _timed(launch_spmm_sched, "spmm", 9)
 launch_spmm_panel = _timed(launch_spmm_panel, "spmm_panel", 8)
+launch_spmm_fused = _timed(launch_spmm_fused, "spmm_fused", 8)
 launch_combine_partials = _timed(launch_combine_partials, "combine_partials", 6)
 launch_add_inplace_f32 = _timed(launch_add_inplace_f32, "add_inplace_f32", 2)
 launch_cast_f32_f16_scaled = _timed(launch_cast_f32_f16_scaled, "cast_f32_f16_scaled", 3)

@@ -70,11 +70,82 @@ class TwoLevelHandle:
     num_nodes: int
     num_edges: int               # of the whole matrix (shared + residual)
     hash_tag: str = None         # tuner key of the residual launches (like hspa_packed.hash_tag in the reference)
+    fused: "FusedRecords" = None  # the residual re-packed for the one-launch kernel (spmm_fused_kernels.hpp), or None
     format_choice: dict = dataclasses.field(default_factory=dict)   # (width, dtype) -> "two-level" | "window" (voltrix.spmm, auto mode)
 
     @property
     def residual(self):
         return self.blk_offsets, self.hspa_packed, self.hind
+
+
+@dataclasses.dataclass
+class FusedRecords:
+    """The residual matrix as per-wave streams of 256-byte stage records for ``spmm_fused_kernel`` (one launch for the
+    whole two-level product, spmm_fused_kernels.hpp).  Layout pinned by ``oracle/oracle_np.py::fused_records``."""
+    wave_ptr: torch.Tensor       # int32 [8 NP + 1]: first record of (panel, wave)
+    records: torch.Tensor        # uint32 [R + 1, 64] (one record of padding)
+    num_records: int
+
+    def nbytes(self) -> int:
+        return self.wave_ptr.numel() * 4 + self.records.numel() * 4
+
+
+RECORD_WORDS = 64
+
+
+def build_fused_records_torch(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tensor, num_nodes: int,
+                              waves: int = DEFAULT_WAVES, row_blocks: int = DEFAULT_ROW_BLOCKS) -> FusedRecords:
+    """Block-format handle of the residual -> ``FusedRecords`` with torch tensor ops on the handle's device (a stable sort
+    of the stages by (wave, first column, row block) + gathers).  The HIP builder (fused_plan.hpp) produces the same bytes;
+    this form also runs on the CPU and is what the tests compare both against the plain-loop definition with."""
+    assert blk_offsets.dtype == torch.int32 and hind.dtype == torch.int32 and hspa_packed.dtype == torch.uint32
+    device = blk_offsets.device
+    num_windows = (num_nodes + 15) // 16
+    panel_rows = waves * row_blocks * 16
+    num_waves = waves * ((num_nodes + panel_rows - 1) // panel_rows)
+    bo = blk_offsets.to(torch.int64)
+    kb0, kb1 = bo[:-1], bo[1:]
+    nblk = kb1 - kb0
+    packed = hspa_packed.view(torch.int32).view(-1, 4)
+    hind64 = hind
+    total_blocks = packed.shape[0]
+    # the reference's empty-window quirk: one all-zero block, nothing to multiply
+    zero_first = (packed[kb0.clamp(max=max(total_blocks - 1, 0))] == 0).all(dim=1) if total_blocks else nblk < 0
+    nstage = torch.where((nblk == 1) & zero_first, torch.zeros_like(nblk), (nblk + 3) // 4)
+    win = torch.repeat_interleave(torch.arange(num_windows, device=device), nstage)
+    first_stage = torch.cumsum(nstage, 0) - nstage
+    sidx = torch.arange(win.numel(), device=device) - first_stage[win]
+    sb = kb0[win] + 4 * sidx
+    first_col = hind64[8 * sb].to(torch.int64)
+    ncols = int(first_col.max()) + 1 if win.numel() else 1
+    order = torch.argsort(((win // row_blocks) * ncols + first_col) * row_blocks + win % row_blocks, stable=True)
+    win, sb = win[order], sb[order]
+    wave_ptr = torch.zeros(num_waves + 1, dtype=torch.int64, device=device)
+    wave_ptr[1:] = torch.cumsum(torch.bincount(win // row_blocks, minlength=num_waves), 0)
+    num_records = int(win.numel())
+    records = torch.zeros((num_records + 1, RECORD_WORDS), dtype=torch.int32, device=device)
+    chunk = 1 << 20          # bounded temporaries (int64 [chunk, 32])
+    for lo in range(0, num_records, chunk):
+        hi = min(lo + chunk, num_records)
+        w_, sb_ = win[lo:hi], sb[lo:hi]
+        end = kb1[w_][:, None]
+        k = torch.arange(32, device=device)[None, :]
+        blk = sb_[:, None] + k // 8
+        inwin = blk < end
+        blk = torch.where(inwin, blk, kb0[w_][:, None])
+        c = k % 8
+        words = packed[blk, 2 * (c >> 2)] | packed[blk, 2 * (c >> 2) + 1]
+        colmask = ((0x11111111 << (c & 3)) & 0xFFFFFFFF).to(torch.int64)
+        used = inwin & (((words.to(torch.int64) & 0xFFFFFFFF) & colmask) != 0)
+        safe = hind64[8 * kb0[w_]][:, None]
+        records[lo:hi, :32] = torch.where(used, hind64[8 * blk + c], safe)
+        t = torch.arange(16, device=device)[None, :]
+        blk = sb_[:, None] + t // 4
+        inwin = blk < end
+        blk = torch.where(inwin, blk, kb0[w_][:, None])
+        records[lo:hi, 32:48] = torch.where(inwin, packed[blk, t % 4], torch.zeros((), dtype=torch.int32, device=device))
+        records[lo:hi, 48] = (w_ % row_blocks).to(torch.int32)
+    return FusedRecords(wave_ptr=wave_ptr.to(torch.int32), records=records.view(torch.uint32), num_records=num_records)
 
 
 def split_shared_columns(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int, panel_rows: int,
@@ -369,6 +440,40 @@ def launch_panel(plan: PanelPlan, feat: torch.Tensor, output: torch.Tensor, accu
                                 feat.dtype == torch.bfloat16, tile, out_scale.data_ptr() if out_scale is not None else 0,
                                 stream)
     capi.check(rc, "voltrix_launch_spmm_panel")
+
+
+# fused kernel tile per feature width: (fs, depth of the shared panel ring)
+def default_fused_tile(embedding_dim: int):
+    if embedding_dim <= 32:
+        return (32, 4)
+    if embedding_dim <= 64:
+        return (64, 4)
+    return (128, 3)
+
+
+def fused_enabled() -> bool:
+    """``VOLTRIX_FUSED=1``: run the two-level product as ONE launch (spmm_fused_kernel: plain stores, no zero fill, no
+    atomics, no second stream, one fixed summation order) instead of the panel kernel beside the window kernel with the
+    atomic join.  Off by default: measured on the reddit-like graph the one-launch kernel takes 2.0 ms against 1.35 ms for
+    the pair (profiles/r03/experiment_fused_*.log) -- it stays as the form for hosts that want a
+    single stream-ordered launch and run-to-run identical bits."""
+    return os.getenv("VOLTRIX_FUSED", "0") in ("1", "on")
+
+
+def launch_fused(plan: PanelPlan, fused: FusedRecords, feat: torch.Tensor, output: torch.Tensor, out_scale=None,
+                 tile=None, stream=None) -> None:
+    """``output = (A_shared + A_resid) @ feat`` in ONE launch (spmm_fused_kernels.hpp): every row of ``output`` is written
+    once, plain stores, fixed summation order.  fp16 / bfloat16 ``feat`` [*, F], float32 ``output`` [N, F]."""
+    assert feat.is_cuda and feat.is_contiguous() and feat.dtype in (torch.float16, torch.bfloat16)
+    assert output.is_cuda and output.is_contiguous() and output.dtype == torch.float32
+    assert plan.waves == DEFAULT_WAVES and plan.row_blocks == DEFAULT_ROW_BLOCKS, "the fused kernel owns 8 x 4 x 16-row panels"
+    f = feat.shape[1]
+    assert output.shape == (plan.num_nodes, f)
+    tile = tile or default_fused_tile(f)
+    stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    rc = capi.launch_spmm_fused(plan, fused, feat.data_ptr(), output.data_ptr(), f, feat.dtype == torch.bfloat16, tile,
+                                out_scale.data_ptr() if out_scale is not None else 0, stream)
+    capi.check(rc, "voltrix_launch_spmm_fused")
 
 
 def min_shared_fraction() -> float:

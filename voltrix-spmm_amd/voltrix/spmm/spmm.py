@@ -104,7 +104,17 @@ def _build_two_level(indptr_d, indices_d, num_nodes, num_cols, waves=hybrid.DEFA
     if plan.num_ksteps == 0 or plan.num_shared_edges < min_share * max(1, indices_d.numel()):
         return None
     pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(resid_indptr, resid_indices, num_nodes, num_cols)
-    return hybrid.TwoLevelHandle(pointer1, hspa_packed, hind, plan, num_nodes, int(indices_d.numel()))
+    two = hybrid.TwoLevelHandle(pointer1, hspa_packed, hind, plan, num_nodes, int(indices_d.numel()))
+    _attach_fused(two)
+    return two
+
+
+def _attach_fused(two) -> None:
+    """Stage records of the one-launch kernel (8 x 4 x 16-row panels with a non-empty plan only)."""
+    plan = two.plan
+    if (hybrid.fused_enabled() and plan.num_ksteps > 0 and plan.waves == hybrid.DEFAULT_WAVES
+            and plan.row_blocks == hybrid.DEFAULT_ROW_BLOCKS):
+        two.fused = hybrid.build_fused_records_torch(two.blk_offsets, two.hspa_packed, two.hind, two.num_nodes)
 
 
 def csr_preprocess_hybrid(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
@@ -123,7 +133,9 @@ def csr_preprocess_hybrid(indptr: torch.Tensor, indices: torch.Tensor, num_nodes
     resid_indptr, resid_indices, plan = hybrid.build_panel_plan(indptr_d, indices_d, num_nodes, num_cols, waves, row_blocks,
                                                                 tau)
     pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(resid_indptr, resid_indices, num_nodes, num_cols)
-    return hybrid.TwoLevelHandle(pointer1, hspa_packed, hind, plan, num_nodes, int(indices.numel()))
+    two = hybrid.TwoLevelHandle(pointer1, hspa_packed, hind, plan, num_nodes, int(indices.numel()))
+    _attach_fused(two)
+    return two
 
 
 def _operand(feat: torch.Tensor):
@@ -213,6 +225,9 @@ def _choose_format(hspa_packed, key, window, two_level) -> str:
 
 
 def _run_two_level(two, operand, output, out_scale, tag_source=None):
+    if two.fused is not None and hybrid.fused_enabled():
+        hybrid.launch_fused(two.plan, two.fused, operand, output, out_scale=out_scale)   # one launch, C written once
+        return
     resid = two.hspa_packed
     if getattr(resid, "hash_tag", None) is None:   # tuner key of the residual launches: the caller's tag + a suffix
         tag = two.hash_tag or getattr(tag_source, "hash_tag", None)
