@@ -212,7 +212,12 @@ void voltrix_launch_spmm_f16_list(void* hspa_packed, void* hind, int num_nodes, 
  * already holds the window kernel's result for the remaining edges); 2 adds with float atomics onto a pre-zeroed output that
  * the window kernel (atomic_out = 1) adds to as well, in any order.  input _Float16 (bfloat16 for _bf16) [*, embedding_dim], 16-byte
  * aligned, embedding_dim % 8 == 0.  Tile: fs in {32,64,128}, depth = ring slots, ksteps per ring slot in {1,2};
- * VOLTRIX_ERR_BAD_CONFIG if the combination is not instantiated.  out_scale as for voltrix_launch_spmm_f16_tile. */
+ * VOLTRIX_ERR_BAD_CONFIG if the combination is not instantiated; VOLTRIX_ERR_BAD_SHAPE for accumulate outside 0..2.
+ * out_scale as for voltrix_launch_spmm_f16_tile.
+ * MEMORY REQUIREMENT of the atomic forms (accumulate == 2 here, atomic_out != 0 in voltrix_launch_spmm_*_sched): they use the
+ * hardware's no-return global_atomic_add_f32, which is only defined on ordinary (coarse-grained) device memory -- hipMalloc,
+ * torch's allocator.  On fine-grained or host-mapped output (hipHostMalloc, hipMallocManaged with fine-grained coherence) the
+ * adds can be lost silently: give such outputs a device-memory staging buffer, or use accumulate 0 / 1. */
 void voltrix_launch_spmm_panel_f16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order,
                                    int num_nodes, int embedding_dim, void* input, void* output, int accumulate, int fs,
                                    int depth, int waves, int row_blocks, int ksteps, void* out_scale, void* stream,

@@ -238,10 +238,13 @@ def longest_first_order(panel_ptr: torch.Tensor, group: int = PANEL_ORDER_GROUP)
 
 
 def build_panel_plan(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
-                     waves: int = DEFAULT_WAVES, row_blocks: int = DEFAULT_ROW_BLOCKS, tau: int = DEFAULT_TAU):
+                     waves: int = DEFAULT_WAVES, row_blocks: int = DEFAULT_ROW_BLOCKS, tau: int = DEFAULT_TAU,
+                     min_share: float = 0.0):
     """CSR on the GPU -> ``(resid_indptr, resid_indices, PanelPlan)`` with the HIP builder (panel_plan.hpp; two launches
     around one host sync that sizes the outputs).  Universes above 2^22 columns -- or (column ranges x edges) above 2e10,
-    the builder's cost -- get an empty plan (everything stays in the window format)."""
+    the builder's cost -- get an empty plan (everything stays in the window format).  ``min_share``: when the count phase
+    finds fewer than that fraction of the edges in shared columns the builder stops there and returns the empty plan (no
+    fill phase, no residual CSR: the format that would lose is never built)."""
     assert indptr.is_cuda and indices.is_cuda and indptr.dtype == torch.int32 and indices.dtype == torch.int32
     assert indptr.is_contiguous() and indices.is_contiguous() and indptr.numel() == num_nodes + 1
     assert waves in (4, 8) and row_blocks in (2, 4) and 1 <= tau <= 65535
@@ -270,6 +273,10 @@ def build_panel_plan(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int
             # exactly what csr_preprocess does with them (universe-free sort path)
             return indptr, indices, empty_plan(num_nodes, waves, row_blocks, tau, device, indices.numel())
         indptr, indices = canonical_csr(indptr, indices, num_nodes, num_cols)   # unsorted rows / duplicates: once
+    if total_ksteps == 0 or indices.numel() - num_resid < min_share * max(1, indices.numel()):
+        plan = empty_plan(num_nodes, waves, row_blocks, tau, device, indices.numel())
+        plan.num_shared_edges = indices.numel() - num_resid      # what the count phase saw (the plan itself is empty)
+        return indptr, indices, plan
     resid_indices = torch.empty(num_resid, dtype=torch.int32, device=device)
     panel_cols = torch.empty(KSTEP * (total_ksteps + 2), dtype=torch.int32, device=device)
     panel_bits = torch.empty((total_ksteps + 1) * waves * 64, dtype=torch.int32, device=device).view(torch.uint32)
@@ -477,16 +484,32 @@ def launch_fused(plan: PanelPlan, fused: FusedRecords, feat: torch.Tensor, outpu
 
 
 def min_shared_fraction() -> float:
-    """Below this fraction of edges in shared columns ``csr_preprocess_hybrid`` keeps the plain window format."""
-    return float(os.getenv("VOLTRIX_HYBRID_MIN_SHARE", "0.2"))
+    """Fraction of the edges that must sit in shared columns for ``csr_preprocess`` to attach the two-level side-car
+    (``VOLTRIX_HYBRID_MIN_SHARE``).  Default 0.4 in ``auto`` mode -- the measured break-even lies between the reddit-like
+    graph (55 % shared: two-level 1.38 ms, window format 1.87 ms) and its uniform-column variant (29 % shared: 2.20 vs
+    1.73 ms), profiles/r02/bench_reddit_uniform_f128_operator.json -- and 0.2 when the side-car is forced
+    (``VOLTRIX_HYBRID=1``) or the first call is allowed to time both forms (``VOLTRIX_HYBRID=tune``)."""
+    default = "0.4" if hybrid_mode() == "auto" else "0.2"
+    return float(os.getenv("VOLTRIX_HYBRID_MIN_SHARE", default))
 
 
 def hybrid_mode() -> str:
-    """``VOLTRIX_HYBRID``: ``auto`` (default) -- ``csr_preprocess`` also builds the two-level side-car when the graph is
-    big and dense enough for it to matter and enough of its edges sit in shared columns; ``1`` -- whenever enough edges
-    sit in shared columns; ``0`` -- never."""
+    """``VOLTRIX_HYBRID``:
+    ``auto`` (default)  ``csr_preprocess`` decides ONCE, from the plan builder's count phase: the two-level side-car is built
+                        when the graph is big and dense enough for the panel kernel to fill the chip AND at least
+                        ``min_shared_fraction()`` of its edges sit in shared columns; ``voltrix.spmm`` then uses it for
+                        every 16-bit-operand call.  No timing, no host sync in the operator, same choice (hence the same
+                        fp32 summation order, the same bits) in every process and on every rank.
+    ``tune``            round-2 behaviour, opt-in: the side-car is built from 20 % shared edges on, and the FIRST
+                        ``voltrix.spmm`` per (width, dtype) times both forms (3 runs each, one host sync, not capturable in
+                        a HIP graph) and keeps the faster, persisted in ``tuned.json`` under the matrix tag + device.
+    ``1``               the side-car whenever enough edges sit in shared columns, used unconditionally;  ``0`` never."""
     v = os.getenv("VOLTRIX_HYBRID", "auto")
-    return "off" if v in ("0", "", "off") else ("on" if v in ("1", "on") else "auto")
+    if v in ("0", "", "off"):
+        return "off"
+    if v in ("1", "on"):
+        return "on"
+    return "tune" if v == "tune" else "auto"
 
 
 # auto mode: below this many edges, or this mean degree, the side-car is not even tried (its build costs a few ms and the
@@ -496,3 +519,17 @@ AUTO_MIN_MEAN_DEGREE = 64
 # ... and one panel workgroup (512 rows) per CU at the very least: below that the panel kernel cannot fill the chip
 # (measured on a 46 k-row banded graph: 0.29 ms with the side-car, 0.24 ms in the window format)
 AUTO_MIN_ROWS = 256 * DEFAULT_WAVES * DEFAULT_ROW_BLOCKS * 16
+
+
+def handle_bytes(tensors) -> int:
+    """Device bytes of a handle's tensors (reporting: bench.py ``handle_bytes``)."""
+    return int(sum(t.numel() * t.element_size() for t in tensors if isinstance(t, torch.Tensor)))
+
+
+def two_level_bytes(two: "TwoLevelHandle") -> int:
+    plan = two.plan
+    total = handle_bytes((two.blk_offsets, two.hspa_packed, two.hind, plan.panel_ptr, plan.panel_cols, plan.panel_bits,
+                          plan.panel_order))
+    if two.fused is not None:
+        total += two.fused.nbytes()
+    return total

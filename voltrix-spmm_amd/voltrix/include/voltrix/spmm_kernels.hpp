@@ -164,11 +164,19 @@ inline int ensure_dynamic_lds(const void* kernel, int bytes) {
   static std::vector<Seen> seen;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return kErrLaunch;
+  // fast path without the lock: the last (kernel, device) this thread raised -- the common case of one kernel launched
+  // over and over from one host thread
+  static thread_local Seen last = {nullptr, -1};
+  if (last.k == kernel && last.dev == dev) return kOk;
   std::lock_guard<std::mutex> lock(mu);
   for (const Seen& s : seen)
-    if (s.k == kernel && s.dev == dev) return kOk;
+    if (s.k == kernel && s.dev == dev) {
+      last = s;
+      return kOk;
+    }
   if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return kErrBadConfig;
   seen.push_back(Seen{kernel, dev});
+  last = seen.back();
   return kOk;
 }
 
@@ -711,10 +719,13 @@ void spmm_tc16_pair_kernel(const SpmmArgs<T> a) {
 // VOLTRIX_SLAB_ORDER=major|minor overrides the rule (experiments).
 inline int slab_major_order(int num_slabs, int slab_row_bytes) {
   if (num_slabs <= 1) return 0;
-  if (const char* e = std::getenv("VOLTRIX_SLAB_ORDER")) {
-    if (e[0] == 'm' && e[1] == 'a') return 1;
-    if (e[0] == 'm' && e[1] == 'i') return 0;
-  }
+  static const int forced = [] {   // read once, not per launch: -1 = the rule below
+    const char* e = std::getenv("VOLTRIX_SLAB_ORDER");
+    if (e && e[0] == 'm' && e[1] == 'a') return 1;
+    if (e && e[0] == 'm' && e[1] == 'i') return 0;
+    return -1;
+  }();
+  if (forced >= 0) return forced;
   return slab_row_bytes >= 128;
 }
 

@@ -383,7 +383,7 @@ template <class T>
 inline int launch_spmm_panel(const int* panel_ptr, const int* panel_cols, const uint32_t* panel_bits,
                              const int* panel_order, int num_nodes, int embedding_dim, const void* input, float* output,
                              int accumulate, const float* out_scale, hipStream_t stream) {
-  if (num_nodes < 0 || embedding_dim < 0) return kErrBadShape;
+  if (num_nodes < 0 || embedding_dim < 0 || accumulate < 0 || accumulate > 2) return kErrBadShape;
   if (num_nodes == 0 || embedding_dim == 0) return kOk;
   if (embedding_dim % 8 != 0 || ((uintptr_t)input & 15)) return kErrBadShape;
   PanelArgs<T> a;
@@ -401,8 +401,11 @@ inline int launch_spmm_panel(const int* panel_ptr, const int* panel_cols, const 
   a.accumulate = accumulate;
   const int slabs = (embedding_dim + T::FS - 1) / T::FS;
   a.meta_nt = slabs == 1;
-  a.throttle = 0;
-  if (const char* e = std::getenv("VOLTRIX_PANEL_THROTTLE")) a.throttle = std::atoi(e);   // experiments
+  static const int throttle_env = [] {   // experiments; read once, not per launch
+    const char* e = std::getenv("VOLTRIX_PANEL_THROTTLE");
+    return e ? std::atoi(e) : 0;
+  }();
+  a.throttle = throttle_env;
   const int lds_rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&spmm_panel_kernel<T>), T::BLOCK_LDS);
   if (lds_rc != kOk) return lds_rc;
   hipLaunchKernelGGL(spmm_panel_kernel<T>, dim3((unsigned)(a.panels_per_xcd * kNumXcd), (unsigned)slabs),

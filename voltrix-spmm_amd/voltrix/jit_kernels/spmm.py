@@ -210,6 +210,42 @@ def handle_unit_table(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, num_
     return table
 
 
+def graph_bucket_keys(blk_offsets: torch.Tensor, num_nodes: int, keys: dict):
+    """The tuner's coarse key (the reference memoises per process only, jit_kernels/tuner.py:44):
+    ``keys`` with the matrix tag replaced by a bucket of statistics of the handle -- log2 of the row count, log2 of the mean
+    TC blocks per window (what the mean degree becomes in the block format), the quartiles of the TC blocks per window in
+    half-octaves, and the coefficient of variation of the window lengths in steps of 0.25 (band graphs, uniform graphs and
+    power-law graphs of one size land in different buckets).  Graphs of one bucket keep the tile and schedule tuned on the
+    first of them.  One small device reduction + one host sync, only when a sweep would otherwise run; cached on the tensor."""
+    import math
+
+    cached = getattr(blk_offsets, "_voltrix_bucket", None)
+    if cached is None or cached[0] != (blk_offsets.data_ptr(), num_nodes):
+        num_windows = (num_nodes + 15) // 16
+        if num_windows == 0:
+            return None
+        nblk = (blk_offsets[1:num_windows + 1] - blk_offsets[:num_windows]).float()
+        sample = nblk[:: max(1, num_windows // (1 << 20))]
+        q = torch.quantile(sample, torch.tensor([0.25, 0.5, 0.75], device=nblk.device))
+        stats = torch.cat([q, nblk.mean()[None], nblk.std(unbiased=False)[None]]).tolist()
+
+        def half_octave(v):
+            return int(round(2 * math.log2(max(v, 1.0))))
+
+        bucket = {"log2_rows": int(round(math.log2(max(num_nodes, 1)))),
+                  "log2_mean_blocks_x2": half_octave(stats[3]),
+                  "quartiles_x2": [half_octave(v) for v in stats[:3]],
+                  "cv_x4": int(round(4 * stats[4] / max(stats[3], 1e-9)))}
+        cached = ((blk_offsets.data_ptr(), num_nodes), bucket)
+        try:
+            blk_offsets._voltrix_bucket = cached
+        except AttributeError:
+            pass
+    out = {k: v for k, v in keys.items() if k != "feature_hash"}
+    out["graph_bucket"] = str(cached[1])
+    return out
+
+
 _UNIT_SCALE = {}
 
 
@@ -274,33 +310,6 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
         assert values.numel() * 4 == hspa_packed.numel() * 128, "value plane: 128 values per TC block"
     space = tile_space(embedding_dim, elem_bytes, input.dtype == torch.bfloat16,
                        TWO_LEVEL_LDS_BUDGET if beside_panel else None, weighted=values is not None)
-    if any(p["SCHED"] == SCHED_UNITS for p in space):
-        table = handle_unit_table(blk_offsets, hspa_packed, num_nodes)
-        partials = torch.empty(max(1, table.num_slots) * 16 * embedding_dim, dtype=torch.float32, device=input.device)
-        units, unit_ptr, cuts = table.units, table.unit_ptr, table.cuts
-        max_units, num_cuts = table.max_units_per_xcd, table.num_cuts
-    else:
-        table, partials = None, out_scale
-        units = unit_ptr = cuts = blk_offsets   # never dereferenced (no SCHED 4 point in the space)
-        max_units = num_cuts = 0
-    if any(p["SCHED"] == SCHED_PAIRS for p in space):
-        table_p = handle_unit_table(blk_offsets, hspa_packed, num_nodes, pairs=True)
-        partials_p = torch.empty(max(1, table_p.num_slots) * 16 * embedding_dim, dtype=torch.float32, device=input.device)
-    else:
-        table_p, partials_p = None, out_scale
-
-    def make_args(out):
-        return (blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, out,
-                window_order(blk_offsets, hspa_packed, num_nodes, 1), window_order(blk_offsets, hspa_packed, num_nodes, 2),
-                window_order(blk_offsets, hspa_packed, num_nodes, 3), out_scale, int(bool(atomic_out)), units, unit_ptr,
-                max_units, cuts, num_cuts, partials,
-                table_p.units if table_p is not None else blk_offsets, table_p.unit_ptr if table_p is not None else blk_offsets,
-                table_p.max_units_per_xcd if table_p is not None else 0, table_p.cuts if table_p is not None else blk_offsets,
-                table_p.num_cuts if table_p is not None else 0, partials_p, int(not defer_combine),
-                row_map if row_map is not None else blk_offsets, int(row_map is not None),
-                values if values is not None else input, torch.cuda.current_stream())
-
-    args = make_args(output)
     keys = {
         "feature_hash": feature_hash(hspa_packed),
         "embedding_dim": embedding_dim,
@@ -309,10 +318,48 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
         "two_level": bool(beside_panel),
         "weighted": values is not None,
     }
-    # tuning runs must not add onto the caller's output: they get a scratch one (only built when a sweep will happen)
+    # unit tables / partial-tile buffers: before the choice is made, those of every schedule in the space (the sweep runs
+    # them all); afterwards only the chosen schedule's
+    chosen = jit_tuner.tuned_point("spmm_kernel", keys).get("SCHED") if jit_tuner.is_tuned("spmm_kernel", keys) else None
+    if chosen is not None:
+        want = lambda sched: chosen == sched                                    # noqa: E731
+    else:
+        want = lambda sched: any(p["SCHED"] == sched for p in space)           # noqa: E731
+    if want(SCHED_UNITS):
+        table = handle_unit_table(blk_offsets, hspa_packed, num_nodes)
+        partials = torch.empty(max(1, table.num_slots) * 16 * embedding_dim, dtype=torch.float32, device=input.device)
+        units, unit_ptr, cuts = table.units, table.unit_ptr, table.cuts
+        max_units, num_cuts = table.max_units_per_xcd, table.num_cuts
+    else:
+        table, partials = None, out_scale
+        units = unit_ptr = cuts = blk_offsets   # never dereferenced (no SCHED 4 point will run)
+        max_units = num_cuts = 0
+    if want(SCHED_PAIRS):
+        table_p = handle_unit_table(blk_offsets, hspa_packed, num_nodes, pairs=True)
+        partials_p = torch.empty(max(1, table_p.num_slots) * 16 * embedding_dim, dtype=torch.float32, device=input.device)
+    else:
+        table_p, partials_p = None, out_scale
+    needs_orders = chosen is None or chosen in ORDER_CHUNKS
+
+    def order(sched):
+        return window_order(blk_offsets, hspa_packed, num_nodes, sched) if needs_orders else blk_offsets
+
+    def make_args(out, combine_now):
+        return (blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, out,
+                order(1), order(2), order(3), out_scale, int(bool(atomic_out)), units, unit_ptr,
+                max_units, cuts, num_cuts, partials,
+                table_p.units if table_p is not None else blk_offsets, table_p.unit_ptr if table_p is not None else blk_offsets,
+                table_p.max_units_per_xcd if table_p is not None else 0, table_p.cuts if table_p is not None else blk_offsets,
+                table_p.num_cuts if table_p is not None else 0, partials_p, int(combine_now),
+                row_map if row_map is not None else blk_offsets, int(row_map is not None),
+                values if values is not None else input, torch.cuda.current_stream())
+
+    args = make_args(output, not defer_combine)
+    # tuning runs: every candidate is timed with its COMPLETE work (the unit-table schedules with their combine pass, also
+    # when the caller defers it), and a launch that adds onto its output gets a scratch one
     tune_args = args
-    if atomic_out and len(space) > 1 and not jit_tuner.is_tuned("spmm_kernel", keys):
-        tune_args = make_args(torch.zeros_like(output))
+    if len(space) > 1 and chosen is None and (atomic_out or defer_combine):
+        tune_args = make_args(torch.zeros_like(output) if atomic_out else output, True)
     runtime = jit_tuner.compile_and_tune(
         name="spmm_kernel",
         keys=keys,
@@ -322,6 +369,7 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
         template=template,
         args=tune_args,
         kernel_tag="spmm",
+        bucket_keys=lambda: graph_bucket_keys(blk_offsets, num_nodes, keys),
     )
     rc = runtime(*args)
     assert rc == 0, f"spmm_kernel failed with return code {rc}"

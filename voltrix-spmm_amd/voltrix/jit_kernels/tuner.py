@@ -40,6 +40,9 @@ class JITTuner:
     def __init__(self) -> None:
         self.tuned: Dict[Any, Any] = {}
         self.tuned_keys: Dict[Any, Dict] = {}
+        # what this process has done so far (tests / bench.py): sweeps run, candidate kernels timed, choices taken from the
+        # persisted exact key / from the persisted graph-statistics bucket
+        self.stats: Dict[str, int] = {"sweeps": 0, "timed_candidates": 0, "stored_hits": 0, "bucket_hits": 0}
 
     # ---- persistent choices ------------------------------------------------------------------------------
     @staticmethod
@@ -78,7 +81,11 @@ class JITTuner:
     # ---- main entry --------------------------------------------------------------------------------------
     def compile_and_tune(self, name: str, keys: Dict[str, Any], space: tuple, includes: tuple, arg_defs: tuple,
                          template: str, args: tuple, kernel_tag: Optional[str] = None,
-                         bench: Optional[Callable] = None):
+                         bench: Optional[Callable] = None, bucket_keys: Optional[Callable[[], Dict[str, Any]]] = None):
+        """``bucket_keys`` (optional, called only when a sweep is about to run): a coarser key for the same choice -- the
+        matrix tag replaced by a bucket of graph statistics.  The sweep's result is stored under
+        both keys; a later process whose exact key has no entry (a new or untagged graph of the same shape class) takes the
+        bucket's choice and runs no sweep: one build (a cache hit when the kernel exists on disk), no timing launches."""
         keys = {k: keys[k] for k in sorted(keys.keys())}
         signature = (name, f"{keys}")
         if signature in self.tuned:
@@ -95,14 +102,27 @@ class JITTuner:
             full.update(tuned_keys)
             return generate(includes, arg_defs, cpp_format(template, full))
 
-        # a choice persisted by an earlier process short-circuits the sweep
+        # a choice persisted by an earlier process short-circuits the sweep: the exact key first, then the bucket
+        bucket_signature = None
         if len(space) > 1:
-            stored = self._load_store().get(f"{signature[0]}|{signature[1]}")
+            store = self._load_store()
+            stored = store.get(f"{signature[0]}|{signature[1]}")
+            hit = "stored_hits"
+            if bucket_keys is not None and (stored is None or stored not in list(space)):
+                bk = bucket_keys()
+                if bk is not None:
+                    bucket_signature = self._signature(name + "@bucket", bk)
+                    stored = store.get(f"{bucket_signature[0]}|{bucket_signature[1]}")
+                    hit = "bucket_hits"
             if stored is not None and stored in list(space):
                 runtime, _ = _build_one(name, arg_defs, render(stored), stored)
-                if runtime is not None:
+                if runtime is not None and runtime(*args) == 0:
                     self.tuned[signature], self.tuned_keys[signature] = runtime, stored
+                    self.stats[hit] += 1
+                    if _debug() or os.getenv(PRINT_AUTOTUNE_FLAG, None):
+                        print(f"JIT kernel {name} with keys {keys}: persisted choice {stored} ({hit})")
                     return runtime
+            self.stats["sweeps"] += 1
 
         workers = max(1, min(len(space), os.cpu_count() or 1))
         with ThreadPoolExecutor(max_workers=workers) as pool:
@@ -123,6 +143,7 @@ class JITTuner:
                     from ..utils import GPU_bench
 
                     elapsed = GPU_bench(lambda: runtime(*args), iters=8, warmup=2, kernel_name=kernel_tag)
+                self.stats["timed_candidates"] += 1
             else:
                 elapsed = 0.0
             if best_time is None or elapsed < best_time:
@@ -137,6 +158,8 @@ class JITTuner:
         self.tuned[signature], self.tuned_keys[signature] = best_runtime, best_keys
         if len(space) > 1:
             self._save_choice(signature, best_keys)
+            if bucket_signature is not None:
+                self._save_choice(bucket_signature, best_keys)
         return best_runtime
 
 

@@ -143,6 +143,8 @@ def bfs_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int,
     in the graph end up in the same 16-row windows and share gathered columns."""
     n = num_nodes
     dev = indptr.device
+    if n == 0:
+        return torch.zeros(0, dtype=torch.int64, device=dev)
     num_cols = n if num_cols is None else num_cols
     sptr, sv = _symmetrised(indptr, indices, n, num_cols)
     sdeg = sptr[1:] - sptr[:-1]

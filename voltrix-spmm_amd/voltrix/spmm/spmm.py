@@ -33,11 +33,14 @@ def csr_preprocess(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, 
     ``hmat_packed_swizzle_kernel``, with the transient fp32 ``hspa``); both give identical bytes.
     Duplicate (row, col) entries count once (bitmap), whereas ``torch.sparse.mm`` sums them (quirk 5).
 
-    Acceleration side-car (``VOLTRIX_HYBRID``, default ``auto``; voltrix/hybrid.py): when enough of the edges sit in
-    columns that several rows of a 512-row panel share, the two-level form of the same matrix is built as well and
-    attached to the ``hspa_packed`` tensor object.  ``voltrix.spmm`` uses it when it finds it; it is a hint, never
-    part of the contract -- a copy of the tensor, ``spmm_kernel``, the C-ABI launches all compute the same product from
-    the three tensors alone.
+    Acceleration side-car (``VOLTRIX_HYBRID``, default ``auto``; voltrix/hybrid.py::hybrid_mode): when the graph is big
+    and dense enough and enough of its edges sit in columns that several rows of a 512-row panel share, the two-level form of
+    the same matrix is built as well and attached to the ``hspa_packed`` tensor object; ``voltrix.spmm`` uses it when it
+    finds it.  The decision is made HERE, once, from the plan builder's counts (deterministic: no timing, no host sync in
+    ``spmm``); the form that is not chosen is never built.  It is a hint, never part of the contract -- a copy of the
+    tensor, ``spmm_kernel``, the C-ABI launches all compute the same product from the three tensors alone.  Memory: the
+    side-car of the reddit-like graph is 0.68 GB (residual handle 305 MB + plan 374 MB) beside the 617 MB reference handle
+    this function must return whatever the format (``voltrix.hybrid.two_level_bytes``).
     """
     assert indptr.is_cpu and indptr.dtype == torch.int32
     assert indices.is_cpu and indices.dtype == torch.int32
@@ -80,7 +83,7 @@ def csr_preprocess_device(indptr: torch.Tensor, indices: torch.Tensor, num_nodes
     mode = hybrid.hybrid_mode()
     big_enough = (indices.numel() >= hybrid.AUTO_MIN_EDGES and num_nodes >= hybrid.AUTO_MIN_ROWS
                   and indices.numel() >= hybrid.AUTO_MIN_MEAN_DEGREE * max(1, num_nodes))
-    if mode == "on" or (mode == "auto" and big_enough):
+    if mode == "on" or (mode in ("auto", "tune") and big_enough):
         two = _build_two_level(indptr, indices, num_nodes, num_cols)
         if two is not None:
             hspa_packed._voltrix_two_level = (two, hspa_packed.data_ptr())
@@ -95,14 +98,14 @@ def two_level_of(hspa_packed: torch.Tensor):
 
 def _build_two_level(indptr_d, indices_d, num_nodes, num_cols, waves=hybrid.DEFAULT_WAVES,
                      row_blocks=hybrid.DEFAULT_ROW_BLOCKS, tau=hybrid.DEFAULT_TAU, min_share=None):
-    """Device CSR -> TwoLevelHandle, or None when fewer than ``min_share`` (VOLTRIX_HYBRID_MIN_SHARE, default 0.2) of
-    the edges land on the panel side: too few for the panel kernel to pay for itself (uniform-random graphs, low
-    degrees) -- the window format of the whole matrix is the better form then."""
-    resid_indptr, resid_indices, plan = hybrid.build_panel_plan(indptr_d, indices_d, num_nodes, num_cols, waves, row_blocks,
-                                                                tau)
+    """Device CSR -> TwoLevelHandle, or None when fewer than ``min_share`` (hybrid.min_shared_fraction()) of the edges land
+    on the panel side: too few for the panel kernel to pay for itself (uniform-random graphs, low degrees) -- the window
+    format of the whole matrix is the better form then."""
     min_share = hybrid.min_shared_fraction() if min_share is None else min_share
+    resid_indptr, resid_indices, plan = hybrid.build_panel_plan(indptr_d, indices_d, num_nodes, num_cols, waves, row_blocks,
+                                                                tau, min_share=min_share)
     if plan.num_ksteps == 0 or plan.num_shared_edges < min_share * max(1, indices_d.numel()):
-        return None
+        return None   # the builder stopped after its count phase: nothing of the two-level form was built
     pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(resid_indptr, resid_indices, num_nodes, num_cols)
     two = hybrid.TwoLevelHandle(pointer1, hspa_packed, hind, plan, num_nodes, int(indices_d.numel()))
     _attach_fused(two)
@@ -185,24 +188,29 @@ def spmm(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tenso
 
     if two is None or exact or two.num_nodes != num_nodes or mode == "off":
         window()
-    elif mode == "on":
-        two_level()
-    else:   # auto: the side-car is a hint -- the first call for this (width, dtype) times both forms and keeps the faster
+    elif mode != "tune":
+        two_level()   # csr_preprocess decided (auto) or the caller did (VOLTRIX_HYBRID=1): stream-ordered, capturable
+    else:   # opt-in: the first call for this (width, dtype) times both forms and keeps the faster (host sync!)
         key = (padded, str(operand.dtype))
         if key not in two.format_choice:
+            assert not torch.cuda.is_current_stream_capturing(), \
+                "VOLTRIX_HYBRID=tune times both formats on the first call: make that call outside the stream capture"
             two.format_choice[key] = _choose_format(hspa_packed, key, window, two_level)
         (two_level if two.format_choice[key] == "two-level" else window)()
     return output if padded == num_feats else output[:, :num_feats].contiguous()
 
 
 def _choose_format(hspa_packed, key, window, two_level) -> str:
-    """Time ``window()`` and ``two_level()`` (both write the caller's output: the last one run is the chosen one's, run
-    again by the caller) and return the faster form's name.  The choice is persisted next to the tile choices
-    (``tuned.json``) under the matrix tag, so that a later process skips the comparison."""
+    """``VOLTRIX_HYBRID=tune`` only.  Time ``window()`` and ``two_level()`` (both write the caller's output: the last one run
+    is the chosen one's, run again by the caller) and return the faster form's name.  One host sync; the choice is
+    persisted next to the tile choices (``tuned.json``) under the matrix tag and the device, so that a later process skips
+    the comparison.  The two forms sum in a different fp32 order: a choice that rests on three timed repetitions can differ
+    between processes and ranks, which is why the default mode decides from the plan's statistics instead."""
     from ..jit_kernels import jit_tuner
     from ..jit_kernels.spmm import feature_hash
 
-    signature = ("spmm_format", f"{{'dtype': '{key[1]}', 'embedding_dim': {key[0]}, 'feature_hash': '{feature_hash(hspa_packed)}'}}")
+    signature = ("spmm_format", f"{{'device': '{torch.cuda.get_device_name(hspa_packed.device)}', 'dtype': '{key[1]}', "
+                                f"'embedding_dim': {key[0]}, 'feature_hash': '{feature_hash(hspa_packed)}'}}")
     stored = jit_tuner._load_store().get(f"{signature[0]}|{signature[1]}")
     if stored in ("two-level", "window") and hasattr(hspa_packed, "hash_tag"):
         return stored

@@ -34,7 +34,9 @@ def calc_diff(x: torch.Tensor, y: torch.Tensor, dtype=torch.float):
 
 
 def _flush_cache():
-    torch.empty(int(256e6 // 4), dtype=torch.int, device="cuda").zero_()
+    # 512 MiB: more than L2 (32 MiB) + the 256 MiB Infinity Cache, the same amount bench.py's cold-cache timing writes (the
+    # reference writes 256 MB for a 50 MB L2, utils.py:277-281; 256e6 bytes here left part of the Infinity Cache warm)
+    torch.empty(512 << 18, dtype=torch.int, device="cuda").zero_()
 
 
 def GPU_bench(func, iters: int = 100, warmup: int = 30, kernel_name=None, flush_l2=None) -> float:
@@ -142,10 +144,10 @@ _NULL = _Null()
 
 
 def bench_kineto(fn, kernel_names, num_tests: int = 30, suppress_kineto_output: bool = False, trace_path=None,
-                 barrier_comm_profiling: bool = False, flush_l2: bool = True):
+                 barrier_comm_profiling: bool = False, flush_l2: bool = False):
     """Average seconds per call of the launches named by ``kernel_names`` (a string or a tuple of strings; a name matches
     when it is contained in the launch's name) inside ``fn`` -- the reference's contract (utils.py:232-321): seconds,
-    one value per name, exactly one launch name may match each.  ``flush_l2`` writes 256 MB before every call."""
+    one value per name, exactly one launch name may match each.  ``flush_l2`` (default False, as in the reference's bench_kineto, utils.py:232) writes 512 MiB before every call."""
     assert trace_path is None and not barrier_comm_profiling, "not supported in this build"
     names = (kernel_names,) if isinstance(kernel_names, str) else tuple(kernel_names)
     fn()  # warm-up (JIT, tuner)
