@@ -62,6 +62,15 @@ def parse_args():
                          "runs on a second stream beside the SpMM of step k, double-buffered B)")
     ap.add_argument("--one-device", action="store_true",
                     help="debug: every rank uses cuda:0 (exercises the sharded path on a 1-GPU box, with --backend gloo)")
+    ap.add_argument("--gather", default="collective", choices=["collective", "p2p"],
+                    help="N > 1: the exchange step -- one all_gather_into_tensor (what RCCL picks over xGMI), or the direct "
+                         "schedule written out as world-1 batched point-to-point copies per rank (voltrix/dist.py)")
+    ap.add_argument("--slabs", type=int, default=1,
+                    help="N > 1: exchange and multiply B in this many feature slabs (gather of slab j+1 beside the SpMM of "
+                         "slab j) instead of overlapping whole steps")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N > 1 code path (process group, sharded operator, all-gather, barriers) also at world "
+                         "size 1: rehearses the RCCL calls of the scaling run on a one-GPU box")
     return ap.parse_args()
 
 
@@ -147,11 +156,17 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    distributed = world > 1 or args.force_dist
+    if distributed:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     os.environ["VOLTRIX_TUNE_SPACE"] = args.tune
     if args.format != "auto":
         os.environ["VOLTRIX_HYBRID"] = "0" if args.format == "window" else "1"
@@ -181,22 +196,33 @@ def main():
     r0, r1 = parts[rank]
     rows_padded = max(1, max(p[1] - p[0] for p in parts))
     local_indptr, local_indices, _ = synth_graphs.generate(workload, device=device, scale=args.scale,
-                                                           rows=None if world == 1 else (r0, r1))
-    if world > 1:
-        local_indices = vdist.remap_columns(local_indices, parts, rows_padded)
+                                                           rows=(r0, r1) if distributed else None)
     local_rows, local_nnz = r1 - r0, local_indices.numel()
     num_cols = world * rows_padded if world > 1 else num_nodes   # ids index the gathered B (padded shards) when sharded
 
+    # ---- preprocess: the operator a drop-in caller uses.  N > 1 (and --force-dist): voltrix.dist.RowShardedSpMM built from
+    # ---- this rank's OWN device-resident shard (no full graph anywhere, no host round trip) -- the advertised class IS the
+    # ---- measured one
+    op = None
     preprocess_ms = None
     for _ in range(2):   # first call pays library load / allocator warm-up; report the second (host wall clock, sync'd)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        handle = voltrix.csr_preprocess_device(local_indptr, local_indices, local_rows, num_cols=num_cols)
+        if distributed:
+            op = vdist.RowShardedSpMM.from_shard(local_indptr, local_indices, num_nodes, parts, mode=args.gather,
+                                                 slabs=args.slabs, exchange_at_world_1=args.force_dist)
+            handle = op.handle
+        else:
+            handle = voltrix.csr_preprocess_device(local_indptr, local_indices, local_rows, num_cols=num_cols)
         torch.cuda.synchronize()
         preprocess_ms = (time.perf_counter() - t0) * 1e3
     handle[1].hash_tag = f"bench/{workload}/s{args.scale}/r{rank}of{world}"
     two = voltrix.two_level_of(handle[1])
     total_blocks = int(handle[0][-1])
+    from voltrix import hybrid as vhybrid
+
+    handle_bytes = {"reference_handle": vhybrid.handle_bytes(handle),
+                    "two_level_side_car": vhybrid.two_level_bytes(two) if two is not None else 0}
 
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     feat_local = torch.randn(local_rows, num_feats, generator=gen, device=device,
@@ -211,17 +237,23 @@ def main():
 
     def spmm(b):
         """The operator call of a drop-in caller (allocates its output, like the reference's spmm.py:101)."""
-        out_holder[0] = voltrix.spmm(*handle, num_nodes=local_rows, num_edges=local_nnz, feat=b)
+        if op is not None:
+            out_holder[0] = op.multiply(b)      # = voltrix.spmm(*op.handle, ...) on the gathered B
+        else:
+            out_holder[0] = voltrix.spmm(*handle, num_nodes=local_rows, num_edges=local_nnz, feat=b)
 
-    spmm(gathered)   # first call: JIT tile / schedule sweep (persisted), unit table, side stream
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    spmm(gathered)   # first call: tile / schedule from the persisted choice, the bucket, or a sweep; unit table; side stream
+    torch.cuda.synchronize()
+    first_call_ms = (time.perf_counter() - t0) * 1e3
+    tuner_stats = dict(jit_tuner.stats)
 
-    in_place = args.backend == "nccl"  # only NCCL/RCCL defines the in-place (send == recv + rank * count) form
-    overlap = world > 1 and not args.no_overlap
-    if world > 1:
+    slab_pipeline = distributed and args.slabs > 1
+    overlap = distributed and not args.no_overlap and not slab_pipeline
+    if distributed:
         # two copies of the gather buffer: while the SpMM of step k reads one, the all-gather of step k+1 fills the other
         bufs = [gathered, gathered.clone()] if overlap else [gathered]
-        sends = [b[rank * rows_padded:(rank + 1) * rows_padded] for b in bufs]
         comm_stream = torch.cuda.Stream(device=device) if overlap else main_stream
         ev_gathered = [None] * len(bufs)   # all-gather into buffer b finished
         ev_consumed = [None] * len(bufs)   # SpMM that read buffer b finished
@@ -229,10 +261,17 @@ def main():
 
     def step(record=None):
         """One pass of the hot path: all-gather(B) (N > 1), then the SpMM that consumes exactly that gathered B."""
-        if world == 1:
+        if not distributed:
             if record is not None:
                 record[0].record()
             spmm(gathered)
+            if record is not None:
+                record[1].record()
+            return
+        if slab_pipeline:       # the operator's own pipeline: slab j + 1 travels while slab j is multiplied
+            if record is not None:
+                record[0].record()
+            out_holder[0] = op(feat_local)
             if record is not None:
                 record[1].record()
             return
@@ -241,7 +280,7 @@ def main():
         with torch.cuda.stream(comm_stream):
             if ev_consumed[b] is not None:
                 comm_stream.wait_event(ev_consumed[b])
-            dist.all_gather_into_tensor(bufs[b], sends[b] if in_place else sends[b].clone())
+            op.gather_into(bufs[b], feat_local)
             ev_gathered[b] = torch.cuda.Event()
             ev_gathered[b].record(comm_stream)
         main_stream.wait_event(ev_gathered[b])
@@ -258,7 +297,7 @@ def main():
 
     # ---- timed region: exactly K steps between barrier + synchronize, MAX over ranks ------------------------------
     kernel_events = []
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -267,10 +306,10 @@ def main():
         step(record=ev)
         kernel_events.append(ev)
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -278,7 +317,12 @@ def main():
 
     # ---- outside the timed region: row-sum check of this rank's result against torch ops on the same gathered B -------
     # (validates shard -> column remap -> all-gather -> SpMM end to end on every rank; fp32 index_add reference, chunked)
-    b_used = gathered if world == 1 else bufs[(step_no[0] - 1) % len(bufs)]
+    if not distributed:
+        b_used = gathered
+    elif slab_pipeline:
+        b_used = op.gather_into(bufs[0], feat_local)
+    else:
+        b_used = bufs[(step_no[0] - 1) % len(bufs)]
     col_sums = b_used.float().sum(dim=1)
     col_abs = b_used.float().abs().sum(dim=1)
     want = torch.zeros(local_rows, dtype=torch.float32, device=device)
@@ -296,14 +340,14 @@ def main():
     for q in range(0, local_rows, 1 << 22):
         got[q:q + (1 << 22)] = out[q:q + (1 << 22)].sum(dim=1)
     check_err = float(((got - want).abs() / (scale + 1e-6)).max()) if local_rows else 0.0
-    if world > 1:
+    if distributed:
         t = torch.tensor([check_err], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         check_err = float(t)
     assert check_err < 1e-4, f"row-sum check failed: {check_err}"
 
     kernel_ms = sum(s.elapsed_time(e) for s, e in kernel_events) / len(kernel_events)
-    if world > 1:
+    if distributed:
         t = torch.tensor([kernel_ms], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         kernel_ms = float(t)
@@ -333,10 +377,10 @@ def main():
     hybrid_env = os.getenv("VOLTRIX_HYBRID", "auto")
     if two is None or hybrid_env in ("0", "off"):
         used_two = False
-    elif hybrid_env in ("1", "on"):
-        used_two = True
-    else:   # auto: the operator timed both forms on its first call and kept the faster
+    elif hybrid_env == "tune":   # opt-in: the operator timed both forms on its first call and kept the faster
         used_two = two.format_choice.get((padded_width, operand_dtype)) == "two-level"
+    else:   # auto (csr_preprocess decided from the plan's statistics: the side-car exists only when it is to be used) / forced
+        used_two = True
     point = tuned(two.hspa_packed if used_two else handle[1], used_two)
 
     def sched_name(p):
@@ -349,22 +393,28 @@ def main():
         return "natural window order" if s == 0 else f"balance schedule, chunk {ORDER_CHUNKS.get(s)}"
 
     # ---- untimed comparison runs (N = 1): the window format alone, and a cold-cache timing --------------------------------
-    extras = {}
-    if world > 1:
+    extras = {"first_call_ms": first_call_ms, "handle_bytes": handle_bytes,
+              "tuner": dict(tuner_stats, note="sweeps / candidates timed / choices taken from the persisted exact key / from the "
+                                              "persisted graph-statistics bucket, up to and including the first call")}
+    if distributed:
         # the two halves of a step on their own ("report all-gather time and SpMM time separately + combined"):
         # three all-gathers back to back on the communication stream, MAX over ranks; the local SpMM is roofline.kernel_ms
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        with torch.cuda.stream(comm_stream):
+        with torch.cuda.stream(comm_stream if overlap else main_stream):
             for _ in range(3):
-                dist.all_gather_into_tensor(bufs[0], sends[0] if in_place else sends[0].clone())
+                op.gather_into(bufs[0], feat_local)
         torch.cuda.synchronize()
         t = torch.tensor([(time.perf_counter() - t0) / 3 * 1e3], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         extras["allgather_ms"] = float(t)
+        extras["allgather_mode"] = args.gather + (f", {args.slabs} feature slabs pipelined" if slab_pipeline else "")
         extras["allgather_bytes_received_per_rank"] = (world - 1) * rows_padded * num_feats * gathered.element_size()
         extras["local_spmm_ms"] = kernel_ms
+        # what the step should take on a fully connected xGMI node, to read the measured one against
+        extras["predicted_ms"] = {k: round(v, 3) for k, v in vdist.predicted_step_ms(
+            world, rows_padded * num_feats * gathered.element_size(), kernel_ms).items()}
     if world == 1 and not args.no_reference_formats:
         def time_ms(fn, iters=10):
             fn()
@@ -383,7 +433,20 @@ def main():
                                                                       feat=gathered))
             extras["window_format_choice"] = dict(tuned(handle[1], False))
             os.environ["VOLTRIX_HYBRID"] = hybrid_env
-            extras["format_choice"] = {f"F={k[0]} {k[1]}": v for k, v in two.format_choice.items()}
+            extras["format_choice"] = ({f"F={k[0]} {k[1]}": v for k, v in two.format_choice.items()} if hybrid_env == "tune"
+                                       else f"two-level: decided by csr_preprocess from the plan's count phase "
+                                            f"({two.plan.num_shared_edges / max(1, local_nnz):.3f} of the edges in shared columns, "
+                                            f"threshold {vhybrid.min_shared_fraction()})")
+            if (used_two and is_f16 and two.plan.waves == vhybrid.DEFAULT_WAVES
+                    and two.plan.row_blocks == vhybrid.DEFAULT_ROW_BLOCKS):
+                # for the record: the same product as ONE launch (spmm_fused_kernel; not the default form)
+                if two.fused is None:
+                    two.fused = vhybrid.build_fused_records_torch(two.blk_offsets, two.hspa_packed, two.hind, two.num_nodes)
+                fused_out = torch.empty(local_rows, num_feats, dtype=torch.float32, device=device)
+                extras["one_launch_form_ms"] = time_ms(lambda: vhybrid.launch_fused(two.plan, two.fused, gathered, fused_out))
+                extras["one_launch_form_max_abs_diff"] = float((fused_out - out).abs().max())
+                two.fused = None
+                del fused_out
         # cold caches: 512 MB written between steps (more than L2 + the 256 MB Infinity Cache), as the reference's
         # bench_kineto does with 256 MB for a 50 MB L2 (utils.py:277-281); the headline number is the warm-cache one
         flush = torch.empty(512 << 20, dtype=torch.uint8, device=device)
@@ -452,7 +515,9 @@ def main():
                 "sparse_format": fmt,
                 "parallelism": f"row-window shards x{world}" + (
                     " (every rank generates its own shard) + RCCL all-gather(B) per step"
-                    + (" (overlapped with the previous step's SpMM)" if overlap else "") if world > 1 else ""),
+                    + (" (overlapped with the previous step's SpMM)" if overlap else "")
+                    + (f"; exchange: {args.gather}" + (f", {args.slabs} feature slabs pipelined" if slab_pipeline else ""))
+                    if distributed else ""),
                 "preprocess_ms": preprocess_ms,
                 "rowsum_check_max_rel_err": check_err,
                 "cache_state": "warm (steps back to back; B stays in the Infinity Cache when it fits)",
@@ -482,7 +547,7 @@ def main():
             line["vendor_gpu_baseline"] = vb
             line["cpu_baseline"] = cpu_baseline(local_indptr, local_indices, num_nodes, num_nodes, num_feats)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -26,23 +26,49 @@ def main(argv=None):
     ap.add_argument("--fp16", action="store_true", help="hand the features over as fp16 (default: fp32 like the reference)")
     ap.add_argument("--csv", default=None, help="append a results.csv row")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--npz", default=None,
+                    help="read the graph from <name>.npz instead of indices.csv / indptr.csv (TC-GNN edge-list archive or a "
+                         "scipy CSR, as graph_gen.py reads them); features are then drawn here (--num_feats, --seed) and the "
+                         "baseline is computed with torch.sparse.mm on the CPU")
+    ap.add_argument("--reorder", action="store_true",
+                    help="with --npz NAME.npz: run on NAME.reorder.npz, the externally reordered file the reference's protocol "
+                         "expects beside it (bench/graph_gen.py:42-45; written by `graph_gen.py --write_reorder`), and mark the "
+                         "results.csv row Reorder=True")
+    ap.add_argument("--num_feats", type=int, default=128)
+    ap.add_argument("--seed", type=int, default=20)
     args = ap.parse_args(argv)
     f = lambda name: os.path.join(args.dir, name)  # noqa: E731
 
-    indices = torch.tensor(np.loadtxt(f("indices.csv"), delimiter=",", dtype=np.int32), dtype=torch.int32)
-    indptr = torch.tensor(np.loadtxt(f("indptr.csv"), delimiter=",", dtype=np.int32), dtype=torch.int32)
-    n = indptr.numel() - 1
-    weight = torch.tensor(np.fromfile(f("feat.csv"), dtype=np.float32)).cuda().view(n, -1)
+    o_base = None
+    if args.npz:
+        from harness.graph_gen import load_npz
+
+        path = args.npz[:-4] + ".reorder.npz" if args.reorder else args.npz
+        assert os.path.exists(path), f"{path} not found" + (" (graph_gen.py --write_reorder writes it)" if args.reorder else "")
+        ip, ix = load_npz(path)
+        indptr, indices = torch.from_numpy(ip), torch.from_numpy(ix)
+        n = indptr.numel() - 1
+        torch.manual_seed(args.seed)
+        weight32 = torch.randn(n, args.num_feats, dtype=torch.float32)
+        o_base = torch.sparse_csr_tensor(indptr, indices, torch.ones(indices.numel()), size=(n, n)) @ weight32
+        weight = weight32.cuda()
+    else:
+        assert not args.reorder, "--reorder names a <name>.reorder.npz: use it with --npz"
+        indices = torch.tensor(np.loadtxt(f("indices.csv"), delimiter=",", dtype=np.int32), dtype=torch.int32)
+        indptr = torch.tensor(np.loadtxt(f("indptr.csv"), delimiter=",", dtype=np.int32), dtype=torch.int32)
+        n = indptr.numel() - 1
+        weight = torch.tensor(np.fromfile(f("feat.csv"), dtype=np.float32)).cuda().view(n, -1)
     if args.fp16:
         weight = weight.half()
     blk_ofs, hspa_packed, hind = voltrix.csr_preprocess(indptr, indices, n)
-    hspa_packed.hash_tag = f"{args.dataset}_{n}_{indices.numel()}"
+    hspa_packed.hash_tag = f"{args.dataset}{'.reorder' if args.reorder else ''}_{n}_{indices.numel()}"
 
     def spmm():
         return voltrix.spmm(blk_ofs, hspa_packed, hind, num_nodes=n, num_edges=indices.numel(), feat=weight)
 
     o = spmm().detach().cpu()
-    o_base = torch.tensor(np.fromfile(f("output_base.csv"), dtype=np.float32).reshape(*o.shape))
+    if o_base is None:
+        o_base = torch.tensor(np.fromfile(f("output_base.csv"), dtype=np.float32).reshape(*o.shape))
     print(f"difference rate: {calc_diff(o, o_base) * 100:.3f}%")
     ms = GPU_bench(spmm, iters=args.iters, warmup=10, kernel_name="spmm")
     print(f"[Voltrix] time: {ms:.4f} ms")
@@ -54,7 +80,7 @@ def main(argv=None):
         with open(args.csv, "a") as out:
             if new:
                 out.write("Method,Dataset,FeatDim,Reorder,Time (ms)\n")
-            out.write(f"voltrix,{args.dataset},{feats},False,{ms:.4f}\n")
+            out.write(f"voltrix,{args.dataset},{feats},{bool(args.reorder)},{ms:.4f}\n")
 
 
 if __name__ == "__main__":

@@ -35,6 +35,28 @@ def load_npz(path):
     return a.indptr.astype(np.int32), a.indices.astype(np.int32)
 
 
+def write_reorder_npz(path, method):
+    """NAME.npz -> NAME.reorder.npz: nodes relabelled so that position k of the order becomes node k (rows AND columns, as
+    the reference's externally reordered files are)."""
+    sys.path.insert(0, os.path.join(REPO, "voltrix-spmm_amd"))
+    from voltrix import reorder
+
+    indptr, indices = load_npz(path)
+    n = len(indptr) - 1
+    if method == "rcm":
+        perm = reorder.rcm_permutation(indptr, indices, n)
+    else:
+        ip, ix = torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda()
+        fn = reorder.spectral_permutation if method == "spectral" else reorder.bfs_permutation
+        perm = fn(ip, ix, n).cpu().numpy()
+    label = np.empty(n, dtype=np.int64)
+    label[perm] = np.arange(n)
+    rows = np.repeat(np.arange(n), np.diff(indptr))
+    out = path[:-4] + ".reorder.npz"
+    np.savez(out, src_li=label[rows], dst_li=label[indices], num_nodes=n)
+    return out
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     src = ap.add_mutually_exclusive_group(required=True)
@@ -45,10 +67,17 @@ def main(argv=None):
     ap.add_argument("--out_dir", default=".")
     ap.add_argument("--only_dense", action="store_true", help="only feat.csv / output_base.csv (reference flag)")
     ap.add_argument("--mtx", action="store_true", help="also write data.mtx")
+    ap.add_argument("--write_reorder", default=None, choices=["spectral", "bfs", "rcm"],
+                    help="with --npz NAME.npz: also write NAME.reorder.npz -- the graph with its nodes relabelled (P A P^T, "
+                         "TC-GNN edge-list layout) by voltrix.reorder's spectral / bfs order (GPU) or scipy's RCM (host): the "
+                         "file the reference's protocol reads with --reorder (bench/graph_gen.py:42-45)")
+    ap.add_argument("--reorder", action="store_true", help="with --npz NAME.npz: dump NAME.reorder.npz instead (reference flag)")
     args = ap.parse_args(argv)
 
     if args.npz:
-        indptr, indices = load_npz(args.npz)
+        if args.write_reorder:
+            write_reorder_npz(args.npz, args.write_reorder)
+        indptr, indices = load_npz(args.npz[:-4] + ".reorder.npz" if args.reorder else args.npz)
     else:
         import synth_graphs
 

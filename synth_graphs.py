@@ -30,6 +30,11 @@ CONFIGS = {
                           band=8192, feat=512, seed=2),
     "papers_like": dict(num_nodes=111059956, mean_deg=1615685872 / 111059956, sigma=1.0, max_deg=20000, band_frac=0.5,
                         band=32768, feat=128, seed=4),
+    # the same graphs with their node LABELS randomly permuted (P A P^T, seed stated): what a dataset looks like before anybody
+    # reordered it -- the locality-reorder evidence of DESIGN.md section 3.4 (reference: bench/graph_gen.py:42-45 reads
+    # externally reordered <name>.reorder.npz files, bench_all.py:120-129 times both)
+    "reddit_shuffled": dict(base="reddit_like", shuffle_seed=101),
+    "products_shuffled": dict(base="products_like", shuffle_seed=102),
     # density 1e-4 of 4 M x 4 M = 1.6e9 edges; Zipf alpha = 2 degrees up to 4e5, uniform columns (load-balance stress)
     "powerlaw_4m": dict(num_nodes=4000000, mean_deg=400.0, law="zipf", alpha=2.0, sigma=0.0, max_deg=400000,
                         band_frac=0.0, band=0, feat=256, seed=3),
@@ -159,10 +164,45 @@ def generate_csr(num_nodes, mean_deg, sigma, max_deg, band_frac, band, seed, dev
     return indptr.to(torch.int32), indices
 
 
+def _resolve(name: str) -> dict:
+    """Config of ``name`` with a ``base=`` entry (label-shuffled variants) merged over its base config."""
+    cfg = dict(CONFIGS[name])
+    if "base" in cfg:
+        cfg = dict(CONFIGS[cfg["base"]], shuffle_seed=cfg["shuffle_seed"], base=cfg["base"])
+    return cfg
+
+
+def shuffle_labels(indptr: torch.Tensor, indices: torch.Tensor, seed: int):
+    """``P A P^T`` for a seeded random relabelling of the nodes: ``(indptr, indices, label)`` with ``label[old] = new`` (int64);
+    rows sorted, int32, on the input's device."""
+    device = indptr.device
+    n = indptr.numel() - 1
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    label = torch.randperm(n, generator=gen, device=device)
+    deg = (indptr[1:] - indptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(n, device=device, dtype=torch.int64), deg)
+    keys = torch.sort(label[rows] * n + label[indices.long()]).values
+    del rows
+    new_rows = torch.div(keys, n, rounding_mode="floor")
+    new_indices = (keys - new_rows * n).to(torch.int32)
+    new_indptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    new_indptr[1:] = torch.cumsum(torch.bincount(new_rows, minlength=n), 0)
+    return new_indptr.to(torch.int32), new_indices, label
+
+
 def target_degrees(name: str, device="cpu", scale: float = 1.0) -> torch.Tensor:
     """int64 [N]: the degree of every row of config ``name`` (what ``generate`` produces with exact degrees) -- lets
     every rank of a sharded run compute the same edge-balanced row partition without building the graph."""
-    cfg = dict(CONFIGS[name])
+    cfg = _resolve(name)
+    if "shuffle_seed" in cfg:   # the base graph's degrees, moved to the rows' new labels
+        base = target_degrees(cfg["base"], device=device, scale=scale)
+        gen = torch.Generator(device=base.device)
+        gen.manual_seed(cfg["shuffle_seed"])
+        label = torch.randperm(base.numel(), generator=gen, device=base.device)
+        out = torch.empty_like(base)
+        out[label] = base
+        return out
     device = torch.device(device)
     n = max(16, int(round(cfg["num_nodes"] * scale)))
     max_deg = int(min(cfg["max_deg"], max(1, n // 2)))
@@ -173,7 +213,12 @@ def target_degrees(name: str, device="cpu", scale: float = 1.0) -> torch.Tensor:
 
 
 def generate(name: str, device="cpu", scale: float = 1.0, rows=None):
-    cfg = dict(CONFIGS[name])
+    cfg = _resolve(name)
+    if "shuffle_seed" in cfg:
+        assert rows is None, "label-shuffled stand-ins are generated whole"
+        indptr, indices, _ = generate(cfg["base"], device=device, scale=scale)
+        indptr, indices, _ = shuffle_labels(indptr, indices, cfg["shuffle_seed"])
+        return indptr, indices, cfg
     indptr, indices = generate_csr(device=device, scale=scale, rows=rows, **cfg)
     return indptr, indices, cfg
 

@@ -21,6 +21,91 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _worker_shard(rank, world, port, num_feats, scale, out_dir, mode, slabs):
+    """The round-3 construction: every rank builds ONLY its own shard (synth_graphs rows=...), partitions from the shared
+    degree sequence, and exchanges B with the chosen schedule."""
+    for p in (REPO, PKG_ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import synth_graphs
+        from oracle import oracle_c
+        from voltrix.dist import RowShardedSpMM, partition_rows
+
+        deg = synth_graphs.target_degrees("reddit_like", scale=scale)
+        n = deg.numel()
+        full_indptr = torch.zeros(n + 1, dtype=torch.int64)
+        full_indptr[1:] = torch.cumsum(deg, 0)
+        parts = partition_rows(full_indptr, n, world)
+        r0, r1 = parts[rank]
+        local_indptr, local_indices, _ = synth_graphs.generate("reddit_like", scale=scale, rows=(r0, r1))
+        gen = torch.Generator().manual_seed(5)
+        feat = torch.randn(n, num_feats, generator=gen)
+        op = RowShardedSpMM.from_shard(
+            local_indptr, local_indices, n, parts, mode=mode, slabs=slabs,
+            local_preprocess=lambda ip, ix, rows: oracle_c.csr_preprocess(ip.numpy(), ix.numpy(), rows),
+            local_spmm=lambda h, rows, e, b: torch.from_numpy(oracle_c.spmm_blocked(h[0], h[1], h[2], rows, b.numpy(), "none")))
+        out = op(feat[r0:r1].contiguous())
+        assert out.shape == (r1 - r0, num_feats)
+        assert torch.equal(out, op(feat[r0:r1].contiguous()))
+        np.save(os.path.join(out_dir, f"out_{rank}.npy"), out.numpy())
+        np.save(os.path.join(out_dir, f"rows_{rank}.npy"), np.array([r0, r1]))
+        np.save(os.path.join(out_dir, f"csr_{rank}.npy"), np.concatenate([local_indptr.numpy(), local_indices.numpy()]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,slabs", [("collective", 1), ("p2p", 1), ("collective", 3), ("p2p", 2)])
+def test_row_sharded_from_own_shard_world2(tmp_path, mode, slabs):
+    from oracle import oracle_c
+
+    world, num_feats, scale = 2, 40, 0.004
+    mp.spawn(_worker_shard, args=(world, _free_port(), num_feats, scale, str(tmp_path), mode, slabs), nprocs=world, join=True)
+    gen = torch.Generator().manual_seed(5)
+    feat = None
+    covered = 0
+    for r in range(world):
+        r0, r1 = np.load(tmp_path / f"rows_{r}.npy")
+        csr = np.load(tmp_path / f"csr_{r}.npy")
+        ip, ix = csr[: r1 - r0 + 1], csr[r1 - r0 + 1:]
+        if feat is None:
+            n = int(ix.max()) + 1 if False else None
+        covered += r1 - r0
+        assert r0 % 16 == 0
+    n = covered
+    feat = torch.randn(n, num_feats, generator=gen)
+    for r in range(world):
+        r0, r1 = np.load(tmp_path / f"rows_{r}.npy")
+        csr = np.load(tmp_path / f"csr_{r}.npy")
+        ip, ix = csr[: r1 - r0 + 1].astype(np.int64), csr[r1 - r0 + 1:].astype(np.int64)
+        ref = np.zeros((r1 - r0, num_feats), np.float64)       # the shard's rows of csr(ones) @ feat, global column ids
+        rows = np.repeat(np.arange(r1 - r0), np.diff(ip))
+        np.add.at(ref, rows, feat.numpy().astype(np.float64)[ix])
+        got = np.load(tmp_path / f"out_{r}.npy")
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-6
+
+
+def test_partition_is_the_same_on_any_device_and_predictions_are_sane():
+    import synth_graphs
+    from voltrix.dist import partition_rows, predicted_step_ms
+
+    deg = synth_graphs.target_degrees("products_like", scale=0.01)
+    indptr = torch.zeros(deg.numel() + 1, dtype=torch.int64)
+    indptr[1:] = torch.cumsum(deg, 0)
+    for world in (1, 2, 3, 8):
+        parts = partition_rows(indptr, deg.numel(), world)
+        assert parts[0][0] == 0 and parts[-1][1] == deg.numel() and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+        edges = [int(indptr[b] - indptr[a]) for a, b in parts]
+        assert max(edges) - min(edges) <= 2 * 16 * int(deg.max())      # balanced to the window granularity
+    pred = predicted_step_ms(8, 3.55e9, 8.0)
+    assert 20 < pred["allgather_direct_ms"] < 27 and 150 < pred["allgather_ring_ms"] < 240
+    assert pred["step_direct_overlapped_ms"] == max(pred["allgather_direct_ms"], 8.0)
+    assert predicted_step_ms(1, 3.55e9, 62.0)["step_direct_ms"] == 62.0
+
+
 def _worker(rank, world, port, num_feats, scale, out_dir):
     for p in (REPO, PKG_ROOT):
         if p not in sys.path:

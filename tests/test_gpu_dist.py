@@ -84,3 +84,25 @@ def test_row_sharded_world2_two_processes_hip_path(cuda_device, tmp_path, mode):
     assert all(r["two_level"] == (mode == "two-level") for r in results)
     if mode == "two-level":
         assert all(r["shared_edges"] > 0 for r in results)
+
+
+@pytest.mark.parametrize("extra", [[], ["--gather", "p2p"], ["--slabs", "2"]])
+def test_bench_n_gt_1_branch_with_a_one_rank_rccl_group(tmp_path, extra):
+    """bench.py's N > 1 code path -- init_process_group("nccl", device_id=...), voltrix.dist.RowShardedSpMM.from_shard on a
+    device-resident shard, the in-place all_gather_into_tensor (or the batched point-to-point form, or the feature-slab
+    pipeline), the barriers, the all-reduced timings and the allgather_ms leg -- in a fresh child process with a ONE-rank RCCL
+    group: the calls the 8-GPU scaling run will make, rehearsed on the one GPU there is."""
+    import json
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", VOLTRIX_TUNE_SPACE="none")
+    run = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--force-dist", "--workload",
+                          "papers_like", "--scale", "0.002", "--steps", "3", "--warmup", "1", "--tune", "none",
+                          "--no-cpu-baseline", *extra], capture_output=True, text=True, env=env, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    line = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["value"] > 0
+    cfg = line["config"]
+    assert cfg["allgather_ms"] > 0 and cfg["local_spmm_ms"] > 0 and cfg["rowsum_check_max_rel_err"] < 1e-4
+    assert "exchange:" in cfg["parallelism"] and cfg["predicted_ms"]["step_direct_ms"] > 0
+    assert cfg["first_call_ms"] > 0 and cfg["handle_bytes"]["reference_handle"] > 0

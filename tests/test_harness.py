@@ -55,3 +55,31 @@ def test_bm_voltrix_on_generated_files(tmp_path, cuda_device):
     assert "difference rate: 0.000%" in out.stdout and "[Voltrix] time:" in out.stdout
     rows = open(tmp_path / "results.csv").read().strip().split("\n")
     assert rows[0] == "Method,Dataset,FeatDim,Reorder,Time (ms)" and rows[1].startswith("voltrix,skewed,64,False,")
+
+
+@pytest.mark.gpu
+def test_bm_voltrix_consumes_a_reorder_npz(tmp_path, cuda_device):
+    """The reference's reorder protocol (bench/graph_gen.py:42-45, bench_all.py:120-129): NAME.reorder.npz beside NAME.npz.
+    graph_gen.py --write_reorder produces it from voltrix.reorder's spectral order, bm_voltrix.py --npz NAME.npz --reorder
+    runs on it and writes the results.csv row with Reorder=True."""
+    import graph_gen
+    import synth_graphs
+
+    ip, ix, _ = synth_graphs.generate("reddit_shuffled", scale=0.02)
+    n = ip.numel() - 1
+    a = sp.csr_matrix((np.ones(ix.numel(), np.float32), ix.numpy(), ip.numpy()), shape=(n, n))
+    coo = a.tocoo()
+    np.savez(tmp_path / "g.npz", src_li=coo.row, dst_li=coo.col, num_nodes=n)
+    out = graph_gen.write_reorder_npz(str(tmp_path / "g.npz"), "spectral")
+    assert out == str(tmp_path / "g.reorder.npz")
+    rip, rix = graph_gen.load_npz(out)
+    assert len(rix) == ix.numel() and sorted(np.diff(rip).tolist()) == sorted(np.diff(ip.numpy()).tolist())   # a relabelling
+    env = dict(os.environ, VOLTRIX_TUNE_SPACE="none")
+    for flag, mark in (([], "False"), (["--reorder"], "True")):
+        run = subprocess.run([sys.executable, os.path.join(REPO, "harness", "bm_voltrix.py"), "--npz", str(tmp_path / "g.npz"),
+                              "--dataset", "g", "--num_feats", "64", "--csv", str(tmp_path / "results.csv"), "--iters", "3",
+                              *flag], capture_output=True, text=True, env=env, timeout=600)
+        assert run.returncode == 0, run.stderr[-2000:]
+        assert "difference rate: 0.000%" in run.stdout and "[Voltrix] time:" in run.stdout
+    rows = open(tmp_path / "results.csv").read().strip().split("\n")
+    assert rows[1].startswith("voltrix,g,64,False,") and rows[2].startswith("voltrix,g,64,True,")

@@ -127,3 +127,44 @@ def test_reordered_handle_writes_c_through_the_permutation(cuda_device, method, 
         assert float((out.cpu() - ref).norm() / ref.norm()) < (1e-6 if dtype == torch.float16 else 1e-3)
         again = voltrix.spmm_reordered(h, feat32.to(dtype).cuda())
         assert torch.equal(out, again)
+
+
+# ---- round 3: spectral order computed with the SpMM kernels, on the label-shuffled BASELINE stand-in -------------------------
+@pytest.mark.gpu
+def test_spectral_order_recovers_the_shuffled_reddit_stand_in(cuda_device, monkeypatch):
+    """reddit_shuffled at scale 0.25 (58 k rows, 28.6 M edges, HALF of them uniformly random -- a breadth-first search sees one
+    giant level): the spectral row order (block subspace iteration on D^-1/2 A D_c^-1 A^T D^-1/2 through voltrix.spmm + local
+    refinement) puts rows that were neighbours before the shuffle back side by side, the reordered handle carries at least as
+    many edges in shared columns as the natural order's, and the product on the UN-permuted graph matches torch.sparse.mm."""
+    import voltrix
+    from oracle import torch_ref
+
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    dev = torch.device("cuda")
+    indptr, indices, _ = synth_graphs.generate("reddit_like", device=dev, scale=0.25)
+    n = indptr.numel() - 1
+    s_indptr, s_indices, label = synth_graphs.shuffle_labels(indptr, indices, 101)
+    perm, info = reorder.spectral_permutation(s_indptr, s_indices, n, return_info=True)
+    assert sorted(perm.tolist()) == list(range(n))
+    assert torch.equal(perm, reorder.spectral_permutation(s_indptr, s_indices, n))      # deterministic
+    natural_of = torch.empty_like(label)
+    natural_of[label] = torch.arange(n, device=dev)
+    spread = (natural_of[perm][1:] - natural_of[perm][:-1]).abs().float().median().item()
+    assert spread < 2048, (spread, info)                       # band half-width 4096; a random order gives ~ n / 3 = 19 k
+
+    monkeypatch.setenv("VOLTRIX_HYBRID", "1")                   # 114 panels: below the auto threshold (one panel per CU)
+    monkeypatch.setenv("VOLTRIX_HYBRID_MIN_SHARE", "0")
+    handle = voltrix.csr_preprocess_reordered(s_indptr, s_indices, n, method="spectral")
+    natural = voltrix.csr_preprocess_device(indptr, indices, n)
+    shuffled = voltrix.csr_preprocess_device(s_indptr, s_indices, n)
+    two_r, two_n, two_s = (voltrix.two_level_of(h) for h in (handle.hspa_packed, natural[1], shuffled[1]))
+    assert two_r is not None and two_n is not None
+    share = lambda two: two.plan.num_shared_edges / indices.numel()       # noqa: E731
+    assert share(two_r) > share(two_n) - 0.02
+    assert int(handle.blk_offsets[-1]) < int(shuffled[0][-1])               # fewer TC blocks than the shuffled order
+    torch.manual_seed(3)
+    feat = torch.randn(n, 128).half()
+    out = voltrix.spmm_reordered(handle, feat.cuda(), hash_tag="spectral_test").cpu()
+    ref = torch_ref.spmm(s_indptr.cpu(), s_indices.cpu(), feat.float(), n)
+    assert float((out - ref).norm() / ref.norm()) < 1e-5
+    assert two_s is None or share(two_s) <= share(two_r)

@@ -11,6 +11,18 @@ balance slack.  Each rank therefore contributes ``rows_padded = max shard rows``
 local CSR are remapped once at setup* to ``owner(col) * rows_padded + (col - row_start[owner(col)])``, so the
 gathered buffer ``[world * rows_padded, F]`` is used as B directly -- no unpadding copy on the hot path.
 
+Round 3: the operator is built from the rank's OWN shard, wherever it lives (``RowShardedSpMM.from_shard``: device CSR
+in, ``csr_preprocess_device``, no host round trip, no full graph on any rank -- what ``bench.py --gpus N`` runs), and the
+exchange step has three forms (``mode``):
+
+  ``collective``  one ``all_gather_into_tensor`` (in place on RCCL): whatever algorithm RCCL picks over xGMI
+  ``p2p``         the direct schedule written out: one send and one receive per peer, batched into one group
+                  (``batch_isend_irecv``), i.e. world - 1 concurrent point-to-point copies per rank -- on a fully
+                  connected xGMI node every link carries exactly one shard (~23 ms for 8 x 3.55 GB
+                  against ~160 ms if the collective falls back to a ring)
+  ``slabs=k``     (with either) B is exchanged and multiplied in k feature slabs: the all-gather of slab j + 1 runs on the
+                  communication stream while the SpMM multiplies slab j
+
 One process per GPU (``torch.distributed``; backend "nccl" is RCCL on ROCm, "gloo" in the CPU tests).
 """
 from __future__ import annotations
@@ -26,20 +38,20 @@ BLK_H = 16
 def partition_rows(indptr: torch.Tensor, num_nodes: int, world_size: int) -> List[Tuple[int, int]]:
     """Contiguous row ranges ``[(row_start, row_end)] * world_size``: starts are multiples of 16, edge counts as
     equal as the window granularity allows (the unit of SpMM work is the gathered row, i.e. ~ an edge).
-    Deterministic: every rank computes the same partition from the same ``indptr``."""
+    Deterministic: every rank computes the same partition from the same ``indptr`` (any device: the search runs where
+    ``indptr`` lives, only the world_size - 1 boundaries come to the host)."""
     assert indptr.numel() == num_nodes + 1
     num_windows = (num_nodes + BLK_H - 1) // BLK_H
-    ip = indptr.to(torch.int64).cpu()
-    win_start = torch.arange(0, num_windows + 1, dtype=torch.int64) * BLK_H
+    dev = indptr.device
+    win_start = torch.arange(0, num_windows + 1, dtype=torch.int64, device=dev) * BLK_H
     win_start[-1] = num_nodes
-    edges_before = ip[win_start]                      # edges before each window boundary
+    edges_before = indptr.to(torch.int64)[win_start]  # edges before each window boundary
     total = int(edges_before[-1])
+    targets = torch.tensor([total * r // world_size for r in range(1, world_size)], dtype=torch.int64, device=dev)
+    found = torch.searchsorted(edges_before, targets, right=False).tolist() if world_size > 1 else []
     bounds = [0]
-    for r in range(1, world_size):
-        target = total * r // world_size
-        w = int(torch.searchsorted(edges_before, torch.tensor(target, dtype=torch.int64), right=False))
-        w = max(bounds[-1], min(w, num_windows))
-        bounds.append(w)
+    for w in found:
+        bounds.append(max(bounds[-1], min(int(w), num_windows)))
     bounds.append(num_windows)
     return [(min(bounds[r] * BLK_H, num_nodes), min(bounds[r + 1] * BLK_H, num_nodes)) for r in range(world_size)]
 
@@ -64,32 +76,68 @@ def remap_columns(indices: torch.Tensor, parts: List[Tuple[int, int]], rows_padd
 class RowShardedSpMM:
     """``C_local = A[rows of this rank, :] @ all_gather(B_local)`` for a binary CSR ``A``.
 
-    ``local_preprocess(indptr_cpu_i32, indices_cpu_i32, n_rows) -> handle`` and
-    ``local_spmm(handle, n_rows, n_edges, feat) -> out`` default to the HIP path (``voltrix.csr_preprocess`` /
-    ``voltrix.spmm``); the CPU tests inject their own.
+    ``local_preprocess(indptr_i32, indices_i32, n_rows) -> handle`` and ``local_spmm(handle, n_rows, n_edges, feat) -> out``
+    default to the HIP path (``voltrix.csr_preprocess_device`` for a shard that lives on the GPU, ``voltrix.csr_preprocess``
+    for a host one; ``voltrix.spmm``); the CPU tests inject their own.  ``mode`` / ``slabs``: module docstring.
     """
 
     def __init__(self, indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, group=None,
                  device: Optional[torch.device] = None, local_preprocess: Optional[Callable] = None,
-                 local_spmm: Optional[Callable] = None, hash_tag: Optional[str] = None):
+                 local_spmm: Optional[Callable] = None, hash_tag: Optional[str] = None, mode: str = "collective",
+                 slabs: int = 1, exchange_at_world_1: bool = False):
+        """From the FULL CSR, present on every rank (any device): partitions, slices and remaps where the tensors live.
+        Convenient for graphs that fit one GPU; at papers100M scale use :meth:`from_shard`."""
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        parts = partition_rows(indptr, num_nodes, world)
+        local_indptr, local_indices = shard_csr(indptr, indices, num_nodes, parts, rank)
+        self._setup(local_indptr, local_indices, num_nodes, parts, group, device, local_preprocess, local_spmm, hash_tag,
+                    mode, slabs, exchange_at_world_1)
+
+    @classmethod
+    def from_shard(cls, local_indptr: torch.Tensor, local_indices: torch.Tensor, num_nodes: int,
+                   parts: List[Tuple[int, int]], group=None, device: Optional[torch.device] = None,
+                   local_preprocess: Optional[Callable] = None, local_spmm: Optional[Callable] = None,
+                   hash_tag: Optional[str] = None, mode: str = "collective", slabs: int = 1,
+                   exchange_at_world_1: bool = False) -> "RowShardedSpMM":
+        """From this rank's OWN rows only: ``local_indptr`` int32 [rows + 1], ``local_indices`` int32 with GLOBAL column ids,
+        ``parts`` the row ranges of all ranks (e.g. ``partition_rows`` on the degree prefix sums, which every rank can compute
+        without the graph).  Nothing of the other shards is ever materialised here; a device CSR stays on the device.
+        ``exchange_at_world_1``: issue the collective also in a one-rank group (rehearsal of the RCCL calls on one GPU)."""
+        self = cls.__new__(cls)
+        self._setup(local_indptr, local_indices, num_nodes, parts, group, device, local_preprocess, local_spmm, hash_tag,
+                    mode, slabs, exchange_at_world_1)
+        return self
+
+    def _setup(self, local_indptr, local_indices, num_nodes, parts, group, device, local_preprocess, local_spmm, hash_tag,
+               mode, slabs, exchange_at_world_1=False):
+        assert mode in ("collective", "p2p") and slabs >= 1
+        self._exchange_always = bool(exchange_at_world_1) and dist.is_initialized()
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        assert len(parts) == self.world_size
         self.num_nodes = num_nodes
-        self.parts = partition_rows(indptr, num_nodes, self.world_size)
+        self.parts = list(parts)
         self.row_start, self.row_end = self.parts[self.rank]
         self.local_rows = self.row_end - self.row_start
+        assert local_indptr.numel() == self.local_rows + 1
         self.rows_padded = max(1, max(p[1] - p[0] for p in self.parts))
         self.device = device
+        self.mode, self.slabs = mode, slabs
 
-        local_indptr, local_indices = shard_csr(indptr, indices, num_nodes, self.parts, self.rank)
-        local_indices = remap_columns(local_indices, self.parts, self.rows_padded)
+        local_indptr = local_indptr.to(torch.int32).contiguous()
+        local_indices = local_indices.to(torch.int32).contiguous()
+        if self.world_size > 1:
+            local_indices = remap_columns(local_indices, self.parts, self.rows_padded)
         self.local_edges = int(local_indices.numel())
+        gathered_rows = self.world_size * self.rows_padded if self.world_size > 1 else num_nodes
         if local_preprocess is None:
-            from .spmm import csr_preprocess  # HIP path; raises if the extension is missing
-            gathered_rows = self.world_size * self.rows_padded  # remapped ids index the all-gather buffer
+            from .spmm import csr_preprocess, csr_preprocess_device  # HIP path; raises if the extension is missing
 
-            def local_preprocess(ip, ix, n_rows):
+            def local_preprocess(ip, ix, n_rows):   # remapped ids index the all-gather buffer
+                if ip.is_cuda:
+                    return csr_preprocess_device(ip, ix, n_rows, num_cols=gathered_rows)
                 return csr_preprocess(ip, ix, n_rows, num_cols=gathered_rows)
         if local_spmm is None:
             from .spmm import spmm as _spmm
@@ -97,34 +145,123 @@ class RowShardedSpMM:
             def local_spmm(handle, n_rows, n_edges, feat):
                 return _spmm(handle[0], handle[1], handle[2], n_rows, n_edges, feat)
         self._local_spmm = local_spmm
-        self.handle = local_preprocess(local_indptr.cpu(), local_indices.cpu(), self.local_rows)
+        self.handle = local_preprocess(local_indptr, local_indices, self.local_rows)
         if hash_tag is not None and hasattr(self.handle[1], "data_ptr"):
             try:
                 self.handle[1].hash_tag = f"{hash_tag}_r{self.rank}of{self.world_size}"
             except AttributeError:
                 pass
-        self._gathered = None
+        self._buffers = {}      # (key, shape, dtype) -> gather buffer
+        self._comm_stream = None
+
+    # ---- the exchange step ------------------------------------------------------------------------------------------
+    def _buffer(self, key, num_feats, like: torch.Tensor) -> torch.Tensor:
+        shape = (self.world_size * self.rows_padded, num_feats)
+        buf = self._buffers.get(key)
+        if buf is None or buf.shape != shape or buf.dtype != like.dtype or buf.device != like.device:
+            buf = torch.zeros(shape, dtype=like.dtype, device=like.device)
+            self._buffers[key] = buf
+        return buf
+
+    def gather_into(self, buf: torch.Tensor, feat_local: torch.Tensor) -> torch.Tensor:
+        """All-gather of B on the CURRENT stream: this rank's ``[local_rows, F]`` into its slice of ``buf``
+        ``[world * rows_padded, F]``, every other rank's into theirs (padding rows are never referenced by the remapped
+        column ids)."""
+        assert feat_local.dim() == 2 and feat_local.shape[0] == self.local_rows and buf.shape[1] == feat_local.shape[1]
+        mine = buf[self.rank * self.rows_padded:(self.rank + 1) * self.rows_padded]
+        if mine.data_ptr() != feat_local.data_ptr():
+            mine[: self.local_rows].copy_(feat_local)
+        if self.world_size == 1 and not self._exchange_always:
+            return buf
+        if self.mode == "p2p":
+            # the direct schedule: world - 1 sends + world - 1 receives in ONE group; peers in rotated order so that at any
+            # moment every rank talks to a different one
+            ops = []
+            for step in range(1, self.world_size):
+                to, frm = (self.rank + step) % self.world_size, (self.rank - step) % self.world_size
+                ops.append(dist.P2POp(dist.isend, mine, to if self.group is None else dist.get_global_rank(self.group, to),
+                                      self.group))
+                ops.append(dist.P2POp(dist.irecv, buf[frm * self.rows_padded:(frm + 1) * self.rows_padded],
+                                      frm if self.group is None else dist.get_global_rank(self.group, frm), self.group))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            return buf
+        send = mine if dist.get_backend(self.group) == "nccl" else mine.clone()  # only NCCL/RCCL defines the in-place form
+        dist.all_gather_into_tensor(buf, send, group=self.group)
+        return buf
 
     def gather(self, feat_local: torch.Tensor) -> torch.Tensor:
-        """All-gather of B: ``[local_rows, F]`` per rank -> ``[world * rows_padded, F]`` (padding rows are never
-        referenced by the remapped column ids)."""
-        assert feat_local.dim() == 2 and feat_local.shape[0] == self.local_rows
-        num_feats = feat_local.shape[1]
-        if self.world_size == 1:
+        """``[local_rows, F]`` per rank -> ``[world * rows_padded, F]`` (a buffer this object keeps and reuses)."""
+        if self.world_size == 1 and not self._exchange_always:
             return feat_local.contiguous()
-        shape = (self.world_size * self.rows_padded, num_feats)
-        if self._gathered is None or self._gathered.shape != shape or self._gathered.dtype != feat_local.dtype:
-            self._gathered = torch.zeros(shape, dtype=feat_local.dtype, device=feat_local.device)
-        if self.local_rows == self.rows_padded:
-            send = feat_local.contiguous()
-        else:
-            send = self._gathered[self.rank * self.rows_padded:(self.rank + 1) * self.rows_padded]
-            send[: self.local_rows].copy_(feat_local)
-        if dist.get_backend(self.group) != "nccl":
-            send = send.clone()  # only NCCL/RCCL defines the in-place (send == recv + rank * count) form
-        dist.all_gather_into_tensor(self._gathered, send, group=self.group)
-        return self._gathered
+        return self.gather_into(self._buffer("whole", feat_local.shape[1], feat_local), feat_local.contiguous())
+
+    def multiply(self, gathered: torch.Tensor) -> torch.Tensor:
+        """The local product on an already gathered B."""
+        return self._local_spmm(self.handle, self.local_rows, self.local_edges, gathered)
+
+    def _comm(self, device) -> "torch.cuda.Stream":
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=device)
+        return self._comm_stream
 
     def __call__(self, feat_local: torch.Tensor) -> torch.Tensor:
-        full = self.gather(feat_local)
-        return self._local_spmm(self.handle, self.local_rows, self.local_edges, full)
+        if self.slabs == 1 or (self.world_size == 1 and not self._exchange_always) or feat_local.shape[1] < 2 * 8:
+            return self.multiply(self.gather(feat_local))
+        # feature-slab pipeline: slab j + 1 travels while slab j is multiplied
+        num_feats = feat_local.shape[1]
+        width = -(-num_feats // self.slabs)
+        width = -(-width // 8) * 8                       # 16-byte rows for every 16-bit slab
+        bounds = [(c, min(num_feats, c + width)) for c in range(0, num_feats, width)]
+        pieces = [feat_local[:, a:b].contiguous() for a, b in bounds]
+        outs = []
+        if not feat_local.is_cuda:                        # CPU groups (tests): same data flow, no streams
+            for j, piece in enumerate(pieces):
+                outs.append(self.multiply(self.gather_into(self._buffer(("slab", j % 2), piece.shape[1], piece), piece)))
+            return torch.cat(outs, dim=1)
+        main, comm = torch.cuda.current_stream(), self._comm(feat_local.device)
+        gathered_ev, consumed_ev = [None, None], [None, None]
+        ready = torch.cuda.Event()
+        ready.record(main)                                # the slabs were cut on `main`
+
+        def launch_gather(j):
+            b = j % 2
+            buf = self._buffer(("slab", b), pieces[j].shape[1], pieces[j])
+            with torch.cuda.stream(comm):
+                comm.wait_event(ready)
+                if consumed_ev[b] is not None:
+                    comm.wait_event(consumed_ev[b])       # the product that read this buffer two slabs ago
+                self.gather_into(buf, pieces[j])
+                gathered_ev[b] = torch.cuda.Event()
+                gathered_ev[b].record(comm)
+            return buf
+
+        bufs = {0: launch_gather(0)}
+        for j in range(len(pieces)):
+            if j + 1 < len(pieces):
+                bufs[j + 1] = launch_gather(j + 1)
+            main.wait_event(gathered_ev[j % 2])
+            outs.append(self.multiply(bufs.pop(j)))
+            consumed_ev[j % 2] = torch.cuda.Event()
+            consumed_ev[j % 2].record(main)
+        return torch.cat(outs, dim=1)
+
+
+def predicted_step_ms(world_size: int, shard_bytes: float, local_spmm_ms: float, link_gbs: float = 153.0,
+                      ring_efficiency: float = 0.8) -> dict:
+    """What one step (all-gather of B + local SpMM) should take on a fully connected xGMI node (MI355X guide: 7 links x
+    ~153 GB/s per GPU), for reading the first measured scaling curve against.  ``shard_bytes`` = bytes
+    one rank contributes.  direct: every rank receives world - 1 shards over world - 1 links in parallel; ring: world - 1
+    sequential hops of one shard over ONE link each.  ``overlapped`` = the exchange of step k + 1 hidden behind the product
+    of step k (the step is whichever is longer)."""
+    w = world_size
+    if w <= 1:
+        return {"allgather_direct_ms": 0.0, "allgather_ring_ms": 0.0, "step_direct_ms": local_spmm_ms,
+                "step_ring_ms": local_spmm_ms, "step_direct_overlapped_ms": local_spmm_ms,
+                "step_ring_overlapped_ms": local_spmm_ms}
+    direct = shard_bytes / (link_gbs * 1e9) * 1e3
+    ring = (w - 1) * shard_bytes / (link_gbs * ring_efficiency * 1e9) * 1e3
+    return {"allgather_direct_ms": direct, "allgather_ring_ms": ring,
+            "step_direct_ms": direct + local_spmm_ms, "step_ring_ms": ring + local_spmm_ms,
+            "step_direct_overlapped_ms": max(direct, local_spmm_ms), "step_ring_overlapped_ms": max(ring, local_spmm_ms)}

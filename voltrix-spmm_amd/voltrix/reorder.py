@@ -172,6 +172,141 @@ def bfs_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int,
     return perm
 
 
+def spectral_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
+                         vectors: int = 32, iterations: int = 16, seed: int = 0, return_info: bool = False,
+                         refine: int = 4, refine_width: int = 8192):
+    """Spectral row order on the device, computed WITH the SpMM kernels (round 3): int64 [N], position k holds row ``perm[k]``.
+
+    Rows that reference the same columns should share a 16-row window (and a 512-row panel).  Their similarity is the
+    co-occurrence matrix ``A A^T``; the leading non-trivial eigenvector of its normalised form
+    ``K = D_r^-1/2 A D_c^-1 A^T D_r^-1/2`` (the Fiedler vector of the row side of the bipartite row-column graph) is a
+    one-dimensional embedding in which such rows are neighbours, and sorting by it is the row order.  Unlike a
+    breadth-first search it sees through a background of random edges: on the reddit-like stand-in half of the edges are
+    uniformly random, every BFS level after the second holds the whole graph, while ``K`` only loses half of its spectrum's
+    scale to them (a uniform background is a rank-one term along the trivial eigenvector).
+
+    Block subspace iteration: ``vectors`` columns, each step two products -- ``A^T Z`` and ``A Y``, i.e. ``voltrix.spmm`` on
+    the handle of ``A`` and on the handle of ``A^T`` (32 columns: the narrow-feature tiles) -- a deflation of the trivial
+    eigenvector and a Cholesky QR; the error of the leading vector shrinks like ``(lambda_33 / lambda_2)^steps``, so two dozen
+    steps are plenty where single-vector power iteration would need thousands.  Rayleigh-Ritz in the final subspace.  Column
+    ids are not relabelled.  Rows without edges go last.  Deterministic for a given ``seed``."""
+    import os
+
+    from .autograd import csr_transpose_device
+    from .project import TUNE_SPACE_FLAG
+    from .spmm.spmm import csr_preprocess_device, spmm
+
+    import time as _time
+
+    n = num_nodes
+    dev = indptr.device
+    assert indptr.is_cuda, "the spectral order runs the SpMM kernels: device CSR"
+    stamps = []
+
+    def stamp(name):
+        if return_info:
+            torch.cuda.synchronize()
+            stamps.append((name, _time.perf_counter()))
+
+    stamp("start")
+    if n == 0:
+        return (torch.zeros(0, dtype=torch.int64, device=dev), {}) if return_info else torch.zeros(0, dtype=torch.int64, device=dev)
+    m = n if num_cols is None else int(num_cols)
+    nnz = int(indices.numel())
+    # the products below are plumbing of a one-time preprocess: default tiles, no tuning sweep, no side-car
+    saved = {k: os.environ.get(k) for k in (TUNE_SPACE_FLAG, "VOLTRIX_HYBRID")}
+    os.environ[TUNE_SPACE_FLAG], os.environ["VOLTRIX_HYBRID"] = "none", "0"
+    try:
+        handle = csr_preprocess_device(indptr, indices, n, num_cols=m)
+        t_indptr, t_indices = csr_transpose_device(indptr, indices, n, m)
+        handle_t = csr_preprocess_device(t_indptr, t_indices, m, num_cols=n)
+        handle[1].hash_tag = handle_t[1].hash_tag = None   # untagged: keyed by address, never persisted
+        stamp("handles of A and A^T")
+        deg_r = (indptr[1:] - indptr[:-1]).float()
+        deg_c = (t_indptr[1:] - t_indptr[:-1]).float()
+        del t_indptr, t_indices
+        ir = torch.where(deg_r > 0, deg_r.clamp(min=1).rsqrt(), torch.zeros_like(deg_r))[:, None]   # D_r^-1/2
+        ic = torch.where(deg_c > 0, 1.0 / deg_c.clamp(min=1), torch.zeros_like(deg_c))[:, None]     # D_c^-1
+        trivial = deg_r.sqrt()[:, None]
+        trivial = trivial / trivial.norm()
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        x = torch.randn(n, vectors, generator=gen, device=dev)
+
+        def apply_k(x):
+            import warnings
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")      # the untagged-handle warning of feature_hash, once per call
+                y = spmm(*handle_t, num_nodes=m, num_edges=nnz, feat=(x * ir).contiguous())
+                return spmm(*handle, num_nodes=n, num_edges=nnz, feat=(y * ic).contiguous()) * ir
+
+        def orthonormalise(x):
+            x = x - trivial @ (trivial.T @ x)
+            for _ in range(2):                     # Cholesky QR, twice: n x 32 against a 32 x 32 factor
+                gram = x.T @ x
+                gram = gram + 1e-10 * torch.trace(gram) * torch.eye(vectors, device=dev)
+                # the 32 x 32 factor on the host with numpy (one small sync per pass: the device solver's set-up costs a
+                # second, torch's CPU LAPACK path 26 ms per call on a 256-core host)
+                chol = np.linalg.cholesky(gram.double().cpu().numpy())
+                x = x @ torch.from_numpy(np.linalg.inv(chol).T.astype(np.float32)).to(dev)
+            return x
+
+        x = orthonormalise(x)
+        x = orthonormalise(apply_k(x))
+        stamp("first product (kernel load, unit tables)")
+        for _ in range(iterations - 1):
+            x = orthonormalise(apply_k(x))
+        kx = apply_k(x)
+        stamp("subspace iteration")
+        proj = (x.T @ kx).double().cpu().numpy()             # Rayleigh-Ritz on the 32 x 32 projection (host: tiny), ascending
+        evals_np, evecs_np = np.linalg.eigh(0.5 * (proj + proj.T))
+        evals = torch.from_numpy(evals_np)
+        fiedler = (x @ torch.from_numpy(evecs_np[:, -1:].astype(np.float32)).to(dev)) * ir   # random-walk coordinates
+        key = torch.where(deg_r > 0, fiedler[:, 0], torch.full_like(deg_r, float("inf")))
+        perm = torch.argsort(key, stable=True)
+        # ---- local refinement.  The global coordinate places a row to within the noise the graph's far (random) edges put
+        # into it: every row's coordinate is the mean of its 2-hop neighbours', and on the reddit-like stand-in half of those
+        # are uniformly random rows (position noise of a few thousand rows).  A row's NEAR neighbours pin it down much
+        # better.  With the current positions p (ranks), take a partition of unity of `bumps` hat functions over the
+        # positions, features phi_b(p_j) and phi_b(p_j) p_j, push both through K (two more products, 2 x bumps columns) and
+        # give every row the mean position of its 2-hop neighbours UNDER THE BUMPS NEAR ITS OWN POSITION only -- far
+        # neighbours fall under other bumps and are ignored.  Each pass shrinks the noise by about the square root of the
+        # near neighbours per row.
+        nz = int((deg_r > 0).sum())
+        for step in range(refine if nz > 4 * refine_width else 0):
+            pos = torch.empty(n, device=dev)
+            pos[perm] = torch.arange(n, device=dev, dtype=torch.float32)
+            # the bumps narrow from pass to pass (refine_width, /2, /4, /4 ...): a narrower window keeps fewer of the random
+            # 2-hop neighbours (three quarters of all 2-hop neighbours on the reddit-like stand-in) beside the local ones
+            bumps = min(124, max(2, int(round(nz / (refine_width / (1 << min(step, 2)))))))
+            width = nz / bumps
+            centres = (torch.arange(bumps, device=dev, dtype=torch.float32) + 0.5) * width
+            phi = (1.0 - (pos[:, None] - centres[None, :]).abs() / width).clamp(min=0.0)
+            phi[:, 0] = torch.where(pos < centres[0], torch.ones_like(pos), phi[:, 0])          # flat beyond the end centres
+            phi[:, -1] = torch.where(pos > centres[-1], torch.ones_like(pos), phi[:, -1])
+            phi = phi * (deg_r > 0)[:, None]
+            pad = (-2 * bumps) % 8
+            both = torch.cat([phi, phi * (pos[:, None] / nz), torch.zeros(n, pad, device=dev)], dim=1)
+            pushed = apply_k(both / ir.clamp(min=1e-20)) / ir.clamp(min=1e-20)   # D_r^-1 A D_c^-1 A^T: plain 2-hop averages
+            mass, moment = pushed[:, :bumps], pushed[:, bumps:2 * bumps]
+            near = phi > 0                                                       # the (at most two) bumps over the row itself
+            den = (mass * near).sum(1)
+            new_pos = torch.where(den > 0, (moment * near).sum(1) / den.clamp(min=1e-30) * nz, pos)
+            key = torch.where(deg_r > 0, new_pos, torch.full_like(deg_r, float("inf")))
+            perm = torch.argsort(key, stable=True)
+        stamp("local refinement")
+        info = {"eigenvalues": evals[-4:].flip(0).tolist(), "iterations": iterations, "vectors": vectors, "refine": refine,
+                "phase_ms": {b[0]: round((b[1] - a[1]) * 1e3, 2) for a, b in zip(stamps, stamps[1:])}}
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return (perm, info) if return_info else perm
+
+
 def degree_permutation_device(indptr: torch.Tensor, num_nodes: int) -> torch.Tensor:
     """Rows by descending degree (stable), on the input's device: equal-length windows, no locality."""
     deg = (indptr[1:] - indptr[:-1]).long()
@@ -207,7 +342,9 @@ class ReorderedHandle:
 def csr_preprocess_reordered(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
                              method="bfs") -> ReorderedHandle:
     """CSR (CPU or CUDA int32) -> handle of the row-reordered matrix for ``spmm_reordered``.  ``method``: "bfs"
-    (Cuthill-McKee levels, default), "degree", or an explicit permutation tensor (position k holds row perm[k])."""
+    (Cuthill-McKee levels, default), "spectral" (Fiedler order of the row co-occurrence matrix, computed with the SpMM
+    kernels: the one that survives a background of random edges), "degree", or an explicit permutation tensor (position k
+    holds row perm[k])."""
     from .jit_kernels import csr_fused_preprocess_kernel
 
     assert indptr.dtype == torch.int32 and indices.dtype == torch.int32 and indptr.numel() == num_nodes + 1
@@ -217,12 +354,19 @@ def csr_preprocess_reordered(indptr: torch.Tensor, indices: torch.Tensor, num_no
         assert perm.numel() == num_nodes and int(torch.sort(perm).values.ne(torch.arange(num_nodes, device=perm.device)).sum()) == 0
     elif method == "bfs":
         perm, name = bfs_permutation(indptr_d, indices_d, num_nodes, num_cols), "bfs"
+    elif method == "spectral":
+        perm, name = spectral_permutation(indptr_d, indices_d, num_nodes, num_cols), "spectral"
     elif method == "degree":
         perm, name = degree_permutation_device(indptr_d, num_nodes), "degree"
     else:
         raise ValueError(f"unknown reorder method {method!r}")
     p_indptr, p_indices = permute_rows_csr(indptr_d, indices_d, num_nodes, perm)
-    pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(p_indptr, p_indices, num_nodes, num_cols)
+    # the operator's own preprocess: the reference handle of A[perm, :] and, when the (reordered!) graph pays for it, the
+    # two-level side-car -- panels are 512 consecutive rows of the NEW order, which is where the reorder put the rows that
+    # share columns
+    from .spmm.spmm import csr_preprocess_device
+
+    pointer1, hspa_packed, hind = csr_preprocess_device(p_indptr, p_indices, num_nodes, num_cols)
     padded = 16 * ((num_nodes + 15) // 16)
     row_map = torch.full((padded,), -1, dtype=torch.int32, device=indptr_d.device)
     row_map[:num_nodes] = perm.to(torch.int32)
@@ -239,6 +383,14 @@ def spmm_reordered(handle: ReorderedHandle, feat: torch.Tensor, hash_tag: str = 
     if hash_tag is not None and getattr(handle.hspa_packed, "hash_tag", None) is None:
         handle.hspa_packed.hash_tag = hash_tag
     num_feats = feat.shape[1]
+    from .spmm.spmm import spmm, two_level_of
+
+    if two_level_of(handle.hspa_packed) is not None:
+        # two-level side-car on the reordered rows: the panel kernel writes its panel's rows in place, so the product comes
+        # out in the handle's row order and one indexed copy (N x F x 4 bytes each way) puts the rows back
+        permuted = spmm(handle.blk_offsets, handle.hspa_packed, handle.hind, num_nodes=handle.num_nodes,
+                        num_edges=handle.num_edges, feat=feat)
+        return torch.empty_like(permuted).index_copy_(0, handle.perm, permuted)
     operand, out_scale, padded, _ = _operand(feat)
     output = torch.empty((handle.num_nodes, padded), dtype=torch.float32, device=feat.device)
     spmm_kernel(handle.blk_offsets, handle.hspa_packed, handle.hind, num_nodes=handle.num_nodes,
