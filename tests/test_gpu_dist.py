@@ -17,6 +17,14 @@ from oracle import torch_ref
 
 pytestmark = pytest.mark.gpu
 
+from conftest import REPO  # noqa: E402
+
+
+def _free_port():
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
 
 def test_row_sharded_world1_hip_path(cuda_device, monkeypatch):
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
