@@ -10,6 +10,8 @@ Tolerances (fp32 output; stated per BASELINE.md section 2 / SURVEY.md section 8c
 """
 import ctypes
 
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -90,6 +92,31 @@ def test_reference_test_inputs_with_autotune(cuda_device, monkeypatch):
     # second call reuses the tuned kernel and gives the same bits
     out2 = voltrix.spmm(blk_offsets, hspa_packed, hind, num_nodes=n, num_edges=indices.numel(), feat=feat.cuda())
     assert torch.equal(out, out2)
+
+
+def test_reference_test_spmm_default_case(cuda_device, monkeypatch):
+    """The reference's tests/test_spmm.py with ITS OWN defaults (:101-106): seed 20, N = 8192, density 0.1 (6.7 M edges),
+    F = 512, fp32 features, hash_tag set by the caller -- on the committed CSR arrays of that input
+    (tests/golden/sprandom_N8192_d0.1_seed20.npz; sp.random streams differ across numpy versions).  The reference prints
+    "difference rate: 0.000%" against cuSPARSE; the same criterion (calc_diff x 100 rounds to 0.000) against the oracle call
+    torch.sparse.mm, plus the element-wise bound of the scaled-fp16 operand."""
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "default")
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sprandom_N8192_d0.1_seed20.npz"))
+    n, f = 8192, 512
+    dense = np.unpackbits(z["bits"], axis=1)[:, :n].astype(bool)      # rows stored as bitmaps, as tests/test_oracle_goldens.py reads them
+    indptr_np = np.concatenate([[0], np.cumsum(dense.sum(1))]).astype(np.int32)
+    indices_np = np.nonzero(dense)[1].astype(np.int32)
+    assert len(indices_np) == 6710886 and len(indptr_np) == n + 1           # the nnz SURVEY.md section 8c records for this input
+    torch.manual_seed(20)
+    feat = torch.randn(n, f, dtype=torch.float32)
+    indptr, indices = torch.from_numpy(indptr_np), torch.from_numpy(indices_np)
+    blk_offsets, hspa_packed, hind = voltrix.csr_preprocess(indptr, indices, n)
+    assert int(blk_offsets[-1]) == 427364                                     # T recorded from the reference's preprocess
+    hspa_packed.hash_tag = "test_20_8192_0.1"
+    out = voltrix.spmm(blk_offsets, hspa_packed, hind, num_nodes=n, num_edges=indices.numel(), feat=feat.cuda())
+    ref = torch_ref.spmm(indptr_np, indices_np, feat, n)
+    assert f"{float(voltrix.utils.calc_diff(out.cpu(), ref)) * 100:.3f}" in ("0.000", "-0.000")
+    _assert_close(out, indptr_np, indices_np, feat, n, "fp16-scaled")
 
 
 def _launch(handle, n, e, feat, is_f16, tile, stream=None, prefill=float("nan")):

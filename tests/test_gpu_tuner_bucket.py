@@ -1,0 +1,46 @@
+"""GPU: the persisted tuning choice keyed by a graph-statistics BUCKET (the reference memoises per
+process only, voltrix/jit_kernels/tuner.py:44,164).  Fresh child processes share one store file: the first one sweeps the
+tile x schedule space for a tagged graph; the second runs the SAME graph without a tag (the exact key cannot match: it hashes
+the buffer address) and must take the bucket's choice -- no sweep, no timing launch, no compile -- and produce the same
+bits; a graph of another shape class misses the bucket and sweeps again."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(REPO, "tests", "tuner_bucket_worker.py")
+
+
+def _run(tmp_path, store, tag, name, graph=None):
+    out, stats = tmp_path / f"{name}.pt", tmp_path / f"{name}.json"
+    cmd = [sys.executable, WORKER, str(store), tag, str(out), str(stats)] + ([graph] if graph else [])
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    return torch.load(out), json.load(open(stats))
+
+
+def test_untagged_graph_of_a_known_bucket_starts_without_a_sweep(tmp_path):
+    store = tmp_path / "tuned.json"
+    out_a, st_a = _run(tmp_path, store, "bucket_test/graph_a", "a")
+    assert st_a["tuner"]["sweeps"] == 1 and st_a["tuner"]["timed_candidates"] > 4 and st_a["tuner"]["bucket_hits"] == 0
+    entries = json.load(open(store))
+    assert any("@bucket" in k and "graph_bucket" in k for k in entries), list(entries)
+    assert any("@bucket" not in k for k in entries)
+
+    out_b, st_b = _run(tmp_path, store, "-", "b")
+    assert st_b["tuner"] == {"sweeps": 0, "timed_candidates": 0, "stored_hits": 0, "bucket_hits": 1}, st_b
+    assert st_b["jit"]["compiled"] == 0, st_b              # the chosen kernel is on disk: a cache hit, no hipcc
+    assert st_b["point"] == st_a["point"]
+    assert torch.equal(out_a, out_b)                       # same tile, same schedule, same summation order: same bits
+
+    out_c, st_c = _run(tmp_path, store, "bucket_test/graph_a", "c")     # the tagged graph again: the exact key hits first
+    assert st_c["tuner"]["stored_hits"] == 1 and st_c["tuner"]["sweeps"] == 0 and torch.equal(out_a, out_c)
+
+    _, st_d = _run(tmp_path, store, "-", "d", graph="cora_like:1.0")     # another shape class: no bucket for it yet
+    assert st_d["tuner"]["sweeps"] == 1 and st_d["tuner"]["bucket_hits"] == 0

@@ -43,7 +43,8 @@
 
 // Diagnostic builds only (harness/experiments/diag.py): bit 0 skips the consume side (LDS reads + MFMA), bit 1 folds every gathered
 // row into the first 1024 rows of B (all L2 hits), bit 2 skips the output stores.  Results are wrong by design; the
-// shipped kernels use 0.
+// shipped kernels use 0.  Bit 3 (harness/experiments/exp_tail_histogram.py) keeps the results RIGHT and makes every wave
+// leave {XCC id, HW id, start, end} (100 MHz ticks) in the int32 buffer passed as `row_map` (which is then not a row map).
 #ifndef VOLTRIX_DIAG
 #define VOLTRIX_DIAG 0
 #endif
@@ -235,6 +236,7 @@ __device__ __forceinline__ void spmm_tc16_body(const SpmmArgs<T>& a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+  const unsigned long long diag_t0 = (VOLTRIX_DIAG & 8) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   // XCD x = blockIdx.x % 8 owns the contiguous window range [x * windows_per_xcd, ...) (blocks b, b+8, ... share an
   // XCD: speed only, any placement is correct); its workgroups walk that range window by window (the slabs of a window
@@ -674,7 +676,7 @@ __device__ __forceinline__ void spmm_tc16_body(const SpmmArgs<T>& a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       orow[j] = orow0 + j;
-      if (a.row_map) orow[j] = a.row_map[orow[j]];
+      if (a.row_map && !(VOLTRIX_DIAG & 8)) orow[j] = a.row_map[orow[j]];
       if (orow[j] >= a.num_nodes) orow[j] = -1;
     }
 #pragma unroll
@@ -695,6 +697,13 @@ __device__ __forceinline__ void spmm_tc16_body(const SpmmArgs<T>& a) {
         }
       }
     }
+  }
+  if ((VOLTRIX_DIAG & 8) && a.row_map && lane == 0) {   // when and where this wave ran
+    int* const stamp = const_cast<int*>(a.row_map) + 4ll * ((long long)blockIdx.x * T::WAVES + wave);
+    stamp[0] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+    stamp[1] = (int)__builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID (CU / SIMD / wave slot)
+    stamp[2] = (int)(unsigned)diag_t0;
+    stamp[3] = (int)(unsigned)__builtin_amdgcn_s_memrealtime();
   }
 }
 

@@ -133,9 +133,14 @@ def kernel_dir(name: str, code: str) -> str:
     return os.path.join(get_cache_dir(), f"kernel.{name}.{hash_to_hex(signature)}")
 
 
+# what this process has done: kernels found in the on-disk / in-memory cache vs. kernels it had to compile (tests, bench.py)
+build_stats = {"cache_hits": 0, "compiled": 0}
+
+
 def build(name: str, arg_defs: tuple, code: str) -> Runtime:
     path = kernel_dir(name, code)
     cached = runtime_cache[path]
+    build_stats["cache_hits" if cached is not None else "compiled"] += 1
     if cached is not None:
         if os.getenv(DEBUG_FLAG, None):
             print(f"Using cached JIT runtime {os.path.basename(path)} during build")

@@ -47,20 +47,33 @@ class JITTuner:
     # ---- persistent choices ------------------------------------------------------------------------------
     @staticmethod
     def _store_path() -> str:
-        return os.path.join(get_default_user_dir(), "tuned.json")
+        """The user's store of choices: ``$VOLTRIX_TUNED_STORE``, else ``tuned.json`` in the JIT cache directory."""
+        return os.environ.get("VOLTRIX_TUNED_STORE") or os.path.join(get_default_user_dir(), "tuned.json")
 
-    def _load_store(self) -> Dict[str, Dict]:
+    @staticmethod
+    def _read(path: str) -> Dict[str, Dict]:
         try:
-            with open(self._store_path(), "r") as f:
-                return json.load(f)
+            with open(path, "r") as f:
+                data = json.load(f)
+            return data if isinstance(data, dict) else {}
         except (OSError, ValueError):
             return {}
 
+    def _load_store(self) -> Dict[str, Dict]:
+        """Shipped defaults (``tuned_defaults.json`` beside this file: graph-statistics BUCKET entries measured on MI355X,
+        harness/collect_tuned.sh) under the user's own store, which wins."""
+        store = self._read(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_defaults.json"))
+        store.pop("_doc", None)
+        if os.environ.get("VOLTRIX_TUNED_DEFAULTS", "1") in ("0", "off"):
+            store = {}
+        store.update(self._read(self._store_path()))
+        return store
+
     def _save_choice(self, signature, tuned_keys) -> None:
-        store = self._load_store()
+        store = self._read(self._store_path())     # the user's file only: shipped defaults are never copied into it
         store[f"{signature[0]}|{signature[1]}"] = tuned_keys
         try:
-            os.makedirs(get_default_user_dir(), exist_ok=True)
+            os.makedirs(os.path.dirname(self._store_path()) or ".", exist_ok=True)
             put(self._store_path(), json.dumps(store, indent=1, sort_keys=True))
         except OSError:
             pass
