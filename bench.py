@@ -441,7 +441,7 @@ def main():
                     and two.plan.row_blocks == vhybrid.DEFAULT_ROW_BLOCKS):
                 # for the record: the same product as ONE launch (spmm_fused_kernel; not the default form)
                 if two.fused is None:
-                    two.fused = vhybrid.build_fused_records_torch(two.blk_offsets, two.hspa_packed, two.hind, two.num_nodes)
+                    two.fused = vhybrid.build_fused_records(two.blk_offsets, two.hspa_packed, two.hind, two.num_nodes)
                 fused_out = torch.empty(local_rows, num_feats, dtype=torch.float32, device=device)
                 extras["one_launch_form_ms"] = time_ms(lambda: vhybrid.launch_fused(two.plan, two.fused, gathered, fused_out))
                 extras["one_launch_form_max_abs_diff"] = float((fused_out - out).abs().max())

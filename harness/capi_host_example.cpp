@@ -3,11 +3,12 @@
 //
 //   CSR (device) -> csr_window_count / csr_fill (the handle) -> unit_table_count / _fill -> spmm_f16_sched + combine_partials
 //                -> panel_plan_count / _fill + residual handle + panel_order -> zero C; panel kernel || window kernel; combine
+//                -> fused_records_count / _fill -> spmm_fused (the same two-level product as ONE launch)
 //
-// and checks both results against a plain CPU loop over the CSR (fp16-rounded B, double accumulation).
+// and checks all three results against a plain CPU loop over the CSR (fp16-rounded B, double accumulation).
 //   build:  hipcc --offload-arch=gfx950 -O2 -std=c++17 -I include harness/capi_host_example.cpp \
 //                 -L voltrix-spmm_amd/lib -lvoltrix_hip -Wl,-rpath,$PWD/voltrix-spmm_amd/lib -o capi_host_example
-//   run:    ./capi_host_example [num_nodes] [mean_degree] [embedding_dim]      (exit code 0 = both formats agree with the CPU)
+//   run:    ./capi_host_example [num_nodes] [mean_degree] [embedding_dim]      (exit code 0 = all three forms agree with the CPU)
 // tests/test_gpu_capi_host.py builds and runs it on the GPU box.
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
@@ -229,10 +230,30 @@ int main(int argc, char** argv) {
   HIP_OK(hipStreamSynchronize(s_main));
   const double err_two_level = max_rel_err(to_host(d_c, (size_t)n * f));
 
+  // ---- 3. the same two-level product as ONE launch: stage records of the residual handle, then spmm_fused (plain stores:
+  // ---- no zero fill, no second stream, no combine pass; the residual handle itself is no longer needed afterwards) ----------
+  const int num_waves_total = 8 * num_panels;
+  void* rec_ws = dev_alloc<char>((size_t)voltrix_fused_records_workspace_bytes(n));
+  int* wave_ptr = dev_alloc<int>(num_waves_total + 1);
+  RC_OK(voltrix_launch_fused_records_count(hr.blk_offsets, hr.hspa_packed, n, rec_ws, wave_ptr, s_main, &rc_));
+  int num_records = 0;
+  HIP_OK(hipMemcpyAsync(&num_records, wave_ptr + num_waves_total, sizeof(int), hipMemcpyDeviceToHost, s_main));
+  HIP_OK(hipStreamSynchronize(s_main));
+  uint32_t* records = dev_alloc<uint32_t>(((size_t)num_records + 1) * 64);
+  RC_OK(voltrix_launch_fused_records_fill(hr.blk_offsets, hr.hspa_packed, hr.hind, n, wave_ptr, num_records, records, s_main,
+                                          &rc_));
+  HIP_OK(hipMemsetAsync(d_c, 0xFF, (size_t)n * f * sizeof(float), s_main));  // NaN pattern: every element must be written
+  const int fused_fs = f <= 32 ? 32 : (f <= 64 ? 64 : 128);
+  RC_OK(voltrix_launch_spmm_fused_f16(panel_ptr, panel_cols, panel_bits, panel_order, wave_ptr, records, n, f, d_b, d_c,
+                                      fused_fs, /*depth=*/fused_fs == 128 ? 3 : 4, /*out_scale=*/nullptr, s_main, &rc_));
+  HIP_OK(hipStreamSynchronize(s_main));
+  const double err_fused = max_rel_err(to_host(d_c, (size_t)n * f));
+
   std::printf("N=%d nnz=%lld F=%d | window format: %d TC blocks, %d units (%d cut windows), rel err %.3e | two-level: %d "
-              "k-steps, %d residual edges (%d units), rel err %.3e\n",
+              "k-steps, %d residual edges (%d units), rel err %.3e | one launch: %d stage records, rel err %.3e\n",
               n, (long long)e, f, h.total_blocks, t.header[0], t.header[1], err_window, ksteps, resid_edges, tr.header[0],
-              err_two_level);
-  const bool ok = err_window < 1e-5 && err_two_level < 1e-5 && std::isfinite(err_window) && std::isfinite(err_two_level);
+              err_two_level, num_records, err_fused);
+  const bool ok = err_window < 1e-5 && err_two_level < 1e-5 && err_fused < 1e-5 && std::isfinite(err_window) &&
+                  std::isfinite(err_two_level) && std::isfinite(err_fused);
   return ok ? 0 : 1;
 }

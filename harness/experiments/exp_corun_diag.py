@@ -16,6 +16,8 @@ PKG = os.path.join(REPO, "voltrix-spmm_amd")
 sys.path[:0] = [REPO, PKG]
 os.environ.setdefault("VOLTRIX_CACHE_DIR", os.path.join(PKG, ".jit_cache"))
 VARIANTS = {"full": 0, "no_mfma": 1, "no_mfma_no_rows": 3, "only_loop_control": 31}
+if os.environ.get("EXP_META"):    # how much do the panel kernel's metadata DMAs (16 of its 24 LDS-DMAs per k-step) cost the pair?
+    VARIANTS = {"full": 0, "no_meta_dma": 16}
 if os.environ.get("EXP_SLEEP"):   # the panel kernel throttled by s_sleep per k-step (name -> quanta)
     VARIANTS = {"full": 0, "sleep1": 0, "sleep2": 0, "sleep4": 0, "sleep8": 0}
 

@@ -247,6 +247,20 @@ void voltrix_launch_spmm_fused_bf16(void* panel_ptr, void* panel_cols, void* pan
                                     void* wave_ptr, void* records, int num_nodes, int embedding_dim, void* input,
                                     void* output, int fs, int depth, void* out_scale, void* stream, int* return_code);
 
+/* Builder of the stage records above (fused_plan.hpp): block-format handle of the RESIDUAL matrix (the handle of
+ * resid_node_pointer / resid_edge_list from the plan builder below, through voltrix_launch_csr_window_count / _fill) ->
+ * (wave_ptr, records), in two phases because the caller owns every buffer:
+ *   phase 1  voltrix_launch_fused_records_count: wave_ptr int32 [8 NP + 1] (NP = ceil(num_nodes / 512)); workspace:
+ *            voltrix_fused_records_workspace_bytes(num_nodes) bytes, device, 16-byte aligned
+ *   (caller reads R = wave_ptr[8 NP] and allocates records uint32 [(R + 1) * 64], 16-byte aligned)
+ *   phase 2  voltrix_launch_fused_records_fill: every word of records is written (the padding record is zero).
+ * Once the records exist the residual handle is no longer needed by voltrix_launch_spmm_fused_*. */
+int64_t voltrix_fused_records_workspace_bytes(int num_nodes);
+void voltrix_launch_fused_records_count(void* blk_offsets, void* hspa_packed, int num_nodes, void* workspace, void* wave_ptr,
+                                        void* stream, int* return_code);
+void voltrix_launch_fused_records_fill(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, void* wave_ptr,
+                                       int64_t num_records, void* records, void* stream, int* return_code);
+
 /* Builder of the panel plan (panel_plan.hpp): CSR on the DEVICE (rows sorted, duplicate-free, ids in [0, num_cols),
  * num_cols <= 2^22) -> residual CSR + plan, in two phases because the caller owns every buffer:
  *   phase 1  voltrix_launch_panel_plan_count: panel_ptr int32[NP+1], resid_node_pointer int32[num_nodes+1], status[1];

@@ -116,3 +116,27 @@ def test_operator_uses_the_one_launch_form_when_asked(fused_on, monkeypatch):
     out = voltrix.spmm(*handle, num_nodes=n, num_edges=indices.numel(), feat=feat.cuda()).cpu()
     ref = torch_ref.spmm(indptr, indices, feat.float(), n)
     assert float((out - ref).norm() / ref.norm()) < 1e-5
+
+
+def test_hip_record_builder_matches_the_definition(fused_on):
+    """fused_plan.hpp (through voltrix_launch_fused_records_count / _fill) == the torch-op builder == the plain-loop definition."""
+    import voltrix
+    from oracle import oracle_np
+    from voltrix import hybrid
+
+    cases = [(_random_csr(3001, 60, seed=11), 3001, 3), (_random_csr(700, 9, seed=12), 700, 2)]
+    ip, ix, _ = synth_graphs.generate("reddit_like", scale=0.05)
+    cases.append(((ip, ix), ip.numel() - 1, 12))
+    for (indptr, indices), n, tau in cases:
+        two = voltrix.csr_preprocess_hybrid(indptr, indices, n, tau=tau)
+        if two.fused is None:      # an empty plan: build the records directly (the builder does not need a plan)
+            two.fused = hybrid.build_fused_records(two.blk_offsets, two.hspa_packed, two.hind, n)
+        ref = hybrid.build_fused_records_torch(two.blk_offsets, two.hspa_packed, two.hind, n)
+        assert two.fused.num_records == ref.num_records
+        assert torch.equal(two.fused.wave_ptr, ref.wave_ptr)
+        assert torch.equal(two.fused.records.view(torch.int32), ref.records.view(torch.int32))
+        if n <= 3001:
+            wp, rec = oracle_np.fused_records(two.blk_offsets.cpu().numpy(), two.hspa_packed.cpu().view(torch.int32).numpy().view(np.uint32),
+                                              two.hind.cpu().numpy(), n)
+            assert np.array_equal(two.fused.wave_ptr.cpu().numpy(), wp)
+            assert np.array_equal(two.fused.records.cpu().view(torch.int32).numpy().view(np.uint32), rec)

@@ -2,6 +2,7 @@
 // builder of its residual stage records (fused_plan.hpp).
 #include <hip/hip_runtime.h>
 
+#include "voltrix/fused_plan.hpp"
 #include "voltrix/spmm_fused_kernels.hpp"
 #include "voltrix_capi.h"
 
@@ -46,6 +47,22 @@ void voltrix_launch_spmm_fused_bf16(void* panel_ptr, void* panel_cols, void* pan
                                 static_cast<const int*>(wave_ptr), static_cast<const uint32_t*>(records), num_nodes,
                                 embedding_dim, input, static_cast<float*>(output),
                                 static_cast<const float*>(out_scale), static_cast<hipStream_t>(stream));
+}
+
+int64_t voltrix_fused_records_workspace_bytes(int num_nodes) { return voltrix::fused_records_workspace_bytes(num_nodes); }
+
+void voltrix_launch_fused_records_count(void* blk_offsets, void* hspa_packed, int num_nodes, void* workspace, void* wave_ptr,
+                                        void* stream, int* return_code) {
+  *return_code = voltrix::fused_records_count(static_cast<const int*>(blk_offsets), static_cast<const uint32_t*>(hspa_packed),
+                                              num_nodes, workspace, static_cast<int*>(wave_ptr),
+                                              static_cast<hipStream_t>(stream));
+}
+
+void voltrix_launch_fused_records_fill(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, void* wave_ptr,
+                                       int64_t num_records, void* records, void* stream, int* return_code) {
+  *return_code = voltrix::fused_records_fill(static_cast<const int*>(blk_offsets), static_cast<const uint32_t*>(hspa_packed),
+                                             static_cast<const int*>(hind), num_nodes, static_cast<const int*>(wave_ptr),
+                                             num_records, static_cast<uint32_t*>(records), static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -37,6 +37,9 @@ SYMBOLS = (
     "voltrix_launch_spmm_panel_bf16",
     "voltrix_launch_spmm_fused_f16",
     "voltrix_launch_spmm_fused_bf16",
+    "voltrix_fused_records_workspace_bytes",
+    "voltrix_launch_fused_records_count",
+    "voltrix_launch_fused_records_fill",
     "voltrix_launch_add_inplace_f32",
     "voltrix_launch_zero_f32",
     "voltrix_panel_plan_workspace_bytes",
@@ -81,6 +84,7 @@ def lib() -> ctypes.CDLL:
         _lib.voltrix_csr_preprocess_workspace_bytes.restype = ctypes.c_int64
         _lib.voltrix_panel_plan_workspace_bytes.restype = ctypes.c_int64
         _lib.voltrix_spmm_f32_workspace_bytes.restype = ctypes.c_int64
+        _lib.voltrix_fused_records_workspace_bytes.restype = ctypes.c_int64
         _lib.voltrix_unit_table_workspace_bytes.restype = ctypes.c_int64
         _lib.voltrix_unit_table_fill_workspace_bytes.restype = ctypes.c_int64
         for name in SYMBOLS:
@@ -276,6 +280,30 @@ def launch_spmm_fused(plan, fused, input_ptr, output_ptr, embedding_dim, bf16, t
        ctypes.c_void_p(output_ptr), ctypes.c_int(tile[0]), ctypes.c_int(tile[1]), ctypes.c_void_p(out_scale),
        ctypes.c_void_p(stream), ctypes.byref(rc))
     return rc.value
+
+
+def build_fused_records(blk_offsets, hspa_packed, hind, num_nodes: int, stream=None):
+    """Stage records of the one-launch kernel through the library's two-phase builder (voltrix/fused_plan.hpp): returns
+    ``(wave_ptr int32 [8 NP + 1], records uint32 [R + 1, 64], R)``.  One host sync."""
+    import torch
+
+    dev = blk_offsets.device
+    stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    num_waves = 8 * ((num_nodes + 511) // 512)
+    workspace = torch.empty(max(16, int(lib().voltrix_fused_records_workspace_bytes(ctypes.c_int(num_nodes)))),
+                            dtype=torch.uint8, device=dev)
+    wave_ptr = torch.empty(num_waves + 1, dtype=torch.int32, device=dev)
+    rc = ctypes.c_int(-1)
+    lib().voltrix_launch_fused_records_count(_ptr(blk_offsets), _ptr(hspa_packed), ctypes.c_int(num_nodes), _ptr(workspace),
+                                             _ptr(wave_ptr), ctypes.c_void_p(stream), ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_fused_records_count")
+    num_records = int(wave_ptr[-1])   # the sync
+    records = torch.empty((num_records + 1, 64), dtype=torch.int32, device=dev).view(torch.uint32)
+    lib().voltrix_launch_fused_records_fill(_ptr(blk_offsets), _ptr(hspa_packed), _ptr(hind), ctypes.c_int(num_nodes),
+                                            _ptr(wave_ptr), ctypes.c_int64(num_records), _ptr(records),
+                                            ctypes.c_void_p(stream), ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_fused_records_fill")
+    return wave_ptr, records, num_records
 
 
 def launch_panel_order(panel_ptr, num_panels: int, order_out, stream, group: int = 1) -> None:

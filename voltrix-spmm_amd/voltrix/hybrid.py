@@ -148,6 +148,15 @@ def build_fused_records_torch(blk_offsets: torch.Tensor, hspa_packed: torch.Tens
     return FusedRecords(wave_ptr=wave_ptr.to(torch.int32), records=records.view(torch.uint32), num_records=num_records)
 
 
+def build_fused_records(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tensor, num_nodes: int) -> FusedRecords:
+    """Block-format handle of the residual (on the GPU) -> ``FusedRecords`` with the library's HIP builder
+    (fused_plan.hpp, two launches around the one host sync that sizes the output); same bytes as
+    :func:`build_fused_records_torch` (tests/test_gpu_fused.py)."""
+    assert blk_offsets.is_cuda and hspa_packed.is_cuda and hind.is_cuda
+    wave_ptr, records, num_records = capi.build_fused_records(blk_offsets, hspa_packed, hind, num_nodes)
+    return FusedRecords(wave_ptr=wave_ptr, records=records, num_records=num_records)
+
+
 def split_shared_columns(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int, panel_rows: int,
                          tau: int):
     """Device CSR -> ``(resid_indptr int32, resid_indices int32, pc int64 [U], rp int64 [Es], inv int64 [Es])``:

@@ -117,7 +117,7 @@ def _attach_fused(two) -> None:
     plan = two.plan
     if (hybrid.fused_enabled() and plan.num_ksteps > 0 and plan.waves == hybrid.DEFAULT_WAVES
             and plan.row_blocks == hybrid.DEFAULT_ROW_BLOCKS):
-        two.fused = hybrid.build_fused_records_torch(two.blk_offsets, two.hspa_packed, two.hind, two.num_nodes)
+        two.fused = hybrid.build_fused_records(two.blk_offsets, two.hspa_packed, two.hind, two.num_nodes)
 
 
 def csr_preprocess_hybrid(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
