@@ -68,6 +68,90 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// s_waitcnt vmcnt(min(m, 63)) for a wave-uniform run-time m.  The count is an immediate of the instruction, so the 64
+// forms sit in a table of 8-byte entries (s_waitcnt ; s_branch end) entered through a computed s_setpc_b64.  (A binary
+// search written as nested ifs was structurised by hipcc into a chain of ~60 flag tests and taken branches per call: about
+// a microsecond per wait, most of the kernel's time.)  PC after s_getpc_b64 = the s_add_u32 below; table = + 12 bytes.
+__device__ __forceinline__ void wait_vm(const int m) {
+  int t;
+  asm volatile("s_min_u32 %[t], %[m], 63\n"
+               "s_lshl_b32 %[t], %[t], 3\n"
+               "s_add_u32 %[t], %[t], 12\n"
+               "s_getpc_b64 vcc\n"
+               "s_add_u32 vcc_lo, vcc_lo, %[t]\n"
+               "s_addc_u32 vcc_hi, vcc_hi, 0\n"
+               "s_setpc_b64 vcc\n"
+               "s_waitcnt vmcnt(0)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(1)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(2)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(3)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(4)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(5)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(6)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(7)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(8)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(9)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(10)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(11)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(12)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(13)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(14)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(15)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(16)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(17)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(18)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(19)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(20)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(21)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(22)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(23)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(24)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(25)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(26)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(27)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(28)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(29)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(30)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(31)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(32)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(33)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(34)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(35)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(36)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(37)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(38)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(39)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(40)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(41)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(42)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(43)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(44)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(45)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(46)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(47)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(48)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(49)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(50)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(51)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(52)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(53)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(54)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(55)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(56)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(57)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(58)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(59)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(60)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(61)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(62)\n s_branch 1f\n"
+               "s_waitcnt vmcnt(63)\n"
+               "1:\n"
+               : [t] "=&s"(t)
+               : [m] "s"(m)
+               : "vcc", "scc", "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 __device__ __forceinline__ void wait_lgkmcnt0() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);  // keep MFMAs / users below the wait (guide rule 18)

@@ -68,7 +68,7 @@ def _lds_bytes(fs, depth, waves, eb, weighted=False):
 
 # LDS a window-kernel workgroup may take when a panel-kernel workgroup (two-level format, 44 KB at FS = 128 / DEPTH 3)
 # has to fit on the same CU beside it
-TWO_LEVEL_LDS_BUDGET = 160 * 1024 - 44 * 1024
+TWO_LEVEL_LDS_BUDGET = 160 * 1024 - 47 * 1024   # panel workgroup: 24 KiB ring + 22.5 KiB grouped metadata (spmm_panel_gm_kernel)
 
 
 def tile_space(embedding_dim: int, elem_bytes: int, bf16: bool = False, max_lds: int = None, weighted: bool = False):
