@@ -149,3 +149,44 @@ def test_two_level_reddit_like_full_size(cuda_device, monkeypatch):
     a = run(x)
     b = _window_runner(win, n, e, f, capi.default_tile(f, True))(x)
     assert torch.equal(a, b)
+
+
+def test_format_policy_is_decided_in_csr_preprocess_at_full_size(cuda_device, monkeypatch):
+    """The default mode (VOLTRIX_HYBRID=auto) at BASELINE size: ``csr_preprocess_device`` attaches the two-level side-car to the
+    reddit-like graph (55 % of the edges in shared columns) and not to its uniform-column variant (29 %: the plan builder stops
+    after its count phase -- nothing of the losing form is built); the operator then runs the chosen form without any timing
+    of its own, the one-launch form of the same product gives the same bits on integers, and the opt-in ``tune`` mode still
+    times both forms on its first call."""
+    from voltrix import hybrid
+
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    monkeypatch.delenv("VOLTRIX_HYBRID", raising=False)
+    monkeypatch.delenv("VOLTRIX_HYBRID_MIN_SHARE", raising=False)
+    indptr, indices, _ = synth_graphs.generate("reddit_uniform", device="cuda")
+    n, e = indptr.numel() - 1, indices.numel()
+    handle = voltrix.csr_preprocess_device(indptr, indices, n)
+    assert voltrix.two_level_of(handle[1]) is None
+    r_indptr, r_indices, plan = hybrid.build_panel_plan(indptr, indices, n, min_share=hybrid.min_shared_fraction())
+    assert plan.num_ksteps == 0 and r_indptr is indptr and r_indices is indices     # stopped after the count phase
+    assert 0.2 < plan.num_shared_edges / e < 0.4
+    del handle, indptr, indices, r_indptr, r_indices
+
+    indptr, indices, _ = synth_graphs.generate("reddit_like", device="cuda")
+    n, e, f = indptr.numel() - 1, indices.numel(), 128
+    handle = voltrix.csr_preprocess_device(indptr, indices, n)
+    handle[1].hash_tag = "policy_test"
+    two = voltrix.two_level_of(handle[1])
+    assert two is not None and two.plan.num_shared_edges > 0.5 * e and two.fused is None and two.format_choice == {}
+    assert hybrid.two_level_bytes(two) < 1.2 * hybrid.handle_bytes(handle)
+    x = _small_ints(n, f, 11)
+    out = voltrix.spmm(*handle, num_nodes=n, num_edges=e, feat=x)
+    assert two.format_choice == {}                                                     # no timed comparison happened
+    two.fused = hybrid.build_fused_records(two.blk_offsets, two.hspa_packed, two.hind, n)
+    one = torch.empty_like(out)
+    hybrid.launch_fused(two.plan, two.fused, x, one)
+    assert torch.equal(out, one)
+    two.fused = None
+    monkeypatch.setenv("VOLTRIX_HYBRID", "tune")
+    monkeypatch.setenv("VOLTRIX_TUNED_STORE", "/tmp/voltrix_policy_test_tuned.json")
+    out_t = voltrix.spmm(*handle, num_nodes=n, num_edges=e, feat=x)
+    assert list(two.format_choice.values())[0] in ("two-level", "window") and torch.equal(out_t, out)
