@@ -241,7 +241,13 @@ def graph_bucket_keys(blk_offsets: torch.Tensor, num_nodes: int, keys: dict):
             blk_offsets._voltrix_bucket = cached
         except AttributeError:
             pass
-    out = {k: v for k, v in keys.items() if k != "feature_hash"}
+    # the ARCHITECTURE, not the marketing name, keys a bucket: the same gfx950 part reports "AMD Instinct MI355X" or "AMD Radeon
+    # Graphics" depending on the driver stack, and the shipped defaults must hit on both
+    out = {k: v for k, v in keys.items() if k not in ("feature_hash", "device")}
+    try:
+        out["arch"] = torch.cuda.get_device_properties(blk_offsets.device).gcnArchName.split(":")[0]
+    except (AttributeError, RuntimeError):
+        out["arch"] = keys.get("device", "unknown")
     out["graph_bucket"] = str(cached[1])
     return out
 
