@@ -104,6 +104,7 @@ def _bfs_levels(sptr, sv, start: int, level, rank, next_rank: int, d0: int):
     (next_rank, last frontier)."""
     dev = sptr.device
     sdeg = sptr[1:] - sptr[:-1]
+    deg_span = int(sdeg.max()) + 1          # once per search, not once per level
     frontier = torch.tensor([start], device=dev, dtype=torch.int64)
     level[start] = d0
     rank[start] = next_rank
@@ -125,7 +126,7 @@ def _bfs_levels(sptr, sv, start: int, level, rank, next_rank: int, d0: int):
         uniq, inv = torch.unique(nb, return_inverse=True)
         best_parent = torch.full((uniq.numel(),), 1 << 62, dtype=torch.int64, device=dev)
         best_parent.scatter_reduce_(0, inv, parent_rank, reduce="amin")
-        order = torch.argsort(best_parent * (int(sdeg.max()) + 1) + sdeg[uniq], stable=True)
+        order = torch.argsort(best_parent * deg_span + sdeg[uniq], stable=True)
         uniq = uniq[order]
         d += 1
         level[uniq] = d
