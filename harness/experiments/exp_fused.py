@@ -13,7 +13,6 @@ import torch  # noqa: E402
 
 import synth_graphs  # noqa: E402
 import voltrix  # noqa: E402
-from voltrix import hybrid  # noqa: E402
 from voltrix.spmm.spmm import _run_two_level  # noqa: E402
 
 

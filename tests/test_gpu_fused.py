@@ -1,8 +1,6 @@
 """GPU: the two-level product in ONE launch (spmm_fused_kernel through the C-ABI entry voltrix_launch_spmm_fused_*) against
 the oracle (torch.sparse.mm on the CPU, the reference's own oracle call), against the round-2 pair of kernels bit for bit
 on integer operands, and run to run."""
-import os
-
 import numpy as np
 import pytest
 import torch

@@ -346,8 +346,6 @@ def csr_preprocess_reordered(indptr: torch.Tensor, indices: torch.Tensor, num_no
     (Cuthill-McKee levels, default), "spectral" (Fiedler order of the row co-occurrence matrix, computed with the SpMM
     kernels: the one that survives a background of random edges), "degree", or an explicit permutation tensor (position k
     holds row perm[k])."""
-    from .jit_kernels import csr_fused_preprocess_kernel
-
     assert indptr.dtype == torch.int32 and indices.dtype == torch.int32 and indptr.numel() == num_nodes + 1
     indptr_d, indices_d = indptr.contiguous().cuda(), indices.contiguous().cuda()
     if isinstance(method, torch.Tensor):
