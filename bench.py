@@ -329,9 +329,11 @@ def main():
     scale = torch.zeros(local_rows, dtype=torch.float32, device=device)
     row_of_edge_chunk = 1 << 27
     ip64 = local_indptr.long()
+    # the shard's column ids are global; the gathered B is laid out in padded shards (voltrix.dist.remap_columns)
+    check_indices = vdist.remap_columns(local_indices, parts, rows_padded) if world > 1 else local_indices
     for e0 in range(0, local_nnz, row_of_edge_chunk):
         e1 = min(local_nnz, e0 + row_of_edge_chunk)
-        cols = local_indices[e0:e1].long()
+        cols = check_indices[e0:e1].long()
         rows = torch.searchsorted(ip64, torch.arange(e0, e1, device=device), right=True) - 1
         want.index_add_(0, rows, col_sums[cols])
         scale.index_add_(0, rows, col_abs[cols])

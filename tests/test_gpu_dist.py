@@ -114,3 +114,19 @@ def test_bench_n_gt_1_branch_with_a_one_rank_rccl_group(tmp_path, extra):
     assert cfg["allgather_ms"] > 0 and cfg["local_spmm_ms"] > 0 and cfg["rowsum_check_max_rel_err"] < 1e-4
     assert "exchange:" in cfg["parallelism"] and cfg["predicted_ms"]["step_direct_ms"] > 0
     assert cfg["first_call_ms"] > 0 and cfg["handle_bytes"]["reference_handle"] > 0
+
+
+@pytest.mark.parametrize("extra", [[], ["--gather", "p2p"], ["--slabs", "2"]])
+def test_bench_two_ranks_share_one_device_over_gloo(extra):
+    """The N = 2 data path of bench.py end to end -- two ranks generate their own shards, ``RowShardedSpMM.from_shard``, the
+    exchange (collective / point-to-point / slab pipeline), the product, and the row-sum check of every rank's result against
+    torch ops on the gathered B (padded-shard layout: the check remaps the shard's global column ids like the operator does)
+    -- as two processes on cuda:0 with gloo, the only two-rank form a one-GPU box allows."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VOLTRIX_TUNE_SPACE="none")
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2",
+                          "--one-device", "--backend", "gloo", "--workload", "reddit_like", "--scale", "0.1", "--steps", "2",
+                          "--warmup", "1", "--tune", "none", *extra], capture_output=True, text=True, env=env, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    line = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["rowsum_check_max_rel_err"] < 1e-4 and line["config"]["allgather_ms"] > 0
