@@ -62,9 +62,10 @@ def parse_args():
                          "runs on a second stream beside the SpMM of step k, double-buffered B)")
     ap.add_argument("--one-device", action="store_true",
                     help="debug: every rank uses cuda:0 (exercises the sharded path on a 1-GPU box, with --backend gloo)")
-    ap.add_argument("--gather", default="collective", choices=["collective", "p2p"],
-                    help="N > 1: the exchange step -- one all_gather_into_tensor (what RCCL picks over xGMI), or the direct "
-                         "schedule written out as world-1 batched point-to-point copies per rank (voltrix/dist.py)")
+    ap.add_argument("--gather", default="collective", choices=["collective", "p2p", "rows"],
+                    help="N > 1: the exchange step -- one all_gather_into_tensor (what RCCL picks over xGMI), the direct "
+                         "schedule written out as world-1 batched point-to-point copies per rank, or only the rows of B the "
+                         "shard references (one all-to-all with uneven splits; voltrix/dist.py)")
     ap.add_argument("--slabs", type=int, default=1,
                     help="N > 1: exchange and multiply B in this many feature slabs (gather of slab j+1 beside the SpMM of "
                          "slab j) instead of overlapping whole steps")
@@ -227,7 +228,10 @@ def main():
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     feat_local = torch.randn(local_rows, num_feats, generator=gen, device=device,
                              dtype=torch.float32).to(torch.float16 if is_f16 else torch.float32)
-    if world > 1:
+    if world > 1 and args.gather == "rows":
+        gathered = torch.zeros(op.compact_rows, num_feats, dtype=feat_local.dtype, device=device)   # own rows | referenced rows
+        gathered[:local_rows].copy_(feat_local)
+    elif world > 1:
         gathered = torch.zeros(world * rows_padded, num_feats, dtype=feat_local.dtype, device=device)
         gathered[rank * rows_padded:rank * rows_padded + local_rows].copy_(feat_local)
     else:
@@ -330,7 +334,10 @@ def main():
     row_of_edge_chunk = 1 << 27
     ip64 = local_indptr.long()
     # the shard's column ids are global; the gathered B is laid out in padded shards (voltrix.dist.remap_columns)
-    check_indices = vdist.remap_columns(local_indices, parts, rows_padded) if world > 1 else local_indices
+    if world > 1 and args.gather == "rows":   # the compact buffer: positions the operator computed at setup
+        check_indices = op.compact_ids(local_indices)
+    else:
+        check_indices = vdist.remap_columns(local_indices, parts, rows_padded) if world > 1 else local_indices
     for e0 in range(0, local_nnz, row_of_edge_chunk):
         e1 = min(local_nnz, e0 + row_of_edge_chunk)
         cols = check_indices[e0:e1].long()
@@ -412,7 +419,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         extras["allgather_ms"] = float(t)
         extras["allgather_mode"] = args.gather + (f", {args.slabs} feature slabs pipelined" if slab_pipeline else "")
-        extras["allgather_bytes_received_per_rank"] = (world - 1) * rows_padded * num_feats * gathered.element_size()
+        extras["allgather_bytes_received_per_rank"] = op.exchange_bytes_received(num_feats, gathered.element_size())
         extras["local_spmm_ms"] = kernel_ms
         # what the step should take on a fully connected xGMI node, to read the measured one against
         extras["predicted_ms"] = {k: round(v, 3) for k, v in vdist.predicted_step_ms(

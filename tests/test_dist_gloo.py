@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker_shard(rank, world, port, num_feats, scale, out_dir, mode, slabs):
+def _worker_shard(rank, world, port, num_feats, scale, out_dir, mode, slabs, graph="reddit_like"):
     """The round-3 construction: every rank builds ONLY its own shard (synth_graphs rows=...), partitions from the shared
     degree sequence, and exchanges B with the chosen schedule."""
     for p in (REPO, PKG_ROOT):
@@ -34,13 +34,13 @@ def _worker_shard(rank, world, port, num_feats, scale, out_dir, mode, slabs):
         from oracle import oracle_c
         from voltrix.dist import RowShardedSpMM, partition_rows
 
-        deg = synth_graphs.target_degrees("reddit_like", scale=scale)
+        deg = synth_graphs.target_degrees(graph, scale=scale)
         n = deg.numel()
         full_indptr = torch.zeros(n + 1, dtype=torch.int64)
         full_indptr[1:] = torch.cumsum(deg, 0)
         parts = partition_rows(full_indptr, n, world)
         r0, r1 = parts[rank]
-        local_indptr, local_indices, _ = synth_graphs.generate("reddit_like", scale=scale, rows=(r0, r1))
+        local_indptr, local_indices, _ = synth_graphs.generate(graph, scale=scale, rows=(r0, r1))
         gen = torch.Generator().manual_seed(5)
         feat = torch.randn(n, num_feats, generator=gen)
         op = RowShardedSpMM.from_shard(
@@ -50,6 +50,9 @@ def _worker_shard(rank, world, port, num_feats, scale, out_dir, mode, slabs):
         out = op(feat[r0:r1].contiguous())
         assert out.shape == (r1 - r0, num_feats)
         assert torch.equal(out, op(feat[r0:r1].contiguous()))
+        if mode == "rows":      # fewer rows travel than the all-gather moves, and only referenced ones
+            assert op.compact_rows <= (r1 - r0) + sum(p[1] - p[0] for i, p in enumerate(parts) if i != rank)
+            assert op.exchange_bytes_received(num_feats, 4) == sum(op._want) * num_feats * 4
         np.save(os.path.join(out_dir, f"out_{rank}.npy"), out.numpy())
         np.save(os.path.join(out_dir, f"rows_{rank}.npy"), np.array([r0, r1]))
         np.save(os.path.join(out_dir, f"csr_{rank}.npy"), np.concatenate([local_indptr.numpy(), local_indices.numpy()]))
@@ -58,7 +61,7 @@ def _worker_shard(rank, world, port, num_feats, scale, out_dir, mode, slabs):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,slabs", [("collective", 1), ("p2p", 1), ("collective", 3), ("p2p", 2)])
+@pytest.mark.parametrize("mode,slabs", [("collective", 1), ("p2p", 1), ("collective", 3), ("p2p", 2), ("rows", 1)])
 def test_row_sharded_from_own_shard_world2(tmp_path, mode, slabs):
     from oracle import oracle_c
 
@@ -86,6 +89,26 @@ def test_row_sharded_from_own_shard_world2(tmp_path, mode, slabs):
         np.add.at(ref, rows, feat.numpy().astype(np.float64)[ix])
         got = np.load(tmp_path / f"out_{r}.npy")
         assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-6
+
+
+def test_referenced_rows_exchange_moves_only_what_the_shards_reference(tmp_path):
+    """world 3, a sparse graph (cora-like: 3.9 edges per row, so every shard references a FRACTION of the others' rows): the
+    referenced-rows exchange gives every rank the product of its own shard and receives fewer rows than an all-gather moves."""
+    world, num_feats = 3, 16
+    mp.spawn(_worker_shard, args=(world, _free_port(), num_feats, 1.0, str(tmp_path), "rows", 1, "cora_like"), nprocs=world,
+             join=True)
+    rows = [tuple(np.load(tmp_path / f"rows_{r}.npy")) for r in range(world)]
+    n = rows[-1][1]
+    feat = torch.randn(n, num_feats, generator=torch.Generator().manual_seed(5))
+    for r, (r0, r1) in enumerate(rows):
+        csr = np.load(tmp_path / f"csr_{r}.npy")
+        ip, ix = csr[: r1 - r0 + 1].astype(np.int64), csr[r1 - r0 + 1:].astype(np.int64)
+        ref = np.zeros((r1 - r0, num_feats), np.float64)
+        np.add.at(ref, np.repeat(np.arange(r1 - r0), np.diff(ip)), feat.numpy().astype(np.float64)[ix])
+        got = np.load(tmp_path / f"out_{r}.npy")
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-6
+        remote_refs = len(np.unique(ix[(ix < r0) | (ix >= r1)]))
+        assert 0 < remote_refs < n - (r1 - r0)                       # a strict subset of the other shards' rows
 
 
 def test_partition_is_the_same_on_any_device_and_predictions_are_sane():

@@ -116,7 +116,7 @@ def test_bench_n_gt_1_branch_with_a_one_rank_rccl_group(tmp_path, extra):
     assert cfg["first_call_ms"] > 0 and cfg["handle_bytes"]["reference_handle"] > 0
 
 
-@pytest.mark.parametrize("extra", [[], ["--gather", "p2p"], ["--slabs", "2"]])
+@pytest.mark.parametrize("extra", [[], ["--gather", "p2p"], ["--slabs", "2"], ["--gather", "rows"]])
 def test_bench_two_ranks_share_one_device_over_gloo(extra):
     """The N = 2 data path of bench.py end to end -- two ranks generate their own shards, ``RowShardedSpMM.from_shard``, the
     exchange (collective / point-to-point / slab pipeline), the product, and the row-sum check of every rank's result against
