@@ -179,9 +179,9 @@ def main():
     from voltrix.jit_kernels.spmm import ORDER_CHUNKS, SCHED_PAIRS, SCHED_UNITS
 
     workload = args.workload or ("reddit_like" if world == 1 else "papers_like")
-    config_index = {"cora_like": 0, "reddit_like": 1, "reddit_uniform": 1, "products_like": 2, "powerlaw_4m": 3,
-                    "papers_like": 4}[workload]
-    cfg = synth_graphs.CONFIGS[workload]
+    config_index = {"cora_like": 0, "reddit_like": 1, "reddit_uniform": 1, "reddit_shuffled": 1, "products_like": 2,
+                    "products_shuffled": 2, "powerlaw_4m": 3, "papers_like": 4}[workload]
+    cfg = synth_graphs._resolve(workload)    # label-shuffled variants inherit their base config
     num_feats = args.feat or cfg["feat"]
     is_f16 = args.dtype == "f16"
     in_bytes = 2 if is_f16 else 4
