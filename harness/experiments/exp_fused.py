@@ -8,6 +8,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path[:0] = [REPO, os.path.join(REPO, "voltrix-spmm_amd")]
 os.environ.setdefault("VOLTRIX_CACHE_DIR", os.path.join(REPO, "voltrix-spmm_amd", ".jit_cache"))
 os.environ.setdefault("VOLTRIX_TUNE_SPACE", "none")
+os.environ["VOLTRIX_FUSED"] = "1"      # csr_preprocess_hybrid builds the stage records only when the one-launch form is asked for
 
 import torch  # noqa: E402
 
@@ -38,6 +39,7 @@ def main():
     two = voltrix.csr_preprocess_hybrid(indptr.cpu(), indices.cpu(), n)
     two.hash_tag = f"exp_fused/{workload}/{scale}"
     fr = two.fused
+    assert fr is not None
     print(f"{workload} x{scale}: N={n} nnz={indices.numel()} k-steps={two.plan.num_ksteps} shared={two.plan.num_shared_edges} "
           f"resid={two.plan.num_resid_edges} records={fr.num_records if fr else None}", flush=True)
     torch.manual_seed(0)

@@ -160,7 +160,14 @@ struct FusedArgs {
   int panels_per_xcd;
   int F;
   int meta_nt;                 // 1: metadata DMAs are non-temporal (one slab covers F: every byte is read once)
+  int* pace;                   // EXPERIMENT (VOLTRIX_FUSED_PACE, exp_fused_pace.py): zeroed int32 [8][kPaceGens][kPaceBlocks]
+                               // arrival counters, or nullptr (shipped).  The workgroups that share an XCD and a dispatch
+                               // generation wait for each other -- bounded, advisory: correctness never depends on it -- at
+                               // pace_blocks points of their column sweep, so that an XCD's 16 k resident rows sweep the
+                               // columns together (the L2-hit lever of DESIGN.md section 3.7)
+  int pace_blocks;
 };
+constexpr int kPaceGens = 8, kPaceBlocks = 64;
 
 template <class T>
 static __global__ __launch_bounds__(T::THREADS) void spmm_fused_kernel(const FusedArgs<T> a) {
@@ -434,7 +441,26 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_fused_kernel(const Fus
     int ds_t = 0, ms_t = 0;                               // k-step t
     int ds_r = (DP - 1) % DP, ms_r = (DP - 1) % MSP;      // k-step t + DP - 1 (rows issued this iteration)
     int ms_m = (2 * DP - 2) % MSP;                        // k-step t + 2 DP - 2 (metadata issued this iteration)
+    // pacing (experiment): this workgroup's cohort = the workgroups of its XCD label in its dispatch generation (32 per XCD
+    // fit at one per CU); sync point b sits at iteration ceil(b nks / blocks)
+    const int pace_gen = (int)(blockIdx.x / kNumXcd) / 32;
+    const int pace_members = pos_end - (xcd * a.panels_per_xcd + 32 * pace_gen) < 32
+                                 ? pos_end - (xcd * a.panels_per_xcd + 32 * pace_gen) : 32;
+    int pace_b = 1, pace_next = a.pace ? (nks + a.pace_blocks - 1) / a.pace_blocks : 0x7FFFFFFF;
     for (int t = 0; t < nks; ++t) {
+      if (a.pace && t == pace_next && blockIdx.y == 0 && pace_gen < kPaceGens) {   // workgroup-uniform
+        if (wave == 0 && lane == 0) {
+          int* const cnt = a.pace + ((xcd * kPaceGens + pace_gen) * kPaceBlocks + pace_b);
+          __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int spin = 0; spin < 64; ++spin) {             // bounded: at most 64 polls (~0.1 ms), then go on regardless
+            if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= pace_members) break;
+            __builtin_amdgcn_s_sleep(8);
+          }
+        }
+        ++pace_b;
+        pace_next = (int)(((long long)pace_b * nks + a.pace_blocks - 1) / a.pace_blocks);
+        if (pace_b >= a.pace_blocks || pace_b >= kPaceBlocks) pace_next = 0x7FFFFFFF;
+      }
       // every panel operation of iteration t - (DP - 1) has landed: this wave's share of k-step t's rows and the
       // metadata of k-step t + DP - 1
       wait_vm(nops - mark_p[0]);
@@ -552,6 +578,23 @@ inline int launch_spmm_fused(const int* panel_ptr, const int* panel_cols, const 
   a.F = embedding_dim;
   const int slabs = (embedding_dim + T::FS - 1) / T::FS;
   a.meta_nt = slabs == 1;
+  a.pace = nullptr;
+  a.pace_blocks = 0;
+  {   // EXPERIMENT: VOLTRIX_FUSED_PACE=<sync points per sweep> (harness/experiments/exp_fused_pace.py); shipped: unset
+    static const int pace_blocks = [] {
+      const char* e = std::getenv("VOLTRIX_FUSED_PACE");
+      const int v = e ? std::atoi(e) : 0;
+      return v < 0 ? 0 : (v > kPaceBlocks ? kPaceBlocks : v);
+    }();
+    if (pace_blocks > 1 && slabs == 1) {
+      static int* counters = nullptr;
+      const size_t bytes = sizeof(int) * kNumXcd * kPaceGens * kPaceBlocks;
+      if (counters == nullptr && hipMalloc(reinterpret_cast<void**>(&counters), bytes) != hipSuccess) return kErrLaunch;
+      if (hipMemsetAsync(counters, 0, bytes, stream) != hipSuccess) return kErrLaunch;
+      a.pace = counters;
+      a.pace_blocks = pace_blocks;
+    }
+  }
   const int lds_rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&spmm_fused_kernel<T>), T::BLOCK_LDS);
   if (lds_rc != kOk) return lds_rc;
   hipLaunchKernelGGL(spmm_fused_kernel<T>, dim3((unsigned)(a.panels_per_xcd * kNumXcd), (unsigned)slabs),
