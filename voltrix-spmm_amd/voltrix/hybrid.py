@@ -460,6 +460,10 @@ def launch_panel(plan: PanelPlan, feat: torch.Tensor, output: torch.Tensor, accu
 
 # fused kernel tile per feature width: (fs, depth of the shared panel ring)
 def default_fused_tile(embedding_dim: int):
+    forced = os.getenv("VOLTRIX_FUSED_TILE")          # "fs,depth" (experiments)
+    if forced:
+        fs, depth = (int(t) for t in forced.split(","))
+        return (fs, depth)
     if embedding_dim <= 32:
         return (32, 4)
     if embedding_dim <= 64:
