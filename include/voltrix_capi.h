@@ -338,6 +338,42 @@ void voltrix_launch_csr_fill(void* node_pointer, void* edge_list, int num_nodes,
                              void* workspace, void* pointer1, void* hspa_packed, void* hind, void* stream,
                              int* return_code);
 
+/* Cuthill-McKee row order on the device (locality reorder; no reference counterpart -- the
+ * reference reads externally reordered <name>.reorder.npz files, bench/graph_gen.py:42-45, bench/bench_all.py:120-129).
+ * Specification (voltrix/reorder_kernels.hpp; oracle/oracle_np.py::cm_order restates it): nodes = rows u < num_nodes;
+ * u, v are neighbours when A[u, v] or A[v, u] is stored (columns >= num_nodes are not nodes); deg(u) = entries of row u of
+ * A + entries of row u of A^T; tie(u) = position of u in the stable sort by deg.  A component is searched breadth first
+ * from `start`; inside level d the nodes are ordered by (rank of the earliest-ranked neighbour of level d - 1, tie).
+ * The result is a function of the CSR alone -- no race decides anything -- whatever the order inside A^T's rows.
+ *   voltrix_launch_csr_transpose: CSR of A^T (t_indptr int32[num_cols + 1], t_indices int32[num_edges]; rows sorted,
+ *       duplicates kept; entries with a column id outside [0, num_cols) left out) -- the search walks row u of A and row u of
+ *       A^T, and the backward pass of the SpMM multiplies with it (voltrix/autograd.py).  Row ids expanded per entry, one
+ *       stable radix sort by column, row pointers by binary search: no atomics.  workspace:
+ *       voltrix_csr_transpose_workspace_bytes(num_edges) bytes, device, 16-byte aligned.
+ *   voltrix_launch_bfs_seed: level[start] = 0 (level int32[num_nodes], -1 = unvisited, kept by the caller across
+ *       components), queue[0] = start (queue int32[num_nodes]), ctrl int32[8] = {head, tail, appended, depth, done, ...},
+ *       level_off int32[num_nodes + 2] (level_off[d] = queue position of level d's first node).
+ *   voltrix_launch_bfs_levels: one single-workgroup launch that walks every level while the frontier stays <= 2048 nodes,
+ *       then `wide_levels` whole-chip levels.  The caller reads ctrl (its sync) and calls again until ctrl[4] != 0; then
+ *       levels = ctrl[3] + 1, nodes of the component = ctrl[1] = level_off[levels], queue[0 .. nodes) = the component level
+ *       by level (order inside a level: arbitrary so far).
+ *   voltrix_launch_cm_rank: orders every level's queue segment (levels <= 1024 nodes: one workgroup walks runs of them,
+ *       LDS bitonic; larger: keys + radix sort, workspace voltrix_cm_rank_workspace_bytes(largest level above 1024) bytes)
+ *       and writes rank[v] = base + position (rank int32[num_nodes]).  level_off_host: HOST copy of level_off[0 .. levels].
+ *       tie int32[num_nodes].  Afterwards queue[0 .. nodes) is the component's order. */
+int64_t voltrix_csr_transpose_workspace_bytes(int64_t num_edges);
+void voltrix_launch_csr_transpose(void* indptr, void* indices, int num_rows, int num_cols, int64_t num_edges, void* workspace,
+                                  void* t_indptr, void* t_indices, void* stream, int* return_code);
+void voltrix_launch_bfs_seed(int start, int num_nodes, void* level, void* queue, void* ctrl, void* level_off, void* stream,
+                             int* return_code);
+void voltrix_launch_bfs_levels(void* indptr, void* indices, void* t_indptr, void* t_indices, int num_nodes, int t_rows,
+                               void* level, void* queue, void* ctrl, void* level_off, int wide_levels, void* stream,
+                               int* return_code);
+int64_t voltrix_cm_rank_workspace_bytes(int64_t max_level);
+void voltrix_launch_cm_rank(void* indptr, void* indices, void* t_indptr, void* t_indices, int num_nodes, int t_rows,
+                            void* level, void* rank, void* tie, void* queue, void* level_off, const int* level_off_host,
+                            int num_levels, int base, void* workspace, void* stream, int* return_code);
+
 #ifdef __cplusplus
 }
 #endif

@@ -395,3 +395,63 @@ def fused_records_to_edges(wave_ptr, records, num_nodes, waves=8, row_blocks=4):
                             assert row < num_nodes
                             edges.append((row, int(rec[16 * half + 4 * g + i])))
     return sorted(edges)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Cuthill-McKee row order.  NOT a restatement of the reference (it has no reorder code: it reads externally reordered
+# <name>.reorder.npz files, bench/graph_gen.py:42-45, bench/bench_all.py:120-129) but of this repository's own
+# specification, voltrix-spmm_amd/voltrix/include/voltrix/reorder_kernels.hpp -- plain loops, the checker of the HIP search
+# and of the torch host form (tests/test_reorder.py, tests/test_gpu_reorder_search.py).
+def cm_order(indptr, indices, num_nodes, num_cols=None, max_components=64):
+    n = int(num_nodes)
+    m = n if num_cols is None else int(num_cols)
+    indptr = np.asarray(indptr, dtype=np.int64)
+    indices = np.asarray(indices, dtype=np.int64)
+    nbrs = [[] for _ in range(n)]
+    deg = np.zeros(n, dtype=np.int64)
+    for u in range(n):
+        for c in indices[indptr[u]:indptr[u + 1]]:
+            deg[u] += 1                       # an entry of row u of A
+            if c < m and c < n:
+                deg[c] += 1                   # ... is an entry of row c of A^T
+            if c < n:
+                nbrs[u].append(int(c))
+                nbrs[int(c)].append(u)
+    tie = np.empty(n, dtype=np.int64)
+    tie[np.argsort(deg, kind="stable")] = np.arange(n)
+    level = np.full(n, -1, dtype=np.int64)
+    rank = np.full(n, -1, dtype=np.int64)
+
+    def search(start, level, rank, base):
+        level[start], rank[start] = 0, base
+        order, frontier, d = [start], [start], 0
+        while True:
+            fresh = {}
+            for u in frontier:
+                for v in nbrs[u]:
+                    if level[v] < 0 or (level[v] == d + 1 and v in fresh):
+                        level[v] = d + 1
+                        fresh[v] = min(fresh.get(v, 1 << 62), rank[u])
+            if not fresh:
+                return order, frontier
+            d += 1
+            frontier = sorted(fresh, key=lambda v: (fresh[v], tie[v]))
+            for v in frontier:
+                rank[v] = base + len(order)
+                order.append(v)
+
+    perm = []
+    for _ in range(max_components):
+        cand = [u for u in range(n) if level[u] < 0 and deg[u] > 0]
+        if not cand:
+            break
+        start = min(cand, key=lambda u: tie[u])
+        probe_level, probe_rank = level.copy(), rank.copy()
+        _, last = search(start, probe_level, probe_rank, len(perm))
+        start = min(last, key=lambda u: tie[u])
+        order, _ = search(start, level, rank, len(perm))
+        perm.extend(order)
+    rest = [u for u in range(n) if rank[u] < 0]
+    rest.sort(key=lambda u: -deg[u])          # stable: ties by id
+    perm.extend(rest)
+    return np.asarray(perm, dtype=np.int64)

@@ -94,6 +94,28 @@ def test_device_bfs_order_regroups_rows_without_relabelling_columns():
     assert sorted(perm2.tolist()) == list(range(n + 3))
 
 
+def test_host_form_of_the_search_matches_its_specification():
+    """bfs_permutation on CPU tensors (torch ops) against the plain-loop restatement of the specification
+    (oracle_np.cm_order): rectangular patterns, components, isolated rows, duplicate and unsorted entries, budgets."""
+    import numpy as np
+
+    from oracle import oracle_np
+
+    rng = np.random.default_rng(11)
+    for _ in range(40):
+        n = int(rng.integers(1, 120))
+        m = int(rng.choice([n, n, n + 5, max(1, n - 7)]))
+        a = rng.random((n, m)) < float(rng.choice([0.01, 0.03, 0.1]))
+        rows = [np.nonzero(r)[0] for r in a]
+        rows = [rng.permutation(np.concatenate([r, r[:1]])) if len(r) and rng.random() < 0.3 else r for r in rows]
+        ip = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+        ix = (np.concatenate(rows) if ip[-1] else np.zeros(0)).astype(np.int32)
+        budget = int(rng.choice([1, 3, 64]))
+        want = oracle_np.cm_order(ip, ix, n, m, max_components=budget)
+        got = reorder.bfs_permutation(torch.from_numpy(ip), torch.from_numpy(ix), n, m, max_components=budget).numpy()
+        assert np.array_equal(want, got)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("method", ["bfs", "degree", "given"])
 def test_reordered_handle_writes_c_through_the_permutation(cuda_device, method, monkeypatch):

@@ -24,15 +24,11 @@ def csr_transpose_device(indptr: torch.Tensor, indices: torch.Tensor, num_rows: 
     """CSR of ``A^T`` ([num_cols, num_rows]) for a device CSR of ``A`` ([num_rows, num_cols]): int32, rows sorted,
     duplicates kept (they count once in the block format, like everywhere else)."""
     assert indptr.is_cuda and indices.is_cuda and indptr.dtype == torch.int32 and indices.dtype == torch.int32
-    dev = indptr.device
-    deg = (indptr[1:] - indptr[:-1]).long()
-    rows = torch.repeat_interleave(torch.arange(num_rows, device=dev, dtype=torch.int64), deg)
-    key = torch.sort(indices.long() * num_rows + rows).values      # by (col, row)
-    t_rows = torch.div(key, num_rows, rounding_mode="floor")
-    t_indices = (key - t_rows * num_rows).to(torch.int32)
-    t_indptr = torch.zeros(num_cols + 1, dtype=torch.int64, device=dev)
-    t_indptr[1:] = torch.cumsum(torch.bincount(t_rows, minlength=num_cols), 0)
-    return t_indptr.to(torch.int32), t_indices
+    from . import capi
+
+    # row ids expanded per entry + one stable radix sort by column + row pointers by binary search (reorder_kernels.hpp;
+    # round 2 sorted 64-bit (col, row) keys with torch ops)
+    return capi.csr_transpose(indptr.contiguous(), indices.contiguous(), num_rows, num_cols)
 
 
 class _SpMMFunction(torch.autograd.Function):

@@ -61,6 +61,12 @@ SYMBOLS = (
     "voltrix_unit_table_fill_workspace_bytes",
     "voltrix_launch_unit_table_count",
     "voltrix_launch_unit_table_fill",
+    "voltrix_csr_transpose_workspace_bytes",
+    "voltrix_launch_csr_transpose",
+    "voltrix_launch_bfs_seed",
+    "voltrix_launch_bfs_levels",
+    "voltrix_cm_rank_workspace_bytes",
+    "voltrix_launch_cm_rank",
 )
 
 
@@ -87,6 +93,8 @@ def lib() -> ctypes.CDLL:
         _lib.voltrix_fused_records_workspace_bytes.restype = ctypes.c_int64
         _lib.voltrix_unit_table_workspace_bytes.restype = ctypes.c_int64
         _lib.voltrix_unit_table_fill_workspace_bytes.restype = ctypes.c_int64
+        _lib.voltrix_cm_rank_workspace_bytes.restype = ctypes.c_int64
+        _lib.voltrix_csr_transpose_workspace_bytes.restype = ctypes.c_int64
         for name in SYMBOLS:
             if name.startswith("voltrix_launch_") or name in ("voltrix_spmm_default_tile", "voltrix_spmm_tile_at"):
                 getattr(_lib, name).restype = None
@@ -407,3 +415,86 @@ launch_spmm_f32_as_f16 = _timed(launch_spmm_f32_as_f16, "spmm_f32_as_f16", 9)
 launch_window_order = _timed(launch_window_order, "window_order", 3)
 launch_csr_window_count = _timed(launch_csr_window_count, "csr_window_count", 8)
 launch_csr_fill = _timed(launch_csr_fill, "csr_fill", 8)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Cuthill-McKee row order on the device (voltrix/reorder_kernels.hpp; include/voltrix_capi.h)
+def csr_transpose(indptr, indices, num_rows: int, num_cols: int, stream=None):
+    """CSR of ``A^T``: int32 ``(t_indptr [num_cols + 1], t_indices [nnz])``, rows sorted, duplicates kept (a stable radix
+    sort by column, voltrix/reorder_kernels.hpp).  No host sync."""
+    import torch
+
+    dev = indptr.device
+    stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    nnz = int(indices.numel())
+    ws = torch.empty(max(16, int(lib().voltrix_csr_transpose_workspace_bytes(ctypes.c_int64(nnz)))), dtype=torch.uint8,
+                     device=dev)
+    t_indptr = torch.empty(num_cols + 1, dtype=torch.int32, device=dev)
+    t_indices = torch.empty(nnz, dtype=torch.int32, device=dev)
+    rc = ctypes.c_int(-1)
+    lib().voltrix_launch_csr_transpose(_ptr(indptr), _ptr(indices), ctypes.c_int(num_rows), ctypes.c_int(num_cols),
+                                       ctypes.c_int64(nnz), _ptr(ws), _ptr(t_indptr), _ptr(t_indices),
+                                       ctypes.c_void_p(stream), ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_csr_transpose")
+    return t_indptr, t_indices
+
+
+class CmSearch:
+    """State of the Cuthill-McKee search of one graph: buffers the C-ABI entries work on (all int32, on the CSR's device)."""
+
+    def __init__(self, indptr, indices, t_indptr, t_indices, num_nodes: int, t_rows: int, tie):
+        import torch
+
+        dev = indptr.device
+        self.graph = (indptr, indices, t_indptr, t_indices)
+        self.n, self.t_rows, self.tie = num_nodes, t_rows, tie
+        self.level = torch.full((num_nodes,), -1, dtype=torch.int32, device=dev)
+        self.rank = torch.full((num_nodes,), -1, dtype=torch.int32, device=dev)
+        self.queue = torch.empty(num_nodes, dtype=torch.int32, device=dev)
+        self.level_off = torch.zeros(num_nodes + 2, dtype=torch.int32, device=dev)
+        self.ctrl = torch.zeros(8, dtype=torch.int32, device=dev)
+        self.syncs = 0
+
+    def _graph_args(self):
+        a, b, c, d = self.graph
+        return (_ptr(a), _ptr(b), _ptr(c), _ptr(d), ctypes.c_int(self.n), ctypes.c_int(self.t_rows))
+
+    def levels(self, start: int, wide_levels: int = 4, stream=None):
+        """Breadth-first levels of ``start``'s component: returns ``(nodes, levels)``; ``queue[:nodes]`` holds the component
+        level by level, ``level_off[:levels + 1]`` the offsets.  One host read per `wide_levels` whole-chip levels (a graph
+        whose frontiers stay narrow is walked by one launch)."""
+        import torch
+
+        stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        rc = ctypes.c_int(-1)
+        lib().voltrix_launch_bfs_seed(ctypes.c_int(int(start)), ctypes.c_int(self.n), _ptr(self.level), _ptr(self.queue),
+                                      _ptr(self.ctrl), _ptr(self.level_off), ctypes.c_void_p(stream), ctypes.byref(rc))
+        check(rc.value, "voltrix_launch_bfs_seed")
+        while True:
+            lib().voltrix_launch_bfs_levels(*self._graph_args(), _ptr(self.level), _ptr(self.queue), _ptr(self.ctrl),
+                                            _ptr(self.level_off), ctypes.c_int(wide_levels), ctypes.c_void_p(stream),
+                                            ctypes.byref(rc))
+            check(rc.value, "voltrix_launch_bfs_levels")
+            ctrl = self.ctrl.tolist()       # the sync
+            self.syncs += 1
+            if ctrl[4]:
+                return ctrl[1], ctrl[3] + 1
+
+    def rank_component(self, levels: int, base: int, stream=None):
+        """Cuthill-McKee order inside the levels of the component in ``queue`` (in place) and ``rank`` = base + position."""
+        import torch
+
+        stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        offsets = self.level_off[:levels + 1].cpu()          # the sync
+        self.syncs += 1
+        sizes = (offsets[1:] - offsets[:-1])
+        big = int(sizes[sizes > 1024].max()) if bool((sizes > 1024).any()) else 0
+        ws = torch.empty(max(16, int(lib().voltrix_cm_rank_workspace_bytes(ctypes.c_int64(big)))), dtype=torch.uint8,
+                         device=self.level.device)
+        host = (ctypes.c_int * (levels + 1))(*offsets.tolist())
+        rc = ctypes.c_int(-1)
+        lib().voltrix_launch_cm_rank(*self._graph_args(), _ptr(self.level), _ptr(self.rank), _ptr(self.tie), _ptr(self.queue),
+                                     _ptr(self.level_off), host, ctypes.c_int(levels), ctypes.c_int(int(base)), _ptr(ws),
+                                     ctypes.c_void_p(stream), ctypes.byref(rc))
+        check(rc.value, "voltrix_launch_cm_rank")
+        return offsets

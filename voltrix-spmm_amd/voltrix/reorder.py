@@ -5,8 +5,9 @@ un-permutes C).  (2) Round 2, the product form: ``csr_preprocess_reordered`` / `
 and carried by the handle.  Only the ROWS of A are regrouped (which 16 rows share a window decides the TC-block fill;
 column ids are not relabelled), so B is gathered as the caller has it, and the SpMM writes row i of the handle to row
 ``row_map[i]`` of C through the kernel's epilogue: no permute pass before, no un-permute pass after.  The row order comes
-from a level-synchronous breadth-first search of the symmetrised pattern on the device (Cuthill-McKee levels from a
-pseudo-peripheral start, torch tensor ops -- plumbing), from the degrees, or from the caller.
+from a level-synchronous breadth-first search of the pattern of A + A^T on the device (Cuthill-McKee levels from a
+pseudo-peripheral start; round 3: HIP kernels, include/voltrix/reorder_kernels.hpp), from a spectral embedding computed with
+the SpMM kernels, from the degrees, or from the caller.
 
 --- round 1 docstring ---
 Locality reorder of a graph before ``csr_preprocess``.
@@ -82,34 +83,46 @@ def bandwidth(indptr, indices, num_nodes: int) -> int:
 import dataclasses  # noqa: E402
 
 
-def _symmetrised(indptr: torch.Tensor, indices: torch.Tensor, n: int, num_cols: int):
-    """CSR of the pattern of A + A^T restricted to the first min(n, num_cols) ids (square part), on the input's device."""
+def _cm_degrees(indptr: torch.Tensor, indices: torch.Tensor, n: int, num_cols: int):
+    """deg(u) = entries of row u of A + entries of row u of A^T, and tie(u) = position of u in the stable sort by deg
+    (the specification in voltrix/include/voltrix/reorder_kernels.hpp)."""
+    deg = (indptr[1:] - indptr[:-1]).long()
+    if indices.numel():
+        into = torch.bincount(indices.long(), minlength=max(n, num_cols))[:n]
+        into = torch.where(torch.arange(n, device=indptr.device) < num_cols, into, torch.zeros_like(into))
+        deg = deg + into
+    tie = torch.empty(n, dtype=torch.int64, device=indptr.device)
+    tie[torch.argsort(deg, stable=True)] = torch.arange(n, device=indptr.device)
+    return deg, tie
+
+
+def _both_directions(indptr: torch.Tensor, indices: torch.Tensor, n: int):
+    """Host form of the search's neighbour lists: CSR over the nodes whose row u lists row u of A (columns < n) followed
+    by row u of A^T -- nothing de-duplicated, like the kernels."""
     dev = indptr.device
     deg = (indptr[1:] - indptr[:-1]).long()
     rows = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int64), deg)
     cols = indices.long()
     keep = cols < n
     rows, cols = rows[keep], cols[keep]
-    key = torch.unique(torch.cat([rows * n + cols, cols * n + rows]))
-    su = torch.div(key, n, rounding_mode="floor")
-    sv = key - su * n
+    su, sv = torch.cat([rows, cols]), torch.cat([cols, rows])
+    order = torch.argsort(su, stable=True)
     sptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     sptr[1:] = torch.cumsum(torch.bincount(su, minlength=n), 0)
-    return sptr, sv
+    return sptr, sv[order]
 
 
-def _bfs_levels(sptr, sv, start: int, level, rank, next_rank: int, d0: int):
-    """Level-synchronous BFS from ``start`` over the unvisited part; fills ``level`` and ``rank`` (Cuthill-McKee order:
-    level by level, inside a level by the rank of the earliest-ranked parent, then by degree).  Returns
-    (next_rank, last frontier)."""
+def _bfs_levels(sptr, sv, tie, start: int, level, rank, next_rank: int):
+    """Level-synchronous search from ``start`` over the unvisited part; fills ``level`` and ``rank`` (inside a level by the
+    rank of the earliest-ranked neighbour of the level before, then by ``tie``).  Returns (next_rank, last level)."""
     dev = sptr.device
+    n = tie.numel()
     sdeg = sptr[1:] - sptr[:-1]
-    deg_span = int(sdeg.max()) + 1          # once per search, not once per level
     frontier = torch.tensor([start], device=dev, dtype=torch.int64)
-    level[start] = d0
+    level[start] = 0
     rank[start] = next_rank
     next_rank += 1
-    d = d0
+    d = 0
     last = frontier
     while frontier.numel():
         counts = sdeg[frontier]
@@ -126,8 +139,7 @@ def _bfs_levels(sptr, sv, start: int, level, rank, next_rank: int, d0: int):
         uniq, inv = torch.unique(nb, return_inverse=True)
         best_parent = torch.full((uniq.numel(),), 1 << 62, dtype=torch.int64, device=dev)
         best_parent.scatter_reduce_(0, inv, parent_rank, reduce="amin")
-        order = torch.argsort(best_parent * deg_span + sdeg[uniq], stable=True)
-        uniq = uniq[order]
+        uniq = uniq[torch.argsort(best_parent * n + tie[uniq])]
         d += 1
         level[uniq] = d
         rank[uniq] = next_rank + torch.arange(uniq.numel(), device=dev)
@@ -136,40 +148,90 @@ def _bfs_levels(sptr, sv, start: int, level, rank, next_rank: int, d0: int):
     return next_rank, last
 
 
+def _cm_permutation_host(indptr, indices, n, num_cols, max_components):
+    """The search with torch tensor ops (CPU tensors: a host utility like ``rcm_permutation``; the device path below runs
+    the HIP kernels)."""
+    dev = indptr.device
+    deg, tie = _cm_degrees(indptr, indices, n, num_cols)
+    sptr, sv = _both_directions(indptr, indices, n)
+    level = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    rank = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    next_rank = 0
+    for _ in range(max_components):
+        cand = torch.where((level < 0) & (deg > 0), tie, torch.full_like(tie, n))
+        start = int(torch.argmin(cand))
+        if int(cand[start]) >= n:
+            break
+        # pseudo-peripheral start: search once, restart from the node of the last level that comes first in the tie order
+        probe_level, probe_rank = level.clone(), rank.clone()
+        _, last = _bfs_levels(sptr, sv, tie, start, probe_level, probe_rank, next_rank)
+        start = int(last[torch.argmin(tie[last])])
+        next_rank, _ = _bfs_levels(sptr, sv, tie, start, level, rank, next_rank)
+    return deg, rank, next_rank
+
+
+def _cm_permutation_device(indptr, indices, n, num_cols, max_components, info=None):
+    """The search on the device: voltrix/include/voltrix/reorder_kernels.hpp through the C-ABI.  Host reads: one per
+    component for the start node, one per search for its size, one for the level offsets -- not one per level."""
+    from . import capi
+
+    dev = indptr.device
+    t_indptr, t_indices = capi.csr_transpose(indptr, indices, n, num_cols)
+    deg = (indptr[1:] - indptr[:-1]).long()                  # _cm_degrees, with A^T's row pointers in place of a bincount
+    k = min(n, num_cols)
+    deg[:k] += (t_indptr[1:k + 1] - t_indptr[:k]).long()
+    tie = torch.empty(n, dtype=torch.int64, device=dev)
+    tie[torch.argsort(deg, stable=True)] = torch.arange(n, device=dev)
+    search = capi.CmSearch(indptr, indices, t_indptr, t_indices, n, num_cols, tie.to(torch.int32))
+    perm = torch.empty(n, dtype=torch.int64, device=dev)
+    base = 0
+    components = 0
+    for _ in range(max_components):
+        cand = torch.where((search.level < 0) & (deg > 0), tie, torch.full_like(tie, n))
+        start = int(torch.argmin(cand))
+        if int(cand[start]) >= n:
+            break
+        nodes, levels = search.levels(start)
+        last = search.queue[int(search.level_off[levels - 1]):nodes].long()
+        start = int(last[torch.argmin(tie[last])])
+        search.level[search.queue[:nodes].long()] = -1
+        nodes, levels = search.levels(start)
+        search.rank_component(levels, base)
+        perm[base:base + nodes] = search.queue[:nodes]
+        base += nodes
+        components += 1
+    if info is not None:
+        info.update(components=components, level_reads=search.syncs)
+    return deg, search.rank.long(), base, perm
+
+
 def bfs_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
-                    max_components: int = 64) -> torch.Tensor:
-    """Cuthill-McKee-style row order on the device: int64 [N], position k holds row ``perm[k]``.  Breadth-first levels
-    of the symmetrised pattern from a pseudo-peripheral start (two sweeps), component by component (the largest
-    ``max_components`` ones; what is left -- isolated rows, tiny components -- follows by degree).  Rows that are close
-    in the graph end up in the same 16-row windows and share gathered columns."""
+                    max_components: int = 64, info: dict = None) -> torch.Tensor:
+    """Cuthill-McKee row order: int64 [N], position k holds row ``perm[k]``.  Breadth-first levels of the pattern of
+    A + A^T from a pseudo-peripheral start (two searches), component by component (``max_components`` of them, each started
+    from the unvisited node of least degree; what is left -- isolated rows, further components -- follows by descending
+    degree).  Rows that are close in the graph end up in the same 16-row windows and share gathered columns.  Device CSR: HIP
+    kernels (reorder_kernels.hpp -- frontier expansion with atomics, per-level key sort; the specification is in that
+    header); CPU CSR: the same specification with torch tensor ops.  Both give the same permutation."""
     n = num_nodes
     dev = indptr.device
     if n == 0:
         return torch.zeros(0, dtype=torch.int64, device=dev)
-    num_cols = n if num_cols is None else num_cols
-    sptr, sv = _symmetrised(indptr, indices, n, num_cols)
-    sdeg = sptr[1:] - sptr[:-1]
-    level = torch.full((n,), -1, dtype=torch.int64, device=dev)
-    rank = torch.full((n,), -1, dtype=torch.int64, device=dev)
-    next_rank = 0
-    big = int(sdeg.max()) + 1 if n else 1
-    for _ in range(max_components):
-        cand = torch.where((level < 0) & (sdeg > 0), sdeg, torch.full_like(sdeg, big))
-        start = int(torch.argmin(cand))
-        if n == 0 or int(cand[start]) >= big:
-            break
-        # pseudo-peripheral start: BFS once, restart from a min-degree node of the last level
-        probe_level = level.clone()
-        probe_rank = rank.clone()
-        _, last = _bfs_levels(sptr, sv, start, probe_level, probe_rank, next_rank, 0)
-        start = int(last[torch.argmin(sdeg[last])])
-        next_rank, _ = _bfs_levels(sptr, sv, start, level, rank, next_rank, 0)
+    num_cols = n if num_cols is None else int(num_cols)
+    if indptr.is_cuda:
+        deg, rank, next_rank, perm = _cm_permutation_device(indptr.contiguous(), indices.contiguous(), n, num_cols,
+                                                            max_components, info)
+    else:
+        deg, rank, next_rank = _cm_permutation_host(indptr, indices, n, num_cols, max_components)
+        perm = torch.empty(n, dtype=torch.int64, device=dev)
     rest = torch.nonzero(rank < 0).flatten()
     if rest.numel():
-        rest = rest[torch.argsort(-sdeg[rest], stable=True)]
+        rest = rest[torch.argsort(-deg[rest], stable=True)]
         rank[rest] = next_rank + torch.arange(rest.numel(), device=dev)
-    perm = torch.empty(n, dtype=torch.int64, device=dev)
-    perm[rank] = torch.arange(n, device=dev)
+    if indptr.is_cuda:
+        perm[next_rank:] = rest
+    else:
+        perm[rank] = torch.arange(n, device=dev)
     return perm
 
 
@@ -322,7 +384,7 @@ def permute_rows_csr(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int
     new_indptr = torch.zeros(num_nodes + 1, dtype=torch.int64, device=dev)
     new_indptr[1:] = torch.cumsum(pdeg, 0)
     shift = torch.repeat_interleave(indptr[:-1].long()[perm] - new_indptr[:-1], pdeg)
-    new_indices = indices[shift + torch.arange(int(new_indptr[-1]), device=dev)]
+    new_indices = indices[shift + torch.arange(indices.numel(), device=dev)]   # every row is kept: no host read for the size
     return new_indptr.to(torch.int32), new_indices.contiguous()
 
 
