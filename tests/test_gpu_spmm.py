@@ -461,7 +461,10 @@ def test_kernel_isolated_timing_hook(cuda_device, monkeypatch):
     two = voltrix.csr_preprocess_hybrid(indptr, indices, n, tau=130)
     two.hash_tag = "timing_hook"
     feat = torch.randn(n, 128, device="cuda")          # fp32: cast + scaled fp16 path
-    t_spmm, t_panel = bench_kineto(lambda: voltrix.spmm_two_level(two, feat), ("spmm_kernel", "spmm_panel"), num_tests=5)
+    for _ in range(2):      # means of five launches of ~50 us each: one stall of the box (seen once: 89 ms) and the mean is off
+        t_spmm, t_panel = bench_kineto(lambda: voltrix.spmm_two_level(two, feat), ("spmm_kernel", "spmm_panel"), num_tests=5)
+        if t_spmm < 1e-2 and t_panel < 1e-2:
+            break
     assert 0 < t_spmm < 1e-2 and 0 < t_panel < 1e-2    # seconds, like the reference
     with KernelTimer() as timer:
         voltrix.spmm_two_level(two, feat)
