@@ -186,3 +186,15 @@ def test_tuner_picks_fastest_valid_and_memoises(tmp_path, monkeypatch):
     tuner2.compile_and_tune(name="toy", keys={"k": 2}, space=space, includes=(), arg_defs=arg_defs,
                             template=template, args=(5,), bench=bench_fn)
     assert len(seen) == 4
+
+
+def test_cache_version_follows_the_include_graph_of_the_jit_kernels():
+    """get_repo_version (reference compiler.py:45-59 hashes its whole include tree): here the hash covers the headers a JIT
+    kernel can include -- the entries the kernel modules name and what those include -- so editing a header of the
+    ahead-of-time library alone (plan builders, unit tables, the search) does not throw the prebuilt kernel cache away."""
+    from voltrix.jit import compiler
+
+    closure = compiler.jit_header_closure()
+    assert {"voltrix/spmm_kernels.hpp", "voltrix/bmat_kernels.hpp", "voltrix/traits.hpp"} <= set(closure)
+    assert "voltrix/reorder_kernels.hpp" not in closure and "voltrix/unit_table.hpp" not in closure
+    assert len(compiler.get_repo_version()) == 12

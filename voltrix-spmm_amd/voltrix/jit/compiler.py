@@ -45,16 +45,42 @@ def get_jit_include_dir() -> str:
 
 
 @functools.lru_cache(maxsize=None)
+def jit_header_closure() -> Tuple[str, ...]:
+    """The device headers a JIT-compiled kernel can see: the ``"voltrix/*.hpp"`` entries named by the kernel modules
+    (``jit_kernels/*.py``: ``includes = (...)``) and everything they include, transitively.  Headers of the ahead-of-time
+    library only (plan builders, unit tables, the search of reorder_kernels.hpp ...) are not in it."""
+    root = get_jit_include_dir()
+    modules = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "jit_kernels"))
+    pattern = re.compile(r'"(%s/[\w./]+\.(?:hpp|h))"' % PROJECT_NAME_ABBR_LOWER)
+    todo = []
+    for fn in sorted(os.listdir(modules)):
+        if fn.endswith(".py"):
+            with open(os.path.join(modules, fn)) as f:
+                todo += pattern.findall(f.read())
+    seen = []
+    while todo:
+        rel = todo.pop()
+        if rel in seen:
+            continue
+        path = os.path.join(root, rel)
+        assert os.path.isfile(path), f"Cannot find device header {path}"
+        seen.append(rel)
+        with open(path) as f:
+            todo += re.findall(r'#include\s+"(%s/[\w./]+)"' % PROJECT_NAME_ABBR_LOWER, f.read())
+    return tuple(sorted(seen))
+
+
+@functools.lru_cache(maxsize=None)
 def get_repo_version() -> str:
-    """md5 over every device header: editing a kernel invalidates the cache (reference compiler.py:45-59)."""
-    root = os.path.join(get_jit_include_dir(), PROJECT_NAME_ABBR_LOWER)
-    assert os.path.isdir(root), f"Cannot find include directory {root}"
+    """md5 over every device header a JIT kernel can include: editing a kernel invalidates the cache (reference
+    compiler.py:45-59 hashes its whole include tree; here the tree also holds the ahead-of-time library's headers, which no
+    JIT kernel sees, so the hash follows the include graph instead -- ``jit_header_closure``)."""
+    root = get_jit_include_dir()
+    assert os.path.isdir(os.path.join(root, PROJECT_NAME_ABBR_LOWER)), f"Cannot find include directory {root}"
     md5 = hashlib.md5()
-    for dirpath, _, filenames in sorted(os.walk(root, followlinks=True)):
-        for fn in sorted(filenames):
-            if fn.endswith((".hpp", ".h")):
-                with open(os.path.join(dirpath, fn), "rb") as f:
-                    md5.update(f.read())
+    for rel in jit_header_closure():
+        with open(os.path.join(root, rel), "rb") as f:
+            md5.update(f.read())
     return md5.hexdigest()[0:12]
 
 
