@@ -176,7 +176,7 @@ def main():
     import voltrix
     from voltrix import dist as vdist
     from voltrix.jit_kernels import jit_tuner
-    from voltrix.jit_kernels.spmm import ORDER_CHUNKS, SCHED_PAIRS, SCHED_UNITS
+    from voltrix.jit_kernels.spmm import ORDER_CHUNKS, SCHED_PAIRS, SCHED_UNITS, slab_launches
 
     workload = args.workload or ("reddit_like" if world == 1 else "papers_like")
     config_index = {"cora_like": 0, "reddit_like": 1, "reddit_uniform": 1, "reddit_shuffled": 1, "products_like": 2,
@@ -497,7 +497,9 @@ def main():
             kernels = ("spmm_tc16_pair_kernel" if point.get("SCHED") == SCHED_PAIRS else "spmm_tc16_kernel") + (
                 " ; combine_partials_kernel" if point.get("SCHED") in (SCHED_UNITS, SCHED_PAIRS) else "")
         tile_desc = {"fs": point.get("FS"), "depth": point.get("DEPTH"), "waves": point.get("WAVES"),
-                     "schedule": sched_name(point)}
+                     "schedule": sched_name(point),
+                     # wide operands: one launch per 256-byte group of column slabs (spmm_kernels.hpp::slab_launch_group)
+                     "launches_per_step": slab_launches(num_feats, point.get("FS") or 128, in_bytes, num_nodes)}
         counter_key = (f"{workload}|F{num_feats}|{args.dtype}|{'two-level' if used_two else 'window'}|"
                        f"{point.get('FS')},{point.get('DEPTH')},{point.get('WAVES')}|sched{point.get('SCHED')}")
         counters = measured_counters(counter_key) if (world == 1 and args.scale == 1.0) else None

@@ -34,6 +34,10 @@ def main():
               "spmm_panel_kernel": "" if two_level else None, "FillFunctor<float>": "" if two_level else None,
               "spmm_fused_kernel": ""}
 
+    # wide operands: the window and panel kernels are launched once per group of column slabs (config.tile.launches_per_step)
+    per_step = int(tile.get("launches_per_step", 1))
+    launches = {"spmm_tc16_pair_kernel": per_step, "spmm_tc16_kernel": per_step, "spmm_panel_kernel": per_step}
+
     def role(name):
         for key, sig in wanted.items():
             if sig is not None and key in name and sig in name:
@@ -50,7 +54,7 @@ def main():
                 by[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, counters in by.items():
             for c, v in counters.items():
-                per[k][c] += v[-steps:] if k != "combine_partials_kernel" else v[-steps:]
+                per[k][c] += v[-steps * launches.get(k, 1):]
     for f in sorted(glob.glob(os.path.join(args.dir, "pass1", "*kernel_trace.csv"))):
         rows = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
@@ -58,21 +62,23 @@ def main():
             if k:
                 rows[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
         for k, v in rows.items():
-            dur[k] = v[-steps:]
+            dur[k] = v[-steps * launches.get(k, 1):]
     mean = lambda v: sum(v) / len(v) if v else 0.0                             # noqa: E731
     out, step = [], collections.defaultdict(float)
     for k in sorted(per):
-        out.append(f"{k}: last {steps} launches per pass, serialised by the profiler {mean(dur[k]):.4f} ms")
+        n = launches.get(k, 1)
+        out.append(f"{k}: last {steps} steps per pass ({n} launch(es) per step), serialised by the profiler "
+                   f"{n * mean(dur[k]):.4f} ms per step")
         for c, v in sorted(per[k].items()):
-            out.append(f"  {c:30s} n={len(v):3d} mean={mean(v):.6g}")
+            out.append(f"  {c:30s} n={len(v):3d} mean per launch={mean(v):.6g}")
         d = per[k]
-        step["fetch_kb"] += mean(d.get("FETCH_SIZE", []))
-        step["write_kb"] += mean(d.get("WRITE_SIZE", []))
-        step["hit"] += mean(d.get("TCC_HIT_sum", []))
-        step["miss"] += mean(d.get("TCC_MISS_sum", []))
-        step["mfma"] += mean(d.get("SQ_VALU_MFMA_BUSY_CYCLES", []))
-        step["busy"] += mean(d.get("GRBM_GUI_ACTIVE", []))
-        step["ms"] += mean(dur[k])
+        step["fetch_kb"] += n * mean(d.get("FETCH_SIZE", []))
+        step["write_kb"] += n * mean(d.get("WRITE_SIZE", []))
+        step["hit"] += n * mean(d.get("TCC_HIT_sum", []))
+        step["miss"] += n * mean(d.get("TCC_MISS_sum", []))
+        step["mfma"] += n * mean(d.get("SQ_VALU_MFMA_BUSY_CYCLES", []))
+        step["busy"] += n * mean(d.get("GRBM_GUI_ACTIVE", []))
+        step["ms"] += n * mean(dur[k])
     alg = bench["roofline"]["algorithmic_bytes"]
     traffic = int((2 * step["fetch_kb"] + step["write_kb"]) * 1024)
     entry = {"traffic_bytes": traffic, "fetch_kb_sum": step["fetch_kb"], "write_kb_sum": step["write_kb"],

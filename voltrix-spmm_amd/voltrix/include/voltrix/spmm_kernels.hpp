@@ -292,6 +292,7 @@ struct SpmmArgs {
                                  // from a row-permuted CSR (locality reorder, voltrix/reorder.py) writes C through it: no
                                  // un-permute pass.  Column ids are never relabelled, so B is gathered as it is.
   int slab_major;                // unit order inside an XCD's range when F spans several slabs (launcher, see slab_major_order)
+  int slab_first;                // this launch covers the column slabs [slab_first, slab_first + num_slabs) of the F-wide operand
   int meta_nt;                   // 1: bitmap / hind DMAs are non-temporal (set by the launcher when one slab covers F, i.e.
                                  // every metadata byte is read exactly once and should not displace rows of B in L2)
   int atomic_out;                // 1: C += result by float atomics (C pre-zeroed; two-level format: no join pass)
@@ -383,7 +384,7 @@ __device__ __forceinline__ void spmm_tc16_body(const SpmmArgs<T>& a) {
     nst_max = nst_u[p] > nst_max ? nst_u[p] : nst_max;
   }
   const int nst = NU * nst_max;   // stages of the wave: stage t = stage t / NU of unit t % NU (a unit past its end idles)
-  const int fs0 = (int)((a.slab_major || NU == 2) ? lu / w_count : lu % a.num_slabs) * FS;
+  const int fs0 = (a.slab_first + (int)((a.slab_major || NU == 2) ? lu / w_count : lu % a.num_slabs)) * FS;
   const int F = a.F;
   auto stage_of = [&](int t) -> int { return st0[t % NU] + st_step[t % NU] * (t / NU); };        // stage of its window
   auto stage_block = [&](int t) -> int { return kb0[t % NU] + kTcbPerStage * stage_of(t); };     // its first TC block
@@ -822,6 +823,31 @@ inline int slab_major_order(int num_slabs, int slab_row_bytes) {
   return slab_row_bytes >= 128;
 }
 
+// Wide operands (F > FS): ONE LAUNCH PER 256-BYTE GROUP OF COLUMN SLABS instead of one grid over all slabs (round 3), when
+// such a group of B fits the Infinity Cache.  Inside one grid the XCDs (and, in the two-level format, the two kernels) drift
+// apart by whole slabs and the caches hold pieces of several slabs at once; launch boundaries keep every CU on the same
+// columns of B.  Measured through the operator, one call (profiles/r03/experiment_slab_calls.log, experiment_slab_groups.log):
+//   reddit-like (233 k rows, 60 MB per 128-column slab)   F=256 2.84 -> 2.58 ms, F=512 6.03-6.08 -> 5.15-5.25, F=1024 12.5 -> 10.5
+//   reddit-uniform                                        F=512 7.46 -> 6.86 ms
+//   products-like (2.45 M rows, 64-column tiles: 627 MB)  F=512 13.48 as one grid; 14.3 one launch per slab, 13.8 per pair
+//   power-law 4 M (1 GB per 128-column slab)              F=256 113.3 as one grid, 110.7 per slab
+// so: a launch covers 256 bytes of every row of B (one slab of 128 fp16 columns, two of 64) when rows x 256 B <= 128 MiB (half
+// the Infinity Cache; the rows of A stand in for the rows of B the launcher does not know -- square adjacency: equal), and the
+// HBM-resident graphs keep the single grid, where the slabs of a window side by side share its metadata and its rows' DRAM
+// pages.  (products-like gains 3.5 % from four calls on CONTIGUOUS 128-column copies of B -- a layout effect, not a launch
+// effect; a slab-major B would cost the caller a reformat pass.)  Slabs of whole 128-byte lines only (the rule of the
+// slab-major order).  VOLTRIX_SLAB_LAUNCHES=0 / 1 forces the single grid / the launches.  Returns the slabs per launch, 0 = one grid.
+inline int slab_launch_group(int num_slabs, int slab_row_bytes, long long rows) {
+  static const int forced = [] {
+    const char* e = std::getenv("VOLTRIX_SLAB_LAUNCHES");
+    return e ? (e[0] == '0' ? 0 : 1) : -1;
+  }();
+  if (forced == 0 || slab_row_bytes < 128) return 0;
+  if (forced < 0 && rows * 256 > (128ll << 20)) return 0;
+  const int group = slab_row_bytes >= 256 ? 1 : 256 / slab_row_bytes;
+  return num_slabs > group ? group : 0;
+}
+
 // ----------------------------------------------------------------------------------------------
 // Host launcher for one tile configuration.
 template <class T>
@@ -832,7 +858,9 @@ inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed,
                             const int* units = nullptr /* int32[U][4] */, const int* unit_ptr = nullptr /* int32[9] */,
                             int max_units_per_xcd = 0, float* partials = nullptr, const int* row_map = nullptr,
                             const void* values = nullptr /* WEIGHTED tiles: in_t[T][16][8] */,
-                            int units_per_wave = 1 /* 2: paired units (unit table, 16-bit binary operand, FS <= 128, one slab or slab-major order; else ignored) */) {
+                            int units_per_wave = 1 /* 2: paired units (unit table, 16-bit binary operand, FS <= 128, one slab or slab-major order; else ignored) */,
+                            int slab_first = 0, int slab_count = 0 /* > 0: only the column slabs [slab_first, slab_first + slab_count) of the operand, one launch;
+                                                                       0: all of them -- one launch per slab_launch_group() slabs, or one grid over all */) {
   if (num_nodes < 0 || embedding_dim < 0) return kErrBadShape;
   if (num_nodes == 0 || embedding_dim == 0) return kOk;
   if (embedding_dim % (16 / T::EB) != 0) return kErrBadShape;  // 16-byte row chunks
@@ -846,12 +874,24 @@ inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed,
   a.num_nodes = num_nodes;
   a.num_windows = (num_nodes + kBlkH - 1) / kBlkH;
   a.F = embedding_dim;
-  a.num_slabs = (embedding_dim + T::FS - 1) / T::FS;
+  const int total_slabs = (embedding_dim + T::FS - 1) / T::FS;
+  if (slab_first < 0 || slab_count < 0 || slab_first + slab_count > total_slabs) return kErrBadShape;
+  if (const int group = slab_count == 0 ? slab_launch_group(total_slabs, T::FS * T::EB, num_nodes) : 0) {
+    for (int s = 0; s < total_slabs; s += group) {
+      const int rc = launch_spmm_tc16<T>(blk_offsets, hspa_packed, hind, num_nodes, embedding_dim, input, output, stream,
+                                         window_order, out_scale, atomic_out, units, unit_ptr, max_units_per_xcd, partials,
+                                         row_map, values, units_per_wave, s, total_slabs - s < group ? total_slabs - s : group);
+      if (rc != kOk) return rc;
+    }
+    return kOk;
+  }
+  a.slab_first = slab_count > 0 ? slab_first : 0;
+  a.num_slabs = slab_count > 0 ? slab_count : total_slabs;
   a.windows_per_xcd = (a.num_windows + kNumXcd - 1) / kNumXcd;
   a.window_order = window_order;
   a.out_scale = out_scale;
   a.atomic_out = atomic_out;
-  a.meta_nt = a.num_slabs == 1;
+  a.meta_nt = total_slabs == 1;   // several slabs (in one launch or one launch each) read the metadata again: keep it cached
   a.slab_major = slab_major_order(a.num_slabs, T::FS * T::EB);
   a.units = reinterpret_cast<const int4*>(units);
   a.unit_ptr = unit_ptr;

@@ -120,6 +120,7 @@ struct PanelArgs {
   int F;
   int throttle;                // s_sleep quanta per k-step group (0; VOLTRIX_PANEL_THROTTLE for experiments)
   int meta_nt;                 // 1: bitmap / column DMAs are non-temporal (launcher: one slab covers F, every byte read once)
+  int slab_first;              // blockIdx.y counts column slabs from here (one launch per slab: launch_spmm_panel)
   int accumulate;              // 0: C = A_shared * B;  1: C += A_shared * B (C holds the window kernel's part, read-add-store);
                                // 2: C += A_shared * B by float atomics (C pre-zeroed, the window kernel adds its part the
                                //    same way, in any order: two addends per element, so the sum does not depend on it)
@@ -141,7 +142,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
   const int pos_end = (xcd + 1) * a.panels_per_xcd < a.num_panels ? (xcd + 1) * a.panels_per_xcd : a.num_panels;
   if (pos >= pos_end) return;  // workgroup-uniform
   const int panel = a.panel_order ? a.panel_order[pos] : pos;
-  const int fs0 = blockIdx.y * FS;
+  const int fs0 = (a.slab_first + blockIdx.y) * FS;
   const int F = a.F;
   const int lane = threadIdx.x & (kWave - 1);
 
@@ -410,7 +411,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_gm_kernel(const 
   const int pos_end = (xcd + 1) * a.panels_per_xcd < a.num_panels ? (xcd + 1) * a.panels_per_xcd : a.num_panels;
   if (pos >= pos_end) return;  // workgroup-uniform
   const int panel = a.panel_order ? a.panel_order[pos] : pos;
-  const int fs0 = blockIdx.y * FS;
+  const int fs0 = (a.slab_first + blockIdx.y) * FS;
   const int F = a.F;
   const int lane = threadIdx.x & (kWave - 1);
   const int ks0 = a.panel_ptr[panel];
@@ -600,7 +601,8 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_gm_kernel(const 
 template <class T>
 inline int launch_spmm_panel(const int* panel_ptr, const int* panel_cols, const uint32_t* panel_bits,
                              const int* panel_order, int num_nodes, int embedding_dim, const void* input, float* output,
-                             int accumulate, const float* out_scale, hipStream_t stream) {
+                             int accumulate, const float* out_scale, hipStream_t stream, int slab_first = 0,
+                             int slab_count = 0 /* as launch_spmm_tc16: > 0 = that window of slabs in one launch */) {
   if (num_nodes < 0 || embedding_dim < 0 || accumulate < 0 || accumulate > 2) return kErrBadShape;
   if (num_nodes == 0 || embedding_dim == 0) return kOk;
   if (embedding_dim % 8 != 0 || ((uintptr_t)input & 15)) return kErrBadShape;
@@ -617,8 +619,20 @@ inline int launch_spmm_panel(const int* panel_ptr, const int* panel_cols, const 
   a.panels_per_xcd = (a.num_panels + kNumXcd - 1) / kNumXcd;
   a.F = embedding_dim;
   a.accumulate = accumulate;
-  const int slabs = (embedding_dim + T::FS - 1) / T::FS;
-  a.meta_nt = slabs == 1;
+  const int total_slabs = (embedding_dim + T::FS - 1) / T::FS;
+  if (slab_first < 0 || slab_count < 0 || slab_first + slab_count > total_slabs) return kErrBadShape;
+  if (const int group = slab_count == 0 ? slab_launch_group(total_slabs, T::ROW_BYTES, num_nodes) : 0) {   // spmm_kernels.hpp
+    for (int s = 0; s < total_slabs; s += group) {
+      const int rc = launch_spmm_panel<T>(panel_ptr, panel_cols, panel_bits, panel_order, num_nodes, embedding_dim, input,
+                                          output, accumulate, out_scale, stream, s,
+                                          total_slabs - s < group ? total_slabs - s : group);
+      if (rc != kOk) return rc;
+    }
+    return kOk;
+  }
+  const int slabs = slab_count > 0 ? slab_count : total_slabs;
+  a.slab_first = slab_count > 0 ? slab_first : 0;
+  a.meta_nt = total_slabs == 1;
   static const int throttle_env = [] {   // experiments; read once, not per launch
     const char* e = std::getenv("VOLTRIX_PANEL_THROTTLE");
     return e ? std::atoi(e) : 0;
