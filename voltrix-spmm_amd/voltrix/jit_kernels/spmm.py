@@ -263,6 +263,10 @@ def graph_bucket_keys(blk_offsets: torch.Tensor, num_nodes: int, keys: dict):
     except (AttributeError, RuntimeError):
         out["arch"] = keys.get("device", "unknown")
     out["graph_bucket"] = str(cached[1])
+    if isinstance(out.get("embedding_dim"), int) and out["embedding_dim"] > 128:
+        # wide operands run as 128-column slabs, one launch per slab (spmm_kernels.hpp::slab_launch_group): a width the
+        # store has not seen takes the choice of any other wide operand of the bucket (the exact width is asked first)
+        return [out, dict(out, embedding_dim="wide")]
     return out
 
 

@@ -94,7 +94,7 @@ class JITTuner:
     # ---- main entry --------------------------------------------------------------------------------------
     def compile_and_tune(self, name: str, keys: Dict[str, Any], space: tuple, includes: tuple, arg_defs: tuple,
                          template: str, args: tuple, kernel_tag: Optional[str] = None,
-                         bench: Optional[Callable] = None, bucket_keys: Optional[Callable[[], Dict[str, Any]]] = None):
+                         bench: Optional[Callable] = None, bucket_keys: Optional[Callable[[], Any]] = None):
         """``bucket_keys`` (optional, called only when a sweep is about to run): a coarser key for the same choice -- the
         matrix tag replaced by a bucket of graph statistics.  The sweep's result is stored under
         both keys; a later process whose exact key has no entry (a new or untagged graph of the same shape class) takes the
@@ -116,17 +116,20 @@ class JITTuner:
             return generate(includes, arg_defs, cpp_format(template, full))
 
         # a choice persisted by an earlier process short-circuits the sweep: the exact key first, then the bucket
-        bucket_signature = None
+        bucket_signatures = []
         if len(space) > 1:
             store = self._load_store()
             stored = store.get(f"{signature[0]}|{signature[1]}")
             hit = "stored_hits"
             if bucket_keys is not None and (stored is None or stored not in list(space)):
-                bk = bucket_keys()
-                if bk is not None:
-                    bucket_signature = self._signature(name + "@bucket", bk)
-                    stored = store.get(f"{bucket_signature[0]}|{bucket_signature[1]}")
+                bk = bucket_keys()      # one key, or several from the finest to the coarsest (the first that hits wins)
+                for one in ([] if bk is None else (bk if isinstance(bk, (list, tuple)) else [bk])):
+                    bucket_signatures.append(self._signature(name + "@bucket", one))
+                for sig in bucket_signatures:
+                    stored = store.get(f"{sig[0]}|{sig[1]}")
                     hit = "bucket_hits"
+                    if stored is not None and stored in list(space):
+                        break
             if stored is not None and stored in list(space):
                 runtime, _ = _build_one(name, arg_defs, render(stored), stored)
                 if runtime is not None and runtime(*args) == 0:
@@ -171,8 +174,8 @@ class JITTuner:
         self.tuned[signature], self.tuned_keys[signature] = best_runtime, best_keys
         if len(space) > 1:
             self._save_choice(signature, best_keys)
-            if bucket_signature is not None:
-                self._save_choice(bucket_signature, best_keys)
+            for sig in bucket_signatures:
+                self._save_choice(sig, best_keys)
         return best_runtime
 
 
