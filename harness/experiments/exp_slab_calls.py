@@ -13,7 +13,6 @@ os.environ.setdefault("VOLTRIX_CACHE_DIR", os.path.join(REPO, "voltrix-spmm_amd"
 import torch  # noqa: E402
 
 import synth_graphs  # noqa: E402
-import voltrix  # noqa: E402
 
 
 def time_ms(fn, iters=10):
@@ -33,7 +32,6 @@ def main():
     feat_dim = int(sys.argv[2]) if len(sys.argv) > 2 else 512
     ip, ix, _ = synth_graphs.generate(name, device="cuda")
     n, nnz = ip.numel() - 1, ix.numel()
-    handle = voltrix.spmm.spmm.csr_preprocess_device(ip, ix, n) if hasattr(voltrix.spmm, "spmm") else None
     from voltrix.spmm.spmm import csr_preprocess_device, spmm
 
     handle = csr_preprocess_device(ip, ix, n)
