@@ -1,0 +1,41 @@
+"""GPU: the one JSON line of ``python bench.py`` at N = 1 -- every key of the driver's contract, the ``roofline`` and
+``cpu_baseline`` objects, and the arithmetic between them -- on a shrunken workload (the driver runs the full one)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_line_carries_the_contract(tmp_path):
+    env = dict(os.environ, VOLTRIX_TUNE_SPACE="none")
+    run = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+                          "--scale", "0.05", "--tune", "none"], capture_output=True, text=True, env=env, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                       # ONE line
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["metric"] == "spmm_gflops" and line["unit"] == "GFLOP/s" and line["higher_is_better"] is True
+    assert line["n_gpus"] == 1 and line["steps"] == 4 and line["warmup"] == 2 and line["vs_baseline"] is None
+    assert line["dtype"] == "f16" and line["data"] == "synthetic" and "workload" in line["config"]
+    cfg, roof, cpu = line["config"], line["roofline"], line["cpu_baseline"]
+    # value = 2 nnz F / time
+    assert abs(line["value"] - 2 * cfg["nnz"] * cfg["feat"] / (line["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * line["value"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
+    # achieved = algorithmic bytes / measured kernel time (HIP events on the launch stream)
+    assert abs(roof["achieved"] - roof["algorithmic_bytes"] / (roof["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * roof["achieved"]
+    want_bytes = 4 * (cfg["nnz"] + cfg["num_nodes"] + 1) + cfg["num_nodes"] * cfg["feat"] * (2 + 4)
+    assert roof["algorithmic_bytes"] == want_bytes
+    assert "traffic" in roof                                     # null off the full-size configurations with PMC passes
+    assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["unit"] == "GFLOP/s"
+    assert isinstance(cpu["sample"], str) and cfg["rowsum_check_max_rel_err"] < 1e-4
+    assert cfg["tile"]["launches_per_step"] == 1 and cfg["first_call_ms"] > 0
