@@ -232,7 +232,7 @@ def test_operator_is_graph_capturable(cuda_device, dtype, monkeypatch):
         _assert_close(out, g["indptr"], g["indices"], feat.float().cpu(), n, mode)
 
 
-@pytest.mark.parametrize("case", ["cora_like fp32", "two-level fp16"])
+@pytest.mark.parametrize("case", ["cora_like fp32", "two-level fp16", "two-level fp16 wide"])
 def test_graphed_operator_replays_either_format(cuda_device, case, monkeypatch):
     """voltrix.GraphedSpMM: the operator captured once, replayed with new features; bit-equal to the eager call, for the
     window format (fp32 features: cast kernels inside the graph) and for the two-level format (two streams, atomics,
@@ -246,7 +246,8 @@ def test_graphed_operator_replays_either_format(cuda_device, case, monkeypatch):
         monkeypatch.setenv("VOLTRIX_HYBRID", "1")
         ip, ix, _ = synth_graphs.generate("reddit_like", device="cuda", scale=0.03)
         n, indptr, indices = ip.numel() - 1, ip.cpu(), ix.cpu()
-        feat = torch.randn(n, 128, device="cuda").half()
+        # "wide": 320 columns = 2.5 slabs of 128, one launch per slab of either kernel inside the captured graph
+        feat = torch.randn(n, 320 if case.endswith("wide") else 128, device="cuda").half()
     handle = voltrix.csr_preprocess(indptr, indices, n)
     handle[1].hash_tag = f"graphed/{case}"
     if not case.startswith("cora"):
