@@ -134,6 +134,25 @@ def vendor_baseline(indptr, indices, num_nodes, num_feats, device):
         return {"name": "torch.sparse.mm on the GPU (hipSPARSE CSR SpMM)", "error": str(exc)[:200]}
 
 
+def gather_model(gather_bytes, l2_hit_frac, operand_bytes, kernel_ms):
+    """A MODEL beside the HBM roofline, for the reader: what the CU's row-gather path delivers for this step's hit mix, from the
+    per-CU rates MI355X_MICROARCH.md measures for rows gathered into LDS (section 'Indexed rows') -- 66-73 GB/s per CU when the
+    rows come out of the XCD's L2, 33.5 / 29-31 / 23-24 when they come from a 38 MB / 151 MB / HBM-sized table -- applied to the
+    gathered bytes with the L2 hit fraction of the PMC passes.  The guide calls its rates lower bounds: frac = model time /
+    measured time may exceed 1 (the HBM-resident graphs do: 7.3 TB/s against the guide's 6.0-6.1 in-order sweep).  None
+    without counters."""
+    if l2_hit_frac is None or not gather_bytes:
+        return None
+    hit_rate = 70.0
+    miss_rate = 33.5 if operand_bytes <= (128 << 20) else (30.0 if operand_bytes <= (256 << 20) else 23.5)
+    per_cu = gather_bytes / 256
+    model_ms = (per_cu * l2_hit_frac / (hit_rate * 1e9) + per_cu * (1.0 - l2_hit_frac) / (miss_rate * 1e9)) * 1e3
+    return {"model_ms": model_ms, "frac": model_ms / kernel_ms,
+            "rates_gb_s_per_cu": {"l2_hit": hit_rate, "l2_miss": miss_rate},
+            "what": "gathered bytes / 256 CUs x (hit fraction / L2-hit gather rate + miss fraction / beyond-L2 gather rate), rates from "
+                    "MI355X_MICROARCH.md 'Indexed rows: gather into LDS'; frac = model time / measured kernel time"}
+
+
 def measured_counters(key):
     """PMC-derived figures of the step (profiles/traffic.json, written from rocprofv3 passes of THIS command): fabric-side
     bytes per step and the matrix-core busy fraction -- only for the exact configuration `key` names (workload, width,
@@ -548,6 +567,8 @@ def main():
                 "gather_bytes": gather_bytes, "gather_gbs": gather_bytes / (kernel_ms * 1e-3) / 1e9,
                 "note": "gather-bound: B rows are served by L2 / Infinity Cache (~8.6-19 TB/s row-gather ceilings), "
                         "see DESIGN.md Roofline",
+                "gather_model": gather_model(gather_bytes, counters.get("l2_hit_frac") if counters else None,
+                                                 num_cols * num_feats * in_bytes, kernel_ms),
             },
         }
         line["config"].update(extras)

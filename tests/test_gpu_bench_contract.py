@@ -36,6 +36,7 @@ def test_bench_line_carries_the_contract(tmp_path):
     want_bytes = 4 * (cfg["nnz"] + cfg["num_nodes"] + 1) + cfg["num_nodes"] * cfg["feat"] * (2 + 4)
     assert roof["algorithmic_bytes"] == want_bytes
     assert "traffic" in roof                                     # null off the full-size configurations with PMC passes
+    assert "gather_model" in roof                                 # a model beside the roofline; null without counters
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["unit"] == "GFLOP/s"
     assert isinstance(cpu["sample"], str) and cfg["rowsum_check_max_rel_err"] < 1e-4
     assert cfg["tile"]["launches_per_step"] == 1 and cfg["first_call_ms"] > 0
