@@ -4,11 +4,13 @@
 //   CSR (device) -> csr_window_count / csr_fill (the handle) -> unit_table_count / _fill -> spmm_f16_sched + combine_partials
 //                -> panel_plan_count / _fill + residual handle + panel_order -> zero C; panel kernel || window kernel; combine
 //                -> fused_records_count / _fill -> spmm_fused (the same two-level product as ONE launch)
+//                -> csr_transpose -> bfs_seed / bfs_levels / cm_rank (the Cuthill-McKee row order of the locality reorder)
 //
-// and checks all three results against a plain CPU loop over the CSR (fp16-rounded B, double accumulation).
+// and checks all three products against a plain CPU loop over the CSR (fp16-rounded B, double accumulation) and the row order
+// against a CPU search.
 //   build:  hipcc --offload-arch=gfx950 -O2 -std=c++17 -I include harness/capi_host_example.cpp \
 //                 -L voltrix-spmm_amd/lib -lvoltrix_hip -Wl,-rpath,$PWD/voltrix-spmm_amd/lib -o capi_host_example
-//   run:    ./capi_host_example [num_nodes] [mean_degree] [embedding_dim]      (exit code 0 = all three forms agree with the CPU)
+//   run:    ./capi_host_example [num_nodes] [mean_degree] [embedding_dim]      (exit code 0 = everything agrees with the CPU)
 // tests/test_gpu_capi_host.py builds and runs it on the GPU box.
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
@@ -249,11 +251,83 @@ int main(int argc, char** argv) {
   HIP_OK(hipStreamSynchronize(s_main));
   const double err_fused = max_rel_err(to_host(d_c, (size_t)n * f));
 
+  // ---- 4. Cuthill-McKee row order of the component of the least-degree node (locality reorder; voltrix/reorder_kernels.hpp):
+  // ---- transpose -> degrees and tie order (host) -> search from a start node -> ranks; checked against a CPU search -----------
+  void* tr_ws = dev_alloc<char>((size_t)voltrix_csr_transpose_workspace_bytes(e));
+  int* t_indptr = dev_alloc<int>(n + 1);
+  int* t_indices = dev_alloc<int>(std::max<int64_t>(e, 1));
+  RC_OK(voltrix_launch_csr_transpose(d_indptr, d_indices, n, n, e, tr_ws, t_indptr, t_indices, s_main, &rc_));
+  const std::vector<int> h_tptr = to_host(t_indptr, n + 1), h_tidx = to_host(t_indices, e);
+  std::vector<int> deg(n), by_deg(n), tie(n);
+  for (int u = 0; u < n; ++u) deg[u] = indptr[u + 1] - indptr[u] + h_tptr[u + 1] - h_tptr[u];
+  for (int u = 0; u < n; ++u) by_deg[u] = u;
+  std::stable_sort(by_deg.begin(), by_deg.end(), [&](int a, int b) { return deg[a] < deg[b]; });
+  for (int k = 0; k < n; ++k) tie[by_deg[k]] = k;
+  int start = -1;
+  for (int k = 0; k < n && start < 0; ++k)
+    if (deg[by_deg[k]] > 0) start = by_deg[k];
+  int* d_tie = dev_alloc<int>(n);
+  int* d_level = dev_alloc<int>(n);
+  int* d_rank = dev_alloc<int>(n);
+  int* d_queue = dev_alloc<int>(n);
+  int* d_level_off = dev_alloc<int>(n + 2);
+  int* d_ctrl = dev_alloc<int>(8);
+  HIP_OK(hipMemcpy(d_tie, tie.data(), n * sizeof(int), hipMemcpyHostToDevice));
+  HIP_OK(hipMemsetAsync(d_level, 0xFF, n * sizeof(int), s_main));   // -1: unvisited
+  HIP_OK(hipMemsetAsync(d_rank, 0xFF, n * sizeof(int), s_main));
+  RC_OK(voltrix_launch_bfs_seed(start, n, d_level, d_queue, d_ctrl, d_level_off, s_main, &rc_));
+  int ctrl[8] = {0};
+  do {   // one single-workgroup launch for the narrow levels + four whole-chip levels per host read
+    RC_OK(voltrix_launch_bfs_levels(d_indptr, d_indices, t_indptr, t_indices, n, n, d_level, d_queue, d_ctrl, d_level_off,
+                                    /*wide_levels=*/4, s_main, &rc_));
+    HIP_OK(hipMemcpyAsync(ctrl, d_ctrl, sizeof(ctrl), hipMemcpyDeviceToHost, s_main));
+    HIP_OK(hipStreamSynchronize(s_main));
+  } while (!ctrl[4]);
+  const int cm_levels = ctrl[3] + 1, cm_nodes = ctrl[1];
+  const std::vector<int> level_off = to_host(d_level_off, cm_levels + 1);
+  int64_t biggest = 0;
+  for (int d = 0; d < cm_levels; ++d)
+    if (level_off[d + 1] - level_off[d] > 1024) biggest = std::max<int64_t>(biggest, level_off[d + 1] - level_off[d]);
+  void* cm_ws = dev_alloc<char>((size_t)std::max<int64_t>(16, voltrix_cm_rank_workspace_bytes(biggest)));
+  RC_OK(voltrix_launch_cm_rank(d_indptr, d_indices, t_indptr, t_indices, n, n, d_level, d_rank, d_tie, d_queue, d_level_off,
+                               level_off.data(), cm_levels, /*base=*/0, cm_ws, s_main, &rc_));
+  HIP_OK(hipStreamSynchronize(s_main));
+  const std::vector<int> order = to_host(d_queue, cm_nodes);
+  // CPU search from the same start over rows of A and of A^T: levels, then (earliest-ranked parent, tie) inside a level
+  std::vector<int> cpu_level(n, -1), cpu_rank(n, -1), cpu_order{start}, frontier{start};
+  cpu_level[start] = 0;
+  cpu_rank[start] = 0;
+  auto for_neighbours = [&](int u, auto&& fn) {
+    for (int p = indptr[u]; p < indptr[u + 1]; ++p) fn(indices[p]);
+    for (int p = h_tptr[u]; p < h_tptr[u + 1]; ++p) fn(h_tidx[p]);
+  };
+  for (int d = 0; !frontier.empty(); ++d) {
+    std::vector<int> next;
+    for (int u : frontier)
+      for_neighbours(u, [&](int v) {
+        if (cpu_level[v] < 0) {
+          cpu_level[v] = d + 1;
+          next.push_back(v);
+        }
+      });
+    std::vector<int> best(n, 0x7fffffff);
+    for (int v : next) for_neighbours(v, [&](int u) { if (cpu_level[u] == d) best[v] = std::min(best[v], cpu_rank[u]); });
+    std::sort(next.begin(), next.end(), [&](int a, int b) { return best[a] != best[b] ? best[a] < best[b] : tie[a] < tie[b]; });
+    for (int v : next) {
+      cpu_rank[v] = (int)cpu_order.size();
+      cpu_order.push_back(v);
+    }
+    frontier.swap(next);
+  }
+  const bool order_ok = order == cpu_order;
+
   std::printf("N=%d nnz=%lld F=%d | window format: %d TC blocks, %d units (%d cut windows), rel err %.3e | two-level: %d "
               "k-steps, %d residual edges (%d units), rel err %.3e | one launch: %d stage records, rel err %.3e\n",
               n, (long long)e, f, h.total_blocks, t.header[0], t.header[1], err_window, ksteps, resid_edges, tr.header[0],
               err_two_level, num_records, err_fused);
+  std::printf("Cuthill-McKee search from row %d: %d rows in %d levels, order %s the CPU search\n", start, cm_nodes, cm_levels,
+              order_ok ? "equals" : "DIFFERS FROM");
   const bool ok = err_window < 1e-5 && err_two_level < 1e-5 && err_fused < 1e-5 && std::isfinite(err_window) &&
-                  std::isfinite(err_two_level) && std::isfinite(err_fused);
+                  std::isfinite(err_two_level) && std::isfinite(err_fused) && order_ok;
   return ok ? 0 : 1;
 }

@@ -1,5 +1,6 @@
 """GPU: a torch-free C++ host on libvoltrix_hip.so (harness/capi_host_example.cpp) -- hipMalloc buffers, the two-phase
-builders (handle, unit table, panel plan, panel order), both formats of the SpMM -- built with hipcc and run as a child
+builders (handle, unit table, panel plan, panel order, stage records), every form of the SpMM, the transpose and the
+Cuthill-McKee search -- built with hipcc and run as a child
 process; it checks its results against a CPU loop and reports through its exit code."""
 import os
 import subprocess
@@ -31,4 +32,4 @@ def test_cpp_host_runs_both_formats_through_the_c_abi(cuda_device, host_binary, 
     proc = subprocess.run([host_binary, str(num_nodes), str(mean_degree), str(num_feats)], capture_output=True, text=True,
                           timeout=300)
     assert proc.returncode == 0, (proc.returncode, proc.stdout[-2000:], proc.stderr[-2000:])
-    assert "rel err" in proc.stdout
+    assert "rel err" in proc.stdout and "order equals the CPU search" in proc.stdout
