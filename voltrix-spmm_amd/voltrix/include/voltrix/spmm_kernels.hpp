@@ -831,8 +831,9 @@ inline int slab_major_order(int num_slabs, int slab_row_bytes) {
 //   reddit-uniform                                        F=512 7.46 -> 6.86 ms
 //   products-like (2.45 M rows, 64-column tiles: 627 MB)  F=512 13.48 as one grid; 14.3 one launch per slab, 13.8 per pair
 //   power-law 4 M (1 GB per 128-column slab)              F=256 113.3 as one grid, 110.7 per slab
-// so: a launch covers 256 bytes of every row of B (one slab of 128 fp16 columns, two of 64) when rows x 256 B <= 128 MiB (half
-// the Infinity Cache; the rows of A stand in for the rows of B the launcher does not know -- square adjacency: equal), and the
+//   reddit-like at 2x / 4x the rows (114 / 228 MiB)     F=512 two-level 14.28 -> 13.56 / 31.97 -> 29.89, window format 23.1 -> 21.4 / 51.8 -> 50.7
+// so: a launch covers 256 bytes of every row of B (one slab of 128 fp16 columns, two of 64) when rows x 256 B <= 256 MiB (the
+// Infinity Cache; the rows of A stand in for the rows of B the launcher does not know -- square adjacency: equal), and the
 // HBM-resident graphs keep the single grid, where the slabs of a window side by side share its metadata and its rows' DRAM
 // pages.  (products-like gains 3.5 % from four calls on CONTIGUOUS 128-column copies of B -- a layout effect, not a launch
 // effect; a slab-major B would cost the caller a reformat pass.)  Slabs of whole 128-byte lines only (the rule of the
@@ -843,7 +844,7 @@ inline int slab_launch_group(int num_slabs, int slab_row_bytes, long long rows) 
     return e ? (e[0] == '0' ? 0 : 1) : -1;
   }();
   if (forced == 0 || slab_row_bytes < 128) return 0;
-  if (forced < 0 && rows * 256 > (128ll << 20)) return 0;
+  if (forced < 0 && rows * 256 > (256ll << 20)) return 0;
   const int group = slab_row_bytes >= 256 ? 1 : 256 / slab_row_bytes;
   return num_slabs > group ? group : 0;
 }

@@ -52,12 +52,12 @@ PAIR_UNIT_FACTOR = float(os.getenv("VOLTRIX_PAIR_UNIT_FACTOR", "1.25"))   # x th
 def slab_launches(embedding_dim: int, fs: int, elem_bytes: int, rows: int) -> int:
     """Kernel launches a call of the window (or panel) kernel makes for an ``embedding_dim``-wide operand: the rule of
     ``spmm_kernels.hpp::slab_launch_group`` restated for reports (bench.py ``config.tile.launches_per_step``,
-    harness/pmc_summarize.py) -- one launch per 256-byte group of column slabs when such a group of B fits half the Infinity
-    Cache, else one grid over all slabs."""
+    harness/pmc_summarize.py) -- one launch per 256-byte group of column slabs when such a group of B fits the Infinity Cache,
+    else one grid over all slabs."""
     slabs = -(-embedding_dim // fs)
     slab_bytes = fs * elem_bytes
     forced = os.getenv("VOLTRIX_SLAB_LAUNCHES")
-    if slab_bytes < 128 or (forced or "")[:1] == "0" or (forced is None and rows * 256 > (128 << 20)):
+    if slab_bytes < 128 or (forced or "")[:1] == "0" or (forced is None and rows * 256 > (256 << 20)):
         return 1
     group = 1 if slab_bytes >= 256 else 256 // slab_bytes
     return -(-slabs // group) if slabs > group else 1
