@@ -443,6 +443,13 @@ def main():
         # what the step should take on a fully connected xGMI node, to read the measured one against
         extras["predicted_ms"] = {k: round(v, 3) for k, v in vdist.predicted_step_ms(
             world, rows_padded * num_feats * gathered.element_size(), kernel_ms).items()}
+        # the 1-GPU point of THIS workload's strong-scaling curve (the driver's own N = 1 run is the headline workload,
+        # reddit-like): measured on one MI355X with the same command and --gpus 1 --workload <this one>, kept in profiles/
+        ref_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03", f"bench_{workload}_f{num_feats}.json")
+        if args.scale == 1.0 and is_f16 and os.path.exists(ref_path):
+            ref = [json.loads(ln) for ln in open(ref_path) if ln.startswith("{")][-1]
+            extras["single_gpu_same_workload"] = {"ms_per_step": ref["ms_per_step"], "value": ref["value"], "unit": ref["unit"],
+                                                  "source": os.path.relpath(ref_path, os.path.dirname(os.path.abspath(__file__)))}
     if world == 1 and not args.no_reference_formats:
         def time_ms(fn, iters=10):
             fn()
