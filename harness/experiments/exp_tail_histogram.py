@@ -7,6 +7,8 @@ CU runs after the median CU has gone idle).
 
     python harness/experiments/exp_tail_histogram.py build
     python harness/experiments/exp_tail_histogram.py run [workload] [scale] [feat]
+    python harness/experiments/exp_tail_histogram.py pair [workload] [scale] [feat]    the two-level step: the stamped window kernel
+                                                    on the residual (two units per wave, atomic epilogue) BESIDE the panel kernel
 """
 import ctypes
 import json
@@ -38,14 +40,21 @@ def run():
     from voltrix.jit_kernels.spmm import ORDER_CHUNKS, PAIR_UNIT_FACTOR
     from voltrix.schedule import default_max_stages, unit_table
 
-    workload = sys.argv[2] if len(sys.argv) > 2 else "powerlaw_4m"
+    pair_mode = sys.argv[1] == "pair"
+    workload = sys.argv[2] if len(sys.argv) > 2 else ("reddit_like" if pair_mode else "powerlaw_4m")
     scale = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
     feat_dim = int(sys.argv[4]) if len(sys.argv) > 4 else synth_graphs.CONFIGS[workload]["feat"]
     dev = torch.device("cuda")
-    os.environ["VOLTRIX_HYBRID"] = "0"
+    os.environ["VOLTRIX_HYBRID"] = "1" if pair_mode else "0"
     indptr, indices, _ = synth_graphs.generate(workload, device=dev, scale=scale)
     n, nnz = indptr.numel() - 1, indices.numel()
     handle = voltrix.csr_preprocess_device(indptr, indices, n)
+    two = None
+    if pair_mode:
+        two = voltrix.two_level_of(handle[1])        # the side-car csr_preprocess_device attached (VOLTRIX_HYBRID=1)
+        assert two is not None
+        handle = two.residual
+        side = torch.cuda.Stream()
     del indptr, indices
     blk = handle[0]
     nst = ((blk[1:] - blk[:-1]) + 3) // 4
@@ -67,6 +76,9 @@ def run():
     tb_p = unit_table(blk, n, max(8, int(PAIR_UNIT_FACTOR * default_max_stages(blk, n) / 1.5)))
     cases = {"natural order": dict(), f"balance schedule (chunk {ORDER_CHUNKS[3]})": dict(order=order),
              "unit table": dict(table=tb), "unit table, two units per wave": dict(table=tb_p, upw=2)}
+    if pair_mode:
+        cases = {"residual alone: unit table, two units per wave": dict(table=tb_p, upw=2),
+                 "residual beside the panel kernel (the two-level step)": dict(table=tb_p, upw=2, panel=True)}
     for name, c in cases.items():
         table = c.get("table")
         units_per_xcd = table.max_units_per_xcd if table is not None else (windows + 7) // 8
@@ -77,14 +89,22 @@ def run():
 
         def launch(stamp_ptr):
             rc = ctypes.c_int(-1)
+            if c.get("panel"):   # zero fill, then the panel kernel on the side stream, as voltrix.hybrid does
+                out.zero_()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    assert capi.launch_spmm_panel(two.plan, feat.data_ptr(), out.data_ptr(), feat_dim, 2, False, (128, 3, 1), 0,
+                                                  side.cuda_stream) == 0
             fn(capi._ptr(handle[0]), capi._ptr(handle[1]), capi._ptr(handle[2]), ctypes.c_int(n), ctypes.c_int(nnz),
                ctypes.c_int(feat_dim), capi._ptr(feat), capi._ptr(out), ctypes.c_int(tile[0]), ctypes.c_int(tile[1]),
                ctypes.c_int(tile[2]), ctypes.c_void_p(c["order"].data_ptr() if "order" in c else 0), ctypes.c_void_p(0),
-               ctypes.c_int(0), ctypes.c_void_p(table.units.data_ptr() if table is not None else 0),
+               ctypes.c_int(1 if pair_mode else 0), ctypes.c_void_p(table.units.data_ptr() if table is not None else 0),
                ctypes.c_void_p(table.unit_ptr.data_ptr() if table is not None else 0),
                ctypes.c_int(table.max_units_per_xcd if table is not None else 0), capi._ptr(partials),
                ctypes.c_void_p(stamp_ptr), ctypes.c_int(c.get("upw", 1)), ctypes.c_void_p(stream), ctypes.byref(rc))
             assert rc.value == 0, rc.value
+            if c.get("panel"):
+                torch.cuda.current_stream().wait_stream(side)
 
         for _ in range(2):
             launch(stamps.data_ptr())
@@ -114,4 +134,4 @@ def run():
 
 
 if __name__ == "__main__":
-    build() if sys.argv[1] == "build" else run()
+    build() if sys.argv[1] == "build" else run()   # "run" or "pair"
