@@ -30,3 +30,22 @@ def test_one_launch_per_slab_gives_the_bits_of_the_single_grid(tmp_path):
     for hybrid in ("0", "1"):
         assert torch.equal(outs["0"][hybrid], outs["1"][hybrid])
         assert torch.equal(outs["1"][hybrid], want)          # integer operands: exact
+
+
+@pytest.mark.parametrize("dtype,mode,width", [(torch.float32, "exact", 200), (torch.bfloat16, "fp16", 320), (torch.float32, "fp16", 264)])
+def test_wide_operands_of_every_dtype_against_the_dense_product(cuda_device, dtype, mode, width, monkeypatch):
+    """Several column slabs (one launch each on a graph this small) for the exact-fp32 tiles (64 columns x 4 bytes), the
+    bfloat16 operand and the scaled-fp16 path of fp32 features, widths that are not multiples of the slab."""
+    import voltrix
+
+    monkeypatch.setenv("VOLTRIX_FP32_MODE", mode)
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    indptr, indices, _ = synth_graphs.generate("reddit_like", scale=0.02)
+    n = indptr.numel() - 1
+    torch.manual_seed(1)
+    feat = torch.randint(-3, 4, (n, width)).to(dtype)          # small integers: exact in every operand type
+    handle = voltrix.csr_preprocess(indptr, indices, n)
+    handle[1].hash_tag = f"wide_{dtype}_{mode}_{width}"
+    out = voltrix.spmm(*handle, num_nodes=n, num_edges=indices.numel(), feat=feat.cuda())
+    want = torch.sparse_csr_tensor(indptr.long(), indices.long(), torch.ones(indices.numel()), size=(n, n)) @ feat.float()
+    assert torch.equal(out.cpu(), want)
