@@ -62,10 +62,15 @@ def parse_args():
                          "runs on a second stream beside the SpMM of step k, double-buffered B)")
     ap.add_argument("--one-device", action="store_true",
                     help="debug: every rank uses cuda:0 (exercises the sharded path on a 1-GPU box, with --backend gloo)")
-    ap.add_argument("--gather", default="collective", choices=["collective", "p2p", "rows"],
+    ap.add_argument("--gather", default="auto", choices=["auto", "collective", "p2p", "rows"],
                     help="N > 1: the exchange step -- one all_gather_into_tensor (what RCCL picks over xGMI), the direct "
                          "schedule written out as world-1 batched point-to-point copies per rank, or only the rows of B the "
-                         "shard references (one all-to-all with uneven splits; voltrix/dist.py)")
+                         "shard references (one all-to-all with uneven splits; voltrix/dist.py).  auto (default): the warm-up "
+                         "times collective against p2p (and the referenced-rows operator when the shards reference < 70 %% of "
+                         "the remote rows), MAX over ranks, and the timed steps run the fastest")
+    ap.add_argument("--rows-below", type=float, default=0.7,
+                    help="--gather auto builds and times the referenced-rows operator when the shards reference less than this "
+                         "fraction of the remote rows")
     ap.add_argument("--slabs", type=int, default=1,
                     help="N > 1: exchange and multiply B in this many feature slabs (gather of slab j+1 beside the SpMM of "
                          "slab j) instead of overlapping whole steps")
@@ -153,6 +158,57 @@ def gather_model(gather_bytes, l2_hit_frac, operand_bytes, kernel_ms):
                     "MI355X_MICROARCH.md 'Indexed rows: gather into LDS'; frac = model time / measured kernel time"}
 
 
+def choose_referenced_rows(op, vdist, local_indptr, local_indices, num_nodes, parts, feat_local, args, device):
+    """--gather auto, second half: is the referenced-rows operator (only the rows of B a shard references travel) worth
+    building?  Only when the shards reference < 70 % of the remote rows (MAX over ranks).  Then it is built beside the
+    all-gather operator and ONE whole step of each (exchange + product, after one warm-up step) is timed, MAX over ranks; the
+    ranks agree on every decision through all-reduces, and a rank that fails to build the candidate makes all ranks drop it."""
+    world, rank = op.world_size, op.rank
+    r0, r1 = parts[rank]
+    remote = local_indices[(local_indices < r0) | (local_indices >= r1)]
+    referenced = int(torch.unique(remote).numel()) if remote.numel() else 0
+    del remote
+    frac = torch.tensor([referenced / max(1, num_nodes - (r1 - r0))], dtype=torch.float64, device=device)
+    dist.all_reduce(frac, op=dist.ReduceOp.MAX)
+    info = {"referenced_fraction_of_remote_rows": float(frac)}
+    if float(frac) >= args.rows_below or args.slabs > 1:
+        return info
+    ok = torch.ones(1, device=device)
+    op_rows = None
+    try:
+        op_rows = vdist.RowShardedSpMM.from_shard(local_indptr, local_indices, num_nodes, parts, mode="rows",
+                                                  exchange_at_world_1=args.force_dist)
+    except RuntimeError as exc:   # e.g. out of memory while building the request lists: every rank must drop the candidate
+        info["rows_error"] = str(exc)[:200]
+        ok.zero_()
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok) == 0.0:
+        return info
+    num_feats = feat_local.shape[1]
+
+    def whole_step(o, buf):
+        o.multiply(o.gather_into(buf, feat_local))
+
+    timings = {}
+    for name, o in (("allgather", op), ("rows", op_rows)):
+        buf = o._buffer("whole", num_feats, feat_local)
+        for _ in range(2):                      # first call: tile choice / unit table of this operator's handle
+            whole_step(o, buf)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        whole_step(o, buf)
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0) * 1e3], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        timings[name] = float(t)
+    info["whole_step_ms"] = timings
+    if timings["rows"] < timings["allgather"]:
+        info["picked"] = "rows"
+        info["op_rows"] = op_rows
+    return info
+
+
 def measured_counters(key):
     """PMC-derived figures of the step (profiles/traffic.json, written from rocprofv3 passes of THIS command): fabric-side
     bytes per step and the matrix-core busy fraction -- only for the exact configuration `key` names (workload, width,
@@ -229,7 +285,8 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if distributed:
-            op = vdist.RowShardedSpMM.from_shard(local_indptr, local_indices, num_nodes, parts, mode=args.gather,
+            op = vdist.RowShardedSpMM.from_shard(local_indptr, local_indices, num_nodes, parts,
+                                                 mode="collective" if args.gather == "auto" else args.gather,
                                                  slabs=args.slabs, exchange_at_world_1=args.force_dist)
             handle = op.handle
         else:
@@ -247,7 +304,25 @@ def main():
     gen = torch.Generator(device=device).manual_seed(1234 + rank)
     feat_local = torch.randn(local_rows, num_feats, generator=gen, device=device,
                              dtype=torch.float32).to(torch.float16 if is_f16 else torch.float32)
-    if world > 1 and args.gather == "rows":
+    # ---- --gather auto: the exchange schedule is chosen from measurement, identically on every rank -------------------
+    gather_mode = args.gather
+    exchange_choice = None
+    if distributed and args.gather == "auto":
+        exchange_choice = {"candidates_ms": op.choose_exchange(feat_local)}      # collective vs p2p: same buffer layout
+        gather_mode = op.mode
+        if world > 1:
+            exchange_choice.update(choose_referenced_rows(op, vdist, local_indptr, local_indices, num_nodes, parts, feat_local,
+                                                          args, device))
+            if exchange_choice.get("picked") == "rows":
+                op = exchange_choice.pop("op_rows")
+                handle = op.handle
+                handle[1].hash_tag = f"bench/{workload}/s{args.scale}/r{rank}of{world}/rows"
+                two = voltrix.two_level_of(handle[1])
+                total_blocks = int(handle[0][-1])
+                gather_mode = "rows"
+            exchange_choice.pop("op_rows", None)
+        exchange_choice["picked"] = gather_mode
+    if world > 1 and gather_mode == "rows":
         gathered = torch.zeros(op.compact_rows, num_feats, dtype=feat_local.dtype, device=device)   # own rows | referenced rows
         gathered[:local_rows].copy_(feat_local)
     elif world > 1:
@@ -353,7 +428,7 @@ def main():
     row_of_edge_chunk = 1 << 27
     ip64 = local_indptr.long()
     # the shard's column ids are global; the gathered B is laid out in padded shards (voltrix.dist.remap_columns)
-    if world > 1 and args.gather == "rows":   # the compact buffer: positions the operator computed at setup
+    if world > 1 and gather_mode == "rows":   # the compact buffer: positions the operator computed at setup
         check_indices = op.compact_ids(local_indices)
     else:
         check_indices = vdist.remap_columns(local_indices, parts, rows_padded) if world > 1 else local_indices
@@ -437,7 +512,9 @@ def main():
         t = torch.tensor([(time.perf_counter() - t0) / 3 * 1e3], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         extras["allgather_ms"] = float(t)
-        extras["allgather_mode"] = args.gather + (f", {args.slabs} feature slabs pipelined" if slab_pipeline else "")
+        extras["allgather_mode"] = gather_mode + (f", {args.slabs} feature slabs pipelined" if slab_pipeline else "")
+        if exchange_choice is not None:
+            extras["exchange_choice"] = exchange_choice   # what the warm-up measured (MAX over ranks) and what it kept
         extras["allgather_bytes_received_per_rank"] = op.exchange_bytes_received(num_feats, gathered.element_size())
         extras["local_spmm_ms"] = kernel_ms
         # what the step should take on a fully connected xGMI node, to read the measured one against
@@ -553,7 +630,8 @@ def main():
                 "parallelism": f"row-window shards x{world}" + (
                     " (every rank generates its own shard) + RCCL all-gather(B) per step"
                     + (" (overlapped with the previous step's SpMM)" if overlap else "")
-                    + (f"; exchange: {args.gather}" + (f", {args.slabs} feature slabs pipelined" if slab_pipeline else ""))
+                    + (f"; exchange: {gather_mode}" + (" (chosen by the warm-up's measurement)" if args.gather == "auto" else "")
+                       + (f", {args.slabs} feature slabs pipelined" if slab_pipeline else ""))
                     if distributed else ""),
                 "preprocess_ms": preprocess_ms,
                 "rowsum_check_max_rel_err": check_err,

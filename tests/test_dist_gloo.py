@@ -111,6 +111,52 @@ def test_referenced_rows_exchange_moves_only_what_the_shards_reference(tmp_path)
         assert 0 < remote_refs < n - (r1 - r0)                       # a strict subset of the other shards' rows
 
 
+def _worker_choose(rank, world, port, out_dir):
+    """choose_exchange: every rank times the candidates with ITS OWN clock (rank 1's is skewed so that the ranks disagree on
+    which schedule was faster locally), the all-reduced MAX must make both keep the same one; own_rows writes B in place."""
+    for p in (REPO, PKG_ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import synth_graphs
+        from oracle import oracle_c
+        from voltrix.dist import RowShardedSpMM
+
+        indptr, indices, _ = synth_graphs.generate("reddit_like", scale=0.004)
+        n = indptr.numel() - 1
+        feat = torch.randn(n, 24, generator=torch.Generator().manual_seed(5))
+        op = RowShardedSpMM(indptr, indices, n,
+                            local_preprocess=lambda ip, ix, rows: oracle_c.csr_preprocess(ip.numpy(), ix.numpy(), rows),
+                            local_spmm=lambda h, rows, e, b: torch.from_numpy(
+                                oracle_c.spmm_blocked(h[0], h[1], h[2], rows, b.numpy(), "none")))
+        ref = op(feat[op.row_start:op.row_end].contiguous())
+        # fake clock: consecutive readings; candidate k's interval on this rank = table[rank][k] seconds
+        table = {0: [0.010, 0.030], 1: [0.050, 0.020]}[rank]    # rank 0 alone would pick collective, rank 1 p2p
+        ticks = []
+        for k in range(2):
+            ticks += [100.0 * k, 100.0 * k + table[k] * 2]      # iters = 2
+        it = iter(ticks)
+        timings = op.choose_exchange(feat[op.row_start:op.row_end], modes=("collective", "p2p"), iters=2, clock=lambda: next(it))
+        # MAX over ranks: collective 50 ms, p2p 30 ms -> p2p on BOTH ranks
+        assert abs(timings["collective"] - 50.0) < 1e-6 and abs(timings["p2p"] - 30.0) < 1e-6, timings
+        assert op.mode == "p2p"
+        mine = op.own_rows(24, feat)                             # the producer writes B straight into the gather buffer
+        mine.copy_(feat[op.row_start:op.row_end])
+        out = op.multiply(op.gather_into(op._buffer("whole", 24, feat), mine))
+        assert torch.equal(out, ref)
+        np.save(os.path.join(out_dir, f"mode_{rank}.npy"), np.array([0 if op.mode == "collective" else 1]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_schedule_is_chosen_from_measurement_and_agreed_on_by_all_ranks(tmp_path):
+    mp.spawn(_worker_choose, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert int(np.load(tmp_path / "mode_0.npy")[0]) == int(np.load(tmp_path / "mode_1.npy")[0]) == 1
+
+
 def test_partition_is_the_same_on_any_device_and_predictions_are_sane():
     import synth_graphs
     from voltrix.dist import partition_rows, predicted_step_ms

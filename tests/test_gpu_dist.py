@@ -63,6 +63,32 @@ def test_row_sharded_operator_with_two_level_format(cuda_device, monkeypatch):
     assert float((out.cpu() - ref).norm() / ref.norm()) < 1e-5
 
 
+def test_slab_pipeline_first_call_is_right(cuda_device, monkeypatch):
+    """with slabs > 1 the gather buffers used to be allocated (and zero-filled on the main stream) AFTER the fork
+    to the communication stream, unordered against the first gather into them -- so the FIRST product of a fresh operator (or
+    after a width / dtype change) could see wiped rows.  One-rank group with the exchange forced on (the all-gather and both
+    streams really run): the first call, a second width, and the first width again, each against the oracle."""
+    import torch.distributed as dist
+
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    from voltrix.dist import RowShardedSpMM
+
+    indptr, indices, _ = synth_graphs.generate("reddit_like", scale=0.02)
+    n = indptr.numel() - 1
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+    try:
+        op = RowShardedSpMM(indptr.cuda(), indices.cuda(), n, hash_tag="dist_slab_first", slabs=3, exchange_at_world_1=True)
+        for width in (96, 40, 96):
+            feat = torch.randn(n, width).half()
+            ref = torch_ref.spmm(indptr, indices, feat.float(), n)
+            for _ in range(2):      # the first call of this width, then a call on the reused buffers
+                out = op(feat.cuda())
+                torch.cuda.synchronize()
+                assert float((out.cpu() - ref).norm() / ref.norm()) < 1e-5, width
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("mode", ["window", "two-level"])
 def test_row_sharded_world2_two_processes_hip_path(cuda_device, tmp_path, mode):
     """Two ranks = two child processes on cuda:0 (3 GPU processes with this one): RowShardedSpMM end to end on the HIP
@@ -94,7 +120,7 @@ def test_row_sharded_world2_two_processes_hip_path(cuda_device, tmp_path, mode):
         assert all(r["shared_edges"] > 0 for r in results)
 
 
-@pytest.mark.parametrize("extra", [[], ["--gather", "p2p"], ["--slabs", "2"]])
+@pytest.mark.parametrize("extra", [[], ["--gather", "collective"], ["--gather", "p2p"], ["--slabs", "2"]])
 def test_bench_n_gt_1_branch_with_a_one_rank_rccl_group(tmp_path, extra):
     """bench.py's N > 1 code path -- init_process_group("nccl", device_id=...), voltrix.dist.RowShardedSpMM.from_shard on a
     device-resident shard, the in-place all_gather_into_tensor (or the batched point-to-point form, or the feature-slab
@@ -114,9 +140,14 @@ def test_bench_n_gt_1_branch_with_a_one_rank_rccl_group(tmp_path, extra):
     assert cfg["allgather_ms"] > 0 and cfg["local_spmm_ms"] > 0 and cfg["rowsum_check_max_rel_err"] < 1e-4
     assert "exchange:" in cfg["parallelism"] and cfg["predicted_ms"]["step_direct_ms"] > 0
     assert cfg["first_call_ms"] > 0 and cfg["handle_bytes"]["reference_handle"] > 0
+    if not extra:   # default = --gather auto: both schedules were timed over RCCL and one of them was kept
+        choice = cfg["exchange_choice"]
+        assert set(choice["candidates_ms"]) == {"collective", "p2p"} and choice["picked"] in ("collective", "p2p")
+        assert all(v > 0 for v in choice["candidates_ms"].values())
 
 
-@pytest.mark.parametrize("extra", [[], ["--gather", "p2p"], ["--slabs", "2"], ["--gather", "rows"]])
+@pytest.mark.parametrize("extra", [[], ["--gather", "collective"], ["--gather", "p2p"], ["--slabs", "2"], ["--gather", "rows"],
+                                   ["--workload", "papers_like", "--scale", "0.002", "--rows-below", "1.01"]])
 def test_bench_two_ranks_share_one_device_over_gloo(extra):
     """The N = 2 data path of bench.py end to end -- two ranks generate their own shards, ``RowShardedSpMM.from_shard``, the
     exchange (collective / point-to-point / slab pipeline), the product, and the row-sum check of every rank's result against
@@ -130,3 +161,9 @@ def test_bench_two_ranks_share_one_device_over_gloo(extra):
     assert run.returncode == 0, run.stderr[-3000:]
     line = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["rowsum_check_max_rel_err"] < 1e-4 and line["config"]["allgather_ms"] > 0
+    if not extra or "--workload" in extra:   # --gather auto: measured choice, the same on both ranks (rank 0 prints it)
+        choice = line["config"]["exchange_choice"]
+        assert choice["picked"] in ("collective", "p2p", "rows") and set(choice["candidates_ms"]) == {"collective", "p2p"}
+        if "--workload" in extra:            # the referenced-rows operator is built beside the all-gather one and both are
+            assert 0 < choice["referenced_fraction_of_remote_rows"] <= 1.0   # (threshold raised: the candidate is always built)
+            assert set(choice["whole_step_ms"]) == {"allgather", "rows"}     # timed, MAX over ranks

@@ -216,12 +216,24 @@ class RowShardedSpMM:
 
     # ---- the exchange step ------------------------------------------------------------------------------------------
     def _buffer(self, key, num_feats, like: torch.Tensor) -> torch.Tensor:
+        """Gather buffer, kept and reused.  ``torch.empty``: the padding rows of a shard are never referenced by the remapped
+        column ids, every other row is written by the exchange -- and an allocation queues no fill kernel that could race
+        with a gather running on another stream (the slab pipeline allocates before it forks, see ``__call__``)."""
         shape = (self.compact_rows if self.mode == "rows" else self.world_size * self.rows_padded, num_feats)
         buf = self._buffers.get(key)
         if buf is None or buf.shape != shape or buf.dtype != like.dtype or buf.device != like.device:
-            buf = torch.zeros(shape, dtype=like.dtype, device=like.device)
+            buf = torch.empty(shape, dtype=like.dtype, device=like.device)
             self._buffers[key] = buf
         return buf
+
+    def own_rows(self, num_feats: int, like: torch.Tensor, key="whole") -> torch.Tensor:
+        """This rank's ``[local_rows, F]`` slice of the gather buffer ``key``: a producer that writes B there (instead of into
+        a tensor of its own) saves the shard-sized copy at the top of every exchange -- ``gather_into`` recognises the slice
+        by its address and sends it as it is."""
+        buf = self._buffer(key, num_feats, like)
+        if self.mode == "rows" and self.world_size > 1:
+            return buf[: self.local_rows]
+        return buf[self.rank * self.rows_padded: self.rank * self.rows_padded + self.local_rows]
 
     def gather_into(self, buf: torch.Tensor, feat_local: torch.Tensor) -> torch.Tensor:
         """All-gather of B on the CURRENT stream: this rank's ``[local_rows, F]`` into its slice of ``buf``
@@ -259,6 +271,49 @@ class RowShardedSpMM:
             return feat_local.contiguous()
         return self.gather_into(self._buffer("whole", feat_local.shape[1], feat_local), feat_local.contiguous())
 
+    def choose_exchange(self, feat_local: torch.Tensor, modes=("collective", "p2p"), iters: int = 2,
+                        clock: Optional[Callable[[], float]] = None) -> dict:
+        """Pick the exchange schedule by MEASUREMENT instead of by flag (first scaling run: nobody knows yet whether RCCL's
+        all-gather goes direct or rings over xGMI).  Times ``iters`` exchanges per candidate after one warm-up, takes the MAX
+        over ranks (one all-reduce per candidate, so every rank sees the same figures and makes the same choice), keeps the
+        fastest as ``self.mode`` and returns ``{mode: ms}``.  Only schedules that share this operator's column layout can be
+        compared here ("collective" and "p2p": the padded all-gather buffer); the referenced-rows exchange is a different
+        operator (its column ids are remapped to a compact buffer) -- build it beside this one and compare whole steps, as
+        ``bench.py --gather auto`` does.  ``clock``: seconds, after a device sync (tests inject a fake one)."""
+        assert self.mode != "rows", "the referenced-rows operator has one schedule"
+        timings = {}
+        if self.world_size == 1 and not self._exchange_always:
+            return timings
+        import time
+
+        def now():
+            if clock is not None:
+                return clock()
+            if feat_local.is_cuda:
+                torch.cuda.synchronize(feat_local.device)
+            return time.perf_counter()
+
+        buf = self._buffer("whole", feat_local.shape[1], feat_local)
+        feat_local = feat_local.contiguous()
+        keep = self.mode
+        for mode in modes:
+            assert mode in ("collective", "p2p")
+            self.mode = mode
+            self.gather_into(buf, feat_local)             # warm-up: connection set-up, RCCL channel allocation
+            if dist.is_initialized():
+                dist.barrier(group=self.group)
+            t0 = now()
+            for _ in range(iters):
+                self.gather_into(buf, feat_local)
+            t = torch.tensor([(now() - t0) / iters * 1e3], dtype=torch.float64,
+                             device=feat_local.device if (dist.is_initialized() and dist.get_backend(self.group) == "nccl")
+                             else "cpu")
+            if dist.is_initialized():
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            timings[mode] = float(t.item())
+        self.mode = min(timings, key=lambda m: (timings[m], modes.index(m))) if timings else keep
+        return timings
+
     def multiply(self, gathered: torch.Tensor) -> torch.Tensor:
         """The local product on an already gathered B."""
         return self._local_spmm(self.handle, self.local_rows, self.local_edges, gathered)
@@ -284,12 +339,17 @@ class RowShardedSpMM:
             return torch.cat(outs, dim=1)
         main, comm = torch.cuda.current_stream(), self._comm(feat_local.device)
         gathered_ev, consumed_ev = [None, None], [None, None]
+        # both slab buffers exist BEFORE the fork: whatever their allocation queues on `main` is ordered before `ready`, hence
+        # before the first gather on `comm` (an allocation inside launch_gather would be unordered against that gather)
+        slab_bufs = [self._buffer(("slab", b), pieces[min(b, len(pieces) - 1)].shape[1], pieces[0]) for b in range(2)]
         ready = torch.cuda.Event()
         ready.record(main)                                # the slabs were cut on `main`
 
         def launch_gather(j):
             b = j % 2
-            buf = self._buffer(("slab", b), pieces[j].shape[1], pieces[j])
+            buf = slab_bufs[b]
+            if buf.shape[1] != pieces[j].shape[1]:        # a narrower last slab: a view of the same storage, no allocation
+                buf = buf.view(-1)[: buf.shape[0] * pieces[j].shape[1]].view(buf.shape[0], pieces[j].shape[1])
             with torch.cuda.stream(comm):
                 comm.wait_event(ready)
                 if consumed_ev[b] is not None:
