@@ -22,7 +22,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 
-TIME_PATTERN = {"Voltrix": "[Voltrix] time: ", "hipSPARSE": "[hipSPARSE] Elapsed time: "}
+TIME_PATTERN = {"Voltrix": "[Voltrix] time: ", "Voltrix-fp16": "[Voltrix] time: ", "hipSPARSE": "[hipSPARSE] Elapsed time: "}
 FEATURE_DIMS = [256, 512, 1024]        # bench_all.py:18
 
 
@@ -51,6 +51,11 @@ def main(argv=None):
     ap.add_argument("--output_file", default="results.csv")
     ap.add_argument("--append", action="store_true")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--direct", action="store_true",
+                    help="the methods read <name>.npz themselves (bm_voltrix.py / bm_sparse.py --npz) instead of the text dump of "
+                         "graph_gen.py: same graph, same protocol, without minutes of np.savetxt / np.loadtxt on a 100 M-edge "
+                         "graph.  Method 'Voltrix-fp16' = the same operator handed fp16 features (the reference has fp32 only)")
+    ap.add_argument("--skip_reorder", action="store_true", help="no Reorder=Y rows (no <name>.reorder.npz is produced)")
     args = ap.parse_args(argv)
     methods = args.methods.split(",")
     assert all(m in TIME_PATTERN for m in methods), f"methods: {sorted(TIME_PATTERN)}"
@@ -66,8 +71,13 @@ def main(argv=None):
         os.makedirs(folder)
         for item in args.synthetic.split(","):
             name, _, scale = item.partition(":")
-            ip, ix, _ = synth_graphs.generate(name, scale=float(scale or 1.0))
-            rows = np.repeat(np.arange(ip.numel() - 1), np.diff(ip.numpy()))
+            import torch
+
+            ip, ix, _ = synth_graphs.generate(name, scale=float(scale or 1.0),
+                                              device="cuda" if torch.cuda.is_available() else "cpu")
+            ip, ix = ip.cpu(), ix.cpu()
+            torch.cuda.empty_cache() if torch.cuda.is_available() else None
+            rows = np.repeat(np.arange(ip.numel() - 1, dtype=np.int32), np.diff(ip.numpy()))
             np.savez(os.path.join(folder, f"{name}.npz"), src_li=rows, dst_li=ix.numpy(), num_nodes=ip.numel() - 1)
     assert folder and os.path.isdir(folder), "give --datasets_folder (or DATASET_PATH) or --synthetic"
     if not args.append and os.path.exists(args.output_file):
@@ -81,7 +91,27 @@ def main(argv=None):
             f.write(f"{method},{name},{dim},{mark},{time}\n")
         print(f"{method} {name} F={dim} reorder={mark}: {time} ms", flush=True)
 
-    for name in npz_names(folder):
+    for name in npz_names(folder) if args.direct else []:
+        path = os.path.join(folder, name + ".npz")
+        rpath = path[:-4] + ".reorder.npz"
+        want_reorder = not args.skip_reorder and any(m.startswith("Voltrix") for m in methods)
+        if want_reorder and not os.path.exists(rpath):
+            gen = run([os.path.join(HERE, "graph_gen.py"), "--npz", path, "--write_reorder", args.reorder_method, "--no_dump"], env)
+            assert gen.returncode == 0, gen.stderr[-2000:]
+        for dim in dims:
+            if "hipSPARSE" in methods:
+                r = run([os.path.join(HERE, "bm_sparse.py"), "--npz", path, "--num_feats", str(dim), "--iters",
+                         str(max(args.iters, 10))], env)
+                record("hipSPARSE", name, dim, "N", scrape("hipSPARSE", r.stdout))
+            for method in [m for m in methods if m.startswith("Voltrix")]:
+                fp16 = ["--fp16"] if method == "Voltrix-fp16" else []
+                for mark, flag in (("N", []), ("Y", ["--reorder"])) if want_reorder else (("N", []),):
+                    r = run([os.path.join(HERE, "bm_voltrix.py"), "--npz", path, "--dataset", name, "--num_feats", str(dim),
+                             "--iters", str(args.iters), *fp16, *flag], env)
+                    if r.returncode != 0:
+                        print(r.stderr[-1500:], file=sys.stderr)
+                    record(method, name, dim, mark, scrape(method, r.stdout))
+    for name in [] if args.direct else npz_names(folder):
         path = os.path.join(folder, name + ".npz")
         for dim in dims:
             dump = os.path.join(work, "dump")

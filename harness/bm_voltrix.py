@@ -27,9 +27,10 @@ def main(argv=None):
     ap.add_argument("--csv", default=None, help="append a results.csv row")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--npz", default=None,
-                    help="read the graph from <name>.npz instead of indices.csv / indptr.csv (TC-GNN edge-list archive or a "
-                         "scipy CSR, as graph_gen.py reads them); features are then drawn here (--num_feats, --seed) and the "
-                         "baseline is computed with torch.sparse.mm on the CPU")
+                    help="read the graph from <name>.npz (TC-GNN edge-list archive or a scipy CSR) or <name>.mtx[.gz] (Matrix "
+                         "Market, the SuiteSparse collection's format) instead of indices.csv / indptr.csv, as graph_gen.py reads "
+                         "them; features are then drawn here (--num_feats, --seed) and the baseline is computed with "
+                         "torch.sparse.mm on the CPU")
     ap.add_argument("--reorder", action="store_true",
                     help="with --npz NAME.npz: run on NAME.reorder.npz, the externally reordered file the reference's protocol "
                          "expects beside it (bench/graph_gen.py:42-45; written by `graph_gen.py --write_reorder`), and mark the "
@@ -41,11 +42,11 @@ def main(argv=None):
 
     o_base = None
     if args.npz:
-        from harness.graph_gen import load_npz
+        from harness.graph_gen import load_graph
 
         path = args.npz[:-4] + ".reorder.npz" if args.reorder else args.npz
         assert os.path.exists(path), f"{path} not found" + (" (graph_gen.py --write_reorder writes it)" if args.reorder else "")
-        ip, ix = load_npz(path)
+        ip, ix = load_graph(path)
         indptr, indices = torch.from_numpy(ip), torch.from_numpy(ix)
         n = indptr.numel() - 1
         torch.manual_seed(args.seed)

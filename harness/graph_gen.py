@@ -8,8 +8,12 @@
     data.mtx                   Matrix Market pattern file (optional)
 
 Input: ``--npz`` a TC-GNN style archive (``src_li``, ``dst_li``, ``num_nodes`` -- what the reference's datasets.zip
-holds) or a scipy.sparse ``save_npz`` CSR file; or ``--synthetic NAME[:scale]`` for the seeded stand-ins of
-synth_graphs.py.  Bench infrastructure, not part of the product package.
+holds) or a scipy.sparse ``save_npz`` CSR file; ``--mtx_in`` a Matrix Market file as the SuiteSparse collection ships them
+(``load_mtx``: coordinate format, pattern / real / integer / complex entries, general / symmetric / skew-symmetric / hermitian
+storage expanded to both triangles; the reference only WRITES data.mtx, bench/graph_gen.py:104-121, and reads its graphs
+from the TC-GNN archives -- BASELINE.json's north_star names SuiteSparse graphs, whose native format this is); or
+``--synthetic NAME[:scale]`` for the seeded stand-ins of synth_graphs.py.  Bench infrastructure (SURVEY.md section 8f rank
+2), not part of the product package.
 """
 import argparse
 import os
@@ -33,6 +37,79 @@ def load_npz(path):
     a.sum_duplicates()
     a.sort_indices()
     return a.indptr.astype(np.int32), a.indices.astype(np.int32)
+
+
+def load_mtx(path, return_values=False):
+    """Matrix Market coordinate file -> CSR ``(indptr int32, indices int32[, values float32])`` of the PATTERN: rows sorted,
+    duplicate entries merged (values summed), explicit zeros kept as edges (the SpMM here is binary: an entry is an edge).
+
+    Header ``%%MatrixMarket matrix coordinate <field> <symmetry>``; ``%`` comment lines; a size line ``M N NNZ``; then NNZ
+    lines ``i j [value [imag]]`` with 1-based indices.  ``symmetric`` / ``hermitian`` / ``skew-symmetric`` files store one
+    triangle: the mirror entries are added (skew: negated; the diagonal is stored once).  ``array`` (dense) files are
+    refused.  ``.mtx.gz`` is read through gzip.  A rectangular matrix M x N is returned as it is (indptr has M + 1 entries);
+    callers that need a square adjacency check the shape."""
+    import gzip
+    import io
+
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "rt") as f:
+        header = f.readline().strip().split()
+        assert len(header) >= 5 and header[0].lower() == "%%matrixmarket" and header[1].lower() == "matrix", \
+            f"{path}: not a Matrix Market file"
+        layout, field, symmetry = header[2].lower(), header[3].lower(), header[4].lower()
+        assert layout == "coordinate", f"{path}: '{layout}' layout (dense) is not a sparse graph"
+        assert field in ("pattern", "real", "integer", "double", "complex") and \
+            symmetry in ("general", "symmetric", "skew-symmetric", "hermitian"), (field, symmetry)
+        line = f.readline()
+        while line and (line.startswith("%") or not line.strip()):
+            line = f.readline()
+        m, n, nnz = (int(t) for t in line.split()[:3])
+        body = f.read()
+    ncol = {"pattern": 2, "complex": 4}.get(field, 3)
+    if nnz:
+        try:    # pandas' C parser: ~10x numpy.loadtxt on SuiteSparse-sized files
+            import pandas as pd
+
+            data = pd.read_csv(io.StringIO(body), sep=r"\s+", header=None, comment="%", dtype=np.float64,
+                               engine="c").to_numpy()
+        except ImportError:
+            data = np.loadtxt(io.StringIO(body), comments="%", ndmin=2, dtype=np.float64)
+    else:
+        data = np.zeros((0, ncol))
+    assert data.shape[0] == nnz and data.shape[1] >= min(ncol, 2), f"{path}: {data.shape[0]} entries, header says {nnz}"
+    rows = data[:, 0].astype(np.int64) - 1
+    cols = data[:, 1].astype(np.int64) - 1
+    vals = data[:, 2].astype(np.float32) if (field != "pattern" and data.shape[1] > 2) else np.ones(nnz, np.float32)
+    assert nnz == 0 or (rows.min() >= 0 and rows.max() < m and cols.min() >= 0 and cols.max() < n), f"{path}: index out of range"
+    if symmetry != "general":
+        off = rows != cols
+        sign = -1.0 if symmetry == "skew-symmetric" else 1.0
+        rows, cols, vals = (np.concatenate([rows, cols[off]]), np.concatenate([cols, rows[off]]),
+                            np.concatenate([vals, sign * vals[off]]))
+    a = sp.coo_matrix((vals, (rows, cols)), shape=(m, n))
+    pattern = sp.coo_matrix((np.ones(len(rows), np.float32), (rows, cols)), shape=(m, n)).tocsr()   # explicit zeros stay edges
+    pattern.sum_duplicates()
+    pattern.sort_indices()
+    indptr, indices = pattern.indptr.astype(np.int32), pattern.indices.astype(np.int32)
+    if not return_values:
+        return indptr, indices
+    a = a.tocsr()
+    a.sum_duplicates()
+    a.sort_indices()
+    # values aligned with the pattern (an entry whose duplicates cancel to 0 is still an edge, with value 0)
+    dense_vals = np.zeros(len(indices), np.float32)
+    prow = np.repeat(np.arange(m), np.diff(indptr))
+    dense_vals[:] = np.asarray(a[prow, indices]).ravel()
+    return indptr, indices, dense_vals
+
+
+def load_graph(path):
+    """Dispatch on the extension: ``.npz`` (TC-GNN archive or scipy CSR) or ``.mtx`` / ``.mtx.gz`` (Matrix Market)."""
+    if path.endswith(".mtx") or path.endswith(".mtx.gz"):
+        indptr, indices = load_mtx(path)
+        assert len(indptr) - 1 >= (int(indices.max()) + 1 if len(indices) else 0), f"{path}: not a square adjacency"
+        return indptr, indices
+    return load_npz(path)
 
 
 def write_reorder_npz(path, method):
@@ -61,6 +138,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     src = ap.add_mutually_exclusive_group(required=True)
     src.add_argument("--npz")
+    src.add_argument("--mtx_in", help="a Matrix Market file (SuiteSparse collection format; .mtx or .mtx.gz)")
     src.add_argument("--synthetic", help="NAME[:scale] from synth_graphs.CONFIGS")
     ap.add_argument("--num_feats", type=int, default=1024)
     ap.add_argument("--seed", type=int, default=20)
@@ -72,12 +150,17 @@ def main(argv=None):
                          "TC-GNN edge-list layout) by voltrix.reorder's spectral / bfs order (GPU) or scipy's RCM (host): the "
                          "file the reference's protocol reads with --reorder (bench/graph_gen.py:42-45)")
     ap.add_argument("--reorder", action="store_true", help="with --npz NAME.npz: dump NAME.reorder.npz instead (reference flag)")
+    ap.add_argument("--no_dump", action="store_true", help="with --write_reorder: only write NAME.reorder.npz, no CSV / raw files")
     args = ap.parse_args(argv)
 
     if args.npz:
         if args.write_reorder:
             write_reorder_npz(args.npz, args.write_reorder)
+            if args.no_dump:
+                return
         indptr, indices = load_npz(args.npz[:-4] + ".reorder.npz" if args.reorder else args.npz)
+    elif args.mtx_in:
+        indptr, indices = load_graph(args.mtx_in)
     else:
         import synth_graphs
 

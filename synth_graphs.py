@@ -35,6 +35,14 @@ CONFIGS = {
     # externally reordered <name>.reorder.npz files, bench_all.py:120-129 times both)
     "reddit_shuffled": dict(base="reddit_like", shuffle_seed=101),
     "products_shuffled": dict(base="products_like", shuffle_seed=102),
+    # reddit-size stochastic block model (round 4): same N / edge count / degree law as reddit_like, but the local half of
+    # the mixture is COMMUNITY structure instead of a band: 40 communities of unequal size (log-normal, sigma 0.8; nodes of a
+    # community are contiguous, i.e. the graph as a community-aware reorder leaves it), 75 % of a row's edges uniform inside its
+    # own community (the Reddit dataset's edge homophily is ~ 0.76 over 41 classes), the rest uniform over all nodes.
+    # reddit_sbm_shuffled = the same graph before anybody reordered it.
+    "reddit_sbm": dict(num_nodes=232965, mean_deg=114615892 / 232965, sigma=1.2, max_deg=21657, band_frac=0.75, band=0,
+                       communities=40, community_sigma=0.8, feat=128, seed=5),
+    "reddit_sbm_shuffled": dict(base="reddit_sbm", shuffle_seed=105),
     # density 1e-4 of 4 M x 4 M = 1.6e9 edges; Zipf alpha = 2 degrees up to 4e5, uniform columns (load-balance stress)
     "powerlaw_4m": dict(num_nodes=4000000, mean_deg=400.0, law="zipf", alpha=2.0, sigma=0.0, max_deg=400000,
                         band_frac=0.0, band=0, feat=256, seed=3),
@@ -79,7 +87,33 @@ def draw_degrees(n, mean_deg, sigma, max_deg, gen, device, law="lognormal", alph
     return lognormal_degrees(n, mean_deg, sigma, max_deg, gen, device)
 
 
-def _top_up(keys, deg, r0, n, gen, device, band_frac=0.0, half=0):
+def community_bounds(n, communities, sigma, seed, device):
+    """int64 [communities + 1]: first node of every community (contiguous node ranges; sizes log-normal with the given
+    sigma, at least 16 nodes each; seeded separately from the edge stream, so every shard of a graph sees the same ones)."""
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(seed * 7919 + 13)
+    w = torch.exp(sigma * torch.randn(communities, generator=gen, dtype=torch.float64))
+    sizes = torch.clamp((w / w.sum() * n).floor().to(torch.int64), min=min(16, max(1, n // communities)))
+    sizes[-1] += n - int(sizes.sum())
+    if int(sizes[-1]) < 1:                                  # tiny test graphs: fall back to equal sizes
+        sizes = torch.full((communities,), n // communities, dtype=torch.int64)
+        sizes[-1] += n - int(sizes.sum())
+    bounds = torch.zeros(communities + 1, dtype=torch.int64)
+    bounds[1:] = torch.cumsum(sizes, 0)
+    return bounds.to(device)
+
+
+def _local_columns(grow, n, gen, device, half=0, bounds=None):
+    """The LOCAL half of the column mixture for global rows ``grow``: a band of +- half around the row, or a uniform node of
+    the row's own community (``bounds``)."""
+    if bounds is not None:
+        c = torch.searchsorted(bounds, grow, right=True) - 1
+        lo, size = bounds[c], bounds[c + 1] - bounds[c]
+        return lo + (torch.rand(grow.numel(), generator=gen, device=device, dtype=torch.float64) * size).long().minimum(size - 1)
+    return (grow + torch.randint(-half, half + 1, (grow.numel(),), generator=gen, device=device, dtype=torch.int64)).clamp_(0, n - 1)
+
+
+def _top_up(keys, deg, r0, n, gen, device, band_frac=0.0, half=0, bounds=None):
     """``keys`` = sorted unique (row - r0) * n + col; adds new columns until every row has deg[row] edges (rows are
     never over-full: the first draw makes at most deg[row] distinct ones).  The new columns follow the config's own
     band / uniform mixture for six rounds, then they are uniform (a hub row can saturate its band)."""
@@ -96,11 +130,10 @@ def _top_up(keys, deg, r0, n, gen, device, band_frac=0.0, half=0):
         want = torch.where(deficit > 0, (deficit * 5) // 4 + 4, torch.zeros_like(deficit))
         crow = torch.repeat_interleave(torch.arange(nrows, device=device, dtype=torch.int64), want)
         ccol = torch.randint(0, n, (crow.numel(),), generator=gen, device=device, dtype=torch.int64)
-        if band_frac > 0 and half > 0 and round_no < 6:
-            local = crow + (r0 + torch.randint(-half, half + 1, (crow.numel(),), generator=gen, device=device,
-                                               dtype=torch.int64))
+        if band_frac > 0 and (half > 0 or bounds is not None) and round_no < 6:
+            local = _local_columns(crow + r0, n, gen, device, half, bounds)
             pick = torch.rand(crow.numel(), generator=gen, device=device) < band_frac
-            ccol = torch.where(pick, local.clamp_(0, n - 1), ccol)
+            ccol = torch.where(pick, local, ccol)
             del local, pick
         cand = torch.unique(crow * n + ccol)
         del crow, ccol
@@ -120,7 +153,7 @@ def _top_up(keys, deg, r0, n, gen, device, band_frac=0.0, half=0):
 
 
 def generate_csr(num_nodes, mean_deg, sigma, max_deg, band_frac, band, seed, device="cpu", scale=1.0, law="lognormal",
-                 alpha=2.0, rows=None, exact_degrees=True, **_):
+                 alpha=2.0, rows=None, exact_degrees=True, communities=0, community_sigma=0.8, **_):
     """Returns ``(indptr int32 [R+1], indices int32 [nnz])`` on ``device`` for the row range ``rows`` (default: all
     ``R = N`` rows; column ids are always global).
 
@@ -143,9 +176,9 @@ def generate_csr(num_nodes, mean_deg, sigma, max_deg, band_frac, band, seed, dev
     e = lrow.numel()
     cols = torch.randint(0, n, (e,), generator=gen, device=device, dtype=torch.int64)
     half = min(band, max(1, n // 4)) if (band_frac > 0 and band > 0) else 0
-    if half > 0:
-        local = lrow + (r0 + torch.randint(-half, half + 1, (e,), generator=gen, device=device, dtype=torch.int64))
-        local = local.clamp_(0, n - 1)
+    bounds = community_bounds(n, communities, community_sigma, seed, device) if (band_frac > 0 and communities > 0) else None
+    if half > 0 or bounds is not None:
+        local = _local_columns(lrow + r0, n, gen, device, half, bounds)
         pick = torch.rand(e, generator=gen, device=device) < band_frac
         cols = torch.where(pick, local, cols)
         del local, pick
@@ -153,7 +186,7 @@ def generate_csr(num_nodes, mean_deg, sigma, max_deg, band_frac, band, seed, dev
     del lrow, cols
     keys = torch.unique(keys, sorted=True)  # sorts by (row, col) and drops duplicate edges
     if exact_degrees:
-        keys = _top_up(keys, deg, r0, n, gen, device, band_frac, half)
+        keys = _top_up(keys, deg, r0, n, gen, device, band_frac, half, bounds)
     lrow = torch.div(keys, n, rounding_mode="floor")
     indices = (keys - lrow * n).to(torch.int32)
     del keys

@@ -9,17 +9,40 @@ No CPU oracle finishes at these sizes, so the checks are the size-independent pr
   (3) checksum of checksums: the column sums of ``A @ x`` equal ``(A^T 1) . x`` computed from the in-degree of every column.
 
 Memory is bounded by checking in row chunks (papers-like: B 28 GB, C 57 GB per result).
+
+Round 4 -- the STATED floating-point tolerance at the stated sizes (``test_*_stated_tolerance``): a random fp16 operand, and
+the reference's own oracle call (``torch.sparse.mm(csr(ones), feat)`` on the CPU, oracle/torch_ref.py) evaluated for a SAMPLE
+of the rows -- 2,048 random ones plus the 64 of highest degree (21 k on reddit-like, 4e5 on the power-law graph) -- on their
+sub-CSR with the referenced rows of B compacted.  Bars, as in tests/test_gpu_spmm.py: element-wise
+``|out - ref| <= (2^-11 + deg 2^-23) (A |B|) + deg 2^-25`` and, the operand being fp16 already (only the accumulation order
+differs), ``<= deg 2^-23 (A |B|)``; norm-wise ``||out - ref|| / ||ref|| <= 1e-3`` over the sampled rows.
 """
+import functools
+
+import numpy as np
 import pytest
 import torch
 
 import synth_graphs
 import voltrix
+from oracle import torch_ref
 from voltrix import capi
 
 pytestmark = pytest.mark.gpu
 
 CHUNK = 1 << 21
+
+
+@functools.lru_cache(maxsize=None)
+def _graph(workload):
+    """One generation per workload and module (reddit 0.5 GB, products 0.5 GB, power-law 6.4 GB, papers 6.5 GB of CSR)."""
+    indptr, indices, _ = synth_graphs.generate(workload, device="cuda")
+    return indptr, indices
+
+
+def teardown_module(module):
+    _graph.cache_clear()
+    torch.cuda.empty_cache()
 
 
 def _launch(handle, n, e, feat, out, tile, order=0):
@@ -97,7 +120,7 @@ def _window_runner(handle, n, e, f, tile, order_chunk=512):
 
 def test_products_like_f512_full_size(cuda_device):
     """BASELINE config 3: N = 2,449,029, 123.7 M edges, F = 512 fp16.  C is 5.0 GB: row * F * 4 passes 2^31 at row 1.05 M."""
-    indptr, indices, cfg = synth_graphs.generate("products_like", device="cuda")
+    indptr, indices = _graph("products_like")
     n, e, f = indptr.numel() - 1, indices.numel(), 512
     assert n == 2449029 and e == int(synth_graphs.target_degrees("products_like", device="cuda").sum())
     assert n * f * 4 > 2 ** 31
@@ -108,7 +131,7 @@ def test_products_like_f512_full_size(cuda_device):
 def test_powerlaw_4m_f256_full_size(cuda_device):
     """BASELINE config 4: 4 M rows, density 1e-4 (1.6e9 edges), Zipf alpha = 2 degrees up to 4e5, F = 256 fp16.
     Windows reach tens of thousands of TC blocks; hind alone is 6.4 GB (8 * block passes 2^31 bytes early)."""
-    indptr, indices, cfg = synth_graphs.generate("powerlaw_4m", device="cuda")
+    indptr, indices = _graph("powerlaw_4m")
     n, e, f = indptr.numel() - 1, indices.numel(), 256
     assert n == 4000000 and abs(e - 1.6e9) < 2e6
     handle = voltrix.csr_fused_preprocess_kernel(indptr, indices, n)[:3]
@@ -119,7 +142,7 @@ def test_powerlaw_4m_f256_full_size(cuda_device):
 
 def test_papers_like_f128_one_gpu(cuda_device):
     """BASELINE config 5 on ONE GPU: N = 111,059,956, 1.6e9 edges, F = 128 fp16 (B = 28.4 GB, C = 56.9 GB)."""
-    indptr, indices, cfg = synth_graphs.generate("papers_like", device="cuda")
+    indptr, indices = _graph("papers_like")
     n, e, f = indptr.numel() - 1, indices.numel(), 128
     assert n == 111059956 and abs(e - 1615685872) < 2e6
     handle = voltrix.csr_fused_preprocess_kernel(indptr, indices, n)[:3]
@@ -132,7 +155,7 @@ def test_two_level_reddit_like_full_size(cuda_device, monkeypatch):
     """BASELINE config 2 (the headline) at full size in the two-level format, through the operator (``voltrix.spmm``):
     same properties, and bit-equality with the window format on integer operands."""
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
-    indptr, indices, cfg = synth_graphs.generate("reddit_like", device="cuda")
+    indptr, indices = _graph("reddit_like")
     n, e, f = indptr.numel() - 1, indices.numel(), 128
     assert n == 232965 and abs(e - 114615892) < 100000
     indptr_c, indices_c = indptr.cpu(), indices.cpu()
@@ -171,7 +194,7 @@ def test_format_policy_is_decided_in_csr_preprocess_at_full_size(cuda_device, mo
     assert 0.2 < plan.num_shared_edges / e < 0.4
     del handle, indptr, indices, r_indptr, r_indices
 
-    indptr, indices, _ = synth_graphs.generate("reddit_like", device="cuda")
+    indptr, indices = _graph("reddit_like")
     n, e, f = indptr.numel() - 1, indices.numel(), 128
     handle = voltrix.csr_preprocess_device(indptr, indices, n)
     handle[1].hash_tag = "policy_test"
@@ -190,3 +213,109 @@ def test_format_policy_is_decided_in_csr_preprocess_at_full_size(cuda_device, mo
     monkeypatch.setenv("VOLTRIX_TUNED_STORE", "/tmp/voltrix_policy_test_tuned.json")
     out_t = voltrix.spmm(*handle, num_nodes=n, num_edges=e, feat=x)
     assert list(two.format_choice.values())[0] in ("two-level", "window") and torch.equal(out_t, out)
+
+
+# ---- the stated floating-point tolerance at the stated sizes (round 4) ------------------------------------------------------
+
+def _random_fp16(rows, f, seed):
+    """randn fp16 [rows, f], generated in chunks (no fp32 copy of a 28 GB operand)."""
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    out = torch.empty(rows, f, dtype=torch.float16, device="cuda")
+    for r in range(0, rows, CHUNK):
+        out[r:r + CHUNK] = torch.randn(min(CHUNK, rows - r), f, generator=gen, device="cuda").half()
+    return out
+
+
+def _sample_rows(indptr, n, seed, num_random=2048, num_top=64):
+    deg = indptr[1:] - indptr[:-1]
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    rnd = torch.randint(0, n, (num_random,), generator=gen, device="cuda")
+    top = torch.topk(deg, num_top).indices
+    return torch.unique(torch.cat([rnd, top, torch.tensor([0, n - 1], device="cuda")]))     # sorted; first and last row too
+
+
+def _sub_problem(indptr, indices, rows, feat):
+    """Sub-CSR of ``rows`` with the referenced rows of ``feat`` compacted: (indptr int32 cpu, indices int32 cpu, B fp32 cpu)."""
+    ip = indptr.long()
+    start, cnt = ip[rows], ip[rows + 1] - ip[rows]
+    sub_ptr = torch.zeros(rows.numel() + 1, dtype=torch.int64, device="cuda")
+    sub_ptr[1:] = torch.cumsum(cnt, 0)
+    total = int(sub_ptr[-1])
+    pos = torch.arange(total, device="cuda") - torch.repeat_interleave(sub_ptr[:-1], cnt) + torch.repeat_interleave(start, cnt)
+    cols = indices[pos].long()
+    used = torch.unique(cols)
+    return (sub_ptr.to(torch.int32).cpu(), torch.searchsorted(used, cols).to(torch.int32).cpu(), feat[used].float().cpu())
+
+
+def _assert_stated_tolerance(out_rows, sub, what):
+    sub_ptr, sub_idx, b_sub = sub
+    rows = sub_ptr.numel() - 1
+    ref = torch_ref.spmm(sub_ptr, sub_idx, b_sub, rows).double().numpy()          # the reference's oracle call, CPU fp32
+    aabs = (torch.sparse_csr_tensor(sub_ptr, sub_idx, torch.ones(sub_idx.numel(), dtype=torch.float64),
+                                    size=(rows, b_sub.shape[0])) @ b_sub.abs().double()).numpy()
+    deg = np.diff(sub_ptr.numpy().astype(np.int64)).astype(np.float64)[:, None]
+    out = out_rows.double().cpu().numpy()
+    assert not np.isnan(out).any(), what
+    err = np.abs(out - ref)
+    assert (err <= (2.0 ** -11 + deg * 2.0 ** -23) * aabs + deg * 2.0 ** -25 + 1e-30).all(), what      # the stated bound
+    assert (err <= deg * 2.0 ** -23 * aabs + 1e-30).all(), what                # fp16 operand: accumulation order only
+    rel = np.linalg.norm(out - ref) / np.linalg.norm(ref)
+    assert rel <= 1e-3, (what, rel)
+    return float(rel), int(deg.max())
+
+
+def _stated_tolerance_window(workload, f, seed, n_expected):
+    indptr, indices = _graph(workload)
+    n, e = indptr.numel() - 1, indices.numel()
+    assert n == n_expected
+    feat = _random_fp16(n, f, seed)
+    rows = _sample_rows(indptr, n, seed)
+    sub = _sub_problem(indptr, indices, rows, feat)
+    handle = voltrix.csr_fused_preprocess_kernel(indptr, indices, n)[:3]
+    out = _window_runner(handle, n, e, f, capi.default_tile(f, True))(feat)
+    rel, dmax = _assert_stated_tolerance(out[rows], sub, f"{workload} window format")
+    return rel, dmax
+
+
+def test_reddit_like_f128_stated_tolerance(cuda_device, monkeypatch):
+    """BASELINE config 2 (headline), random fp16 operand, rows of degree up to 21 k: the window format through the C-ABI, the
+    operator's default (two-level side-car, panel + window kernels joined by float atomics) and the one-launch form."""
+    from voltrix import hybrid
+
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    monkeypatch.delenv("VOLTRIX_HYBRID", raising=False)
+    monkeypatch.delenv("VOLTRIX_FUSED", raising=False)
+    rel, dmax = _stated_tolerance_window("reddit_like", 128, 21, 232965)
+    assert dmax > 15000
+    indptr, indices = _graph("reddit_like")
+    n, e, f = indptr.numel() - 1, indices.numel(), 128
+    feat = _random_fp16(n, f, 21)
+    rows = _sample_rows(indptr, n, 21)
+    sub = _sub_problem(indptr, indices, rows, feat)
+    handle = voltrix.csr_preprocess_device(indptr, indices, n)
+    handle[1].hash_tag = "stated_tolerance_reddit"
+    two = voltrix.two_level_of(handle[1])
+    assert two is not None                                                            # the default IS the two-level form here
+    out = voltrix.spmm(*handle, num_nodes=n, num_edges=e, feat=feat)
+    _assert_stated_tolerance(out[rows], sub, "reddit_like two-level default")
+    two.fused = hybrid.build_fused_records(two.blk_offsets, two.hspa_packed, two.hind, n)
+    monkeypatch.setenv("VOLTRIX_FUSED", "1")
+    one = voltrix.spmm(*handle, num_nodes=n, num_edges=e, feat=feat)
+    _assert_stated_tolerance(one[rows], sub, "reddit_like one-launch form")
+
+
+def test_products_like_f512_stated_tolerance(cuda_device):
+    """BASELINE config 3: N = 2,449,029, F = 512 (C is 5 GB: sampled rows on both sides of the 2^31-byte offset)."""
+    rel, dmax = _stated_tolerance_window("products_like", 512, 22, 2449029)
+    assert dmax > 5000
+
+
+def test_powerlaw_4m_f256_stated_tolerance(cuda_device):
+    """BASELINE config 4: rows of degree up to 4e5 (a window of > 20 k TC blocks), F = 256."""
+    rel, dmax = _stated_tolerance_window("powerlaw_4m", 256, 23, 4000000)
+    assert dmax > 300000
+
+
+def test_papers_like_f128_stated_tolerance(cuda_device):
+    """BASELINE config 5 on one GPU: B = 28 GB, C = 57 GB; the sampled rows reference rows of B all over it."""
+    _stated_tolerance_window("papers_like", 128, 24, 111059956)

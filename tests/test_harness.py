@@ -101,3 +101,75 @@ def test_bench_all_sweeps_methods_and_writes_the_reference_csv(tmp_path, cuda_de
     assert [r[:4] for r in rows[1:]] == [["hipSPARSE", "reddit_like", "64", "N"], ["Voltrix", "reddit_like", "64", "N"],
                                          ["Voltrix", "reddit_like", "64", "Y"]]
     assert all(0 < float(r[4]) < 100 for r in rows[1:]), rows
+
+
+def _write_mtx(path, header, entries, m, n, comments=("% a comment", "%")):
+    with open(path, "w") as f:
+        f.write(header + "\n")
+        for c in comments:
+            f.write(c + "\n")
+        f.write(f"{m} {n} {len(entries)}\n")
+        for e in entries:
+            f.write(" ".join(str(x) for x in e) + "\n")
+
+
+def test_matrix_market_reader(tmp_path):
+    """harness/graph_gen.py::load_mtx against scipy.io.mmread on the forms the SuiteSparse collection uses: pattern general,
+    real symmetric (one triangle stored, diagonal once), integer skew-symmetric, duplicates, comment lines, gzip, and the
+    file graph_gen.py itself writes (data.mtx)."""
+    import gzip
+
+    import graph_gen
+    from scipy.io import mmread
+
+    rng = np.random.default_rng(3)
+    n = 37
+    # 1. pattern general, with a duplicate entry and an empty row
+    ent = sorted({(int(i), int(j)) for i, j in rng.integers(1, n + 1, (150, 2)) if i != 5})
+    ent.append(ent[0])
+    _write_mtx(tmp_path / "p.mtx", "%%MatrixMarket matrix coordinate pattern general", ent, n, n)
+    ip, ix = graph_gen.load_mtx(str(tmp_path / "p.mtx"))
+    ref = sp.coo_matrix((np.ones(len(ent)), ([e[0] - 1 for e in ent], [e[1] - 1 for e in ent])), shape=(n, n)).tocsr()
+    ref.sum_duplicates()
+    ref.sort_indices()
+    assert np.array_equal(ip, ref.indptr) and np.array_equal(ix, ref.indices) and ip[5] == ip[4]       # row 5 (1-based) is empty
+    # 2. real symmetric: lower triangle + diagonal, expanded to both triangles; values follow
+    low = sorted({(int(max(i, j)), int(min(i, j))) for i, j in rng.integers(1, n + 1, (120, 2))})
+    ent = [(i, j, round(float(v), 3)) for (i, j), v in zip(low, rng.normal(size=len(low)))]
+    _write_mtx(tmp_path / "s.mtx", "%%MatrixMarket matrix coordinate real symmetric", ent, n, n)
+    ip, ix, vals = graph_gen.load_mtx(str(tmp_path / "s.mtx"), return_values=True)
+    ref = mmread(str(tmp_path / "s.mtx")).tocsr()
+    ref.sort_indices()
+    assert np.array_equal(ip, ref.indptr) and np.array_equal(ix, ref.indices) and np.allclose(vals, ref.data, atol=1e-6)
+    dense = np.zeros((n, n), bool)
+    dense[np.repeat(np.arange(n), np.diff(ip)), ix] = True
+    assert (dense == dense.T).all()
+    # 3. integer skew-symmetric (no diagonal): mirrored with the sign flipped; the PATTERN is symmetric
+    ent = [(i, j, int(v)) for (i, j), v in zip([e for e in low if e[0] != e[1]], rng.integers(1, 9, len(low)))]
+    _write_mtx(tmp_path / "k.mtx", "%%MatrixMarket matrix coordinate integer skew-symmetric", ent, n, n)
+    ip, ix, vals = graph_gen.load_mtx(str(tmp_path / "k.mtx"), return_values=True)
+    ref = mmread(str(tmp_path / "k.mtx")).tocsr()
+    ref.sort_indices()
+    assert np.array_equal(ip, ref.indptr) and np.array_equal(ix, ref.indices) and np.allclose(vals, ref.data)
+    # 4. gzip, and graph_gen's own data.mtx round trip through load_graph
+    with open(tmp_path / "p.mtx", "rb") as src, gzip.open(tmp_path / "p2.mtx.gz", "wb") as dst:
+        dst.write(src.read())
+    ip2, ix2 = graph_gen.load_graph(str(tmp_path / "p2.mtx.gz"))
+    ip1, ix1 = graph_gen.load_mtx(str(tmp_path / "p.mtx"))
+    assert np.array_equal(ip1, ip2) and np.array_equal(ix1, ix2)
+    g, nn = _make(tmp_path)
+    ip3, ix3 = graph_gen.load_graph(str(tmp_path / "data.mtx"))
+    assert np.array_equal(ip3, g["indptr"]) and np.array_equal(ix3, g["indices"])
+    # 5. the --mtx_in source of graph_gen.py writes the reference's files from a SuiteSparse-format input
+    graph_gen.main(["--mtx_in", str(tmp_path / "s.mtx"), "--num_feats", "8", "--out_dir", str(tmp_path / "from_mtx")])
+    assert np.array_equal(np.loadtxt(tmp_path / "from_mtx" / "indptr.csv", delimiter=",", dtype=np.int32), ref_indptr(tmp_path))
+    # 6. dense ('array') files and malformed headers are refused loudly
+    (tmp_path / "d.mtx").write_text("%%MatrixMarket matrix array real general\n2 2\n1\n2\n3\n4\n")
+    with pytest.raises(AssertionError):
+        graph_gen.load_mtx(str(tmp_path / "d.mtx"))
+
+
+def ref_indptr(tmp_path):
+    from scipy.io import mmread
+
+    return mmread(str(tmp_path / "s.mtx")).tocsr().indptr.astype(np.int32)
