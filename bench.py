@@ -254,7 +254,8 @@ def main():
     from voltrix.jit_kernels.spmm import ORDER_CHUNKS, SCHED_PAIRS, SCHED_UNITS, slab_launches
 
     workload = args.workload or ("reddit_like" if world == 1 else "papers_like")
-    config_index = {"cora_like": 0, "reddit_like": 1, "reddit_uniform": 1, "reddit_shuffled": 1, "products_like": 2,
+    config_index = {"cora_like": 0, "reddit_like": 1, "reddit_uniform": 1, "reddit_shuffled": 1, "reddit_sbm": 1,
+                    "reddit_sbm_shuffled": 1, "products_like": 2,
                     "products_shuffled": 2, "powerlaw_4m": 3, "papers_like": 4}[workload]
     cfg = synth_graphs._resolve(workload)    # label-shuffled variants inherit their base config
     num_feats = args.feat or cfg["feat"]
@@ -587,7 +588,7 @@ def main():
             fmt = {"format": "two-level (voltrix/hybrid.py): panel kernel on the shared columns || window kernel on the "
                              "residual (two streams), float-atomic epilogues onto a zero-filled C (no second buffer, no "
                              "add pass); cut windows of the unit table summed by the combine pass after the join",
-                   "join": os.getenv("VOLTRIX_TWO_LEVEL_JOIN", "atomic"),
+                   "join": "atomic",
                    "panel_rows": two.plan.panel_rows, "tau": two.plan.tau,
                    "shared_edge_fraction_rank0": two.plan.num_shared_edges / max(1, local_nnz),
                    "panel_ksteps_rank0": two.plan.num_ksteps, "residual_tc_blocks_rank0": resid_blocks}

@@ -65,12 +65,12 @@ struct Handle {  // the reference's three tensors
 
 static Handle preprocess(const int* d_indptr, const int* d_indices, int n, int num_cols, int64_t e, hipStream_t s) {
   const int W = (n + VOLTRIX_BLK_H - 1) / VOLTRIX_BLK_H;
-  void* ws = dev_alloc<char>((size_t)voltrix_csr_preprocess_workspace_bytes(n, num_cols, e));
+  void* ws = dev_alloc<char>((size_t)voltrix_csr_preprocess_workspace_bytes(n, num_cols, e, VOLTRIX_CSR_AUTO));
   int* block_partition = dev_alloc<int>(W);
   int* status = dev_alloc<int>(1);
   Handle h{};
   h.blk_offsets = dev_alloc<int>(W + 1);
-  RC_OK(voltrix_launch_csr_window_count((void*)d_indptr, (void*)d_indices, n, num_cols, e, ws, block_partition,
+  RC_OK(voltrix_launch_csr_window_count((void*)d_indptr, (void*)d_indices, n, num_cols, e, VOLTRIX_CSR_AUTO, ws, block_partition,
                                         h.blk_offsets, status, s, &rc_));
   int bad = 0;
   HIP_OK(hipMemcpyAsync(&h.total_blocks, h.blk_offsets + W, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -82,7 +82,7 @@ static Handle preprocess(const int* d_indptr, const int* d_indices, int n, int n
   }
   h.hspa_packed = dev_alloc<uint32_t>(4 * (size_t)h.total_blocks);
   h.hind = dev_alloc<int>(8 * (size_t)h.total_blocks);
-  RC_OK(voltrix_launch_csr_fill((void*)d_indptr, (void*)d_indices, n, num_cols, e, ws, h.blk_offsets, h.hspa_packed,
+  RC_OK(voltrix_launch_csr_fill((void*)d_indptr, (void*)d_indices, n, num_cols, e, VOLTRIX_CSR_AUTO, ws, h.blk_offsets, h.hspa_packed,
                                 h.hind, s, &rc_));
   HIP_OK(hipStreamSynchronize(s));
   HIP_OK(hipFree(ws));
@@ -221,9 +221,9 @@ int main(int argc, char** argv) {
   HIP_OK(hipMemsetAsync(d_c, 0, (size_t)n * f * sizeof(float), s_main));
   HIP_OK(hipEventRecord(fork, s_main));
   HIP_OK(hipStreamWaitEvent(s_side, fork, 0));
-  RC_OK(voltrix_launch_spmm_panel_f16(panel_ptr, panel_cols, panel_bits, panel_order, n, f, d_b, d_c, /*accumulate=*/2,
-                                      /*fs=*/128, /*depth=*/3, waves, row_blocks, /*ksteps=*/1, /*out_scale=*/nullptr,
-                                      s_side, &rc_));
+  RC_OK(voltrix_launch_spmm_panel_f16(panel_ptr, panel_cols, panel_bits, panel_order, n, f, d_b, /*input_rows=*/n, d_c,
+                                      /*accumulate=*/2, /*fs=*/128, /*depth=*/3, waves, row_blocks, /*ksteps=*/1,
+                                      VOLTRIX_SLAB_AUTO, /*out_scale=*/nullptr, s_side, &rc_));
   HIP_OK(hipEventRecord(join, s_side));
   window_spmm(hr, tr, n, resid_edges, f, d_b, d_c, /*atomic_out=*/1, partials_r, s_main);
   HIP_OK(hipStreamWaitEvent(s_main, join, 0));

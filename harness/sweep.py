@@ -58,7 +58,7 @@ def tuned_point(hspa_packed, f, beside_panel, dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workloads", default="reddit_like,reddit_uniform,products_like")
+    ap.add_argument("--workloads", default="reddit_like,reddit_uniform,reddit_sbm,products_like")
     ap.add_argument("--feats", default="32,128,512")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--cpu", action="store_true")

@@ -36,8 +36,10 @@
 extern "C" {
 #endif
 
-#define VOLTRIX_ABI_VERSION 1
+#define VOLTRIX_ABI_VERSION 2 /* 2 (round 4): explicit path / slab_policy / input_rows arguments instead of environment reads */
 
+#define VOLTRIX_CSR_AUTO (-1)  /* `path` of the fused preprocess entry points: the library's rule (0 sort, 1 bitmap, 2 mixed) */
+#define VOLTRIX_SLAB_AUTO (-1) /* `slab_policy` of the panel kernel (0 one grid over all column slabs, 1 one launch per group) */
 #define VOLTRIX_BLK_H 16 /* rows per row window           (voltrix/spmm/spmm.py:12) */
 #define VOLTRIX_BLK_W 8  /* condensed columns per TC block (voltrix/spmm/spmm.py:13) */
 
@@ -190,14 +192,6 @@ void voltrix_launch_unit_table_fill(void* blk_offsets, int num_nodes, void* work
 void voltrix_launch_window_order(void* blk_offsets, int num_nodes, int chunk, void* order_out, void* stream,
                                  int* return_code);
 
-/* Stage-list executor (C-stationary schedule; spmm_list_kernels.hpp).  entries: int32[n][4] = {first TC block,
- * count | g << 8 | flush << 16, window, 0}; wave_ptr: int32[num_waves + 1] offsets into entries, each wave's list ending
- * with 2*depth+1 padding entries (count 0, a valid block).  Built by voltrix/schedule.py; the math and the handle are
- * those of voltrix_launch_spmm_f16.  fs in {64,128}, depth in {3,4}, groups (windows resident per wave) in {1,2,4,8}. */
-void voltrix_launch_spmm_f16_list(void* hspa_packed, void* hind, int num_nodes, int embedding_dim, void* input,
-                                  void* output, void* entries, void* wave_ptr, int num_waves, int fs, int depth,
-                                  int groups, void* stream, int* return_code);
-
 /* Panel kernel: the shared-column half of the two-level condensed format (spmm_panel_kernels.hpp; no reference
  * counterpart).  A panel = waves * row_blocks * 16 consecutive rows; per panel the plan lists the columns referenced by
  * several of its rows, cut into k-steps of 32:
@@ -214,18 +208,22 @@ void voltrix_launch_spmm_f16_list(void* hspa_packed, void* hind, int num_nodes, 
  * aligned, embedding_dim % 8 == 0.  Tile: fs in {32,64,128}, depth = ring slots, ksteps per ring slot in {1,2};
  * VOLTRIX_ERR_BAD_CONFIG if the combination is not instantiated; VOLTRIX_ERR_BAD_SHAPE for accumulate outside 0..2.
  * out_scale as for voltrix_launch_spmm_f16_tile.
+ * input_rows = rows of `input` (0: num_nodes, a square adjacency); slab_policy: how an operand wider than the tile's fs is
+ * launched -- -1 (VOLTRIX_SLAB_AUTO) one launch per 256-byte group of column slabs when such a group of `input`
+ * (input_rows x 256 bytes) fits the 256 MiB Infinity Cache, else one grid over all slabs; 0 always one grid; 1 always the
+ * launches.  Same bits either way.
  * MEMORY REQUIREMENT of the atomic forms (accumulate == 2 here, atomic_out != 0 in voltrix_launch_spmm_*_sched): they use the
  * hardware's no-return global_atomic_add_f32, which is only defined on ordinary (coarse-grained) device memory -- hipMalloc,
  * torch's allocator.  On fine-grained or host-mapped output (hipHostMalloc, hipMallocManaged with fine-grained coherence) the
  * adds can be lost silently: give such outputs a device-memory staging buffer, or use accumulate 0 / 1. */
 void voltrix_launch_spmm_panel_f16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order,
-                                   int num_nodes, int embedding_dim, void* input, void* output, int accumulate, int fs,
-                                   int depth, int waves, int row_blocks, int ksteps, void* out_scale, void* stream,
-                                   int* return_code);
+                                   int num_nodes, int embedding_dim, void* input, int64_t input_rows, void* output,
+                                   int accumulate, int fs, int depth, int waves, int row_blocks, int ksteps,
+                                   int slab_policy, void* out_scale, void* stream, int* return_code);
 void voltrix_launch_spmm_panel_bf16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order,
-                                    int num_nodes, int embedding_dim, void* input, void* output, int accumulate, int fs,
-                                    int depth, int waves, int row_blocks, int ksteps, void* out_scale, void* stream,
-                                    int* return_code);
+                                    int num_nodes, int embedding_dim, void* input, int64_t input_rows, void* output,
+                                    int accumulate, int fs, int depth, int waves, int row_blocks, int ksteps,
+                                    int slab_policy, void* out_scale, void* stream, int* return_code);
 
 /* The two-level format in ONE launch (spmm_fused_kernels.hpp; round 3).  One 512-thread workgroup per 512-row panel
  * (waves = 8, row_blocks = 4) computes the whole product for its rows: the shared columns from the panel plan (arrays as for
@@ -288,15 +286,6 @@ void voltrix_launch_panel_plan_fill(void* node_pointer, void* edge_list, int num
 void voltrix_launch_panel_order(void* panel_ptr, int num_panels, int group, void* order_out, void* stream,
                                 int* return_code);
 
-/* dst[i] = 0, float32, count % 4 == 0, 16-byte aligned, written with non-temporal stores: the zero fill of `output` in front
- * of the two-level step (accumulate = 2 / atomic_out = 1) for hosts without a fill of their own.  (Measured against an
- * ordinary fill: the fill 0.021 -> 0.028 ms, the step unchanged; hipMemsetAsync is as good.) */
-void voltrix_launch_zero_f32(void* dst, int64_t count, void* stream, int* return_code);
-
-/* dst[i] += src[i], float32, count % 4 == 0, both 16-byte aligned: joins the two halves of the two-level format when
- * the window kernel (-> dst) and the panel kernel (accumulate = 0 -> src) ran side by side on two streams. */
-void voltrix_launch_add_inplace_f32(void* dst, void* src, int64_t count, void* stream, int* return_code);
-
 /* Default tile for a feature width; is_f16 selects the operand type.  Always succeeds. */
 void voltrix_spmm_default_tile(int embedding_dim, int is_f16, int* fs, int* depth, int* waves);
 
@@ -319,7 +308,7 @@ void voltrix_launch_cast_f32_f16_scaled(void* src, void* dst, int64_t count, voi
  * preprocess, the O(TCb*E) rescan or the 512-byte/TC-block fp32 `hspa` intermediate.  Two phases because the
  * caller owns every buffer and T is data dependent:
  *   phase 1  voltrix_launch_csr_window_count: block_partition[W], pointer1[W+1], status[1] (device int32)
- *            workspace: voltrix_csr_preprocess_workspace_bytes(num_nodes, num_cols, num_edges) bytes, device, 16-B aligned
+ *            workspace: voltrix_csr_preprocess_workspace_bytes(num_nodes, num_cols, num_edges, path) bytes, device, 16-B aligned
  *   (caller reads T = pointer1[W] and status[0], allocates hspa_packed uint32[4T] and hind int32[8T])
  *   phase 2  voltrix_launch_csr_fill: writes hspa_packed and hind (every word), same workspace, same num_cols.
  * num_cols = the column universe: every id in edge_list lies in [0, num_cols) (square adjacency: num_nodes; a row shard
@@ -327,15 +316,16 @@ void voltrix_launch_cast_f32_f16_scaled(void* src, void* dst, int64_t count, voi
  * from an LDS bitmap + popcounts when the universe fits LDS (num_cols <= 2^19) and is small next to a window's edge
  * list, otherwise from a per-window sort (needs the 4-byte-per-edge key workspace); universes of 2 .. 16 bitmap ranges
  * (up to 2^23 columns) sort the windows up to 8192 edges and send only the bigger ones through the bitmap kernels, one
- * sweep per range ("mixed"); VOLTRIX_CSR_PATH=sort|bitmap|mixed in the environment overrides the choice.  status[0] = number of edges with an id outside [0, num_cols) (outside
+ * sweep per range ("mixed").  path = -1 (VOLTRIX_CSR_AUTO): that rule; 0 sort / 1 bitmap / 2 mixed force a path where it is
+ * applicable (the same value in all three calls; how the tests reach every path on one graph).  status[0] = number of edges with an id outside [0, num_cols) (outside
  * [0, 2^28) when num_cols <= 0): the handle is valid only if it is 0 (callers retry with num_cols = 0 or reject).
  * Output is bit-identical to preprocess + hmat_gen + hmat_packed_swizzle on every path. */
-int64_t voltrix_csr_preprocess_workspace_bytes(int num_nodes, int num_cols, int64_t num_edges);
+int64_t voltrix_csr_preprocess_workspace_bytes(int num_nodes, int num_cols, int64_t num_edges, int path);
 void voltrix_launch_csr_window_count(void* node_pointer, void* edge_list, int num_nodes, int num_cols, int64_t num_edges,
-                                     void* workspace, void* block_partition, void* pointer1, void* status, void* stream,
-                                     int* return_code);
+                                     int path, void* workspace, void* block_partition, void* pointer1, void* status,
+                                     void* stream, int* return_code);
 void voltrix_launch_csr_fill(void* node_pointer, void* edge_list, int num_nodes, int num_cols, int64_t num_edges,
-                             void* workspace, void* pointer1, void* hspa_packed, void* hind, void* stream,
+                             int path, void* workspace, void* pointer1, void* hspa_packed, void* hind, void* stream,
                              int* return_code);
 
 /* Cuthill-McKee row order on the device (locality reorder; no reference counterpart -- the

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     lib = capi.lib()
     for name in _declared_functions():
         assert hasattr(lib, name), f"libvoltrix_hip.so does not export {name}"
-    assert lib.voltrix_abi_version() == 1
+    assert lib.voltrix_abi_version() == 2
 
 
 def test_tile_space_enumeration_and_defaults():
@@ -63,7 +63,7 @@ def test_host_preprocess_entry_point_matches_golden(csr_fixture):
     assert (e2c == g["edge_to_column"]).all() and (e2r == g["edge_to_row"]).all()
 
 
-def test_host_preprocess_multithreaded_is_deterministic(monkeypatch):
+def test_host_preprocess_is_deterministic_and_equals_the_oracle(monkeypatch):
     import scipy.sparse as sp
 
     np.random.seed(3)
@@ -71,8 +71,7 @@ def test_host_preprocess_multithreaded_is_deterministic(monkeypatch):
     indptr, indices = a.indptr.astype(np.int32), a.indices.astype(np.int32)
     ptr = lambda x: x.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
     outs = []
-    for threads in ("1", "7"):
-        monkeypatch.setenv("VOLTRIX_PREPROCESS_THREADS", threads)
+    for _ in range(2):     # threads over windows (hardware_concurrency): two runs, same bytes
         bp, e2c = np.zeros(250, np.int32), np.zeros(indices.size, np.int32)
         e2r, p1 = np.zeros(indices.size, np.int32), np.zeros(251, np.int32)
         rc = ctypes.c_int(-1)
@@ -110,7 +109,6 @@ def test_return_codes_on_bad_arguments(monkeypatch):
     # sort path (column universe too large for the LDS bitmap): one uint32 key per edge; bitmap path: scan scratch only
     assert capi.csr_preprocess_workspace_bytes(2449029, 2449029, 123718280) >= 4 * 123718280
     assert 0 < capi.csr_preprocess_workspace_bytes(232965, 232965, 114615892) < 1 << 20
-    monkeypatch.setenv("VOLTRIX_CSR_PATH", "sort")
-    assert capi.csr_preprocess_workspace_bytes(232965, 232965, 114615892) >= 4 * 114615892
+    assert capi.csr_preprocess_workspace_bytes(232965, 232965, 114615892, "sort") >= 4 * 114615892
     with pytest.raises(capi.VoltrixError, match="return code 3"):
         capi.check(3, "x")

@@ -48,6 +48,7 @@ def test_row_sharded_operator_with_two_level_format(cuda_device, monkeypatch):
     import synth_graphs
     from oracle import torch_ref
     from voltrix import dist as vdist
+    from voltrix import two_level_of as voltrix_two_level_of
 
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
     monkeypatch.setenv("VOLTRIX_HYBRID", "1")
@@ -55,8 +56,8 @@ def test_row_sharded_operator_with_two_level_format(cuda_device, monkeypatch):
     indptr, indices, _ = synth_graphs.generate("reddit_like", scale=0.006)
     n = indptr.numel() - 1
     op = vdist.RowShardedSpMM(indptr, indices, n, device=cuda_device, hash_tag="dist_two_level")
-    hint = getattr(op.handle[1], "_voltrix_two_level", None)
-    assert hint is not None and hint[0].plan.num_ksteps > 0
+    hint = voltrix_two_level_of(op.handle[1])
+    assert hint is not None and hint.plan.num_ksteps > 0
     feat = torch.randn(n, 64).half()
     out = op(feat.cuda())
     ref = torch_ref.spmm(indptr, indices, feat.float(), n)

@@ -56,11 +56,12 @@ ROUTES = ["fused-sort", "fused-bitmap", "fused-mixed", "fused-auto", "reference"
 
 def _set_route(monkeypatch, route):
     """fused-sort / fused-bitmap / fused-mixed force one of the rank algorithms of the fused preprocess
-    (VOLTRIX_CSR_PATH; mixed = windows up to 8192 edges sorted, bigger ones through the bitmap kernels)."""
-    monkeypatch.setenv("VOLTRIX_PREPROCESS", route.split("-")[0])
-    monkeypatch.delenv("VOLTRIX_CSR_PATH", raising=False)
+    (VOLTRIX_PREPROCESS=fused:<path>, which the operator hands to the library as the ``path`` ARGUMENT of its entry points;
+    mixed = windows up to 8192 edges sorted, bigger ones through the bitmap kernels)."""
     if route in ("fused-sort", "fused-bitmap", "fused-mixed"):
-        monkeypatch.setenv("VOLTRIX_CSR_PATH", route.split("-")[1])
+        monkeypatch.setenv("VOLTRIX_PREPROCESS", "fused:" + route.split("-")[1])
+    else:
+        monkeypatch.setenv("VOLTRIX_PREPROCESS", route.split("-")[0])
 
 
 @pytest.mark.parametrize("route", ROUTES)
@@ -89,12 +90,11 @@ def test_non_square_universe_and_unstaged_window(cuda_device, path, monkeypatch)
     """96 rows x 12000 columns: with the universe declared, the bitmap path takes its global-atomics branch for the
     1125-block window; without it (default universe = num_nodes) out-of-universe ids are detected and the sort path
     redoes the work -- both give the oracle's bytes."""
-    monkeypatch.setenv("VOLTRIX_CSR_PATH", path)
     indptr, indices, n = CASES["huge_window"]
     ip = torch.as_tensor(np.asarray(indptr), dtype=torch.int32).cuda()
     ix = torch.as_tensor(np.asarray(indices), dtype=torch.int32).cuda()
     for num_cols in (12000, None, 0):
-        handle = voltrix.csr_fused_preprocess_kernel(ip, ix, n, num_cols=num_cols)[:3]
+        handle = voltrix.csr_fused_preprocess_kernel(ip, ix, n, num_cols=num_cols, path=path)[:3]
         _check(handle, indptr, indices, n)
 
 
@@ -102,7 +102,6 @@ def test_bitmap_path_with_several_column_ranges(cuda_device, monkeypatch):
     """Universe of 1.3 M columns = 3 bitmap ranges of 2^19: columns clustered so that some ranges are empty for some
     windows, partial TC blocks straddle range boundaries, one window exceeds the LDS stage inside a single range and
     one window's columns all sit in the first range (pending partial block flushed at the end)."""
-    monkeypatch.setenv("VOLTRIX_CSR_PATH", "bitmap")
     rng = np.random.default_rng(5)
     ncols, nrows = 1_300_000, 80
     deg = rng.integers(0, 60, nrows)
@@ -120,13 +119,12 @@ def test_bitmap_path_with_several_column_ranges(cuda_device, monkeypatch):
     indices = np.concatenate(rows)
     ip = torch.as_tensor(indptr, dtype=torch.int32).cuda()
     ix = torch.as_tensor(indices, dtype=torch.int32).cuda()
-    handle = voltrix.csr_fused_preprocess_kernel(ip, ix, nrows, num_cols=ncols)[:3]
+    handle = voltrix.csr_fused_preprocess_kernel(ip, ix, nrows, num_cols=ncols, path="bitmap")[:3]
     _check(handle, indptr, indices, nrows)
     for path in ("sort", "mixed"):   # mixed: window 0 (11200 edges) through the bitmap kernels, the others sorted
-        monkeypatch.setenv("VOLTRIX_CSR_PATH", path)
-        handle = voltrix.csr_fused_preprocess_kernel(ip, ix, nrows, num_cols=ncols)[:3]
+        handle = voltrix.csr_fused_preprocess_kernel(ip, ix, nrows, num_cols=ncols, path=path)[:3]
         _check(handle, indptr, indices, nrows)
-    monkeypatch.delenv("VOLTRIX_CSR_PATH")   # 3 ranges: the default choice is the mixed path
+    # 3 ranges: the default choice is the mixed path
     handle = voltrix.csr_fused_preprocess_kernel(ip, ix, nrows, num_cols=ncols)[:3]
     _check(handle, indptr, indices, nrows)
 
@@ -162,11 +160,10 @@ def test_low_level_kernel_wrappers_like_reference_test(cuda_device):
 
 @pytest.mark.parametrize("path", ["sort", "bitmap", "mixed"])
 def test_fused_preprocess_mid_size_with_large_windows(cuda_device, path, monkeypatch):
-    monkeypatch.setenv("VOLTRIX_CSR_PATH", path)
     indptr, indices, _ = synth_graphs.generate("reddit_like", device="cuda", scale=0.02)
     n = indptr.numel() - 1
     assert int((indptr[16::16] - indptr[:-16:16]).max()) > 8192  # exercises the global-memory sort
-    p1, packed, hind, bp = voltrix.csr_fused_preprocess_kernel(indptr, indices, n)
+    p1, packed, hind, bp = voltrix.csr_fused_preprocess_kernel(indptr, indices, n, path=path)
     _check((p1, packed, hind), indptr.cpu().numpy(), indices.cpu().numpy(), n)
     assert np.array_equal(bp.cpu().numpy(), np.diff(p1.cpu().numpy()))
 
@@ -175,7 +172,6 @@ def test_mixed_path_power_law_windows(cuda_device, monkeypatch):
     """Power-law stand-in at 1/64 size with its full-size density (62.5 k rows, Zipf degrees: windows from a few hundred to
     tens of thousands of edges) over a 1.2 M-column universe (3 bitmap ranges): the default choice is the mixed path --
     wave sort, workgroup LDS sort and bitmap kernels all take windows -- and must give the oracle's bytes."""
-    monkeypatch.delenv("VOLTRIX_CSR_PATH", raising=False)
     n, ncols = 62_500, 1_200_000
     g = torch.Generator(device="cuda").manual_seed(12)
     deg = synth_graphs.zipf_degrees(n, 400.0, 2.0, ncols // 4, g, torch.device("cuda"))
@@ -200,7 +196,6 @@ def test_bucket_ranking_mid_size_windows_and_clustered_columns(cuda_device, path
     a 2 M-column universe: uniform columns; a tight band; 3000 edges on one column + singletons; exactly 8192 edges;
     exactly 2049 edges; a window whose 6000 edges sit on 900 neighbouring columns (the clustering test hands it on to
     the workgroup sort); and one of 11200 edges (global-memory sort, or the bitmap kernels on range-grouped keys).  Oracle bytes on every route."""
-    monkeypatch.setenv("VOLTRIX_CSR_PATH", path)
     rng = np.random.default_rng(77)
     ncols = 2_000_000
 
@@ -224,5 +219,5 @@ def test_bucket_ranking_mid_size_windows_and_clustered_columns(cuda_device, path
     per_window = np.diff(indptr[::16])
     assert per_window[3] == 8192 and per_window[4] == 2049 and per_window[6] > 8192 and (per_window > 2048).all()
     ip, ix = torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda()
-    p1, packed, hind, _ = voltrix.csr_fused_preprocess_kernel(ip, ix, n, num_cols=ncols)
+    p1, packed, hind, _ = voltrix.csr_fused_preprocess_kernel(ip, ix, n, num_cols=ncols, path=path)
     _check((p1, packed, hind), indptr, indices, n)

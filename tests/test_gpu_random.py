@@ -86,8 +86,6 @@ def test_random_graphs_two_level_format(cuda_device, seed, monkeypatch):
     from voltrix import hybrid
 
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
-    monkeypatch.setenv("VOLTRIX_HYBRID_STREAMS", str(seed % 2))
-    monkeypatch.setenv("VOLTRIX_TWO_LEVEL_JOIN", "atomic" if seed % 4 < 2 else "add")
     rng = np.random.default_rng(2000 + seed)
     n = int(rng.integers(1, 900))
     num_feats = int(rng.choice([1, 8, 17, 32, 50, 64, 96, 128, 160, 264]))
@@ -112,7 +110,7 @@ def test_random_graphs_two_level_format(cuda_device, seed, monkeypatch):
     deg = np.diff(indptr.astype(np.int64)).astype(np.float64)
     aabs = oracle_np.spmm_csr(indptr, indices, np.abs(feat.numpy().astype(np.float64)), n)
     for dtype in (torch.float16, torch.float32):
-        out = voltrix.spmm_two_level(handle, feat.to(dtype).cuda())
+        out = voltrix.spmm_two_level(handle, feat.to(dtype).cuda(), concurrent=bool(seed % 2))
         assert out.shape == (n, num_feats) and out.dtype == torch.float32
         got = out.cpu().numpy().astype(np.float64)
         assert not np.isnan(got).any()

@@ -1,35 +1,39 @@
 """GPU: wide operands as one launch per column slab (spmm_kernels.hpp::slab_launches, round 3) against one grid over all
 slabs -- same bits for the window format and for the two-level pair, and both equal to the dense product."""
-import os
-import subprocess
-import sys
-
 import pytest
 import torch
 
 import synth_graphs
-from conftest import REPO
 
 pytestmark = pytest.mark.gpu
-WORKER = os.path.join(REPO, "tests", "slab_launch_worker.py")
 
 
-def test_one_launch_per_slab_gives_the_bits_of_the_single_grid(tmp_path):
-    outs = {}
-    for mode in ("0", "1"):
-        path = tmp_path / f"out_{mode}.pt"
-        run = subprocess.run([sys.executable, WORKER, str(path)], capture_output=True, text=True, timeout=900,
-                             env=dict(os.environ, VOLTRIX_SLAB_LAUNCHES=mode))
-        assert run.returncode == 0, run.stderr[-3000:]
-        outs[mode] = torch.load(path)
+def test_one_launch_per_slab_gives_the_bits_of_the_single_grid(cuda_device, monkeypatch):
+    """The slab policy is an ARGUMENT of every launch (jit_kernels/spmm.py::SLAB_POLICY -> launch_spmm_tc16 / the panel
+    entry points): forced to one grid and to one launch per slab group, window format and two-level pair."""
+    import voltrix
+    from voltrix.jit_kernels import spmm as wrapper
+
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
     indptr, indices, _ = synth_graphs.generate("reddit_like", scale=0.04)
     n = indptr.numel() - 1
     torch.manual_seed(0)
-    feat = torch.randint(-4, 5, (n, 320)).float()
-    want = torch.sparse_csr_tensor(indptr.long(), indices.long(), torch.ones(indices.numel()), size=(n, n)) @ feat
+    feat = torch.randint(-4, 5, (n, 320)).half()       # 2.5 slabs of 128 columns; integers: every summation order is exact
+    want = torch.sparse_csr_tensor(indptr.long(), indices.long(), torch.ones(indices.numel()), size=(n, n)) @ feat.float()
+    outs = {}
     for hybrid in ("0", "1"):
-        assert torch.equal(outs["0"][hybrid], outs["1"][hybrid])
-        assert torch.equal(outs["1"][hybrid], want)          # integer operands: exact
+        monkeypatch.setenv("VOLTRIX_HYBRID", hybrid)
+        monkeypatch.setenv("VOLTRIX_HYBRID_MIN_SHARE", "0")
+        handle = voltrix.csr_preprocess(indptr, indices, n)
+        handle[1].hash_tag = f"slab_launches_{hybrid}"
+        assert (voltrix.two_level_of(handle[1]) is not None) == (hybrid == "1")
+        for policy in (0, 1, -1):
+            monkeypatch.setattr(wrapper, "SLAB_POLICY", policy)
+            outs[hybrid, policy] = voltrix.spmm(*handle, num_nodes=n, num_edges=indices.numel(), feat=feat.cuda()).cpu()
+        assert wrapper.slab_launches(320, 128, 2, n, 0) == 1 and wrapper.slab_launches(320, 128, 2, n, 1) == 3
+    for hybrid in ("0", "1"):
+        assert torch.equal(outs[hybrid, 0], outs[hybrid, 1]) and torch.equal(outs[hybrid, -1], outs[hybrid, 1])
+        assert torch.equal(outs[hybrid, 1], want)          # integer operands: exact
 
 
 @pytest.mark.parametrize("dtype,mode,width", [(torch.float32, "exact", 200), (torch.bfloat16, "fp16", 320), (torch.float32, "fp16", 264)])

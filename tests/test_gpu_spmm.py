@@ -349,10 +349,10 @@ def test_window_order_schedule_is_a_sorted_permutation_and_changes_no_bit(cuda_d
 
 @pytest.mark.parametrize("kind,num_feats,tile", [("f16", 264, (128, 3, 4)), ("f16", 512, (64, 3, 4)), ("bf16", 320, (128, 3, 4)),
                                                  ("f16", 96, (32, 4, 4)), ("f32", 200, (64, 3, 1))])
-def test_slab_order_changes_no_bit(cuda_device, kind, num_feats, tile, monkeypatch):
-    """F > FS: window-major and slab-major unit orders (spmm_kernels.hpp::slab_major_order; rule: slab-major from 128-byte
-    row pieces on) give the same bits -- every output element has the same addends in the same order -- with the natural
-    window order and with a unit table; last slab partially filled in every case."""
+def test_several_column_slabs_with_and_without_a_unit_table(cuda_device, kind, num_feats, tile, monkeypatch):
+    """F > FS: the unit order over (window, slab) the launcher picks (spmm_kernels.hpp::slab_major_order: slab-major from
+    128-byte row pieces on, window-major below) gives the same bits with the natural window order and with a unit table --
+    every output element has the same addends in the same order; last slab partially filled in every case."""
     from voltrix.schedule import unit_table
 
     indptr, indices, _ = synth_graphs.generate("reddit_like", device="cuda", scale=0.05)
@@ -364,11 +364,7 @@ def test_slab_order_changes_no_bit(cuda_device, kind, num_feats, tile, monkeypat
     feat = torch.randn(n, num_feats, device="cuda").to(dtype)
     s = torch.cuda.current_stream().cuda_stream
     outs = {}
-    for order in ("minor", "major", None):
-        if order is None:
-            monkeypatch.delenv("VOLTRIX_SLAB_ORDER")
-        else:
-            monkeypatch.setenv("VOLTRIX_SLAB_ORDER", order)
+    for order in ("rule",):
         out = torch.full((n, num_feats), float("nan"), device="cuda")
         if kind == "f32":
             rc = capi.launch_spmm(handle[0].data_ptr(), handle[1].data_ptr(), handle[2].data_ptr(), n, e, num_feats,
@@ -389,9 +385,9 @@ def test_slab_order_changes_no_bit(cuda_device, kind, num_feats, tile, monkeypat
     torch.cuda.synchronize()
     for key, out in outs.items():
         assert not torch.isnan(out).any(), key
-        assert torch.equal(out, outs[("minor", key[1])]), key
+        assert torch.equal(out, outs[("rule", "natural")]), key
     ref = torch_ref.spmm(indptr.cpu().numpy(), indices.cpu().numpy(), feat.float().cpu(), n)
-    got = outs[("major", "natural")].cpu()
+    got = outs[("rule", "natural")].cpu()
     assert torch.linalg.norm(got - ref) / torch.linalg.norm(ref) <= 1e-3
 
 

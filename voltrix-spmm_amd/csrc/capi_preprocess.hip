@@ -36,26 +36,26 @@ void voltrix_launch_hmat_packed_swizzle(int num_row_windows, void* pointer1, voi
                                                   nullptr);
 }
 
-int64_t voltrix_csr_preprocess_workspace_bytes(int num_nodes, int num_cols, int64_t num_edges) {
-  return voltrix::csr_preprocess_workspace_bytes(num_nodes, num_cols, num_edges);
+int64_t voltrix_csr_preprocess_workspace_bytes(int num_nodes, int num_cols, int64_t num_edges, int path) {
+  return voltrix::csr_preprocess_workspace_bytes(num_nodes, num_cols, num_edges, path);
 }
 
 void voltrix_launch_csr_window_count(void* node_pointer, void* edge_list, int num_nodes, int num_cols, int64_t num_edges,
-                                     void* workspace, void* block_partition, void* pointer1, void* status, void* stream,
-                                     int* return_code) {
+                                     int path, void* workspace, void* block_partition, void* pointer1, void* status,
+                                     void* stream, int* return_code) {
   *return_code = voltrix::csr_window_count(static_cast<const int*>(node_pointer), static_cast<const int*>(edge_list),
                                            num_nodes, num_cols, num_edges, workspace, static_cast<int*>(block_partition),
                                            static_cast<int*>(pointer1), static_cast<int*>(status),
-                                           static_cast<hipStream_t>(stream));
+                                           static_cast<hipStream_t>(stream), path);
 }
 
 void voltrix_launch_csr_fill(void* node_pointer, void* edge_list, int num_nodes, int num_cols, int64_t num_edges,
-                             void* workspace, void* pointer1, void* hspa_packed, void* hind, void* stream,
+                             int path, void* workspace, void* pointer1, void* hspa_packed, void* hind, void* stream,
                              int* return_code) {
   *return_code = voltrix::csr_fill(static_cast<const int*>(node_pointer), static_cast<const int*>(edge_list), num_nodes,
                                    num_cols, num_edges, workspace, static_cast<const int*>(pointer1),
                                    static_cast<uint32_t*>(hspa_packed), static_cast<int*>(hind),
-                                   static_cast<hipStream_t>(stream));
+                                   static_cast<hipStream_t>(stream), path);
 }
 
 }  // extern "C"

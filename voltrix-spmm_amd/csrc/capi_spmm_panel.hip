@@ -19,12 +19,13 @@ namespace {
 template <bool BF16>
 int dispatch(int fs, int depth, int waves, int rb, int ks, const int* panel_ptr, const int* panel_cols,
              const uint32_t* panel_bits, const int* panel_order, int num_nodes, int embedding_dim, const void* input,
-             float* output, int accumulate, const float* out_scale, hipStream_t stream) {
+             float* output, int accumulate, const float* out_scale, hipStream_t stream, int64_t input_rows,
+             int slab_policy) {
 #define X(FS, D, W, RB, KS)                                                                                          \
   if (fs == FS && depth == D && waves == W && rb == RB && ks == KS)                                                  \
     return voltrix::launch_spmm_panel<voltrix::PanelTile<FS, D, W, RB, KS, BF16>>(                                   \
         panel_ptr, panel_cols, panel_bits, panel_order, num_nodes, embedding_dim, input, output, accumulate, out_scale, \
-        stream);
+        stream, 0, 0, input_rows, slab_policy);
   VOLTRIX_PANEL_SPACE(X)
 #undef X
   return voltrix::kErrBadConfig;
@@ -35,40 +36,31 @@ int dispatch(int fs, int depth, int waves, int rb, int ks, const int* panel_ptr,
 extern "C" {
 
 void voltrix_launch_spmm_panel_f16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order,
-                                   int num_nodes, int embedding_dim, void* input, void* output, int accumulate, int fs,
-                                   int depth, int waves, int row_blocks, int ksteps, void* out_scale, void* stream,
-                                   int* return_code) {
+                                   int num_nodes, int embedding_dim, void* input, int64_t input_rows, void* output,
+                                   int accumulate, int fs, int depth, int waves, int row_blocks, int ksteps,
+                                   int slab_policy, void* out_scale, void* stream, int* return_code) {
   *return_code = dispatch<false>(fs, depth, waves, row_blocks, ksteps, static_cast<const int*>(panel_ptr),
                                  static_cast<const int*>(panel_cols), static_cast<const uint32_t*>(panel_bits),
                                  static_cast<const int*>(panel_order), num_nodes, embedding_dim, input,
                                  static_cast<float*>(output), accumulate, static_cast<const float*>(out_scale),
-                                 static_cast<hipStream_t>(stream));
+                                 static_cast<hipStream_t>(stream), input_rows, slab_policy);
 }
 
 void voltrix_launch_spmm_panel_bf16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order,
-                                    int num_nodes, int embedding_dim, void* input, void* output, int accumulate, int fs,
-                                    int depth, int waves, int row_blocks, int ksteps, void* out_scale, void* stream,
-                                    int* return_code) {
+                                    int num_nodes, int embedding_dim, void* input, int64_t input_rows, void* output,
+                                    int accumulate, int fs, int depth, int waves, int row_blocks, int ksteps,
+                                    int slab_policy, void* out_scale, void* stream, int* return_code) {
   *return_code = dispatch<true>(fs, depth, waves, row_blocks, ksteps, static_cast<const int*>(panel_ptr),
                                 static_cast<const int*>(panel_cols), static_cast<const uint32_t*>(panel_bits),
                                 static_cast<const int*>(panel_order), num_nodes, embedding_dim, input,
                                 static_cast<float*>(output), accumulate, static_cast<const float*>(out_scale),
-                                static_cast<hipStream_t>(stream));
+                                static_cast<hipStream_t>(stream), input_rows, slab_policy);
 }
 
 void voltrix_launch_panel_order(void* panel_ptr, int num_panels, int group, void* order_out, void* stream,
                                 int* return_code) {
   *return_code = voltrix::panel_order(static_cast<const int*>(panel_ptr), num_panels, group, static_cast<int*>(order_out),
                                       static_cast<hipStream_t>(stream));
-}
-
-void voltrix_launch_zero_f32(void* dst, int64_t count, void* stream, int* return_code) {
-  *return_code = voltrix::zero_f32_nt(static_cast<float*>(dst), count, static_cast<hipStream_t>(stream));
-}
-
-void voltrix_launch_add_inplace_f32(void* dst, void* src, int64_t count, void* stream, int* return_code) {
-  *return_code = voltrix::add_inplace_f32(static_cast<float*>(dst), static_cast<const float*>(src), count,
-                                          static_cast<hipStream_t>(stream));
 }
 
 int64_t voltrix_panel_plan_workspace_bytes(int num_nodes, int waves, int row_blocks) {

@@ -11,9 +11,10 @@ from .spmm import *  # noqa: F401,F403
 from .spmm import (BLK_H, BLK_W, csr_preprocess, csr_preprocess_device, csr_preprocess_hybrid, spmm, spmm_two_level,
                    two_level_of)
 from .hybrid import TwoLevelHandle
+from .sidecar import copy_side_car, load_handle, save_handle
 from .reorder import ReorderedHandle, csr_preprocess_reordered, spmm_reordered
 from .weighted import WeightedHandle, csr_preprocess_weighted, spmm_weighted
 from .graphed import GraphedSpMM
-from . import autograd, hybrid, jit, utils
+from . import autograd, hybrid, jit, sidecar, utils
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"

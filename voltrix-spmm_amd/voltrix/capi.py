@@ -32,7 +32,6 @@ SYMBOLS = (
     "voltrix_launch_spmm_f16_sched",
     "voltrix_launch_spmm_bf16_sched",
     "voltrix_launch_combine_partials",
-    "voltrix_launch_spmm_f16_list",
     "voltrix_launch_spmm_panel_f16",
     "voltrix_launch_spmm_panel_bf16",
     "voltrix_launch_spmm_fused_f16",
@@ -40,8 +39,6 @@ SYMBOLS = (
     "voltrix_fused_records_workspace_bytes",
     "voltrix_launch_fused_records_count",
     "voltrix_launch_fused_records_fill",
-    "voltrix_launch_add_inplace_f32",
-    "voltrix_launch_zero_f32",
     "voltrix_panel_plan_workspace_bytes",
     "voltrix_launch_panel_plan_count",
     "voltrix_launch_panel_plan_fill",
@@ -135,25 +132,30 @@ def tiles(is_f16: bool):
     return out
 
 
-def csr_preprocess_workspace_bytes(num_nodes: int, num_cols: int, num_edges: int) -> int:
+CSR_PATHS = {None: -1, "auto": -1, "sort": 0, "bitmap": 1, "mixed": 2}   # `path` of the fused preprocess entry points
+SLAB_AUTO, SLAB_ONE_GRID, SLAB_LAUNCHES = -1, 0, 1                       # `slab_policy` of the SpMM launchers
+
+
+def csr_preprocess_workspace_bytes(num_nodes: int, num_cols: int, num_edges: int, path=None) -> int:
     return int(lib().voltrix_csr_preprocess_workspace_bytes(ctypes.c_int(num_nodes), ctypes.c_int(num_cols),
-                                                            ctypes.c_int64(num_edges)))
+                                                            ctypes.c_int64(num_edges), ctypes.c_int(CSR_PATHS[path])))
 
 
 def launch_csr_window_count(indptr, indices, num_nodes, num_cols, workspace, block_partition, pointer1, status,
-                            stream) -> None:
+                            stream, path=None) -> None:
     rc = ctypes.c_int(-1)
     lib().voltrix_launch_csr_window_count(_ptr(indptr), _ptr(indices), ctypes.c_int(num_nodes), ctypes.c_int(num_cols),
-                                          ctypes.c_int64(indices.numel()), _ptr(workspace), _ptr(block_partition),
-                                          _ptr(pointer1), _ptr(status), ctypes.c_void_p(stream), ctypes.byref(rc))
+                                          ctypes.c_int64(indices.numel()), ctypes.c_int(CSR_PATHS[path]), _ptr(workspace),
+                                          _ptr(block_partition), _ptr(pointer1), _ptr(status), ctypes.c_void_p(stream),
+                                          ctypes.byref(rc))
     check(rc.value, "voltrix_launch_csr_window_count")
 
 
-def launch_csr_fill(indptr, indices, num_nodes, num_cols, workspace, pointer1, hspa_packed, hind, stream) -> None:
+def launch_csr_fill(indptr, indices, num_nodes, num_cols, workspace, pointer1, hspa_packed, hind, stream, path=None) -> None:
     rc = ctypes.c_int(-1)
     lib().voltrix_launch_csr_fill(_ptr(indptr), _ptr(indices), ctypes.c_int(num_nodes), ctypes.c_int(num_cols),
-                                  ctypes.c_int64(indices.numel()), _ptr(workspace), _ptr(pointer1), _ptr(hspa_packed),
-                                  _ptr(hind), ctypes.c_void_p(stream), ctypes.byref(rc))
+                                  ctypes.c_int64(indices.numel()), ctypes.c_int(CSR_PATHS[path]), _ptr(workspace),
+                                  _ptr(pointer1), _ptr(hspa_packed), _ptr(hind), ctypes.c_void_p(stream), ctypes.byref(rc))
     check(rc.value, "voltrix_launch_csr_fill")
 
 
@@ -251,29 +253,18 @@ def launch_spmm_f32_as_f16(blk_offsets, hspa_packed, hind, num_nodes, num_edges,
     return rc.value
 
 
-def launch_spmm_list(hspa_packed, hind, num_nodes, embedding_dim, input_ptr, output_ptr, entries, wave_ptr, num_waves,
-                     tile, stream) -> int:
-    """Stage-list executor; ``tile`` = (fs, depth, groups).  Returns the return code."""
-    rc = ctypes.c_int(-1)
-    lib().voltrix_launch_spmm_f16_list(ctypes.c_void_p(hspa_packed), ctypes.c_void_p(hind), ctypes.c_int(num_nodes),
-                                       ctypes.c_int(embedding_dim), ctypes.c_void_p(input_ptr),
-                                       ctypes.c_void_p(output_ptr), _ptr(entries), _ptr(wave_ptr),
-                                       ctypes.c_int(num_waves), ctypes.c_int(tile[0]), ctypes.c_int(tile[1]),
-                                       ctypes.c_int(tile[2]), ctypes.c_void_p(stream), ctypes.byref(rc))
-    return rc.value
-
-
-def launch_spmm_panel(plan, input_ptr, output_ptr, embedding_dim, accumulate, bf16, tile, out_scale, stream) -> int:
+def launch_spmm_panel(plan, input_ptr, output_ptr, embedding_dim, accumulate, bf16, tile, out_scale, stream,
+                      input_rows: int = 0, slab_policy: int = SLAB_AUTO) -> int:
     """Panel kernel (shared-column half of the two-level format); ``plan`` = voltrix.hybrid.PanelPlan, ``tile`` =
-    (fs, depth, ksteps).  Returns the return code."""
+    (fs, depth, ksteps); ``input_rows`` = rows of the dense operand (0: the plan's rows).  Returns the return code."""
     rc = ctypes.c_int(-1)
     fn = lib().voltrix_launch_spmm_panel_bf16 if bf16 else lib().voltrix_launch_spmm_panel_f16
     order = plan.panel_order.data_ptr() if plan.panel_order is not None else 0
     fn(_ptr(plan.panel_ptr), _ptr(plan.panel_cols), _ptr(plan.panel_bits), ctypes.c_void_p(order),
-       ctypes.c_int(plan.num_nodes), ctypes.c_int(embedding_dim), ctypes.c_void_p(input_ptr), ctypes.c_void_p(output_ptr),
-       ctypes.c_int(int(accumulate)), ctypes.c_int(tile[0]), ctypes.c_int(tile[1]), ctypes.c_int(plan.waves),
-       ctypes.c_int(plan.row_blocks), ctypes.c_int(tile[2]), ctypes.c_void_p(out_scale), ctypes.c_void_p(stream),
-       ctypes.byref(rc))
+       ctypes.c_int(plan.num_nodes), ctypes.c_int(embedding_dim), ctypes.c_void_p(input_ptr), ctypes.c_int64(input_rows),
+       ctypes.c_void_p(output_ptr), ctypes.c_int(int(accumulate)), ctypes.c_int(tile[0]), ctypes.c_int(tile[1]),
+       ctypes.c_int(plan.waves), ctypes.c_int(plan.row_blocks), ctypes.c_int(tile[2]), ctypes.c_int(slab_policy),
+       ctypes.c_void_p(out_scale), ctypes.c_void_p(stream), ctypes.byref(rc))
     return rc.value
 
 
@@ -321,13 +312,6 @@ def launch_panel_order(panel_ptr, num_panels: int, order_out, stream, group: int
     check(rc.value, "voltrix_launch_panel_order")
 
 
-def launch_zero_f32(tensor, stream) -> None:
-    """``tensor`` (float32, contiguous, numel % 4 == 0) <- 0 with non-temporal stores."""
-    rc = ctypes.c_int(-1)
-    lib().voltrix_launch_zero_f32(_ptr(tensor), ctypes.c_int64(tensor.numel()), ctypes.c_void_p(stream), ctypes.byref(rc))
-    check(rc.value, "voltrix_launch_zero_f32")
-
-
 def panel_plan_workspace_bytes(num_nodes: int, waves: int, row_blocks: int) -> int:
     return int(lib().voltrix_panel_plan_workspace_bytes(ctypes.c_int(num_nodes), ctypes.c_int(waves),
                                                         ctypes.c_int(row_blocks)))
@@ -352,13 +336,6 @@ def launch_panel_plan_fill(indptr, indices, num_nodes, num_cols, waves, row_bloc
                                          ctypes.c_int64(total_ksteps), _ptr(resid_indices), _ptr(panel_cols),
                                          _ptr(panel_bits), ctypes.c_void_p(stream), ctypes.byref(rc))
     check(rc.value, "voltrix_launch_panel_plan_fill")
-
-
-def launch_add_inplace_f32(dst, src, stream) -> None:
-    rc = ctypes.c_int(-1)
-    lib().voltrix_launch_add_inplace_f32(_ptr(dst), _ptr(src), ctypes.c_int64(dst.numel()), ctypes.c_void_p(stream),
-                                         ctypes.byref(rc))
-    check(rc.value, "voltrix_launch_add_inplace_f32")
 
 
 def launch_window_order(blk_offsets, num_nodes, order_out, stream, chunk: int = 256) -> None:
@@ -408,7 +385,6 @@ launch_spmm_sched = _timed(launch_spmm_sched, "spmm", 9)
 launch_spmm_panel = _timed(launch_spmm_panel, "spmm_panel", 8)
 launch_spmm_fused = _timed(launch_spmm_fused, "spmm_fused", 8)
 launch_combine_partials = _timed(launch_combine_partials, "combine_partials", 6)
-launch_add_inplace_f32 = _timed(launch_add_inplace_f32, "add_inplace_f32", 2)
 launch_cast_f32_f16_scaled = _timed(launch_cast_f32_f16_scaled, "cast_f32_f16_scaled", 3)
 launch_cast_f32_f16 = _timed(launch_cast_f32_f16, "cast_f32_f16", 2)
 launch_spmm_f32_as_f16 = _timed(launch_spmm_f32_as_f16, "spmm_f32_as_f16", 9)

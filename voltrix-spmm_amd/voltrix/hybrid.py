@@ -214,10 +214,7 @@ def empty_plan(num_nodes, waves, row_blocks, tau, device, num_edges):
                      num_shared_edges=0, num_resid_edges=num_edges)
 
 
-PANEL_ORDER_GROUP = int(os.environ.get("VOLTRIX_PANEL_GROUP", "1"))   # consecutive panels launched side by side (1: plain longest-first)
-
-
-def longest_first_order(panel_ptr: torch.Tensor, group: int = PANEL_ORDER_GROUP) -> torch.Tensor:
+def longest_first_order(panel_ptr: torch.Tensor, group: int = 1) -> torch.Tensor:
     """Launch order of the panel kernel: int32 [NP], position -> panel; inside every XCD's contiguous range of positions
     (spmm_panel_kernel: blockIdx % 8 picks the range) GROUPS of ``group`` consecutive panels, the groups with the most k-steps
     first, the panels of a group in their natural order; ``group`` = 1 (shipped): plain longest-first.  455 workgroups on
@@ -225,8 +222,8 @@ def longest_first_order(panel_ptr: torch.Tensor, group: int = PANEL_ORDER_GROUP)
     longest-first leaves the short ones for the end (1.42 ms, profiles/r02/experiment_tau_reddit.log).  Groups of neighbours
     launched side by side share their band columns through L2: 1.323 -> 1.282 ms for the bare kernel pair
     (experiment_panel_groups.log), but nothing through the operator (1.357 vs 1.360 ms, bench_ab_panel_group.txt: the zero
-    fill of C between the steps costs the window kernel more than the panel kernel gains), so it stays an option
-    (``VOLTRIX_PANEL_GROUP``).  Speed only."""
+    fill of C between the steps costs the window kernel more than the panel kernel gains), so the operator keeps group = 1.
+    Speed only."""
     num_panels = panel_ptr.numel() - 1
     if num_panels <= 0:
         return torch.zeros(0, dtype=torch.int32, device=panel_ptr.device)
@@ -374,29 +371,19 @@ def side_stream(device) -> "torch.cuda.Stream":
     return _SIDE_STREAMS[key]
 
 
-def concurrent_enabled() -> bool:
-    """VOLTRIX_HYBRID_STREAMS=0: run the panel kernel after the window kernel on the caller's stream (accumulate mode)."""
-    return os.getenv("VOLTRIX_HYBRID_STREAMS", "1") not in ("0", "off")
-
-
-def join_mode() -> str:
-    """How the two halves meet in C.  ``atomic`` (default): C is zero-filled, both kernels add their part with float
-    atomics (two addends per element: the sum does not depend on who comes first) -- no second buffer, no extra pass.
-    ``add``: the panel kernel writes a second buffer that one more pass adds onto C (round 1)."""
-    mode = os.getenv("VOLTRIX_TWO_LEVEL_JOIN", "atomic")
-    assert mode in ("atomic", "add"), mode
-    return mode
-
-
 def run_two_level(plan: PanelPlan, operand: torch.Tensor, output: torch.Tensor, run_window, out_scale=None,
-                  tile=None) -> None:
+                  tile=None, concurrent: bool = True) -> None:
     """``output = A_resid @ operand + A_shared @ operand``.  ``run_window(atomic)`` enqueues the window kernel for the
     residual handle on the current stream; with ``atomic`` it adds onto ``output``, otherwise it stores every row.  It
     returns None or a ``PendingCombine`` (jit_kernels/spmm.py).
 
     The panel kernel runs on a side stream while the window kernel runs on the caller's stream (the first is
-    matrix-core bound, the second gather bound: they overlap on the same CUs).  Stream-ordered, no host sync; capturable
-    (fork / join through events)."""
+    matrix-core bound, the second gather bound: they overlap on the same CUs).  They meet in C through float atomics: C is
+    zero-filled, both kernels ADD their part -- two addends per element onto a zero, so the sum does not depend on who comes
+    first -- and the partial tiles of cut windows are added by the combine pass after the join (C then holds the panel's part,
+    complete).  Stream-ordered, no host sync; capturable (fork / join through events).  ``concurrent=False``: one stream, the
+    window kernel stores, the panel kernel adds onto it afterwards (read-add-store) -- for callers that cannot spare a second
+    stream; slower, same result up to fp32 summation order."""
     def finish(pending):
         if pending is not None:      # cut windows of a unit-table schedule: sum their partial tiles (fixed order)
             pending.run()
@@ -404,45 +391,29 @@ def run_two_level(plan: PanelPlan, operand: torch.Tensor, output: torch.Tensor, 
     if plan.num_ksteps == 0:
         finish(run_window(False))
         return
-    if not concurrent_enabled():
+    if not concurrent:
         finish(run_window(False))
         launch_panel(plan, operand, output, accumulate=1, out_scale=out_scale, tile=tile)
         return
+    from .utils import timed_launch
+
     main = torch.cuda.current_stream()
     side = side_stream(operand.device)
-    atomic = join_mode() == "atomic"
-    if atomic:
-        from .utils import timed_launch
-
-        with timed_launch("zero_fill", main):
-            # VOLTRIX_ZERO_FILL=nt: the library's fill with non-temporal stores (so that C does not push B's rows out of the
-            # caches) -- measured: the fill itself 0.021 -> 0.028 ms, the step unchanged (profiles/r02/bench_ab_zero_fill.txt)
-            if os.environ.get("VOLTRIX_ZERO_FILL", "torch") == "nt" and output.is_contiguous() and output.numel() % 4 == 0:
-                capi.launch_zero_f32(output, main.cuda_stream)
-            else:
-                output.zero_()
-        target = output
-    else:
-        target = torch.empty_like(output)        # allocated on `main`; its last use (the add) is on `main` too
+    with timed_launch("zero_fill", main):
+        output.zero_()
     fork = torch.cuda.Event()
     fork.record(main)
     side.wait_event(fork)                        # operand / out_scale / the zero fill were produced on `main`
-    launch_panel(plan, operand, target, accumulate=2 if atomic else 0, out_scale=out_scale, tile=tile,
-                 stream=side.cuda_stream)
+    launch_panel(plan, operand, output, accumulate=2, out_scale=out_scale, tile=tile, stream=side.cuda_stream)
     join = torch.cuda.Event()
     join.record(side)
-    pending = run_window(atomic)
-    if not atomic:
-        finish(pending)                          # stores the cut windows' rows of `output`
+    pending = run_window(True)
     main.wait_event(join)
-    if atomic:
-        finish(pending)                          # adds onto rows that now hold the panel kernel's part, complete
-    else:
-        capi.launch_add_inplace_f32(output, target, main.cuda_stream)
+    finish(pending)                              # adds onto rows that now hold the panel kernel's part, complete
 
 
 def launch_panel(plan: PanelPlan, feat: torch.Tensor, output: torch.Tensor, accumulate, out_scale=None,
-                 tile=None, stream=None) -> None:
+                 tile=None, stream=None, slab_policy: int = None) -> None:
     """``output (+)= A_shared @ feat`` for fp16 / bfloat16 ``feat`` [*, F] and float32 ``output`` [N, F].
     ``accumulate``: 0 / False store, 1 / True read-add-store, 2 float atomics (include/voltrix_capi.h)."""
     assert feat.is_cuda and feat.is_contiguous() and feat.dtype in (torch.float16, torch.bfloat16)
@@ -452,18 +423,18 @@ def launch_panel(plan: PanelPlan, feat: torch.Tensor, output: torch.Tensor, accu
     tile = tile or default_panel_tile(f, plan.waves, plan.row_blocks)
     assert tile is not None, f"no panel tile for F={f} with {plan.waves} waves"
     stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    if slab_policy is None:
+        from .jit_kernels import spmm as _spmm_wrapper    # the one place the operator's slab policy lives (tests flip it)
+
+        slab_policy = _spmm_wrapper.SLAB_POLICY
     rc = capi.launch_spmm_panel(plan, feat.data_ptr(), output.data_ptr(), f, int(accumulate),
                                 feat.dtype == torch.bfloat16, tile, out_scale.data_ptr() if out_scale is not None else 0,
-                                stream)
+                                stream, input_rows=feat.shape[0], slab_policy=slab_policy)
     capi.check(rc, "voltrix_launch_spmm_panel")
 
 
 # fused kernel tile per feature width: (fs, depth of the shared panel ring)
 def default_fused_tile(embedding_dim: int):
-    forced = os.getenv("VOLTRIX_FUSED_TILE")          # "fs,depth" (experiments)
-    if forced:
-        fs, depth = (int(t) for t in forced.split(","))
-        return (fs, depth)
     if embedding_dim <= 32:
         return (32, 4)
     if embedding_dim <= 64:

@@ -41,7 +41,6 @@ inline int preprocess(const int32_t* edgeList, const int32_t* nodePointer, int n
   if (num_nodes < 0 || blockSize_h != kBlkH || blockSize_w != kBlkW) return kErrBadShape;
   const int64_t num_windows = ((int64_t)num_nodes + kBlkH - 1) / kBlkH;
   unsigned hw = std::thread::hardware_concurrency();
-  if (const char* env = std::getenv("VOLTRIX_PREPROCESS_THREADS")) hw = (unsigned)std::max(1, atoi(env));
   const int64_t num_edges = num_nodes > 0 ? nodePointer[num_nodes] : 0;
   int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(hw ? hw : 1, std::max<int64_t>(1, num_edges / 65536)));
 

@@ -1199,19 +1199,19 @@ static __global__ __launch_bounds__(kBmThreads) void csr_bitmap_fill_kernel(cons
 //           the power-law stand-in (4 M columns = 8 ranges; median window 3.2 k edges, 13 % of the windows above 8 k
 //           with 55 % of the edges) every window through the bitmap kernels cost ~100 us of sweeps and barriers;
 //   sort    unknown universes; more ranges than that: bitmap or sort for every window by the same cost estimate.
-// VOLTRIX_CSR_PATH=sort|bitmap|mixed overrides (bitmap is honoured only when 0 < num_cols <= 2^25, mixed when <= 2^23).
-enum CsrPath { kCsrSort = 0, kCsrBitmap = 1, kCsrMixed = 2 };
+// `forced` (an ARGUMENT of the three entry points, the same value in all of them; kCsrAuto = the rule): kCsrSort /
+// kCsrBitmap / kCsrMixed override it (bitmap is honoured only when 0 < num_cols <= 2^25, mixed when <= 2^23) -- how the
+// tests reach every path on one graph.  Nothing is read from the environment here.
+enum CsrPath { kCsrAuto = -1, kCsrSort = 0, kCsrBitmap = 1, kCsrMixed = 2 };
 constexpr int kMixedMaxPasses = kBmMaxGroups;
 
-inline CsrPath csr_path(int num_nodes, int num_cols, long long num_edges) {
+inline CsrPath csr_path(int num_nodes, int num_cols, long long num_edges, int forced = kCsrAuto) {
   if (num_cols <= 0 || num_nodes <= 0) return kCsrSort;
   const long long passes = ((long long)num_cols + kBmMaxCols - 1) / kBmMaxCols;  // column ranges per window
   if (passes > 64) return kCsrSort;
-  if (const char* e = std::getenv("VOLTRIX_CSR_PATH")) {
-    if (e[0] == 's') return kCsrSort;
-    if (e[0] == 'b') return kCsrBitmap;
-    if (e[0] == 'm' && passes <= kMixedMaxPasses) return kCsrMixed;   // the range groups of the listed windows: <= 16
-  }
+  if (forced == kCsrSort) return kCsrSort;
+  if (forced == kCsrBitmap) return kCsrBitmap;
+  if (forced == kCsrMixed && passes <= kMixedMaxPasses) return kCsrMixed;   // the range groups of the listed windows: <= 16
   if (passes > 1 && passes <= kMixedMaxPasses) return kCsrMixed;
   const long long W = ((long long)num_nodes + kBlkH - 1) / kBlkH;
   const double per_window = (double)num_edges / (double)W;       // mean edges per window
@@ -1224,8 +1224,8 @@ inline CsrPath csr_path(int num_nodes, int num_cols, long long num_edges) {
   const double sort_cost = per_window <= (double)kWsKeys ? 2.0 * per_window : per_window * lg * (lg + 1.0) / 8.0;
   return bitmap_cost <= sort_cost ? kCsrBitmap : kCsrSort;
 }
-inline bool csr_use_bitmap(int num_nodes, int num_cols, long long num_edges) {
-  return csr_path(num_nodes, num_cols, num_edges) == kCsrBitmap;
+inline bool csr_use_bitmap(int num_nodes, int num_cols, long long num_edges, int forced = kCsrAuto) {
+  return csr_path(num_nodes, num_cols, num_edges, forced) == kCsrBitmap;
 }
 
 template <class K>
@@ -1256,10 +1256,10 @@ struct CsrWorkspace {
 // the bucket kernels flag keys in bit 31: column ids below 2^27 (num_cols <= 0: unknown universe -> not used)
 inline bool csr_use_buckets(int num_cols) { return num_cols > 0 && (unsigned)num_cols <= kBkMaxCols; }
 
-inline CsrWorkspace csr_workspace(void* base, int num_nodes, int num_cols, long long num_edges) {
+inline CsrWorkspace csr_workspace(void* base, int num_nodes, int num_cols, long long num_edges, int forced_path = kCsrAuto) {
   const long long W = ((long long)num_nodes + kBlkH - 1) / kBlkH;
   const long long nchunks = (W + kScanChunk - 1) / kScanChunk + 1;
-  const CsrPath path = csr_path(num_nodes, num_cols, num_edges);
+  const CsrPath path = csr_path(num_nodes, num_cols, num_edges, forced_path);
   const bool buckets = path != kCsrBitmap && csr_use_buckets(num_cols);
   char* p = static_cast<char*>(base);
   CsrWorkspace ws;
@@ -1282,8 +1282,8 @@ inline CsrWorkspace csr_workspace(void* base, int num_nodes, int num_cols, long 
   ws.bytes = p - static_cast<char*>(base);
   return ws;
 }
-inline long long csr_preprocess_workspace_bytes(int num_nodes, int num_cols, long long num_edges) {
-  return csr_workspace(nullptr, num_nodes, num_cols, num_edges).bytes;
+inline long long csr_preprocess_workspace_bytes(int num_nodes, int num_cols, long long num_edges, int forced_path = kCsrAuto) {
+  return csr_workspace(nullptr, num_nodes, num_cols, num_edges, forced_path).bytes;
 }
 
 inline int csr_check(int num_nodes, long long num_edges) {
@@ -1297,7 +1297,8 @@ inline int csr_check(int num_nodes, long long num_edges) {
 // status[0] <- number of edges whose column id lies outside [0, num_cols) (num_cols <= 0: outside [0, 2^28)); the
 // handle is only meaningful when it is 0 (the bitmap path skips such edges, the sort path truncates them).
 inline int csr_window_count(const int* indptr, const int* indices, int num_nodes, int num_cols, long long num_edges,
-                            void* workspace, int* block_partition, int* pointer1, int* status, hipStream_t stream) {
+                            void* workspace, int* block_partition, int* pointer1, int* status, hipStream_t stream,
+                            int forced_path = kCsrAuto) {
   if (int rc = csr_check(num_nodes, num_edges)) return rc;
   if (((uintptr_t)workspace & 15) || status == nullptr || num_cols > (1 << 28)) return kErrBadShape;
   const int W = (num_nodes + kBlkH - 1) / kBlkH;
@@ -1305,8 +1306,8 @@ inline int csr_window_count(const int* indptr, const int* indices, int num_nodes
   if (W == 0) {
     return hipMemsetAsync(pointer1, 0, sizeof(int), stream) == hipSuccess ? kOk : kErrLaunch;
   }
-  const CsrPath path = csr_path(num_nodes, num_cols, num_edges);
-  const CsrWorkspace ws = csr_workspace(workspace, num_nodes, num_cols, num_edges);
+  const CsrPath path = csr_path(num_nodes, num_cols, num_edges, forced_path);
+  const CsrWorkspace ws = csr_workspace(workspace, num_nodes, num_cols, num_edges, forced_path);
   uint32_t* const keys = ws.keys;
   int* const chunk_sums = ws.chunk_sums;
   const int nchunks = (W + kScanChunk - 1) / kScanChunk;
@@ -1356,13 +1357,14 @@ inline int csr_window_count(const int* indptr, const int* indices, int num_nodes
 }
 
 inline int csr_fill(const int* indptr, const int* indices, int num_nodes, int num_cols, long long num_edges,
-                    void* workspace, const int* pointer1, uint32_t* hspa_packed, int* hind, hipStream_t stream) {
+                    void* workspace, const int* pointer1, uint32_t* hspa_packed, int* hind, hipStream_t stream,
+                    int forced_path = kCsrAuto) {
   if (int rc = csr_check(num_nodes, num_edges)) return rc;
   if (((uintptr_t)workspace & 15) || ((uintptr_t)hspa_packed & 15) || ((uintptr_t)hind & 15)) return kErrBadShape;
   const int W = (num_nodes + kBlkH - 1) / kBlkH;
   if (W == 0) return kOk;
-  const CsrPath path = csr_path(num_nodes, num_cols, num_edges);
-  const CsrWorkspace ws = csr_workspace(workspace, num_nodes, num_cols, num_edges);
+  const CsrPath path = csr_path(num_nodes, num_cols, num_edges, forced_path);
+  const CsrWorkspace ws = csr_workspace(workspace, num_nodes, num_cols, num_edges, forced_path);
   const bool buckets = path != kCsrBitmap && csr_use_buckets(num_cols);
   const int* big_count = buckets ? ws.counts + 1 : ws.counts;
   const int* big_queue = buckets ? ws.queue_big : ws.queue;

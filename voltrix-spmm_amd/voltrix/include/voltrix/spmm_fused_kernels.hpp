@@ -37,7 +37,7 @@
 
 #include "voltrix/spmm_panel_kernels.hpp"
 
-// Diagnostic builds only (harness/experiments/exp_fused_diag.py): bit 0 drops the residual half-steps, bit 1 the panel
+// Diagnostic builds only (-DVOLTRIX_EXPERIMENTAL, traits.hpp; harness/experiments/exp_fused_diag.py): bit 0 drops the residual half-steps, bit 1 the panel
 // loop (the whole residual then runs barrier-free), bit 2 folds every residual row into the first 1024 rows of B (all L2
 // hits).  Results are wrong by design; shipped kernels use 0.
 #ifndef VOLTRIX_FUSED_DIAG
@@ -483,13 +483,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_fused_kernel(const Fus
         q_err -= nks;
         ++q;
       }
-#ifdef VOLTRIX_FUSED_STAGGER
-      // waves v and v + 4 share a SIMD: one does its half-steps BEFORE the k-step's matrix work, the other AFTER it, so
-      // that the gather-latency-bound half of one overlaps the MFMA-bound half of the other between the same two barriers
-      const int q_pre = wave >= 4 ? q : 0;
-#else
       const int q_pre = (q + 1) >> 1;
-#endif
       for (int s = 0; s < q_pre && h < H; ++s) resid_step();
 
       const unsigned mt = meta_p + (unsigned)ms_t * T::META_P_BYTES;
@@ -558,7 +552,7 @@ template <class T>
 inline int launch_spmm_fused(const int* panel_ptr, const int* panel_cols, const uint32_t* panel_bits,
                              const int* panel_order, const int* wave_ptr, const uint32_t* records, int num_nodes,
                              int embedding_dim, const void* input, float* output, const float* out_scale,
-                             hipStream_t stream) {
+                             hipStream_t stream, int pace_blocks = 0 /* sync points per column sweep (0: none) */) {
   if (num_nodes < 0 || embedding_dim < 0) return kErrBadShape;
   if (num_nodes == 0 || embedding_dim == 0) return kOk;
   if (embedding_dim % 8 != 0 || ((uintptr_t)input & 15) || ((uintptr_t)records & 15)) return kErrBadShape;
@@ -580,20 +574,14 @@ inline int launch_spmm_fused(const int* panel_ptr, const int* panel_cols, const 
   a.meta_nt = slabs == 1;
   a.pace = nullptr;
   a.pace_blocks = 0;
-  {   // EXPERIMENT: VOLTRIX_FUSED_PACE=<sync points per sweep> (harness/experiments/exp_fused_pace.py); shipped: unset
-    static const int pace_blocks = [] {
-      const char* e = std::getenv("VOLTRIX_FUSED_PACE");
-      const int v = e ? std::atoi(e) : 0;
-      return v < 0 ? 0 : (v > kPaceBlocks ? kPaceBlocks : v);
-    }();
-    if (pace_blocks > 1 && slabs == 1) {
-      static int* counters = nullptr;
-      const size_t bytes = sizeof(int) * kNumXcd * kPaceGens * kPaceBlocks;
-      if (counters == nullptr && hipMalloc(reinterpret_cast<void**>(&counters), bytes) != hipSuccess) return kErrLaunch;
-      if (hipMemsetAsync(counters, 0, bytes, stream) != hipSuccess) return kErrLaunch;
-      a.pace = counters;
-      a.pace_blocks = pace_blocks;
-    }
+  pace_blocks = pace_blocks < 0 ? 0 : (pace_blocks > kPaceBlocks ? kPaceBlocks : pace_blocks);
+  if (pace_blocks > 1 && slabs == 1) {
+    static int* counters = nullptr;
+    const size_t bytes = sizeof(int) * kNumXcd * kPaceGens * kPaceBlocks;
+    if (counters == nullptr && hipMalloc(reinterpret_cast<void**>(&counters), bytes) != hipSuccess) return kErrLaunch;
+    if (hipMemsetAsync(counters, 0, bytes, stream) != hipSuccess) return kErrLaunch;
+    a.pace = counters;
+    a.pace_blocks = pace_blocks;
   }
   const int lds_rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&spmm_fused_kernel<T>), T::BLOCK_LDS);
   if (lds_rc != kOk) return lds_rc;

@@ -41,7 +41,7 @@
 
 #include "voltrix/traits.hpp"
 
-// Diagnostic builds only (harness/experiments/diag.py): bit 0 skips the consume side (LDS reads + MFMA), bit 1 folds every gathered
+// Diagnostic builds only (-DVOLTRIX_EXPERIMENTAL, traits.hpp; harness/experiments/diag.py): bit 0 skips the consume side (LDS reads + MFMA), bit 1 folds every gathered
 // row into the first 1024 rows of B (all L2 hits), bit 2 skips the output stores.  Results are wrong by design; the
 // shipped kernels use 0.  Bit 3 (harness/experiments/exp_tail_histogram.py) keeps the results RIGHT and makes every wave
 // leave {XCC id, HW id, start, end} (100 MHz ticks) in the int32 buffer passed as `row_map` (which is then not a row map).
@@ -810,18 +810,7 @@ void spmm_tc16_pair_kernel(const SpmmArgs<T> a) {
 // F=128 FS=64: 2.53 -> 2.06 ms); with 64-byte pieces two neighbouring slabs share every line and window-major wins
 // (F=64 FS=32: 1.55 vs 2.30 ms) -- profiles/r02/experiment_slab_order.log.  The panel kernel's grid (slab = blockIdx.y)
 // is slab-major by construction, so the two kernels of the two-level format walk the slabs in step.
-// VOLTRIX_SLAB_ORDER=major|minor overrides the rule (experiments).
-inline int slab_major_order(int num_slabs, int slab_row_bytes) {
-  if (num_slabs <= 1) return 0;
-  static const int forced = [] {   // read once, not per launch: -1 = the rule below
-    const char* e = std::getenv("VOLTRIX_SLAB_ORDER");
-    if (e && e[0] == 'm' && e[1] == 'a') return 1;
-    if (e && e[0] == 'm' && e[1] == 'i') return 0;
-    return -1;
-  }();
-  if (forced >= 0) return forced;
-  return slab_row_bytes >= 128;
-}
+inline int slab_major_order(int num_slabs, int slab_row_bytes) { return num_slabs > 1 && slab_row_bytes >= 128; }
 
 // Wide operands (F > FS): ONE LAUNCH PER 256-BYTE GROUP OF COLUMN SLABS instead of one grid over all slabs (round 3), when
 // such a group of B fits the Infinity Cache.  Inside one grid the XCDs (and, in the two-level format, the two kernels) drift
@@ -837,14 +826,14 @@ inline int slab_major_order(int num_slabs, int slab_row_bytes) {
 // HBM-resident graphs keep the single grid, where the slabs of a window side by side share its metadata and its rows' DRAM
 // pages.  (products-like gains 3.5 % from four calls on CONTIGUOUS 128-column copies of B -- a layout effect, not a launch
 // effect; a slab-major B would cost the caller a reformat pass.)  Slabs of whole 128-byte lines only (the rule of the
-// slab-major order).  VOLTRIX_SLAB_LAUNCHES=0 / 1 forces the single grid / the launches.  Returns the slabs per launch, 0 = one grid.
-inline int slab_launch_group(int num_slabs, int slab_row_bytes, long long rows) {
-  static const int forced = [] {
-    const char* e = std::getenv("VOLTRIX_SLAB_LAUNCHES");
-    return e ? (e[0] == '0' ? 0 : 1) : -1;
-  }();
-  if (forced == 0 || slab_row_bytes < 128) return 0;
-  if (forced < 0 && rows * 256 > (256ll << 20)) return 0;
+// slab-major order).  `rows` = the rows of B (the dense operand), which is what has to fit the cache: a row shard of a
+// multi-GPU run has few rows of A and all the rows of the gathered B.  `policy`: kSlabAuto = the rule, kSlabOneGrid /
+// kSlabLaunches force either form (callers that know better, tests) -- an ARGUMENT of the launchers, nothing is read from
+// the environment on the launch path.  Returns the slabs per launch, 0 = one grid.
+enum SlabPolicy : int { kSlabAuto = -1, kSlabOneGrid = 0, kSlabLaunches = 1 };
+inline int slab_launch_group(int num_slabs, int slab_row_bytes, long long rows, int policy = kSlabAuto) {
+  if (policy == kSlabOneGrid || slab_row_bytes < 128) return 0;
+  if (policy == kSlabAuto && rows * 256 > (256ll << 20)) return 0;
   const int group = slab_row_bytes >= 256 ? 1 : 256 / slab_row_bytes;
   return num_slabs > group ? group : 0;
 }
@@ -861,7 +850,9 @@ inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed,
                             const void* values = nullptr /* WEIGHTED tiles: in_t[T][16][8] */,
                             int units_per_wave = 1 /* 2: paired units (unit table, 16-bit binary operand, FS <= 128, one slab or slab-major order; else ignored) */,
                             int slab_first = 0, int slab_count = 0 /* > 0: only the column slabs [slab_first, slab_first + slab_count) of the operand, one launch;
-                                                                       0: all of them -- one launch per slab_launch_group() slabs, or one grid over all */) {
+                                                                       0: all of them -- one launch per slab_launch_group() slabs, or one grid over all */,
+                            long long input_rows = 0 /* rows of the dense operand (0: num_nodes, a square adjacency) */,
+                            int slab_policy = kSlabAuto) {
   if (num_nodes < 0 || embedding_dim < 0) return kErrBadShape;
   if (num_nodes == 0 || embedding_dim == 0) return kOk;
   if (embedding_dim % (16 / T::EB) != 0) return kErrBadShape;  // 16-byte row chunks
@@ -877,7 +868,9 @@ inline int launch_spmm_tc16(const int* blk_offsets, const uint32_t* hspa_packed,
   a.F = embedding_dim;
   const int total_slabs = (embedding_dim + T::FS - 1) / T::FS;
   if (slab_first < 0 || slab_count < 0 || slab_first + slab_count > total_slabs) return kErrBadShape;
-  if (const int group = slab_count == 0 ? slab_launch_group(total_slabs, T::FS * T::EB, num_nodes) : 0) {
+  if (const int group = slab_count == 0 ? slab_launch_group(total_slabs, T::FS * T::EB,
+                                                            input_rows > 0 ? input_rows : (long long)num_nodes, slab_policy)
+                                        : 0) {
     for (int s = 0; s < total_slabs; s += group) {
       const int rc = launch_spmm_tc16<T>(blk_offsets, hspa_packed, hind, num_nodes, embedding_dim, input, output, stream,
                                          window_order, out_scale, atomic_out, units, unit_ptr, max_units_per_xcd, partials,

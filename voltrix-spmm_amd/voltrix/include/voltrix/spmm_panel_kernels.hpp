@@ -40,17 +40,11 @@
 
 #include "voltrix/spmm_kernels.hpp"
 
-// Diagnostic builds only (harness/experiments/panel_diag.py, exp_corun_diag.py): bit 0 skips the MFMAs, bit 1 the row DMAs,
+// Diagnostic builds only (-DVOLTRIX_EXPERIMENTAL, traits.hpp; harness/experiments/panel_diag.py, exp_corun_diag.py): bit 0 skips the MFMAs, bit 1 the row DMAs,
 // bit 2 the barrier, bit 3 the fragment reads, bit 4 the metadata DMAs of the loop.  Results are wrong by design; shipped kernels use 0.
 #ifndef VOLTRIX_PANEL_DIAG
 #define VOLTRIX_PANEL_DIAG 0
 #endif
-// Experiment builds only: s_sleep of that many 64-clock quanta at the top of every k-step group (yield issue slots and
-// memory pipes to the window kernel beside it).  Shipped kernels: 0.
-#ifndef VOLTRIX_PANEL_SLEEP
-#define VOLTRIX_PANEL_SLEEP 0
-#endif
-
 namespace voltrix {
 
 
@@ -118,7 +112,6 @@ struct PanelArgs {
   int num_panels;
   int panels_per_xcd;
   int F;
-  int throttle;                // s_sleep quanta per k-step group (0; VOLTRIX_PANEL_THROTTLE for experiments)
   int meta_nt;                 // 1: bitmap / column DMAs are non-temporal (launcher: one slab covers F, every byte read once)
   int slab_first;              // blockIdx.y counts column slabs from here (one launch per slab: launch_spmm_panel)
   int accumulate;              // 0: C = A_shared * B;  1: C += A_shared * B (C holds the window kernel's part, read-add-store);
@@ -244,22 +237,6 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
     int ds_r = (D - 1) % D, ms_r = (D - 1) % MS;         // group t + D - 1 (rows issued this step)
     int ms_m = (2 * D - 2) % MS;                         // group t + 2D - 2 (metadata issued this step)
     for (int t = 0; t < ngroups; ++t) {
-      if (VOLTRIX_PANEL_SLEEP) __builtin_amdgcn_s_sleep(VOLTRIX_PANEL_SLEEP);
-      // Optional throttle (VOLTRIX_PANEL_THROTTLE, experiments): sleeping a few 64-clock quanta per k-step leaves issue
-      // slots, LDS and memory pipes to the gather-bound window-kernel waves next to this workgroup.  Bare kernel pair, back
-      // to back: 1.341 -> 1.295 ms with 4 quanta (profiles/r02/experiment_corun_diag_sleep.log); through the operator the
-      // panel kernel has no such slack (1.28 vs 1.34 ms) and every setting loses (1.350 / 1.360 / 1.366 / 1.381 ms for 0 / 3 /
-      // 4 / 6 quanta, profiles/r02/bench_ab_panel_throttle.txt).  Shipped: 0.
-      switch (a.throttle) {  // workgroup-uniform; s_sleep takes an immediate
-        case 0: break;
-        case 1: __builtin_amdgcn_s_sleep(1); break;
-        case 2: __builtin_amdgcn_s_sleep(2); break;
-        case 3: __builtin_amdgcn_s_sleep(3); break;
-        case 4: __builtin_amdgcn_s_sleep(4); break;
-        case 5: __builtin_amdgcn_s_sleep(5); break;
-        case 6: __builtin_amdgcn_s_sleep(6); break;
-        default: __builtin_amdgcn_s_sleep(8); break;
-      }
       // rows of group t (issued D-1 steps ago) and the metadata of group t+D-1 must have landed; the D-2 younger
       // steps may stay in flight.  Steps past ngroups-D+1 issue nothing.
       const int young = ngroups - 1 - t;
@@ -378,231 +355,15 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
   }
 }
 
-// ---- grouped metadata (round 3) -------------------------------------------------------------------------------------
-// spmm_panel_kernel issues three LDS-DMAs per wave and k-step -- its share of the gathered rows (1 KiB), its 64 adjacency
-// words (256 B) and the step's column ids (256 B, half of them the next step's) -- 24 per k-step and workgroup for 8 KiB of
-// rows.  An LDS-DMA costs the CU's address path about the same whatever its size, and the pair of kernels is bound by what a
-// CU can issue and retire per gathered kilobyte.  Here a wave fetches its adjacency words for FOUR
-// k-steps with one global_load_lds_dwordx4 (lanes 16 j .. 16 j + 15 read the 256 bytes of k-step 4 g + j: the per-lane source
-// address makes the plan's layout irrelevant) and the column ids of TWO k-steps with the dword DMA it already issued:
-// 1.75 DMAs per wave and k-step instead of 3 (14 instead of 24 per workgroup), same plan, same bits.  The DMA mix per step
-// is no longer constant, so the waits are exact run-time counts (wait_vm: operations issued since the awaited group).
-// KS == 1 tiles only.
-constexpr int panel_gm_bits_groups(int depth) { return (depth + 2) / 4 + 1; }
-constexpr int panel_gm_cols_groups(int depth) { return depth / 2 + 2; }
-
-template <class T>
-static __global__ __launch_bounds__(T::THREADS) void spmm_panel_gm_kernel(const PanelArgs<T> a) {
-  static_assert(T::KS == 1, "grouped metadata: one k-step per ring slot");
-  constexpr int FS = T::FS, D = T::DEPTH, RB = T::RB;
-  constexpr int ROW_BYTES = T::ROW_BYTES, STAGE_BYTES = T::STAGE_BYTES, DPW = T::DPW;
-  constexpr int RPD = T::ROWS_PER_DMA, LPR = T::LANES_PER_ROW, SLOTS = T::SLOTS;
-  // ring slots: groups of 4 k-steps of adjacency words (1 KiB) and of 2 k-steps of column ids (256 B).  Group g of the words is
-  // issued at step 4 g - (D - 1) over group g - BITS_GROUPS, last read at step 4 (g - BITS_GROUPS) + 3: BITS_GROUPS > (D + 2) / 4;
-  // group c of the ids is issued at step 2 c - 2 (D - 1) over group c - COLS_GROUPS, last read at step 2 (c - COLS_GROUPS) + 1 -
-  // (D - 1): COLS_GROUPS > D / 2
-  constexpr int BITS_GROUPS = panel_gm_bits_groups(D), COLS_GROUPS = panel_gm_cols_groups(D);
-  constexpr int META_WAVE = BITS_GROUPS * 1024 + COLS_GROUPS * 256;
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-  const int xcd = blockIdx.x % kNumXcd;
-  const int pos = xcd * a.panels_per_xcd + (int)(blockIdx.x / kNumXcd);
-  const int pos_end = (xcd + 1) * a.panels_per_xcd < a.num_panels ? (xcd + 1) * a.panels_per_xcd : a.num_panels;
-  if (pos >= pos_end) return;  // workgroup-uniform
-  const int panel = a.panel_order ? a.panel_order[pos] : pos;
-  const int fs0 = (a.slab_first + blockIdx.y) * FS;
-  const int F = a.F;
-  const int lane = threadIdx.x & (kWave - 1);
-  const int ks0 = a.panel_ptr[panel];
-  const int nks = a.panel_ptr[panel + 1] - ks0;
-  if (nks == 0 && a.accumulate) return;  // workgroup-uniform: nothing to add
-
-  float4_t acc[RB][SLOTS];
-#pragma unroll
-  for (int j = 0; j < RB; ++j)
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) acc[j][s] = float4_t{0.f, 0.f, 0.f, 0.f};
-
-  const unsigned data0 = (unsigned)(uintptr_t)(lds_ptr)smem;
-  const unsigned bits0 = data0 + T::DATA_LDS + (unsigned)wave * META_WAVE;
-  const unsigned cols0 = bits0 + BITS_GROUPS * 1024;
-
-  if (nks > 0) {
-    const unsigned row_bytes = (unsigned)F * 2u;
-    const int dma0 = (wave * DPW) % T::NDMA;
-    const char* cbase[DPW];
-    unsigned hr_off[DPW];
-#pragma unroll
-    for (int d = 0; d < DPW; ++d) {
-      const int r = (dma0 + d) * RPD + lane / LPR;
-      const int c = lane % LPR;
-      int col = fs0 + (((c >> 1) ^ slot_swizzle<SLOTS>(r & 31)) * 16) + (c & 1) * 8;
-      col = col < F ? col : fs0;
-      unsigned long long cb = (unsigned long long)((const char*)a.input + (long long)col * 2);
-      asm volatile("" : "+v"(cb));
-      cbase[d] = (const char*)cb;
-      hr_off[d] = 4 * r;
-    }
-    const uint32_t* const bits_base = a.panel_bits + ((long long)ks0 * T::WAVES + wave) * kWave;
-    const int* const cols_base = a.panel_cols + (long long)ks0 * kStageK;
-    int nops = 0;
-    // adjacency words of k-steps 4 g .. 4 g + 3 (clamped to the panel's last k-step: re-read, never consumed): 1 operation
-    auto issue_bits = [&](const int g) {
-      int ml = lane;
-      asm volatile("" : "+v"(ml));
-      int ks = 4 * g + (ml >> 4);
-      ks = ks < nks ? ks : nks - 1;
-      const uint32_t* const src = bits_base + (long long)ks * (T::WAVES * kWave) + 4 * (ml & 15);
-      const unsigned dst = bits0 + (unsigned)(g % BITS_GROUPS) * 1024;
-      if (a.meta_nt)   // workgroup-uniform; the cache policy is an immediate of the instruction
-        __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(uintptr_t)dst, 16, 0, 2);
-      else
-        __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(uintptr_t)dst, 16, 0, 0);
-      nops += 1;
-    };
-    // column ids of k-steps 2 c, 2 c + 1 (the plan pads panel_cols by two k-steps): 1 operation
-    auto issue_cols = [&](const int c) {
-      int ml = lane;
-      asm volatile("" : "+v"(ml));
-      const unsigned dst = cols0 + (unsigned)(c % COLS_GROUPS) * 256;
-      if (a.meta_nt)
-        dma_b32_nt(cols_base + (long long)c * (2 * kStageK) + ml, dst);
-      else
-        dma_b32(cols_base + (long long)c * (2 * kStageK) + ml, dst);
-      nops += 1;
-    };
-    auto issue_rows = [&](const int ks, const int ds) {   // rows of k-step ks into ring slot ds: DPW operations
-      const unsigned cslot = cols0 + (unsigned)((ks >> 1) % COLS_GROUPS) * 256 + 128u * (unsigned)(ks & 1);
-      const unsigned dst = data0 + (unsigned)ds * STAGE_BYTES + (unsigned)dma0 * 1024u;
-      unsigned hrow[DPW];
-#pragma unroll
-      for (int d = 0; d < DPW; ++d) hrow[d] = lds_read_b32(cslot + hr_off[d]);
-      wait_lgkmcnt0();
-#pragma unroll
-      for (int d = 0; d < DPW; ++d) dma_b128(cbase[d] + (unsigned long long)hrow[d] * row_bytes, dst + d * 1024);
-      nops += DPW;
-    };
-    // what step t issues besides its rows: the bits group whose first k-step is t + D - 1 (it must have landed when that
-    // k-step is consumed, D - 1 steps later) and the ids group whose first k-step is t + 2 (D - 1) (landed when its rows are
-    // issued, D - 1 steps before their consumption)
-    auto issue_meta_for_step = [&](const int t) {
-      const int kb = t + D - 1, kc = t + 2 * (D - 1);
-      if ((kb & 3) == 0 && kb < nks) issue_bits(kb >> 2);
-      if ((kc & 1) == 0 && kc < nks) issue_cols(kc >> 1);
-    };
-
-    // ---- prologue: the ids of k-steps 0 .. D-2 (what the virtual steps before -(D-1) would have fetched), then the virtual
-    // ---- steps -(D-1) .. -1 themselves
-    for (int kc = 0; kc < D - 1 && kc < nks; kc += 2) issue_cols(kc >> 1);
-    wait_vmcnt<0>();
-    __builtin_amdgcn_sched_barrier(0);
-    int mark[D - 1];   // mark[i]: nops after the issues of the step that is D - 1 - i steps back
-#pragma unroll
-    for (int s = 0; s < D - 1; ++s) {   // virtual steps -(D-1) .. -1: rows of k-steps 0 .. D-2 and their share of metadata
-      if (s < nks) issue_rows(s, s % D);
-      issue_meta_for_step(s - (D - 1));
-      mark[s] = nops;
-    }
-
-    const int g = lane >> 4;
-    const int q = (lane >> 2) & 3, p = lane & 3;
-    const int trow = 8 * g + q;
-    const int tr_z = slot_swizzle<SLOTS>(trow);
-    unsigned rd_off = trow * ROW_BYTES + 8 * p + (tr_z << 5);
-    int tr_delta[3];
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      tr_delta[b] = ((tr_z >> b) & 1) ? -(32 << b) : (32 << b);
-      asm volatile("" : "+v"(tr_delta[b]));
-    }
-    asm volatile("" : "+v"(rd_off));
-
-    int ds_t = 0, ds_r = (D - 1) % D;
-    for (int t = 0; t < nks; ++t) {
-      wait_vm(nops - mark[0]);        // every operation of step t - (D - 1) has landed (rows of k-step t among them)
-      __builtin_amdgcn_s_barrier();   // everybody's share of k-step t has landed; everybody is done reading k-step t - 1
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + D - 1 < nks) issue_rows(t + D - 1, ds_r);   // into the slot k-step t - 1 has just left
-      issue_meta_for_step(t);
-#pragma unroll
-      for (int i = 0; i < D - 2; ++i) mark[i] = mark[i + 1];
-      mark[D - 2] = nops;
-
-      const unsigned aw_addr = bits0 + (unsigned)((t >> 2) % BITS_GROUPS) * 1024 + 256u * (unsigned)(t & 3) + 4 * lane;
-      const unsigned dt = data0 + (unsigned)ds_t * STAGE_BYTES + rd_off;
-      ds_t = ds_t + 1 == D ? 0 : ds_t + 1;
-      ds_r = ds_r + 1 == D ? 0 : ds_r + 1;
-      const unsigned aw = lds_read_b32(aw_addr);
-      unsigned taddr[SLOTS];
-      taddr[0] = dt;
-#pragma unroll
-      for (int b = 0; (1 << b) < SLOTS; ++b)
-#pragma unroll
-        for (int s = (1 << b); s < (2 << b) && s < SLOTS; ++s) taddr[s] = taddr[s - (1 << b)] + tr_delta[b];
-      uint2_t blo[SLOTS], bhi[SLOTS];
-#pragma unroll
-      for (int s = 0; s < SLOTS; ++s) {
-        blo[s] = lds_read_tr16_b64<0>(taddr[s]);
-        bhi[s] = lds_read_tr16_b64<4 * ROW_BYTES>(taddr[s]);
-      }
-      wait_lgkmcnt0();
-#pragma unroll
-      for (int j = 0; j < RB; ++j) {
-        const half8_t afrag = adjacency_to_half8_x2(aw, 4 * j);
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-          const uint4_t bq = {blo[s][0], blo[s][1], bhi[s][0], bhi[s][1]};
-          if constexpr (T::BF16)
-            acc[j][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, afrag),
-                                                                __builtin_bit_cast(bf16x8_t, bq), acc[j][s], 0, 0, 0);
-          else
-            acc[j][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, __builtin_bit_cast(half8_t, bq), acc[j][s], 0, 0, 0);
-        }
-      }
-    }
-    wait_vmcnt<0>();  // nothing of this workgroup may still be writing LDS when it is released
-  }
-
-  // ---- epilogue (as spmm_panel_kernel) -------------------------------------------------------------------------------------
-  const float oscale = kAScaleInv * (a.out_scale ? *a.out_scale : 1.0f);
-  const int prow0 = panel * T::PANEL_ROWS + wave * (RB * 16) + 4 * (lane >> 4);
-  const int ocol0 = fs0 + (lane & 15);
-#pragma unroll
-  for (int j = 0; j < RB; ++j) {
-    float prev[SLOTS][4];
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = prow0 + 16 * j + i, col = ocol0 + 16 * s;
-        prev[s][i] = (a.accumulate == 1 && col < F && row < a.num_nodes) ? a.output[(long long)row * F + col] : 0.0f;
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = prow0 + 16 * j + i, col = ocol0 + 16 * s;
-        if (col < F && row < a.num_nodes) {
-          float* const dst = a.output + ((long long)row * F + col);
-          if (a.accumulate == 2)
-            unsafeAtomicAdd(dst, acc[j][s][i] * oscale);
-          else
-            *dst = prev[s][i] + acc[j][s][i] * oscale;
-        }
-      }
-    }
-  }
-}
-
 // Host launcher.  The plan arrays must be padded as the builder pads them: panel_cols by 2 k-steps (64 ints) and
 // panel_bits by one k-step beyond S = panel_ptr[NP] (the metadata DMAs fetch 64 column ids at a time).
 template <class T>
 inline int launch_spmm_panel(const int* panel_ptr, const int* panel_cols, const uint32_t* panel_bits,
                              const int* panel_order, int num_nodes, int embedding_dim, const void* input, float* output,
                              int accumulate, const float* out_scale, hipStream_t stream, int slab_first = 0,
-                             int slab_count = 0 /* as launch_spmm_tc16: > 0 = that window of slabs in one launch */) {
+                             int slab_count = 0 /* as launch_spmm_tc16: > 0 = that window of slabs in one launch */,
+                             long long input_rows = 0 /* rows of the dense operand (0: num_nodes) */,
+                             int slab_policy = kSlabAuto) {
   if (num_nodes < 0 || embedding_dim < 0 || accumulate < 0 || accumulate > 2) return kErrBadShape;
   if (num_nodes == 0 || embedding_dim == 0) return kOk;
   if (embedding_dim % 8 != 0 || ((uintptr_t)input & 15)) return kErrBadShape;
@@ -621,7 +382,9 @@ inline int launch_spmm_panel(const int* panel_ptr, const int* panel_cols, const 
   a.accumulate = accumulate;
   const int total_slabs = (embedding_dim + T::FS - 1) / T::FS;
   if (slab_first < 0 || slab_count < 0 || slab_first + slab_count > total_slabs) return kErrBadShape;
-  if (const int group = slab_count == 0 ? slab_launch_group(total_slabs, T::ROW_BYTES, num_nodes) : 0) {   // spmm_kernels.hpp
+  if (const int group = slab_count == 0 ? slab_launch_group(total_slabs, T::ROW_BYTES,
+                                                            input_rows > 0 ? input_rows : (long long)num_nodes, slab_policy)
+                                        : 0) {   // spmm_kernels.hpp
     for (int s = 0; s < total_slabs; s += group) {
       const int rc = launch_spmm_panel<T>(panel_ptr, panel_cols, panel_bits, panel_order, num_nodes, embedding_dim, input,
                                           output, accumulate, out_scale, stream, s,
@@ -633,80 +396,10 @@ inline int launch_spmm_panel(const int* panel_ptr, const int* panel_cols, const 
   const int slabs = slab_count > 0 ? slab_count : total_slabs;
   a.slab_first = slab_count > 0 ? slab_first : 0;
   a.meta_nt = total_slabs == 1;
-  static const int throttle_env = [] {   // experiments; read once, not per launch
-    const char* e = std::getenv("VOLTRIX_PANEL_THROTTLE");
-    return e ? std::atoi(e) : 0;
-  }();
-  a.throttle = throttle_env;
-  if constexpr (T::KS == 1) {
-    // VOLTRIX_PANEL_META=grouped: 14 instead of 24 LDS-DMAs per k-step and workgroup.  Measured through the operator on the
-    // reddit-like pair (A/B on one box, profiles/r03/bench_ab_panel_grouped_meta.txt): the panel kernel itself 1.25-1.27 ->
-    // 1.20-1.21 ms beside the window kernel, the window kernel unchanged (1.32-1.33 ms: it is the longer of the two), the step
-    // 1.346 / 1.369 -> 1.371 / 1.389 ms -- no gain, so the round-2 form stays the default.
-    static const bool grouped = [] {
-      const char* e = std::getenv("VOLTRIX_PANEL_META");
-      return e && e[0] == 'g';
-    }();
-    constexpr int kGmLds = T::DATA_LDS + T::WAVES * (panel_gm_bits_groups(T::DEPTH) * 1024 + panel_gm_cols_groups(T::DEPTH) * 256);
-    static_assert(kGmLds <= 160 * 1024, "LDS per CU");
-    if (grouped) {
-      const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&spmm_panel_gm_kernel<T>), kGmLds);
-      if (rc != kOk) return rc;
-      hipLaunchKernelGGL(spmm_panel_gm_kernel<T>, dim3((unsigned)(a.panels_per_xcd * kNumXcd), (unsigned)slabs),
-                         dim3(T::THREADS), kGmLds, stream, a);
-      return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
-    }
-  }
   const int lds_rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&spmm_panel_kernel<T>), T::BLOCK_LDS);
   if (lds_rc != kOk) return lds_rc;
   hipLaunchKernelGGL(spmm_panel_kernel<T>, dim3((unsigned)(a.panels_per_xcd * kNumXcd), (unsigned)slabs),
                      dim3(T::THREADS), T::BLOCK_LDS, stream, a);
-  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
-}
-
-// dst += src (float32, count % 4 == 0, 16-byte aligned): joins the two halves of the two-level format when the window
-// kernel and the panel kernel ran side by side on two streams into two buffers.
-static __global__ __launch_bounds__(256) void add_inplace_f32_kernel(float* __restrict__ dst, const float* __restrict__ src,
-                                                                const long long n4) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    float4 d = reinterpret_cast<float4*>(dst)[i];
-    const float4 x = reinterpret_cast<const float4*>(src)[i];
-    d.x += x.x;
-    d.y += x.y;
-    d.z += x.z;
-    d.w += x.w;
-    reinterpret_cast<float4*>(dst)[i] = d;
-  }
-}
-
-// dst <- 0 with NON-TEMPORAL stores (float32, count % 4 == 0, 16-byte aligned): the zero fill of C in front of the two-level
-// step (both kernels add onto it).  C (119 MB on the headline graph) is written once here and touched again only by the
-// kernels' atomics.  (Measured: no gain over an ordinary fill on the headline graph -- 0.028 vs 0.021 ms for the fill, the
-// step unchanged, profiles/r02/bench_ab_zero_fill.txt; the Python host keeps torch's fill.)
-static __global__ __launch_bounds__(256) void zero_f32_nt_kernel(float* __restrict__ dst, const long long n4) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  const f4 z = {0.f, 0.f, 0.f, 0.f};
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
-    __builtin_nontemporal_store(z, reinterpret_cast<f4*>(dst) + i);
-}
-
-inline int zero_f32_nt(float* dst, long long count, hipStream_t stream) {
-  if (count < 0 || (count % 4) != 0 || ((uintptr_t)dst & 15)) return kErrBadShape;
-  if (count == 0) return kOk;
-  const long long n4 = count / 4;
-  const int blocks = (int)(n4 / 256 + 1 < 256 * 16 ? n4 / 256 + 1 : 256 * 16);
-  hipLaunchKernelGGL(zero_f32_nt_kernel, dim3(blocks), dim3(256), 0, stream, dst, n4);
-  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
-}
-
-inline int add_inplace_f32(float* dst, const float* src, long long count, hipStream_t stream) {
-  if (count < 0 || (count % 4) != 0 || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) return kErrBadShape;
-  if (count == 0) return kOk;
-  const long long n4 = count / 4;
-  const int blocks = (int)(n4 / 256 + 1 < 256 * 16 ? n4 / 256 + 1 : 256 * 16);
-  hipLaunchKernelGGL(add_inplace_f32_kernel, dim3(blocks), dim3(256), 0, stream, dst, src, n4);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

@@ -23,7 +23,6 @@ from ..project import (
     HIPCC_COMPILER_FLAG,
     JIT_PRINT_NVCC_COMMAND_FLAG,
     NVCC_COMPILER_FLAG,
-    OFFLOAD_ARCH_FLAG,
     PROJECT_NAME_ABBR_LOWER,
     PROJECT_NAME_FULL_LOWER,
     PTXAS_VERBOSE_FLAG,
@@ -106,7 +105,7 @@ get_nvcc_compiler = get_hipcc_compiler  # drop-in alias (reference name)
 
 
 def get_offload_arch() -> str:
-    return os.getenv(OFFLOAD_ARCH_FLAG, "gfx950")
+    return "gfx950"   # the one target of this package (MI355X / CDNA4)
 
 
 def get_default_user_dir() -> str:

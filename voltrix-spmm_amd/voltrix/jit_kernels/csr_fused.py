@@ -6,10 +6,13 @@ import torch
 from .. import capi
 
 
-def csr_fused_preprocess_kernel(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None):
+def csr_fused_preprocess_kernel(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
+                                path: str = None):
     """``num_cols``: the column universe (every id in ``indices`` is in ``[0, num_cols)``); default ``num_nodes`` (square
     adjacency, the reference's contract).  It only selects the rank algorithm (LDS bitmap vs per-window sort); ids
-    outside it are detected on the device and the preprocess is redone with the universe-free sort path."""
+    outside it are detected on the device and the preprocess is redone with the universe-free sort path.  ``path``: None /
+    "auto" = the library's rule, "sort" | "bitmap" | "mixed" force a rank algorithm where it applies (same bytes on every
+    path; the operator passes what ``VOLTRIX_PREPROCESS=fused:<path>`` says)."""
     assert indptr.is_cuda and indptr.dtype == torch.int32 and indptr.is_contiguous()
     assert indices.is_cuda and indices.dtype == torch.int32 and indices.is_contiguous()
     assert indptr.numel() == num_nodes + 1
@@ -23,10 +26,10 @@ def csr_fused_preprocess_kernel(indptr: torch.Tensor, indices: torch.Tensor, num
     pointer1 = torch.empty(num_row_windows + 1, dtype=torch.int32, device=device)
     status = torch.empty(1, dtype=torch.int32, device=device)
     while True:
-        workspace = torch.empty(capi.csr_preprocess_workspace_bytes(num_nodes, num_cols, num_edges), dtype=torch.uint8,
+        workspace = torch.empty(capi.csr_preprocess_workspace_bytes(num_nodes, num_cols, num_edges, path), dtype=torch.uint8,
                                 device=device)
         capi.launch_csr_window_count(indptr, indices, num_nodes, num_cols, workspace, block_partition, pointer1, status,
-                                     stream)
+                                     stream, path)
         # host sync point, as in the reference (spmm.py:44): T and the out-of-universe count in one copy
         total_blocks, outside = torch.cat([pointer1[-1:], status]).tolist()
         if outside == 0:
@@ -36,5 +39,5 @@ def csr_fused_preprocess_kernel(indptr: torch.Tensor, indices: torch.Tensor, num
         num_cols = 0  # ids beyond the declared universe (e.g. a non-square operand): universe-free sort path
     hspa_packed = torch.empty(total_blocks * 4, dtype=torch.uint32, device=device)
     hind = torch.empty(total_blocks * 8, dtype=torch.int32, device=device)
-    capi.launch_csr_fill(indptr, indices, num_nodes, num_cols, workspace, pointer1, hspa_packed, hind, stream)
+    capi.launch_csr_fill(indptr, indices, num_nodes, num_cols, workspace, pointer1, hspa_packed, hind, stream, path)
     return pointer1, hspa_packed, hind, block_partition

@@ -23,7 +23,8 @@ __return_code = voltrix::launch_spmm_tc16<voltrix::SpmmTile<{FS}, {DEPTH}, {WAVE
     out_scale, atomic_out,
     {SCHED} == 4 ? units : ({SCHED} == 5 ? units_p : nullptr), {SCHED} == 5 ? unit_ptr_p : unit_ptr,
     {SCHED} == 5 ? max_units_per_xcd_p : max_units_per_xcd, {SCHED} == 5 ? partials_p : partials,
-    has_row_map != 0 ? row_map : nullptr, {WEIGHTED} != 0 ? (const void*)values : nullptr, {SCHED} == 5 ? 2 : 1);
+    has_row_map != 0 ? row_map : nullptr, {WEIGHTED} != 0 ? (const void*)values : nullptr, {SCHED} == 5 ? 2 : 1,
+    0, 0, input_rows, slab_policy);
 if (__return_code == 0 && {SCHED} == 4 && combine_now != 0)
   __return_code = voltrix::combine_partials(cuts, num_cuts, partials, output, num_nodes, embedding_dim, atomic_out, stream,
                                             has_row_map != 0 ? row_map : nullptr);
@@ -46,18 +47,23 @@ SCHED_UNITS = 4
 # 1.365 -> 1.293 ms (profiles/r02/experiment_pair_units.log).  16-bit binary operand, four-wave tiles; with several column
 # slabs the launch is slab-major (slabs of 128 bytes and more) and a pair never straddles two slabs.
 SCHED_PAIRS = 5
-PAIR_UNIT_FACTOR = float(os.getenv("VOLTRIX_PAIR_UNIT_FACTOR", "1.25"))   # x the median window length (experiments: 1.0 .. 1.5)
+PAIR_UNIT_FACTOR = 1.25   # x the median window length (measured: 1.0 .. 1.5 within 1 %, profiles/r02/experiment_pair_units.log)
+
+# How an operand wider than the tile's slab is launched (spmm_kernels.hpp::slab_launch_group): -1 = the library's rule (one
+# launch per 256-byte group of column slabs when such a group of B fits the Infinity Cache), 0 = always one grid, 1 = always
+# the launches.  A module attribute the operator passes down as an ARGUMENT of every launch (tests flip it to compare the two
+# forms bit for bit); nothing on the launch path reads the environment.
+SLAB_POLICY = -1
 
 
-def slab_launches(embedding_dim: int, fs: int, elem_bytes: int, rows: int) -> int:
-    """Kernel launches a call of the window (or panel) kernel makes for an ``embedding_dim``-wide operand: the rule of
-    ``spmm_kernels.hpp::slab_launch_group`` restated for reports (bench.py ``config.tile.launches_per_step``,
-    harness/pmc_summarize.py) -- one launch per 256-byte group of column slabs when such a group of B fits the Infinity Cache,
-    else one grid over all slabs."""
+def slab_launches(embedding_dim: int, fs: int, elem_bytes: int, rows: int, policy: int = None) -> int:
+    """Kernel launches a call of the window (or panel) kernel makes for an ``embedding_dim``-wide operand of ``rows`` rows:
+    the rule of ``spmm_kernels.hpp::slab_launch_group`` restated for reports (bench.py ``config.tile.launches_per_step``,
+    harness/pmc_summarize.py)."""
+    policy = SLAB_POLICY if policy is None else policy
     slabs = -(-embedding_dim // fs)
     slab_bytes = fs * elem_bytes
-    forced = os.getenv("VOLTRIX_SLAB_LAUNCHES")
-    if slab_bytes < 128 or (forced or "")[:1] == "0" or (forced is None and rows * 256 > (256 << 20)):
+    if slab_bytes < 128 or policy == 0 or (policy < 0 and rows * 256 > (256 << 20)):
         return 1
     group = 1 if slab_bytes >= 256 else 256 // slab_bytes
     return -(-slabs // group) if slabs > group else 1
@@ -82,7 +88,7 @@ def _lds_bytes(fs, depth, waves, eb, weighted=False):
 
 # LDS a window-kernel workgroup may take when a panel-kernel workgroup (two-level format, 44 KB at FS = 128 / DEPTH 3)
 # has to fit on the same CU beside it
-TWO_LEVEL_LDS_BUDGET = 160 * 1024 - 47 * 1024   # panel workgroup: 24 KiB ring + 22.5 KiB grouped metadata (spmm_panel_gm_kernel)
+TWO_LEVEL_LDS_BUDGET = 160 * 1024 - 47 * 1024   # panel workgroup: 24 KiB ring + 20 KiB metadata + slack
 
 
 def tile_space(embedding_dim: int, elem_bytes: int, bf16: bool = False, max_lds: int = None, weighted: bool = False):
@@ -90,15 +96,12 @@ def tile_space(embedding_dim: int, elem_bytes: int, bf16: bool = False, max_lds:
     ``max_lds``: keep only tiles whose workgroup fits that many bytes of LDS; ``weighted``: the A operand is a value
     plane, 1 KiB more per metadata slot)."""
     points = tuple(dict(point, BF16=int(bf16), WEIGHTED=int(weighted)) for point in _tile_space(embedding_dim, elem_bytes))
-    pairs_allowed = os.getenv("VOLTRIX_PAIR_UNITS", "1") != "0"   # 0: never two units per wave (A/B runs)
-    if not pairs_allowed:
-        points = tuple(p for p in points if p["SCHED"] != SCHED_PAIRS)
     if weighted:
         assert elem_bytes == 2
         points = tuple(p for p in points if p["SCHED"] != SCHED_PAIRS)   # paired units: binary operand only
         points = tuple(p for p in points if _lds_bytes(p["FS"], p["DEPTH"], p["WAVES"], 2, True) <= 160 * 1024
                        and (2 + 32 * p["FS"] * 2 // 1024) * (p["DEPTH"] - 1) <= 63)
-    if (max_lds is not None and not weighted and pairs_allowed and os.getenv(TUNE_SPACE_FLAG, "default") == "none"
+    if (max_lds is not None and not weighted and os.getenv(TUNE_SPACE_FLAG, "default") == "none"
             and len(points) == 1
             and points[0]["EB"] == 2 and (points[0]["FS"] >= 64 or embedding_dim <= points[0]["FS"])):
         # the single untuned point beside a panel workgroup: two units per wave (measured: 1.365 -> 1.293 ms for the pair)
@@ -142,6 +145,61 @@ def _tile_space(embedding_dim: int, elem_bytes: int):
                     for sched in scheds:
                         space.append({"FS": fs, "DEPTH": d, "WAVES": w, "EB": elem_bytes, "SCHED": sched})
     return tuple(space)
+
+
+# ---- the bounded sweep (round 4) ----------------------------------------------------------------------
+SAMPLE_MIN_WINDOWS = 1 << 14     # below this many windows the sweep times the whole handle
+SAMPLE_CHUNKS = 4                # contiguous window ranges of the sample, spread over the handle
+SAMPLE_FRACTION = 16             # 1 / this of the windows in all
+
+
+def sample_ranges(num_windows: int):
+    """Window ranges ``[(w0, w1)]`` the sweep times its candidates on: the whole handle when it is small, else
+    ``SAMPLE_CHUNKS`` contiguous ranges centred at (2 k + 1) / (2 SAMPLE_CHUNKS) of the windows, 1 / ``SAMPLE_FRACTION`` of
+    them in all.  A contiguous range of a block-format handle is itself a handle (``blk_offsets[w0 : w1 + 1]`` holds absolute
+    TC-block offsets into the same ``hspa_packed`` / ``hind``), so a sample launch is the SAME kernel with a shifted
+    pointer, fewer rows and its own schedule arrays: nothing is copied."""
+    if num_windows <= SAMPLE_MIN_WINDOWS:
+        return [(0, num_windows)]
+    size = max(SAMPLE_MIN_WINDOWS // (2 * SAMPLE_CHUNKS), num_windows // (SAMPLE_FRACTION * SAMPLE_CHUNKS))
+    out = []
+    for k in range(SAMPLE_CHUNKS):
+        centre = (2 * k + 1) * num_windows // (2 * SAMPLE_CHUNKS)
+        w0 = max(0, min(num_windows - size, centre - size // 2))
+        out.append((w0, w0 + size))
+    return out
+
+
+def sweep_stages(space, best=None):
+    """The two stages of the bounded sweep.  Stage 1 (``best`` None): one candidate per tile SHAPE (FS, DEPTH, WAVES), each
+    with the most robust schedule its operand type has -- the unit table for 16-bit operands (balanced on every graph
+    measured: tails 0.7-1.7 %), the chunk-512 balance schedule for fp32 ones -- so that shapes are compared on equal terms.
+    Stage 2: the other schedules of the winning shape (natural order, balance chunks 512 / 2048, two units per wave; chunk 128
+    never won a sweep and is left to ``VOLTRIX_TUNE_SPACE=full``).  default space: 8 + 4 = 12 candidates instead of 44."""
+    def shape(p):
+        return (p["FS"], p["DEPTH"], p["WAVES"], p["EB"])
+
+    shapes = {}
+    for p in space:
+        shapes.setdefault(shape(p), []).append(p)
+
+    def robust(points):
+        for pref in (SCHED_UNITS, 2, 0):
+            for p in points:
+                if p["SCHED"] == pref:
+                    return p
+        return points[0]
+
+    if best is None:
+        return [robust(points) for points in shapes.values()]
+    points = shapes[shape(best)]
+    first = robust(points)
+    return [p for p in points if p is not first and p["SCHED"] != 1]
+
+
+def sweep_budget_s(step_s: float) -> float:
+    """Wall-clock cap of one sweep: max(2 s, 20 x the full-size step)."""
+    return max(2.0, 20.0 * step_s)
 
 
 def window_order(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, num_nodes: int, sched: int = 1) -> torch.Tensor:
@@ -198,6 +256,8 @@ def arg_defs_for(dtype):
         ("row_map", torch.int32),
         ("has_row_map", int),
         ("values", dtype),
+        ("input_rows", int),
+        ("slab_policy", int),
         ("stream", torch.cuda.Stream),
     )
 
@@ -376,7 +436,7 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
                 table_p.max_units_per_xcd if table_p is not None else 0, table_p.cuts if table_p is not None else blk_offsets,
                 table_p.num_cuts if table_p is not None else 0, partials_p, int(combine_now),
                 row_map if row_map is not None else blk_offsets, int(row_map is not None),
-                values if values is not None else input, torch.cuda.current_stream())
+                values if values is not None else input, int(input.shape[0]), int(SLAB_POLICY), torch.cuda.current_stream())
 
     args = make_args(output, not defer_combine)
     # tuning runs: every candidate is timed with its COMPLETE work (the unit-table schedules with their combine pass, also
@@ -384,18 +444,70 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
     tune_args = args
     if len(space) > 1 and chosen is None and (atomic_out or defer_combine):
         tune_args = make_args(torch.zeros_like(output) if atomic_out else output, True)
-    runtime = jit_tuner.compile_and_tune(
-        name="spmm_kernel",
-        keys=keys,
-        space=space,
-        includes=includes,
-        arg_defs=arg_defs_for(input.dtype),
-        template=template,
-        args=tune_args,
-        kernel_tag="spmm",
-        bucket_keys=lambda: graph_bucket_keys(blk_offsets, num_nodes, keys),
-    )
+
+    def sample_args():
+        """(argument tuples of the sample launches, fraction of the handle they cover): called by the tuner only when a
+        sweep really runs.  Every range gets its own schedule arrays (window orders, unit tables, partial tiles)."""
+        from ..schedule import default_max_stages, unit_table
+
+        num_windows = (num_nodes + 15) // 16
+        ranges = sample_ranges(num_windows)
+        if len(ranges) == 1 and ranges[0] == (0, num_windows):
+            return [tune_args], 1.0
+        out_full = tune_args[7]
+        launches, covered = [], 0
+        for w0, w1 in ranges:
+            sub = blk_offsets[w0:w1 + 1]
+            n_sub = min(num_nodes, 16 * w1) - 16 * w0
+            covered += w1 - w0
+            a = list(tune_args)
+            a[0], a[3] = sub, n_sub
+            a[7] = out_full if row_map is not None else out_full[16 * w0:16 * w0 + n_sub]
+            for slot, sched in ((8, 1), (9, 2), (10, 3)):
+                a[slot] = window_order(sub, hspa_packed, n_sub, sched) if needs_orders else sub
+            if want(SCHED_UNITS):
+                t = unit_table(sub, n_sub)
+                a[13], a[14], a[15], a[16], a[17] = t.units, t.unit_ptr, t.max_units_per_xcd, t.cuts, t.num_cuts
+                a[18] = torch.empty(max(1, t.num_slots) * 16 * embedding_dim, dtype=torch.float32, device=input.device)
+            if want(SCHED_PAIRS):
+                t = unit_table(sub, n_sub, max(8, int(PAIR_UNIT_FACTOR * default_max_stages(sub, n_sub) / 1.5)))
+                a[19], a[20], a[21], a[22], a[23] = t.units, t.unit_ptr, t.max_units_per_xcd, t.cuts, t.num_cuts
+                a[24] = torch.empty(max(1, t.num_slots) * 16 * embedding_dim, dtype=torch.float32, device=input.device)
+            a[25] = 1                                       # combine now: the candidate's complete work
+            if row_map is not None:
+                a[26] = row_map[16 * w0:16 * w1]
+            launches.append(tuple(a))
+        return launches, covered / max(1, num_windows)
+
+    staged = os.getenv(TUNE_SPACE_FLAG, "default") != "full"    # "full": every point of the (larger) space, still on the sample
+
+    def tune(use_store=True):
+        return jit_tuner.compile_and_tune(
+            name="spmm_kernel",
+            keys=keys,
+            space=space,
+            includes=includes,
+            arg_defs=arg_defs_for(input.dtype),
+            template=template,
+            args=tune_args,
+            kernel_tag="spmm",
+            bucket_keys=lambda: graph_bucket_keys(blk_offsets, num_nodes, keys),
+            use_store=use_store,
+            sample_args=sample_args,
+            stages=sweep_stages if staged else None,
+            budget_s=sweep_budget_s,
+        )
+
+    runtime = tune()
     rc = runtime(*args)
+    signature = jit_tuner._signature("spmm_kernel", keys)
+    if rc != 0 and signature in jit_tuner.unvalidated:
+        # a persisted / bucket choice that is illegal for THESE arguments: forget it and sweep (its first launch was the
+        # validation -- no extra launch is spent on choices that are fine)
+        jit_tuner.forget("spmm_kernel", keys)
+        runtime = tune(use_store=False)
+        rc = runtime(*args)
+    jit_tuner.unvalidated.discard(signature)
     assert rc == 0, f"spmm_kernel failed with return code {rc}"
     if defer_combine:
         sched = jit_tuner.tuned_point("spmm_kernel", keys).get("SCHED")

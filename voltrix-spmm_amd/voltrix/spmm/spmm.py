@@ -15,7 +15,7 @@ from ..jit_kernels import (
     preprocess_kernel,
     spmm_kernel,
 )
-from .. import capi, hybrid
+from .. import capi, hybrid, sidecar
 from ..project import FP32_MODE_FLAG, PREPROCESS_FLAG
 
 BLK_H = 16
@@ -46,7 +46,7 @@ def csr_preprocess(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, 
     assert indices.is_cpu and indices.dtype == torch.int32
     assert indptr.numel() == num_nodes + 1
 
-    if os.getenv(PREPROCESS_FLAG, "fused") != "reference":
+    if preprocess_mode()[0] != "reference":
         return csr_preprocess_device(indptr.contiguous().cuda(), indices.contiguous().cuda(), num_nodes, num_cols)
 
     num_edges = indices.numel()
@@ -73,27 +73,39 @@ def csr_preprocess(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, 
     return pointer1, hspa_packed, hind
 
 
+def preprocess_mode():
+    """``VOLTRIX_PREPROCESS``: ``fused`` (default: one H2D copy + the fused GPU preprocess, rank algorithm chosen by the
+    library) | ``fused:sort`` / ``fused:bitmap`` / ``fused:mixed`` (the same with that rank algorithm forced where it
+    applies: tests, experiments) | ``reference`` (the reference's own three-stage pipeline).  -> (mode, path or None)."""
+    mode, _, path = os.getenv(PREPROCESS_FLAG, "fused").partition(":")
+    assert mode in ("fused", "reference") and (path or "auto") in ("auto", "sort", "bitmap", "mixed"), \
+        f"{PREPROCESS_FLAG}={os.getenv(PREPROCESS_FLAG)}"
+    return mode, (path or None)
+
+
 def csr_preprocess_device(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None):
     """``csr_preprocess`` for a CSR that already lives on the GPU (extension: the reference takes CPU tensors only; graph
     pipelines and the row-sharded operator build their shards on the device).  Same handle, same side-car policy."""
     assert indptr.is_cuda and indptr.dtype == torch.int32 and indices.is_cuda and indices.dtype == torch.int32
     assert indptr.numel() == num_nodes + 1
     indptr, indices = indptr.contiguous(), indices.contiguous()
-    pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(indptr, indices, num_nodes, num_cols)
+    path = preprocess_mode()[1]
+    pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(indptr, indices, num_nodes, num_cols, path=path)
     mode = hybrid.hybrid_mode()
     big_enough = (indices.numel() >= hybrid.AUTO_MIN_EDGES and num_nodes >= hybrid.AUTO_MIN_ROWS
                   and indices.numel() >= hybrid.AUTO_MIN_MEAN_DEGREE * max(1, num_nodes))
+    two = None
     if mode == "on" or (mode in ("auto", "tune") and big_enough):
         two = _build_two_level(indptr, indices, num_nodes, num_cols)
-        if two is not None:
-            hspa_packed._voltrix_two_level = (two, hspa_packed.data_ptr())
+    # the decision -- a side-car or "window format" -- is recorded for the MEMORY of hspa_packed (voltrix/sidecar.py): views
+    # and re-packed tuples of the handle keep it, it dies with the storage
+    sidecar.register(hspa_packed, two)
     return pointer1, hspa_packed, hind
 
 
 def two_level_of(hspa_packed: torch.Tensor):
-    """The ``TwoLevelHandle`` that ``csr_preprocess`` attached to this tensor object, or None."""
-    hint = getattr(hspa_packed, "_voltrix_two_level", None)
-    return hint[0] if hint is not None and hint[1] == hspa_packed.data_ptr() else None
+    """The ``TwoLevelHandle`` that ``csr_preprocess`` recorded for this handle (any tensor over the same memory), or None."""
+    return sidecar.lookup(hspa_packed)[1]
 
 
 def _build_two_level(indptr_d, indices_d, num_nodes, num_cols, waves=hybrid.DEFAULT_WAVES,
@@ -106,7 +118,8 @@ def _build_two_level(indptr_d, indices_d, num_nodes, num_cols, waves=hybrid.DEFA
                                                                 tau, min_share=min_share)
     if plan.num_ksteps == 0 or plan.num_shared_edges < min_share * max(1, indices_d.numel()):
         return None   # the builder stopped after its count phase: nothing of the two-level form was built
-    pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(resid_indptr, resid_indices, num_nodes, num_cols)
+    pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(resid_indptr, resid_indices, num_nodes, num_cols,
+                                                                 path=preprocess_mode()[1])
     two = hybrid.TwoLevelHandle(pointer1, hspa_packed, hind, plan, num_nodes, int(indices_d.numel()))
     _attach_fused(two)
     return two
@@ -135,7 +148,8 @@ def csr_preprocess_hybrid(indptr: torch.Tensor, indices: torch.Tensor, num_nodes
     indptr_d, indices_d = indptr.contiguous().cuda(), indices.contiguous().cuda()
     resid_indptr, resid_indices, plan = hybrid.build_panel_plan(indptr_d, indices_d, num_nodes, num_cols, waves, row_blocks,
                                                                 tau)
-    pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(resid_indptr, resid_indices, num_nodes, num_cols)
+    pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(resid_indptr, resid_indices, num_nodes, num_cols,
+                                                                 path=preprocess_mode()[1])
     two = hybrid.TwoLevelHandle(pointer1, hspa_packed, hind, plan, num_nodes, int(indices.numel()))
     _attach_fused(two)
     return two
@@ -176,8 +190,11 @@ def spmm(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tenso
     num_feats = feat.shape[1]
     operand, out_scale, padded, exact = _operand(feat)
     output = torch.empty((num_nodes, padded), dtype=torch.float32, device=feat.device)
-    two = two_level_of(hspa_packed)
+    known, two = sidecar.lookup(hspa_packed)
     mode = hybrid.hybrid_mode()
+    if not known and mode == "auto" and not exact:
+        sidecar.warn_if_unknown(hspa_packed, num_nodes, num_edges, hybrid.AUTO_MIN_EDGES, hybrid.AUTO_MIN_ROWS,
+                                hybrid.AUTO_MIN_MEAN_DEGREE)
 
     def window():
         spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes=num_nodes, num_edges=num_edges, embedding_dim=padded,
@@ -232,7 +249,7 @@ def _choose_format(hspa_packed, key, window, two_level) -> str:
     return best
 
 
-def _run_two_level(two, operand, output, out_scale, tag_source=None):
+def _run_two_level(two, operand, output, out_scale, tag_source=None, concurrent=True):
     if two.fused is not None and hybrid.fused_enabled():
         hybrid.launch_fused(two.plan, two.fused, operand, output, out_scale=out_scale)   # one launch, C written once
         return
@@ -248,12 +265,13 @@ def _run_two_level(two, operand, output, out_scale, tag_source=None):
                            output=output, out_scale=out_scale, atomic_out=atomic,
                            beside_panel=two.plan.num_ksteps > 0, defer_combine=True)
 
-    hybrid.run_two_level(two.plan, operand, output, run_window, out_scale=out_scale)
+    hybrid.run_two_level(two.plan, operand, output, run_window, out_scale=out_scale, concurrent=concurrent)
 
 
-def spmm_two_level(handle: "hybrid.TwoLevelHandle", feat: torch.Tensor):
+def spmm_two_level(handle: "hybrid.TwoLevelHandle", feat: torch.Tensor, concurrent: bool = True):
     """``csr(ones) @ feat`` for a ``TwoLevelHandle`` (``csr_preprocess_hybrid``): float32 ``[num_nodes, F]``, on the
-    current stream (the panel kernel runs beside the window kernel on a side stream, joined through events).  ``feat``
+    current stream (the panel kernel runs beside the window kernel on a side stream, joined through events;
+    ``concurrent=False``: both on the caller's stream, the panel kernel adding onto the window kernel's result).  ``feat``
     as for ``spmm``; the panel kernel takes a 16-bit operand, so ``VOLTRIX_FP32_MODE=exact`` is refused unless the plan
     is empty."""
     assert isinstance(handle, hybrid.TwoLevelHandle)
@@ -262,5 +280,5 @@ def spmm_two_level(handle: "hybrid.TwoLevelHandle", feat: torch.Tensor):
     assert not (exact and handle.plan.num_ksteps > 0), \
         "the panel kernel takes a 16-bit operand (unset VOLTRIX_FP32_MODE=exact or use csr_preprocess)"
     output = torch.empty((handle.num_nodes, padded), dtype=torch.float32, device=feat.device)
-    _run_two_level(handle, operand, output, out_scale)
+    _run_two_level(handle, operand, output, out_scale, concurrent=concurrent)
     return output if padded == num_feats else output[:, :num_feats].contiguous()
