@@ -364,6 +364,12 @@ void voltrix_launch_cm_rank(void* indptr, void* indices, void* t_indptr, void* t
                             void* level, void* rank, void* tie, void* queue, void* level_off, const int* level_off_host,
                             int num_levels, int base, void* workspace, void* stream, int* return_code);
 
+/* out = inv(chol(gram + eps trace(gram) I))^T for a k x k symmetric positive semi-definite gram (float32, row-major,
+ * k <= 64), float32 [k][k]: the small factor of a Cholesky QR (X <- X out has orthonormal columns), on the device so that
+ * the spectral row order's subspace iteration (voltrix/reorder.py) has no host sync per step.  One workgroup, double
+ * arithmetic.  VOLTRIX_ERR_BAD_SHAPE for k outside 1..64. */
+void voltrix_launch_chol_inv_transposed(void* gram, int k, double eps, void* out, void* stream, int* return_code);
+
 #ifdef __cplusplus
 }
 #endif

@@ -189,3 +189,65 @@ def test_spectral_order_recovers_the_shuffled_reddit_stand_in(cuda_device, monke
     out = voltrix.spmm_reordered(handle, feat.cuda(), hash_tag="spectral_test").cpu()
     ref = torch_ref.spmm(s_indptr.cpu(), s_indices.cpu(), feat.float(), n)
     assert float((out - ref).norm() / ref.norm()) < 1e-5
+
+
+# ---- round 4: method="auto" -- never worse than no reorder ----------------------------------------------------------------
+def _median_ms(fn, reps=7, batch=5):
+    for _ in range(3):
+        fn()
+    times = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(batch):
+            fn()
+        e.record()
+        e.synchronize()
+        times.append(s.elapsed_time(e) / batch)
+    return sorted(times)[len(times) // 2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph,scale,expect", [("reddit_shuffled", 0.25, "not-bfs"), ("reddit_like", 0.25, "identity"),
+                                                ("products_shuffled", 0.08, "identity")])
+def test_auto_reorder_is_never_worse_than_no_reorder(cuda_device, graph, scale, expect, monkeypatch):
+    """VERDICT r3 item 4.  ``method="auto"`` (the default): the breadth-first and the spectral order are judged by the format's
+    own statistics (TC blocks, edges in shared columns, longest panel -- count phases only, deterministic) and the caller's order
+    is kept unless one of them clearly pays.  On the label-shuffled reddit-like graph the breadth-first order degenerates into
+    a degree sort (hub panels: 3x the time) and must be rejected; on the natural-order graph and on the products-like graph
+    (degree 50: the TC-block count does not depend on the order) the identity must be kept.  In every case the product is
+    right and the step is at most 1.05x the un-reordered one."""
+    import voltrix
+    from oracle import torch_ref
+
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    monkeypatch.setenv("VOLTRIX_HYBRID", "1")                   # scaled graphs are below the auto thresholds of the side-car
+    dev = torch.device("cuda")
+    indptr, indices, _ = synth_graphs.generate(graph, device=dev, scale=scale)
+    n, e = indptr.numel() - 1, indices.numel()
+    info = {}
+    handle = voltrix.csr_preprocess_reordered(indptr, indices, n, info=info)          # method="auto"
+    assert handle.method.startswith("auto:") and info["picked"] == handle.method[5:]
+    assert set(info["report"]) >= {"identity", "bfs"}
+    if expect == "identity":
+        assert info["picked"] == "identity" and handle.row_map is None, info
+    else:
+        assert info["picked"] != "bfs", info
+        if info["picked"] != "identity":
+            assert info["report"][info["picked"]]["score"] <= 0.97 * info["report"]["identity"]["score"]
+    plain = voltrix.csr_preprocess_device(indptr, indices, n)
+    plain[1].hash_tag = f"auto_reorder_plain/{graph}"
+    feat = torch.randn(n, 128, device=dev).half()
+    out = voltrix.spmm_reordered(handle, feat, hash_tag=f"auto_reorder/{graph}")
+    rows = torch.randperm(n, device=dev)[:4096].sort().values                         # oracle on a sample of the rows
+    ip = indptr.long()
+    cnt = ip[rows + 1] - ip[rows]
+    sub_ptr = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=dev)
+    sub_ptr[1:] = torch.cumsum(cnt, 0)
+    pos = (torch.arange(int(sub_ptr[-1]), device=dev) - torch.repeat_interleave(sub_ptr[:-1], cnt)
+           + torch.repeat_interleave(ip[rows], cnt))
+    ref = torch_ref.spmm(sub_ptr.to(torch.int32).cpu(), indices[pos].cpu(), feat.float().cpu(), rows.numel())
+    assert float((out[rows].cpu() - ref).norm() / ref.norm()) < 1e-5
+    t_auto = _median_ms(lambda: voltrix.spmm_reordered(handle, feat))
+    t_plain = _median_ms(lambda: voltrix.spmm(*plain, num_nodes=n, num_edges=e, feat=feat))
+    assert t_auto <= 1.05 * t_plain + 0.01, (t_auto, t_plain, info)

@@ -49,4 +49,9 @@ void voltrix_launch_cm_rank(void* indptr, void* indices, void* t_indptr, void* t
                                   base, workspace, static_cast<hipStream_t>(stream));
 }
 
+void voltrix_launch_chol_inv_transposed(void* gram, int k, double eps, void* out, void* stream, int* return_code) {
+  *return_code = voltrix::chol_inv_transposed(static_cast<const float*>(gram), k, eps, static_cast<float*>(out),
+                                              static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

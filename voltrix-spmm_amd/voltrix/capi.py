@@ -64,6 +64,7 @@ SYMBOLS = (
     "voltrix_launch_bfs_levels",
     "voltrix_cm_rank_workspace_bytes",
     "voltrix_launch_cm_rank",
+    "voltrix_launch_chol_inv_transposed",
 )
 
 
@@ -413,6 +414,21 @@ def csr_transpose(indptr, indices, num_rows: int, num_cols: int, stream=None):
                                        ctypes.c_void_p(stream), ctypes.byref(rc))
     check(rc.value, "voltrix_launch_csr_transpose")
     return t_indptr, t_indices
+
+
+def chol_inv_transposed(gram, eps: float = 1e-10, stream=None):
+    """``inv(chol(gram + eps trace I))^T`` of a k x k float32 Gram matrix on its device (k <= 64); no host sync."""
+    import torch
+
+    k = gram.shape[0]
+    assert gram.is_cuda and gram.dtype == torch.float32 and gram.shape == (k, k) and gram.is_contiguous()
+    out = torch.empty_like(gram)
+    stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    rc = ctypes.c_int(-1)
+    lib().voltrix_launch_chol_inv_transposed(_ptr(gram), ctypes.c_int(k), ctypes.c_double(eps), _ptr(out),
+                                             ctypes.c_void_p(stream), ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_chol_inv_transposed")
+    return out
 
 
 class CmSearch:

@@ -21,6 +21,8 @@ Plan layout: see spmm_panel_kernels.hpp; pinned bit-exactly by ``oracle/oracle_n
 """
 from __future__ import annotations
 
+import contextlib
+import contextvars
 import dataclasses
 import os
 
@@ -477,6 +479,20 @@ def min_shared_fraction() -> float:
     return float(os.getenv("VOLTRIX_HYBRID_MIN_SHARE", default))
 
 
+_MODE_OVERRIDE = contextvars.ContextVar("voltrix_hybrid_mode", default=None)
+
+
+@contextlib.contextmanager
+def mode_override(value: str):
+    """``with mode_override("0"):`` -- VOLTRIX_HYBRID for the calls of this context (thread / task) only; used by
+    library-internal callers (the spectral reorder's products never want a side-car) instead of mutating os.environ."""
+    token = _MODE_OVERRIDE.set(value)
+    try:
+        yield
+    finally:
+        _MODE_OVERRIDE.reset(token)
+
+
 def hybrid_mode() -> str:
     """``VOLTRIX_HYBRID``:
     ``auto`` (default)  ``csr_preprocess`` decides ONCE, from the plan builder's count phase: the two-level side-car is built
@@ -488,7 +504,8 @@ def hybrid_mode() -> str:
                         ``voltrix.spmm`` per (width, dtype) times both forms (3 runs each, one host sync, not capturable in
                         a HIP graph) and keeps the faster, persisted in ``tuned.json`` under the matrix tag + device.
     ``1``               the side-car whenever enough edges sit in shared columns, used unconditionally;  ``0`` never."""
-    v = os.getenv("VOLTRIX_HYBRID", "auto")
+    v = _MODE_OVERRIDE.get()
+    v = os.getenv("VOLTRIX_HYBRID", "auto") if v is None else v
     if v in ("0", "", "off"):
         return "off"
     if v in ("1", "on"):

@@ -399,4 +399,54 @@ inline int csr_transpose(const int* indptr, const int* indices, int num_rows, in
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
+// ----------------------------------------------------------------------------------------------------------------------
+// Cholesky QR of the spectral order's subspace iteration (voltrix/reorder.py::spectral_permutation), the small factor on the
+// device (round 4): gram = X^T X (k x k, k <= 64, fp32) -> out = inv(chol(gram + eps trace(gram) I))^T (fp32), so that
+// X <- X @ out has orthonormal columns.  Rounds 2-3 took the factor on the host with numpy: two device -> host syncs per
+// iteration step.  One workgroup of 64 threads, arithmetic in double in LDS (k = 32: 16 KiB), column-by-column Cholesky
+// (thread j owns row j of the trailing update) and one forward substitution per thread for the inverse.  A pivot that is
+// not positive (rank-deficient subspace) is replaced by eps trace: the column is then a small multiple of noise, which the
+// next deflation / iteration step repairs -- the host form raised instead.
+constexpr int kCholMax = 64;
+
+static __global__ __launch_bounds__(64) void chol_inv_transposed_kernel(const float* __restrict__ gram, const int k,
+                                                                      const double eps, float* __restrict__ out) {
+  __shared__ double a[kCholMax][kCholMax + 1];
+  __shared__ double inv[kCholMax][kCholMax + 1];
+  const int t = threadIdx.x;
+  double trace = 0.0;
+  for (int i = 0; i < k; ++i) trace += (double)gram[i * k + i];
+  if (t < k)
+    for (int c = 0; c < k; ++c) a[t][c] = 0.5 * ((double)gram[t * k + c] + (double)gram[c * k + t]) + (t == c ? eps * trace : 0.0);
+  __syncthreads();
+  for (int j = 0; j < k; ++j) {           // right-looking: after step j column j of `a` holds column j of L
+    const double d = a[j][j] > 0.0 ? a[j][j] : (eps * trace > 0.0 ? eps * trace : 1e-300);
+    const double piv = __builtin_sqrt(d);
+    __syncthreads();
+    if (t == j) a[j][j] = piv;
+    if (t > j && t < k) a[t][j] = a[t][j] / piv;
+    __syncthreads();
+    if (t > j && t < k)
+      for (int c = j + 1; c <= t; ++c) a[t][c] -= a[t][j] * a[c][j];
+    __syncthreads();
+  }
+  // inv(L): thread c solves L x = e_c (x lower triangular column c)
+  if (t < k) {
+    for (int r = 0; r < k; ++r) {
+      double v = (r == t) ? 1.0 : 0.0;
+      for (int m = t; m < r; ++m) v -= a[r][m] * inv[m][t];
+      inv[r][t] = r < t ? 0.0 : v / a[r][r];
+    }
+  }
+  __syncthreads();
+  if (t < k)
+    for (int c = 0; c < k; ++c) out[t * k + c] = (float)inv[c][t];     // transposed
+}
+
+inline int chol_inv_transposed(const float* gram, int k, double eps, float* out, hipStream_t stream) {
+  if (k < 1 || k > kCholMax || gram == nullptr || out == nullptr) return kErrBadShape;
+  hipLaunchKernelGGL(chol_inv_transposed_kernel, dim3(1), dim3(64), 0, stream, gram, k, eps, out);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
 }  // namespace voltrix

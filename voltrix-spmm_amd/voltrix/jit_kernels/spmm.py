@@ -5,6 +5,8 @@ reference's ``model`` 0/1/2; the tuner key adds the feature width, operand dtype
 (the reference keys on the tag alone, so the model picked at the first F is reused for every F -- SURVEY.md
 section 8a quirk 9).
 """
+import contextlib
+import contextvars
 import os
 import warnings
 
@@ -13,6 +15,25 @@ import torch
 from ..jit.compiler import hash_to_hex
 from ..project import TUNE_SPACE_FLAG
 from .tuner import jit_tuner
+
+# Per-context override of VOLTRIX_TUNE_SPACE (library-internal callers such as the spectral reorder run their products with
+# the default tiles whatever the process environment says -- without touching os.environ, which every other thread reads)
+_TUNE_SPACE_OVERRIDE = contextvars.ContextVar("voltrix_tune_space", default=None)
+
+
+def tune_space_mode() -> str:
+    return _TUNE_SPACE_OVERRIDE.get() or os.getenv(TUNE_SPACE_FLAG, "default")
+
+
+@contextlib.contextmanager
+def tune_space(mode: str):
+    """``with tune_space("none"):`` -- VOLTRIX_TUNE_SPACE for the calls of this context (thread / task) only."""
+    token = _TUNE_SPACE_OVERRIDE.set(mode)
+    try:
+        yield
+    finally:
+        _TUNE_SPACE_OVERRIDE.reset(token)
+
 
 includes = ('"voltrix/spmm_kernels.hpp"',)
 template = """
@@ -101,7 +122,7 @@ def tile_space(embedding_dim: int, elem_bytes: int, bf16: bool = False, max_lds:
         points = tuple(p for p in points if p["SCHED"] != SCHED_PAIRS)   # paired units: binary operand only
         points = tuple(p for p in points if _lds_bytes(p["FS"], p["DEPTH"], p["WAVES"], 2, True) <= 160 * 1024
                        and (2 + 32 * p["FS"] * 2 // 1024) * (p["DEPTH"] - 1) <= 63)
-    if (max_lds is not None and not weighted and os.getenv(TUNE_SPACE_FLAG, "default") == "none"
+    if (max_lds is not None and not weighted and tune_space_mode() == "none"
             and len(points) == 1
             and points[0]["EB"] == 2 and (points[0]["FS"] >= 64 or embedding_dim <= points[0]["FS"])):
         # the single untuned point beside a panel workgroup: two units per wave (measured: 1.365 -> 1.293 ms for the pair)
@@ -118,7 +139,7 @@ def tile_space(embedding_dim: int, elem_bytes: int, bf16: bool = False, max_lds:
 
 
 def _tile_space(embedding_dim: int, elem_bytes: int):
-    mode = os.getenv(TUNE_SPACE_FLAG, "default")
+    mode = tune_space_mode()
     fs_max = 128
     fs_fit = 32 if embedding_dim <= 32 else (64 if embedding_dim <= 64 else fs_max)
     if mode == "none":  # the ahead-of-time library's default tile (csrc/capi_common.hpp::default_tile) + unit table
@@ -479,7 +500,7 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
             launches.append(tuple(a))
         return launches, covered / max(1, num_windows)
 
-    staged = os.getenv(TUNE_SPACE_FLAG, "default") != "full"    # "full": every point of the (larger) space, still on the sample
+    staged = tune_space_mode() != "full"    # "full": every point of the (larger) space, still on the sample
 
     def tune(use_store=True):
         return jit_tuner.compile_and_tune(

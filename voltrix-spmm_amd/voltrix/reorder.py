@@ -253,10 +253,9 @@ def spectral_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes:
     eigenvector and a Cholesky QR; the error of the leading vector shrinks like ``(lambda_33 / lambda_2)^steps``, so two dozen
     steps are plenty where single-vector power iteration would need thousands.  Rayleigh-Ritz in the final subspace.  Column
     ids are not relabelled.  Rows without edges go last.  Deterministic for a given ``seed``."""
-    import os
-
+    from . import capi, hybrid
     from .autograd import csr_transpose_device
-    from .project import TUNE_SPACE_FLAG
+    from .jit_kernels import spmm as spmm_wrapper
     from .spmm.spmm import csr_preprocess_device, spmm
 
     import time as _time
@@ -276,10 +275,9 @@ def spectral_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes:
         return (torch.zeros(0, dtype=torch.int64, device=dev), {}) if return_info else torch.zeros(0, dtype=torch.int64, device=dev)
     m = n if num_cols is None else int(num_cols)
     nnz = int(indices.numel())
-    # the products below are plumbing of a one-time preprocess: default tiles, no tuning sweep, no side-car
-    saved = {k: os.environ.get(k) for k in (TUNE_SPACE_FLAG, "VOLTRIX_HYBRID")}
-    os.environ[TUNE_SPACE_FLAG], os.environ["VOLTRIX_HYBRID"] = "none", "0"
-    try:
+    # the products below are plumbing of a one-time preprocess: default tiles, no tuning sweep, no side-car -- as overrides of
+    # THIS context (other threads of the process keep what the environment says; rounds 2-3 rewrote os.environ here)
+    with spmm_wrapper.tune_space("none"), hybrid.mode_override("0"):
         handle = csr_preprocess_device(indptr, indices, n, num_cols=m)
         t_indptr, t_indices = csr_transpose_device(indptr, indices, n, m)
         handle_t = csr_preprocess_device(t_indptr, t_indices, m, num_cols=n)
@@ -307,12 +305,9 @@ def spectral_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes:
         def orthonormalise(x):
             x = x - trivial @ (trivial.T @ x)
             for _ in range(2):                     # Cholesky QR, twice: n x 32 against a 32 x 32 factor
-                gram = x.T @ x
-                gram = gram + 1e-10 * torch.trace(gram) * torch.eye(vectors, device=dev)
-                # the 32 x 32 factor on the host with numpy (one small sync per pass: the device solver's set-up costs a
-                # second, torch's CPU LAPACK path 26 ms per call on a 256-core host)
-                chol = np.linalg.cholesky(gram.double().cpu().numpy())
-                x = x @ torch.from_numpy(np.linalg.inv(chol).T.astype(np.float32)).to(dev)
+                # the small factor on the DEVICE (reorder_kernels.hpp::chol_inv_transposed_kernel, one workgroup, double
+                # arithmetic): no host sync per step (rounds 2-3: numpy on the host, two syncs per step)
+                x = x @ capi.chol_inv_transposed((x.T @ x).contiguous(), 1e-10)
             return x
 
         x = orthonormalise(x)
@@ -361,12 +356,6 @@ def spectral_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes:
         stamp("local refinement")
         info = {"eigenvalues": evals[-4:].flip(0).tolist(), "iterations": iterations, "vectors": vectors, "refine": refine,
                 "phase_ms": {b[0]: round((b[1] - a[1]) * 1e3, 2) for a, b in zip(stamps, stamps[1:])}}
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
     return (perm, info) if return_info else perm
 
 
@@ -388,6 +377,95 @@ def permute_rows_csr(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int
     return new_indptr.to(torch.int32), new_indices.contiguous()
 
 
+# ---- method="auto": candidates judged by the format's own statistics, identity kept unless one clearly pays (round 4) ------
+AUTO_MIN_GAIN = 0.03           # a candidate must cut the format's gather estimate by this much ...
+AUTO_MAX_PANEL_FACTOR = 2.0    # ... without piling the shared columns of hub rows into a few very long panels
+
+
+def order_statistics(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None) -> dict:
+    """What a row order does to the block format, from the COUNT phases of the two preprocess builders only (no handle is
+    built): TC blocks of the window format, the fraction of the edges in columns that >= tau rows of a 512-row panel share,
+    the panel plan's k-steps in all and in its longest panel, and ``score`` -- an estimate of the rows of B one product gathers:
+    TC blocks x (1 - 0.9 x shared fraction) when the two-level side-car would be built (a shared edge costs about a tenth of
+    a residual one), the TC blocks alone otherwise.  One host sync."""
+    from . import capi, hybrid
+
+    dev = indptr.device
+    num_cols = num_nodes if num_cols is None else int(num_cols)
+    stream = torch.cuda.current_stream().cuda_stream
+    windows = (num_nodes + 15) // 16
+    ws = torch.empty(capi.csr_preprocess_workspace_bytes(num_nodes, num_cols, indices.numel()), dtype=torch.uint8, device=dev)
+    part = torch.empty(windows, dtype=torch.int32, device=dev)
+    pointer1 = torch.empty(windows + 1, dtype=torch.int32, device=dev)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    capi.launch_csr_window_count(indptr, indices, num_nodes, num_cols, ws, part, pointer1, status, stream)
+    waves, rb, tau = hybrid.DEFAULT_WAVES, hybrid.DEFAULT_ROW_BLOCKS, hybrid.DEFAULT_TAU
+    plan_ok = (num_cols <= hybrid.MAX_PLAN_COLS and num_nodes > 0
+               and ((num_cols + (1 << 16) - 1) >> 16) * indices.numel() <= hybrid.MAX_PLAN_EDGE_PASSES)
+    if plan_ok:
+        panels = (num_nodes + waves * rb * 16 - 1) // (waves * rb * 16)
+        pws = torch.empty(capi.panel_plan_workspace_bytes(num_nodes, waves, rb), dtype=torch.uint8, device=dev)
+        panel_ptr = torch.empty(panels + 1, dtype=torch.int32, device=dev)
+        resid_ptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+        pstatus = torch.empty(1, dtype=torch.int32, device=dev)
+        capi.check(capi.launch_panel_plan_count(indptr, indices, num_nodes, num_cols, waves, rb, tau, pws, panel_ptr,
+                                                resid_ptr, pstatus, stream), "voltrix_launch_panel_plan_count")
+        longest = (panel_ptr[1:] - panel_ptr[:-1]).max()[None]
+        blocks, outside, ksteps, resid, bad, longest = torch.cat(
+            [pointer1[-1:], status, panel_ptr[-1:], resid_ptr[-1:], pstatus, longest.to(torch.int32)]).tolist()
+        plan_ok = bad == 0
+    else:
+        blocks, outside = torch.cat([pointer1[-1:], status]).tolist()
+        ksteps = resid = longest = 0
+    nnz = int(indices.numel())
+    share = (nnz - resid) / max(1, nnz) if plan_ok else 0.0
+    big = (nnz >= hybrid.AUTO_MIN_EDGES and num_nodes >= hybrid.AUTO_MIN_ROWS
+           and nnz >= hybrid.AUTO_MIN_MEAN_DEGREE * max(1, num_nodes))
+    two_level = plan_ok and big and share >= hybrid.min_shared_fraction()
+    return {"tc_blocks": int(blocks), "shared_fraction": share, "ksteps": int(ksteps), "longest_panel_ksteps": int(longest),
+            "two_level": bool(two_level), "ids_outside_universe": int(outside),
+            "score": float(blocks) * (1.0 - 0.9 * share) if two_level else float(blocks)}
+
+
+def auto_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
+                     candidates=("bfs", "spectral"), info: dict = None):
+    """The safe default: every candidate order is judged by ``order_statistics`` of the row-permuted CSR
+    against the order the caller's rows already have, and the IDENTITY is kept unless a candidate cuts the score by
+    ``AUTO_MIN_GAIN`` (3 %: what fewer TC blocks or more shared edges are worth) without the hub pile-up a degenerate
+    breadth-first order produces (its level order turns into a degree sort on graphs with a background of random edges: the
+    plan's longest panel then holds the shared columns of 512 hub rows and the panel kernel's tail triples the step --
+    5.7 ms against 1.78 ms on the label-shuffled reddit-like graph).  Deterministic: statistics of the
+    format, no timing.  Returns ``(perm or None, name)``; None = keep the caller's order."""
+    report = {"identity": order_statistics(indptr, indices, num_nodes, num_cols)}
+    base = report["identity"]
+    best, best_name, best_score = None, "identity", base["score"]
+    for name in candidates:
+        if name == "bfs":
+            perm = bfs_permutation(indptr, indices, num_nodes, num_cols)
+        elif name == "spectral":
+            if num_nodes < 4 * 8192:        # a one-dimensional embedding of a few thousand rows regroups nothing a window sees
+                continue
+            perm = spectral_permutation(indptr, indices, num_nodes, num_cols, iterations=12)
+        elif name == "degree":
+            perm = degree_permutation_device(indptr, num_nodes)
+        else:
+            raise ValueError(f"unknown candidate order {name!r}")
+        p_indptr, p_indices = permute_rows_csr(indptr, indices, num_nodes, perm)
+        st = order_statistics(p_indptr, p_indices, num_nodes, num_cols)
+        del p_indptr, p_indices
+        per_panel = st["ksteps"] / max(1, (num_nodes + 511) // 512)
+        st["balanced"] = (not st["two_level"]) or st["longest_panel_ksteps"] <= max(
+            AUTO_MAX_PANEL_FACTOR * base["longest_panel_ksteps"], 4.0 * per_panel, 64)
+        st["accepted"] = bool(st["balanced"] and st["score"] <= (1.0 - AUTO_MIN_GAIN) * base["score"]
+                              and st["score"] < best_score)
+        report[name] = st
+        if st["accepted"]:
+            best, best_name, best_score = perm, name, st["score"]
+    if info is not None:
+        info.update(report=report, picked=best_name)
+    return best, best_name
+
+
 @dataclasses.dataclass(eq=False)
 class ReorderedHandle:
     """Reference-format handle of ``A[perm, :]`` + the map that sends its rows back: not a tuple, because the three
@@ -395,7 +473,7 @@ class ReorderedHandle:
     blk_offsets: torch.Tensor
     hspa_packed: torch.Tensor
     hind: torch.Tensor
-    row_map: torch.Tensor        # int32 [16 W]: handle row -> row of C, -1 for the padding rows of the last window
+    row_map: torch.Tensor        # int32 [16 W]: handle row -> row of C, -1 for the padding rows of the last window; None = identity
     perm: torch.Tensor           # int64 [N]
     num_nodes: int
     num_edges: int
@@ -403,14 +481,24 @@ class ReorderedHandle:
 
 
 def csr_preprocess_reordered(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
-                             method="bfs") -> ReorderedHandle:
-    """CSR (CPU or CUDA int32) -> handle of the row-reordered matrix for ``spmm_reordered``.  ``method``: "bfs"
-    (Cuthill-McKee levels, default), "spectral" (Fiedler order of the row co-occurrence matrix, computed with the SpMM
-    kernels: the one that survives a background of random edges), "degree", or an explicit permutation tensor (position k
-    holds row perm[k])."""
+                             method="auto", info: dict = None) -> ReorderedHandle:
+    """CSR (CPU or CUDA int32) -> handle of the row-reordered matrix for ``spmm_reordered``.  ``method``: "auto" (default,
+    round 4: the breadth-first and the spectral order are tried and judged by the format's own statistics; the caller's order
+    is KEPT unless one of them clearly pays -- never worse than no reorder, ``auto_permutation``), "bfs" (Cuthill-McKee
+    levels), "spectral" (Fiedler order of the row co-occurrence matrix, computed with the SpMM kernels: the one that survives a
+    background of random edges), "degree", "identity", or an explicit permutation tensor (position k holds row perm[k]).
+    ``info``: dict that receives the statistics ``auto`` decided on."""
     assert indptr.dtype == torch.int32 and indices.dtype == torch.int32 and indptr.numel() == num_nodes + 1
     indptr_d, indices_d = indptr.contiguous().cuda(), indices.contiguous().cuda()
-    if isinstance(method, torch.Tensor):
+    if method == "auto":
+        perm, name = auto_permutation(indptr_d, indices_d, num_nodes, num_cols, info=info)
+        if perm is None:
+            perm, name = torch.arange(num_nodes, device=indptr_d.device), "auto:identity"
+        else:
+            name = "auto:" + name
+    elif method == "identity":
+        perm, name = torch.arange(num_nodes, device=indptr_d.device), "identity"
+    elif isinstance(method, torch.Tensor):
         perm, name = method.to(indptr_d.device, torch.int64), "given"
         assert perm.numel() == num_nodes and int(torch.sort(perm).values.ne(torch.arange(num_nodes, device=perm.device)).sum()) == 0
     elif method == "bfs":
@@ -421,7 +509,10 @@ def csr_preprocess_reordered(indptr: torch.Tensor, indices: torch.Tensor, num_no
         perm, name = degree_permutation_device(indptr_d, num_nodes), "degree"
     else:
         raise ValueError(f"unknown reorder method {method!r}")
-    p_indptr, p_indices = permute_rows_csr(indptr_d, indices_d, num_nodes, perm)
+    if name.endswith("identity"):
+        p_indptr, p_indices = indptr_d, indices_d
+    else:
+        p_indptr, p_indices = permute_rows_csr(indptr_d, indices_d, num_nodes, perm)
     # the operator's own preprocess: the reference handle of A[perm, :] and, when the (reordered!) graph pays for it, the
     # two-level side-car -- panels are 512 consecutive rows of the NEW order, which is where the reorder put the rows that
     # share columns
@@ -429,8 +520,10 @@ def csr_preprocess_reordered(indptr: torch.Tensor, indices: torch.Tensor, num_no
 
     pointer1, hspa_packed, hind = csr_preprocess_device(p_indptr, p_indices, num_nodes, num_cols)
     padded = 16 * ((num_nodes + 15) // 16)
-    row_map = torch.full((padded,), -1, dtype=torch.int32, device=indptr_d.device)
-    row_map[:num_nodes] = perm.to(torch.int32)
+    row_map = None
+    if not name.endswith("identity"):       # the identity order needs no map: the kernels write C in place
+        row_map = torch.full((padded,), -1, dtype=torch.int32, device=indptr_d.device)
+        row_map[:num_nodes] = perm.to(torch.int32)
     return ReorderedHandle(pointer1, hspa_packed, hind, row_map, perm, num_nodes, int(indices.numel()), name)
 
 
@@ -446,6 +539,9 @@ def spmm_reordered(handle: ReorderedHandle, feat: torch.Tensor, hash_tag: str = 
     num_feats = feat.shape[1]
     from .spmm.spmm import spmm, two_level_of
 
+    if handle.row_map is None:       # identity order (method "auto" kept the caller's rows): the plain operator
+        return spmm(handle.blk_offsets, handle.hspa_packed, handle.hind, num_nodes=handle.num_nodes,
+                    num_edges=handle.num_edges, feat=feat)
     if two_level_of(handle.hspa_packed) is not None:
         # two-level side-car on the reordered rows: the panel kernel writes its panel's rows in place, so the product comes
         # out in the handle's row order and one indexed copy (N x F x 4 bytes each way) puts the rows back
