@@ -77,8 +77,11 @@ def main(argv=None):
                                               device="cuda" if torch.cuda.is_available() else "cpu")
             ip, ix = ip.cpu(), ix.cpu()
             torch.cuda.empty_cache() if torch.cuda.is_available() else None
-            rows = np.repeat(np.arange(ip.numel() - 1, dtype=np.int32), np.diff(ip.numpy()))
-            np.savez(os.path.join(folder, f"{name}.npz"), src_li=rows, dst_li=ix.numpy(), num_nodes=ip.numel() - 1)
+            import scipy.sparse as sp
+
+            n_ = ip.numel() - 1      # a scipy CSR archive (uncompressed): loads without the edge-list -> CSR conversion
+            sp.save_npz(os.path.join(folder, f"{name}.npz"),
+                        sp.csr_matrix((np.ones(ix.numel(), np.int8), ix.numpy(), ip.numpy()), shape=(n_, n_)), compressed=False)
     assert folder and os.path.isdir(folder), "give --datasets_folder (or DATASET_PATH) or --synthetic"
     if not args.append and os.path.exists(args.output_file):
         os.remove(args.output_file)

@@ -234,7 +234,9 @@ int main(int argc, char** argv) {
 
   // ---- 3. the same two-level product as ONE launch: stage records of the residual handle, then spmm_fused (plain stores:
   // ---- no zero fill, no second stream, no combine pass; the residual handle itself is no longer needed afterwards) ----------
-  const int num_waves_total = 8 * num_panels;
+  int fused_waves = 0, fused_row_blocks = 0;
+  voltrix_fused_panel_geometry(&fused_waves, &fused_row_blocks);   // 4 x 8 since round 4: never a constant of the host's own
+  const int num_waves_total = fused_waves * num_panels;
   void* rec_ws = dev_alloc<char>((size_t)voltrix_fused_records_workspace_bytes(n));
   int* wave_ptr = dev_alloc<int>(num_waves_total + 1);
   RC_OK(voltrix_launch_fused_records_count(hr.blk_offsets, hr.hspa_packed, n, rec_ws, wave_ptr, s_main, &rc_));
@@ -247,7 +249,8 @@ int main(int argc, char** argv) {
   HIP_OK(hipMemsetAsync(d_c, 0xFF, (size_t)n * f * sizeof(float), s_main));  // NaN pattern: every element must be written
   const int fused_fs = f <= 32 ? 32 : (f <= 64 ? 64 : 128);
   RC_OK(voltrix_launch_spmm_fused_f16(panel_ptr, panel_cols, panel_bits, panel_order, wave_ptr, records, n, f, d_b, d_c,
-                                      fused_fs, /*depth=*/fused_fs == 128 ? 3 : 4, /*out_scale=*/nullptr, s_main, &rc_));
+                                      fused_fs, /*depth=*/fused_fs == 128 ? 3 : 4, /*pace_blocks=*/0, /*out_scale=*/nullptr,
+                                      s_main, &rc_));
   HIP_OK(hipStreamSynchronize(s_main));
   const double err_fused = max_rel_err(to_host(d_c, (size_t)n * f));
 

@@ -64,10 +64,21 @@ def main():
     ref = torch.sparse_csr_tensor(indptr.long(), indices.long(), torch.ones(indices.numel(), device=dev), size=(n, n)) @ feat.float()
     print(f"random operand: rel err vs torch.sparse.mm (GPU, fp32) {float((out_f - ref).norm() / ref.norm()):.3e}", flush=True)
     os.environ["VOLTRIX_FUSED"] = "1"
+    from voltrix import hybrid
+
     t_f = time_ms(lambda: _run_two_level(two, feat, out_f, None))
+    paced = {}
+    for blocks in (8, 16, 32, 48):
+        hybrid.FUSED_PACE_BLOCKS = blocks
+        _run_two_level(two, ints, out_f, None)
+        torch.cuda.synchronize()
+        same = bool((out_f == out_p).all())                      # pacing is advisory: same bits
+        paced[blocks] = (time_ms(lambda: _run_two_level(two, feat, out_f, None)), same)
+    hybrid.FUSED_PACE_BLOCKS = 0
     os.environ["VOLTRIX_FUSED"] = "0"
     t_p = time_ms(lambda: _run_two_level(two, feat, out_p, None))
-    print(f"one launch {t_f:.4f} ms   pair (round 2) {t_p:.4f} ms", flush=True)
+    print(f"one launch {t_f:.4f} ms   pair {t_p:.4f} ms   one launch paced (sync points: ms, bits equal): "
+          + ", ".join(f"{b}: {t:.4f} {ok}" for b, (t, ok) in paced.items()), flush=True)
 
 
 if __name__ == "__main__":

@@ -225,34 +225,43 @@ void voltrix_launch_spmm_panel_bf16(void* panel_ptr, void* panel_cols, void* pan
                                     int accumulate, int fs, int depth, int waves, int row_blocks, int ksteps,
                                     int slab_policy, void* out_scale, void* stream, int* return_code);
 
-/* The two-level format in ONE launch (spmm_fused_kernels.hpp; round 3).  One 512-thread workgroup per 512-row panel
- * (waves = 8, row_blocks = 4) computes the whole product for its rows: the shared columns from the panel plan (arrays as for
+/* The two-level format in ONE launch (spmm_fused_kernels.hpp; round 3, rebuilt in round 4).  One 256-thread workgroup per
+ * 512-row panel -- four waves, one per SIMD, eight 16-row blocks each; the plan keeps its waves = 8 x row_blocks = 4 layout --
+ * computes the whole product for its rows: the shared columns from the panel plan (arrays as for
  * voltrix_launch_spmm_panel_f16) and the residual edges from per-wave streams of stage records, into the same accumulators;
  * output [num_nodes, embedding_dim] float32 is written once with plain stores (every row; no zero fill, no atomics, no
  * second stream, no combine pass; the summation order is fixed, so results are run-to-run identical).
- *   wave_ptr int32 [8 NP + 1]    first record of (panel p, wave v) at index 8 p + v; wave v owns windows 32 p + 4 v + j, j < 4
+ *   wave_ptr int32 [4 NP + 1]    first record of (panel p, wave v) at index 4 p + v; wave v owns windows 32 p + 8 v + j, j < 8
  *   records  uint32 [R + 1][64]  16-byte aligned; one record = one stage (4 TC blocks = 32 condensed columns) of ONE of the
  *                                wave's windows: words 0..31 rows of `input` (unused columns repeat a real one), 32..47 the
  *                                stage's 16 bitmap words (hspa_packed order), word 48 = j; a wave's records are sorted by
  *                                their first column; one record of padding at the end.  Built from the block-format handle of
  *                                the residual matrix by voltrix_launch_fused_records_* below.
  * Tile: fs in {32,64,128}, depth = slots of the shared panel ring (3, or 4 below fs 128); VOLTRIX_ERR_BAD_CONFIG otherwise.
+ * pace_blocks: 0 / 1 = none; n > 1 (one column slab only) = the workgroups that share an XCD and a dispatch generation wait
+ * for each other at n points of their column sweep (bounded polls on counters the library keeps: advisory, the result never
+ * depends on it) so that an XCD's resident rows sweep the sorted columns together and share gathered rows through its L2.
  * input / out_scale as for voltrix_launch_spmm_panel_f16. */
 void voltrix_launch_spmm_fused_f16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order,
                                    void* wave_ptr, void* records, int num_nodes, int embedding_dim, void* input,
-                                   void* output, int fs, int depth, void* out_scale, void* stream, int* return_code);
+                                   void* output, int fs, int depth, int pace_blocks, void* out_scale, void* stream,
+                                   int* return_code);
 void voltrix_launch_spmm_fused_bf16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order,
                                     void* wave_ptr, void* records, int num_nodes, int embedding_dim, void* input,
-                                    void* output, int fs, int depth, void* out_scale, void* stream, int* return_code);
+                                    void* output, int fs, int depth, int pace_blocks, void* out_scale, void* stream,
+                                   int* return_code);
 
 /* Builder of the stage records above (fused_plan.hpp): block-format handle of the RESIDUAL matrix (the handle of
  * resid_node_pointer / resid_edge_list from the plan builder below, through voltrix_launch_csr_window_count / _fill) ->
  * (wave_ptr, records), in two phases because the caller owns every buffer:
- *   phase 1  voltrix_launch_fused_records_count: wave_ptr int32 [8 NP + 1] (NP = ceil(num_nodes / 512)); workspace:
+ *   phase 1  voltrix_launch_fused_records_count: wave_ptr int32 [4 NP + 1] (NP = ceil(num_nodes / 512)); workspace:
  *            voltrix_fused_records_workspace_bytes(num_nodes) bytes, device, 16-byte aligned
- *   (caller reads R = wave_ptr[8 NP] and allocates records uint32 [(R + 1) * 64], 16-byte aligned)
+ *   (caller reads R = wave_ptr[4 NP] and allocates records uint32 [(R + 1) * 64], 16-byte aligned)
  *   phase 2  voltrix_launch_fused_records_fill: every word of records is written (the padding record is zero).
  * Once the records exist the residual handle is no longer needed by voltrix_launch_spmm_fused_*. */
+/* How the one-launch kernel splits a 512-row panel: waves per workgroup (4) x 16-row blocks per wave (8).  wave_ptr has
+ * waves * NP + 1 entries; hosts size it from THIS call, not from a constant of their own. */
+void voltrix_fused_panel_geometry(int* waves, int* row_blocks);
 int64_t voltrix_fused_records_workspace_bytes(int num_nodes);
 void voltrix_launch_fused_records_count(void* blk_offsets, void* hspa_packed, int num_nodes, void* workspace, void* wave_ptr,
                                         void* stream, int* return_code);

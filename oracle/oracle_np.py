@@ -326,7 +326,7 @@ def panel_to_edges(panel_ptr, panel_cols, panel_bits, num_nodes, waves, row_bloc
 
 
 # ------------------------------------------------------- residual stage records of the one-launch two-level format
-def fused_records(pointer1, hspa_packed, hind, num_nodes, waves=8, row_blocks=4):
+def fused_records(pointer1, hspa_packed, hind, num_nodes, waves=4, row_blocks=8):
     """Definition (plain loops) of the per-wave stage-record stream that ``spmm_fused_kernel`` consumes
     (spmm_fused_kernels.hpp; no reference counterpart): the block-format handle of the RESIDUAL matrix, re-packed.
 
@@ -377,23 +377,25 @@ def fused_records(pointer1, hspa_packed, hind, num_nodes, waves=8, row_blocks=4)
     return wave_ptr, np.stack(records)
 
 
-def fused_records_to_edges(wave_ptr, records, num_nodes, waves=8, row_blocks=4):
-    """Consumer-side interpreter of the record stream (what spmm_fused_kernel's half-stages multiply): sorted (row, col)."""
+def fused_records_to_edges(wave_ptr, records, num_nodes, waves=4, row_blocks=8):
+    """Consumer-side interpreter of the record stream (what one stage of spmm_fused_kernel multiplies: lane (g, R) of the
+    MFMA A operand holds row R of TC block g -- nibble R & 7 of bitmap words 4 g + (R >> 3) (columns 0-3) and 4 g + 2 + (R >> 3)
+    (columns 4-7) -- against the rows of B in words 8 g .. 8 g + 7): sorted (row, col)."""
     edges = []
     for gw in range(len(wave_ptr) - 1):
         for r in range(int(wave_ptr[gw]), int(wave_ptr[gw + 1])):
             rec = records[r]
-            j = int(rec[48]) & 3
-            for half in range(2):
-                for lane in range(64):
-                    g, row16 = lane >> 4, lane & 15
-                    word = int(rec[32 + 8 * half + 4 * (g >> 1) + (row16 >> 3) + 2 * (g & 1)])
+            j = int(rec[48]) & (row_blocks - 1)
+            for lane in range(64):
+                g, row16 = lane >> 4, lane & 15
+                for hi in range(2):
+                    word = int(rec[32 + 4 * g + 2 * hi + (row16 >> 3)])
                     nib = (word >> (4 * (row16 & 7))) & 0xF
                     for i in range(4):
                         if (nib >> i) & 1:
                             row = BLK_H * (row_blocks * gw + j) + row16
                             assert row < num_nodes
-                            edges.append((row, int(rec[16 * half + 4 * g + i])))
+                            edges.append((row, int(rec[8 * g + 4 * hi + i])))
     return sorted(edges)
 
 

@@ -29,6 +29,8 @@ def test_library_exports_every_declared_symbol():
     for name in _declared_functions():
         assert hasattr(lib, name), f"libvoltrix_hip.so does not export {name}"
     assert lib.voltrix_abi_version() == 2
+    from voltrix import hybrid
+    assert capi.fused_panel_geometry() == (hybrid.FUSED_WAVES, hybrid.FUSED_ROW_BLOCKS) == (4, 8)
 
 
 def test_tile_space_enumeration_and_defaults():

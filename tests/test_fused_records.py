@@ -28,11 +28,11 @@ def _check(indptr, indices, n, tau, ncols=None):
     assert np.array_equal(fr.wave_ptr.numpy(), wave_ptr)
     assert np.array_equal(fr.records.view(torch.int32).numpy().view(np.uint32), records)
     assert fr.num_records == len(records) - 1 and not records[-1].any()
-    # every wave's records sweep the columns in order; row blocks 0 .. 3 only
+    # every wave's records sweep the columns in order; row blocks 0 .. 7 only
     for gw in range(len(wave_ptr) - 1):
         first = records[wave_ptr[gw]:wave_ptr[gw + 1], 0].astype(np.int64)
         assert (np.diff(first) >= 0).all()
-    assert (records[:, 48] < 4).all()
+    assert (records[:, 48] < 8).all() and len(wave_ptr) - 1 == 4 * ((n + 511) // 512)
     edges = oracle_np.fused_records_to_edges(wave_ptr, records, n)
     resid = sorted((r, int(c)) for r in range(n) for c in rx.numpy()[ri[r]:ri[r + 1]])
     assert edges == resid

@@ -383,12 +383,14 @@ def test_several_column_slabs_with_and_without_a_unit_table(cuda_device, kind, n
             outs[(order, "table")] = out_t
         outs[(order, "natural")] = out
     torch.cuda.synchronize()
+    ref = torch_ref.spmm(indptr.cpu().numpy(), indices.cpu().numpy(), feat.float().cpu(), n)
     for key, out in outs.items():
         assert not torch.isnan(out).any(), key
-        assert torch.equal(out, outs[("rule", "natural")]), key
-    ref = torch_ref.spmm(indptr.cpu().numpy(), indices.cpu().numpy(), feat.float().cpu(), n)
-    got = outs[("rule", "natural")].cpu()
-    assert torch.linalg.norm(got - ref) / torch.linalg.norm(ref) <= 1e-3
+        got = out.cpu()            # the unit table sums the cut windows' partial tiles in unit order: another fp32 order
+        assert torch.linalg.norm(got - ref) / torch.linalg.norm(ref) <= (1e-3 if kind != "f32" else 1e-6), key
+    if ("rule", "table") in outs:
+        a, b = outs[("rule", "table")], outs[("rule", "natural")]
+        assert float((a - b).norm() / b.norm()) < 1e-5
 
 
 def test_cast_entry_point(cuda_device):

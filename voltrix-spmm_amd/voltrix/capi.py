@@ -36,6 +36,7 @@ SYMBOLS = (
     "voltrix_launch_spmm_panel_bf16",
     "voltrix_launch_spmm_fused_f16",
     "voltrix_launch_spmm_fused_bf16",
+    "voltrix_fused_panel_geometry",
     "voltrix_fused_records_workspace_bytes",
     "voltrix_launch_fused_records_count",
     "voltrix_launch_fused_records_fill",
@@ -269,27 +270,37 @@ def launch_spmm_panel(plan, input_ptr, output_ptr, embedding_dim, accumulate, bf
     return rc.value
 
 
-def launch_spmm_fused(plan, fused, input_ptr, output_ptr, embedding_dim, bf16, tile, out_scale, stream) -> int:
+def launch_spmm_fused(plan, fused, input_ptr, output_ptr, embedding_dim, bf16, tile, out_scale, stream,
+                      pace_blocks: int = 0) -> int:
     """The two-level product in one launch; ``plan`` = voltrix.hybrid.PanelPlan (8 waves x 4 row blocks), ``fused`` =
-    voltrix.hybrid.FusedRecords, ``tile`` = (fs, depth).  Returns the return code."""
+    voltrix.hybrid.FusedRecords (4 waves x 8 row blocks), ``tile`` = (fs, depth), ``pace_blocks`` = sync points per column
+    sweep between the workgroups of an XCD (0: none).  Returns the return code."""
     rc = ctypes.c_int(-1)
     fn = lib().voltrix_launch_spmm_fused_bf16 if bf16 else lib().voltrix_launch_spmm_fused_f16
     order = plan.panel_order.data_ptr() if plan.panel_order is not None else 0
     fn(_ptr(plan.panel_ptr), _ptr(plan.panel_cols), _ptr(plan.panel_bits), ctypes.c_void_p(order), _ptr(fused.wave_ptr),
        _ptr(fused.records), ctypes.c_int(plan.num_nodes), ctypes.c_int(embedding_dim), ctypes.c_void_p(input_ptr),
-       ctypes.c_void_p(output_ptr), ctypes.c_int(tile[0]), ctypes.c_int(tile[1]), ctypes.c_void_p(out_scale),
-       ctypes.c_void_p(stream), ctypes.byref(rc))
+       ctypes.c_void_p(output_ptr), ctypes.c_int(tile[0]), ctypes.c_int(tile[1]), ctypes.c_int(int(pace_blocks)),
+       ctypes.c_void_p(out_scale), ctypes.c_void_p(stream), ctypes.byref(rc))
     return rc.value
+
+
+def fused_panel_geometry():
+    """``(waves, row_blocks)`` of the one-launch kernel's 512-row panel, asked of the library (4 x 8 since round 4)."""
+    waves, row_blocks = ctypes.c_int(0), ctypes.c_int(0)
+    lib().voltrix_fused_panel_geometry(ctypes.byref(waves), ctypes.byref(row_blocks))
+    assert waves.value * row_blocks.value * 16 == 512, (waves.value, row_blocks.value)
+    return waves.value, row_blocks.value
 
 
 def build_fused_records(blk_offsets, hspa_packed, hind, num_nodes: int, stream=None):
     """Stage records of the one-launch kernel through the library's two-phase builder (voltrix/fused_plan.hpp): returns
-    ``(wave_ptr int32 [8 NP + 1], records uint32 [R + 1, 64], R)``.  One host sync."""
+    ``(wave_ptr int32 [waves NP + 1], records uint32 [R + 1, 64], R)``.  One host sync."""
     import torch
 
     dev = blk_offsets.device
     stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
-    num_waves = 8 * ((num_nodes + 511) // 512)
+    num_waves = fused_panel_geometry()[0] * ((num_nodes + 511) // 512)
     workspace = torch.empty(max(16, int(lib().voltrix_fused_records_workspace_bytes(ctypes.c_int(num_nodes)))),
                             dtype=torch.uint8, device=dev)
     wave_ptr = torch.empty(num_waves + 1, dtype=torch.int32, device=dev)
@@ -298,6 +309,7 @@ def build_fused_records(blk_offsets, hspa_packed, hind, num_nodes: int, stream=N
                                              _ptr(wave_ptr), ctypes.c_void_p(stream), ctypes.byref(rc))
     check(rc.value, "voltrix_launch_fused_records_count")
     num_records = int(wave_ptr[-1])   # the sync
+    assert 0 <= num_records <= 4 * (hspa_packed.numel() // 16 + 1), num_records   # at most one record per TC block
     records = torch.empty((num_records + 1, 64), dtype=torch.int32, device=dev).view(torch.uint32)
     lib().voltrix_launch_fused_records_fill(_ptr(blk_offsets), _ptr(hspa_packed), _ptr(hind), ctypes.c_int(num_nodes),
                                             _ptr(wave_ptr), ctypes.c_int64(num_records), _ptr(records),

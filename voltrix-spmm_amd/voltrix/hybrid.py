@@ -35,6 +35,9 @@ DEFAULT_WAVES = 8
 DEFAULT_ROW_BLOCKS = 4
 DEFAULT_TAU = 3
 KSTEP = 32
+# the one-launch kernel's own split of a 512-row panel (spmm_fused_kernels.hpp): four waves (one per SIMD) x eight row blocks
+FUSED_WAVES = 4
+FUSED_ROW_BLOCKS = 8
 
 
 @dataclasses.dataclass
@@ -84,7 +87,7 @@ class TwoLevelHandle:
 class FusedRecords:
     """The residual matrix as per-wave streams of 256-byte stage records for ``spmm_fused_kernel`` (one launch for the
     whole two-level product, spmm_fused_kernels.hpp).  Layout pinned by ``oracle/oracle_np.py::fused_records``."""
-    wave_ptr: torch.Tensor       # int32 [8 NP + 1]: first record of (panel, wave)
+    wave_ptr: torch.Tensor       # int32 [4 NP + 1]: first record of (panel, wave); wave v owns windows 32 p + 8 v + j
     records: torch.Tensor        # uint32 [R + 1, 64] (one record of padding)
     num_records: int
 
@@ -96,7 +99,7 @@ RECORD_WORDS = 64
 
 
 def build_fused_records_torch(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tensor, num_nodes: int,
-                              waves: int = DEFAULT_WAVES, row_blocks: int = DEFAULT_ROW_BLOCKS) -> FusedRecords:
+                              waves: int = FUSED_WAVES, row_blocks: int = FUSED_ROW_BLOCKS) -> FusedRecords:
     """Block-format handle of the residual -> ``FusedRecords`` with torch tensor ops on the handle's device (a stable sort
     of the stages by (wave, first column, row block) + gathers).  The HIP builder (fused_plan.hpp) produces the same bytes;
     this form also runs on the CPU and is what the tests compare both against the plain-loop definition with."""
@@ -155,6 +158,7 @@ def build_fused_records(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hi
     (fused_plan.hpp, two launches around the one host sync that sizes the output); same bytes as
     :func:`build_fused_records_torch` (tests/test_gpu_fused.py)."""
     assert blk_offsets.is_cuda and hspa_packed.is_cuda and hind.is_cuda
+    assert capi.fused_panel_geometry() == (FUSED_WAVES, FUSED_ROW_BLOCKS), "library / package out of step"
     wave_ptr, records, num_records = capi.build_fused_records(blk_offsets, hspa_packed, hind, num_nodes)
     return FusedRecords(wave_ptr=wave_ptr, records=records, num_records=num_records)
 
@@ -444,6 +448,11 @@ def default_fused_tile(embedding_dim: int):
     return (128, 3)
 
 
+# sync points per column sweep between the workgroups of an XCD (spmm_fused_kernels.hpp "pace"); 0 = none.  A module
+# attribute the operator passes down as an argument (experiments set it; nothing is read from the environment at launch).
+FUSED_PACE_BLOCKS = 0
+
+
 def fused_enabled() -> bool:
     """``VOLTRIX_FUSED=1``: run the two-level product as ONE launch (spmm_fused_kernel: plain stores, no zero fill, no
     atomics, no second stream, one fixed summation order) instead of the panel kernel beside the window kernel with the
@@ -454,7 +463,7 @@ def fused_enabled() -> bool:
 
 
 def launch_fused(plan: PanelPlan, fused: FusedRecords, feat: torch.Tensor, output: torch.Tensor, out_scale=None,
-                 tile=None, stream=None) -> None:
+                 tile=None, stream=None, pace_blocks: int = None) -> None:
     """``output = (A_shared + A_resid) @ feat`` in ONE launch (spmm_fused_kernels.hpp): every row of ``output`` is written
     once, plain stores, fixed summation order.  fp16 / bfloat16 ``feat`` [*, F], float32 ``output`` [N, F]."""
     assert feat.is_cuda and feat.is_contiguous() and feat.dtype in (torch.float16, torch.bfloat16)
@@ -464,8 +473,9 @@ def launch_fused(plan: PanelPlan, fused: FusedRecords, feat: torch.Tensor, outpu
     assert output.shape == (plan.num_nodes, f)
     tile = tile or default_fused_tile(f)
     stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    pace_blocks = FUSED_PACE_BLOCKS if pace_blocks is None else pace_blocks
     rc = capi.launch_spmm_fused(plan, fused, feat.data_ptr(), output.data_ptr(), f, feat.dtype == torch.bfloat16, tile,
-                                out_scale.data_ptr() if out_scale is not None else 0, stream)
+                                out_scale.data_ptr() if out_scale is not None else 0, stream, pace_blocks)
     capi.check(rc, "voltrix_launch_spmm_fused")
 
 

@@ -3,7 +3,7 @@
 // Block-format handle of the RESIDUAL matrix (blk_offsets, hspa_packed, hind) -> (wave_ptr, records), bit-identical to the
 // plain-loop definition in oracle/oracle_np.py::fused_records (layout: spmm_fused_kernels.hpp, include/voltrix_capi.h).
 // Two phases around the one host sync the caller needs anyway (the record count sizes the output):
-//   count  one thread per (panel, wave): stages of its four windows (a window whose only TC block is all zero -- the
+//   count  one thread per (panel, wave): stages of its kFusedRowBlocks (8) windows (a window whose only TC block is all zero -- the
 //          reference's empty-window quirk -- has none), then an exclusive scan -> wave_ptr
 //   fill   one wave64 per (panel, wave): its windows' stages merged by first column (ties: lower row block), one 256-byte
 //          record per step written by the 64 lanes: 32 rows of B (columns nobody references and blocks past the window's end

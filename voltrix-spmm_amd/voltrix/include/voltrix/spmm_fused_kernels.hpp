@@ -1,34 +1,43 @@
-// Voltrix-SpMM for MI355X (gfx950) -- the two-level format in ONE launch (round 3).
+// Voltrix-SpMM for MI355X (gfx950) -- the two-level format in ONE launch (round 3; rebuilt in round 4).
 //
-// spmm_panel_kernel + spmm_tc16_pair_kernel ran side by side on two streams and met in C through a zero fill and two
-// float-atomic epilogues.  Here one 512-thread workgroup owns a 512-row panel for the whole
-// product: every wave keeps the accumulators of its four 16-row blocks (128 registers) and feeds them from BOTH halves
-// of the format,
+// spmm_panel_kernel + spmm_tc16_pair_kernel run side by side on two streams and meet in C through a zero fill and two
+// float-atomic epilogues.  Here one workgroup owns a 512-row panel for the whole product: every wave
+// keeps the accumulators of its 16-row blocks in registers and feeds them from BOTH halves of the format,
 //
 //   shared columns    the panel plan (panel_ptr / panel_cols / panel_bits, spmm_panel_kernels.hpp): 32 rows of B gathered
-//                     once per k-step into a ring shared by the workgroup (one s_barrier per k-step), 32 x
-//                     v_mfma_f32_16x16x32_f16 per wave and k-step;
+//                     once per k-step into a ring shared by the workgroup (one s_barrier per k-step), one
+//                     v_mfma_f32_16x16x32_f16 per row block and 16-column slot;
 //   residual columns  the edges the plan left in the reference's window format, re-packed per wave into a stream of
-//                     256-byte STAGE RECORDS (32 condensed columns of ONE of the wave's four windows: 32 rows of B, the
-//                     16 bitmap words, the row block), the wave's four windows merged in column order so that its 64 rows
-//                     sweep the sorted columns together.  A record is consumed in two half-stages of 16 gathered rows
-//                     (4 KiB at FS = 128) through a wave-private ring of three half-slots, v_mfma_f32_16x16x16_f16, no
-//                     barrier;
+//                     256-byte STAGE RECORDS (32 condensed columns of ONE of the wave's windows: 32 rows of B, the 16 bitmap
+//                     words, the row block), the wave's windows merged in column order so that its rows sweep the sorted
+//                     columns together; consumed through a wave-private ring, no barrier;
 //
-// interleaved: every k-step of the panel loop is followed by the wave's share of residual half-stages (spread evenly
-// over the k-steps), so the matrix-core-bound and the gather-bound halves still overlap -- inside one wave now, not
-// between two kernels -- and C is written ONCE with plain stores: no zero fill, no atomics, no second stream, no combine
-// pass, and the result does not depend on any timing (one fixed summation order per row).
+// and C is written ONCE with plain stores: no zero fill, no atomics, no second stream, no combine pass, one fixed
+// summation order per row (run-to-run identical bits).
+//
+// Round 4 geometry.  Round 3 ran 8 waves x 4 row blocks: two waves per SIMD, 128 accumulator registers
+// each, and the residual as HALF stages (16 rows, 4 KiB, K = 16 MFMAs) through 8 rings of 3 x 4 KiB -- twice the
+// wait -> read -> issue round trips per gathered byte of the window kernel, 30-37 GB/s per CU where that kernel does 55
+// (2.03 ms against 1.35 ms for the pair).  Now: FOUR waves x EIGHT row blocks -- one wave per SIMD with the whole register
+// file (256 accumulator registers in the AGPR half, the rest for fragments and addresses), the residual as WHOLE stages
+// (32 rows, 8 KiB, K = 32 MFMAs: the window kernel's own inner loop) through 4 rings of 3 x 8 KiB, every B fragment of a
+// panel k-step read from LDS once per 8 row blocks instead of once per 4.  The plan keeps its 8 x 4 layout: wave v reads the
+// adjacency words of plan waves 2 v and 2 v + 1.
+//
+// Accumulators and the compiler.  A record's row block is data, the accumulators are registers: the residual MFMAs pick
+// one of eight accumulator sets at run time.  Every MFMA of this kernel is inline asm with the accumulator tied in place
+// ("+a": the AGPR file), the eight-way scalar branch of the residual sits INSIDE one asm statement that ties all eight
+// candidate sets -- no control flow the register allocator can see, no copies (a C++ switch around the builtin made hipcc
+// copy every accumulator per step; mixing builtin MFMAs with "+a" asm made it shuttle them between the two halves of the
+// register file).  Hazards the compiler cannot see are padded inside the strings (s_nop 1 after the VALU-written A operand).
 //
 // vmcnt bookkeeping.  The two pipelines issue a data-dependent mix of LDS-DMAs, so no wait count is a compile-time
 // constant.  Every wave counts the vector-memory operations it has issued (`nops`, a scalar) and remembers the count
-// after each group it will wait for (`mark`); "that group has landed" is then s_waitcnt vmcnt(nops - mark), EXACT, picked
-// from the 64 immediates by a scalar binary search (wait_vm): loads retire in issue order, so everything up to the mark is
-// done as soon as at most nops - mark operations are outstanding.  Nothing else in the loop may issue vector memory
-// operations (the ISA listing is checked for that: the loop holds only global_load_lds_* and MFMA / LDS / scalar code).
+// after each group it will wait for (`mark`); "that group has landed" is then s_waitcnt vmcnt(nops - mark), EXACT, through
+// the jump table of wait_vm (spmm_kernels.hpp).  Nothing else in the loop may issue vector memory operations.
 //
-// LDS (FS = 128, DP = 3): panel ring 24 KiB + panel metadata 8 x 2.5 KiB + residual rings 8 x 12 KiB + residual
-// metadata 8 x 1 KiB = 148 KiB: one workgroup per CU, two waves per SIMD with 256 registers each.
+// LDS (FS = 128, DP = 3): panel ring 24 KiB + panel metadata 4 x 5 x 768 B + residual rings 4 x 24 KiB + records 4 x 2 KiB
+// = 143 KiB: one workgroup per CU.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -37,24 +46,22 @@
 
 #include "voltrix/spmm_panel_kernels.hpp"
 
-// Diagnostic builds only (-DVOLTRIX_EXPERIMENTAL, traits.hpp; harness/experiments/exp_fused_diag.py): bit 0 drops the residual half-steps, bit 1 the panel
-// loop (the whole residual then runs barrier-free), bit 2 folds every residual row into the first 1024 rows of B (all L2
-// hits).  Results are wrong by design; shipped kernels use 0.
+// Diagnostic builds only (-DVOLTRIX_EXPERIMENTAL, traits.hpp; harness/experiments/exp_fused_diag.py): bit 0 drops the residual
+// steps, bit 1 the panel loop (the whole residual then runs barrier-free), bit 2 folds every residual row into the first 1024
+// rows of B (all L2 hits).  Results are wrong by design; shipped kernels use 0.
 #ifndef VOLTRIX_FUSED_DIAG
 #define VOLTRIX_FUSED_DIAG 0
 #endif
 
 namespace voltrix {
 
-typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-typedef short short4_t __attribute__((ext_vector_type(4)));
-
-constexpr int kFusedWaves = 8;          // waves per workgroup
-constexpr int kFusedRowBlocks = 4;      // 16-row blocks (= windows) per wave
-constexpr int kFusedPanelRows = kFusedWaves * kFusedRowBlocks * kBlkH;   // 512
+constexpr int kFusedWaves = 4;          // waves per workgroup: one per SIMD
+constexpr int kFusedRowBlocks = 8;      // 16-row blocks (= windows) per wave
+constexpr int kFusedPanelRows = kFusedWaves * kFusedRowBlocks * kBlkH;   // 512 = the plan's 8 x 4 x 16
+constexpr int kFusedPlanWaves = 8;      // the panel plan's own geometry (panel_bits: one word per plan wave and lane)
 constexpr int kRecordWords = 64;        // a residual stage record: 32 hind | 16 bitmap words | row block | pad
 constexpr int kRecordBytes = 4 * kRecordWords;
-constexpr int kRecordBlockWord = 48;    // word holding the record's row block (0 .. 3) inside its wave
+constexpr int kRecordBlockWord = 48;    // word holding the record's row block (0 .. 7) inside its wave
 
 //   FS     feature slab per workgroup (32, 64 or 128 columns of B / C)
 //   DP     slots of the shared panel ring (k-steps of gathered rows in flight per workgroup): 3 or 4
@@ -70,87 +77,123 @@ struct FusedTile {
   static constexpr int SLOTS = FS / 16;
   static constexpr int LANES_PER_ROW = ROW_BYTES / 16;
   static constexpr int ROWS_PER_DMA = 1024 / ROW_BYTES;
-  // ---- panel half (geometry of PanelTile<FS, DP, 8, 4, 1>) ----
-  static constexpr int KSTEP_BYTES = kStageK * ROW_BYTES;
+  // ---- panel half ----
+  static constexpr int KSTEP_BYTES = kStageK * ROW_BYTES;           // 32 gathered rows
   static constexpr int NDMA_P = KSTEP_BYTES / 1024;                 // row DMAs per k-step, shared out over the waves
   static_assert(NDMA_P % WAVES == 0 || WAVES % NDMA_P == 0, "row DMAs per k-step vs waves");
   static constexpr int DPW = NDMA_P >= WAVES ? NDMA_P / WAVES : 1;  // per wave (surplus waves repeat the first ones)
-  static constexpr int META_P_BYTES = 512;                          // 64 adjacency words + 64 column ids (32 used)
+  static constexpr int META_P_BYTES = 768;                          // 2 x 64 adjacency words + 64 column ids (32 used)
   static constexpr int MSP = 2 * DP - 1;                            // metadata slots per wave
+  static constexpr int VM_PER_KSTEP = DPW + 3;
   static constexpr int DATA_P = DP * KSTEP_BYTES;
-  // ---- residual half: half-stages of 16 gathered rows ----
-  static constexpr int DR = 3;                                      // half-slots in the wave-private ring
-  static constexpr int HALF_BYTES = 16 * ROW_BYTES;
-  static constexpr int NDMA_R = HALF_BYTES / 1024;
-  static_assert(NDMA_R >= 1, "a half-stage is at least one 1-KiB DMA");
-  static constexpr int MSR = 4;                                     // record slots per wave
+  // ---- residual half: whole stages of 32 gathered rows ----
+  static constexpr int DR = 3;                                      // stage slots in the wave-private ring
+  static constexpr int STAGE_BYTES = KSTEP_BYTES;
+  static constexpr int NDMA_R = STAGE_BYTES / 1024;
+  static constexpr int REC_AHEAD = DR;                              // record of stage h + DR + REC_AHEAD is fetched at step h
+  static constexpr int MSR = 2 * DR + 2;                            // record slots per wave
   static constexpr int OFF_META_P = DATA_P;
   static constexpr int OFF_RING_R = OFF_META_P + WAVES * MSP * META_P_BYTES;
-  static constexpr int OFF_META_R = OFF_RING_R + WAVES * DR * HALF_BYTES;
+  static constexpr int OFF_META_R = OFF_RING_R + WAVES * DR * STAGE_BYTES;
   static constexpr int BLOCK_LDS = OFF_META_R + WAVES * MSR * kRecordBytes;
   static_assert(BLOCK_LDS <= 160 * 1024, "LDS per CU");
+  // most operations a wave can have in flight: DP - 1 k-steps of the panel pipeline + DR stages and 2 DR records
+  static_assert((DP - 1) * VM_PER_KSTEP + DR * NDMA_R + 2 * DR + 2 <= 63, "vmcnt is a 6-bit counter on gfx9");
 };
 
-// Residual half-slot image: 16 rows; a transposed read touches, per 32-lane half, the 8 rows 8y .. 8y + 7 (lane group g
-// reads rows 4g .. 4g + 3).  Logical 32-byte slot s of row r lives at physical slot s ^ half_swizzle(r): the 8 rows of a
-// half land on distinct bank groups for every FS.
-template <int SLOTS>
-__device__ __forceinline__ constexpr int half_swizzle(int r) {
-  return SLOTS >= 8 ? (r & 7) : (SLOTS == 4 ? ((r >> 1) & 3) : ((r >> 2) & 1));
-}
-
-// one adjacency nibble (4 condensed columns of one row) -> two packed fp16x2 registers holding 2.0 / 0.0
-__device__ __forceinline__ half4_t nibble_to_half4_x2(const unsigned n) {
-  unsigned z;
-  asm("v_lshl_or_b32 %0, %1, 15, %1" : "=v"(z) : "v"(n));
-  uint2_t r;
-  r[0] = (z << 14) & 0x40004000u;  // columns 0, 1
-  r[1] = (z << 12) & 0x40004000u;  // columns 2, 3
-  return __builtin_bit_cast(half4_t, r);
-}
-
-// acc[j][s] += A x B[s] for NS consecutive 16-column slots, j a wave-uniform run-time value in 0 .. 3, on
-// v_mfma_f32_16x16x16_f16 (_bf16).  The accumulators are registers and the row block is data, so one of four register
-// sets has to be picked at run time.  A C++ switch around the builtin made hipcc split the accumulators' live ranges at
-// the join: 128 accumulator registers copied per half-step (1.3 us per half-step and wave instead of 0.2).  Here the
-// four-way scalar branch sits INSIDE one asm statement that ties all four candidate sets in place ("+v"): no control
-// flow the register allocator can see, no copies.  Hazards: the MFMAs of a statement touch different accumulators; the
-// A / B operands come from VALU / LDS results the compiler has already waited for; the next reader of an accumulator
-// (next k-step, a later half-step, the epilogue) is hundreds of cycles and at least one s_waitcnt away.
-#define VOLTRIX_MFMA16(OP, C, B) OP " %" #C ", %[a], %[" #B "], %" #C "\n"
+// ---- MFMAs as inline asm on the accumulator file ------------------------------------------------------------------------
+// acc[s] += A x B[s] for the NS 16-column slots of ONE row block.  s_nop 1: the A operand may have been written by the VALU
+// instruction just before the statement (cdna_hip_programming.md section 5.7 item 2).
+#define VOLTRIX_MF(OP, I) OP " %" #I ", %[a], %[b" #I "], %" #I "\n"
 template <bool BF16>
-__device__ __forceinline__ void mfma16_select4(float4_t (&c0)[4], float4_t (&c1)[4], float4_t (&c2)[4], float4_t (&c3)[4],
-                                               const half4_t a, const uint2_t (&b)[4], const int j) {
-#define VOLTRIX_MFMA16_BODY(OP)                                                                                       \
-  asm volatile("s_cmp_lt_u32 %[j], 2\n s_cbranch_scc1 2f\n s_cmp_eq_u32 %[j], 2\n s_cbranch_scc1 1f\n"              \
-               VOLTRIX_MFMA16(OP, 12, b0) VOLTRIX_MFMA16(OP, 13, b1) VOLTRIX_MFMA16(OP, 14, b2) VOLTRIX_MFMA16(OP, 15, b3) \
-               "s_branch 9f\n1:\n"                                                                                   \
-               VOLTRIX_MFMA16(OP, 8, b0) VOLTRIX_MFMA16(OP, 9, b1) VOLTRIX_MFMA16(OP, 10, b2) VOLTRIX_MFMA16(OP, 11, b3)   \
-               "s_branch 9f\n2:\n s_cmp_eq_u32 %[j], 0\n s_cbranch_scc1 3f\n"                                        \
-               VOLTRIX_MFMA16(OP, 4, b0) VOLTRIX_MFMA16(OP, 5, b1) VOLTRIX_MFMA16(OP, 6, b2) VOLTRIX_MFMA16(OP, 7, b3)     \
-               "s_branch 9f\n3:\n"                                                                                   \
-               VOLTRIX_MFMA16(OP, 0, b0) VOLTRIX_MFMA16(OP, 1, b1) VOLTRIX_MFMA16(OP, 2, b2) VOLTRIX_MFMA16(OP, 3, b3)     \
-               "9:\n"                                                                                                \
-               : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3]), \
-                 "+v"(c2[0]), "+v"(c2[1]), "+v"(c2[2]), "+v"(c2[3]), "+v"(c3[0]), "+v"(c3[1]), "+v"(c3[2]), "+v"(c3[3]) \
-               : [a] "v"(a), [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]), [j] "s"(j)               \
+__device__ __forceinline__ void mfma_block(float4_t (&acc)[8], const half8_t a, const uint4_t (&b)[8]) {
+#define VOLTRIX_BODY(OP)                                                                                                  \
+  asm volatile("s_nop 1\n" VOLTRIX_MF(OP, 0) VOLTRIX_MF(OP, 1) VOLTRIX_MF(OP, 2) VOLTRIX_MF(OP, 3) VOLTRIX_MF(OP, 4)      \
+               VOLTRIX_MF(OP, 5) VOLTRIX_MF(OP, 6) VOLTRIX_MF(OP, 7)                                                       \
+               : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]), "+a"(acc[4]), "+a"(acc[5]), "+a"(acc[6]), "+a"(acc[7]) \
+               : [a] "v"(a), [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]), [b4] "v"(b[4]), [b5] "v"(b[5]), \
+                 [b6] "v"(b[6]), [b7] "v"(b[7]))
+  if constexpr (BF16)
+    VOLTRIX_BODY("v_mfma_f32_16x16x32_bf16");
+  else
+    VOLTRIX_BODY("v_mfma_f32_16x16x32_f16");
+#undef VOLTRIX_BODY
+}
+template <bool BF16>
+__device__ __forceinline__ void mfma_block(float4_t (&acc)[4], const half8_t a, const uint4_t (&b)[4]) {
+#define VOLTRIX_BODY(OP)                                                                                                  \
+  asm volatile("s_nop 1\n" VOLTRIX_MF(OP, 0) VOLTRIX_MF(OP, 1) VOLTRIX_MF(OP, 2) VOLTRIX_MF(OP, 3)                        \
+               : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3])                                                   \
+               : [a] "v"(a), [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]))
+  if constexpr (BF16)
+    VOLTRIX_BODY("v_mfma_f32_16x16x32_bf16");
+  else
+    VOLTRIX_BODY("v_mfma_f32_16x16x32_f16");
+#undef VOLTRIX_BODY
+}
+template <bool BF16>
+__device__ __forceinline__ void mfma_block(float4_t (&acc)[2], const half8_t a, const uint4_t (&b)[2]) {
+#define VOLTRIX_BODY(OP)                                                                                                  \
+  asm volatile("s_nop 1\n" VOLTRIX_MF(OP, 0) VOLTRIX_MF(OP, 1)                                                            \
+               : "+a"(acc[0]), "+a"(acc[1])                                                                               \
+               : [a] "v"(a), [b0] "v"(b[0]), [b1] "v"(b[1]))
+  if constexpr (BF16)
+    VOLTRIX_BODY("v_mfma_f32_16x16x32_bf16");
+  else
+    VOLTRIX_BODY("v_mfma_f32_16x16x32_f16");
+#undef VOLTRIX_BODY
+}
+#undef VOLTRIX_MF
+
+// acc[j][i] += A x B[i], i < 4, for a wave-uniform run-time row block j in 0 .. 7: the eight-way scalar branch inside one
+// statement that ties all 32 candidate accumulators (operand number 4 j + i = c[j][i]).  The MFMAs of a statement touch
+// different accumulators; the next reader of any of them is at least one s_waitcnt away.
+template <bool BF16>
+__device__ __forceinline__ void mfma_select8(float4_t (&c)[8][4], const half8_t a, const uint4_t (&b)[4], const int j) {
+#define VOLTRIX_MS(OP, C, B) OP " %" #C ", %[a], %[" #B "], %" #C "\n"
+#define VOLTRIX_ROW(OP, C0, C1, C2, C3) VOLTRIX_MS(OP, C0, b0) VOLTRIX_MS(OP, C1, b1) VOLTRIX_MS(OP, C2, b2) VOLTRIX_MS(OP, C3, b3)
+#define VOLTRIX_BODY(OP)                                                                                                  \
+  asm volatile("s_nop 1\n"                                                                                                \
+               "s_cmp_lt_u32 %[j], 4\n s_cbranch_scc1 14f\n"                                                              \
+               "s_cmp_lt_u32 %[j], 6\n s_cbranch_scc1 16f\n"                                                              \
+               "s_cmp_eq_u32 %[j], 6\n s_cbranch_scc1 26f\n"                                                              \
+               VOLTRIX_ROW(OP, 28, 29, 30, 31) "s_branch 99f\n"                                                           \
+               "26:\n" VOLTRIX_ROW(OP, 24, 25, 26, 27) "s_branch 99f\n"                                                   \
+               "16:\n s_cmp_eq_u32 %[j], 4\n s_cbranch_scc1 24f\n"                                                        \
+               VOLTRIX_ROW(OP, 20, 21, 22, 23) "s_branch 99f\n"                                                           \
+               "24:\n" VOLTRIX_ROW(OP, 16, 17, 18, 19) "s_branch 99f\n"                                                   \
+               "14:\n s_cmp_lt_u32 %[j], 2\n s_cbranch_scc1 12f\n"                                                        \
+               "s_cmp_eq_u32 %[j], 2\n s_cbranch_scc1 22f\n"                                                              \
+               VOLTRIX_ROW(OP, 12, 13, 14, 15) "s_branch 99f\n"                                                           \
+               "22:\n" VOLTRIX_ROW(OP, 8, 9, 10, 11) "s_branch 99f\n"                                                     \
+               "12:\n s_cmp_eq_u32 %[j], 0\n s_cbranch_scc1 20f\n"                                                        \
+               VOLTRIX_ROW(OP, 4, 5, 6, 7) "s_branch 99f\n"                                                               \
+               "20:\n" VOLTRIX_ROW(OP, 0, 1, 2, 3)                                                                        \
+               "99:\n"                                                                                                    \
+               : "+a"(c[0][0]), "+a"(c[0][1]), "+a"(c[0][2]), "+a"(c[0][3]), "+a"(c[1][0]), "+a"(c[1][1]), "+a"(c[1][2]), \
+                 "+a"(c[1][3]), "+a"(c[2][0]), "+a"(c[2][1]), "+a"(c[2][2]), "+a"(c[2][3]), "+a"(c[3][0]), "+a"(c[3][1]), \
+                 "+a"(c[3][2]), "+a"(c[3][3]), "+a"(c[4][0]), "+a"(c[4][1]), "+a"(c[4][2]), "+a"(c[4][3]), "+a"(c[5][0]), \
+                 "+a"(c[5][1]), "+a"(c[5][2]), "+a"(c[5][3]), "+a"(c[6][0]), "+a"(c[6][1]), "+a"(c[6][2]), "+a"(c[6][3]), \
+                 "+a"(c[7][0]), "+a"(c[7][1]), "+a"(c[7][2]), "+a"(c[7][3])                                               \
+               : [a] "v"(a), [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]), [j] "s"(j)                    \
                : "scc")
   if constexpr (BF16)
-    VOLTRIX_MFMA16_BODY("v_mfma_f32_16x16x16_bf16");
+    VOLTRIX_BODY("v_mfma_f32_16x16x32_bf16");
   else
-    VOLTRIX_MFMA16_BODY("v_mfma_f32_16x16x16_f16");
-#undef VOLTRIX_MFMA16_BODY
+    VOLTRIX_BODY("v_mfma_f32_16x16x32_f16");
+#undef VOLTRIX_BODY
+#undef VOLTRIX_ROW
+#undef VOLTRIX_MS
 }
-#undef VOLTRIX_MFMA16
 
 template <class T>
 struct FusedArgs {
   using in_t = typename std::conditional<T::BF16, bfloat16_bits, _Float16>::type;
   const int* panel_ptr;        // [NP+1]
   const int* panel_cols;       // [32 * (S + 2)]
-  const uint32_t* panel_bits;  // [(S + 1) * 8 * 64]
+  const uint32_t* panel_bits;  // [(S + 1) * 8 * 64]   (the plan's 8 x 4 layout)
   const int* panel_order;      // optional: launch position -> panel (longest first); nullptr = natural
-  const int* wave_ptr;         // [8 NP + 1]: first residual stage record of (panel, wave)
+  const int* wave_ptr;         // [4 NP + 1]: first residual stage record of (panel, wave)
   const uint32_t* records;     // [R + 1][64]
   const in_t* input;
   float* output;
@@ -160,19 +203,18 @@ struct FusedArgs {
   int panels_per_xcd;
   int F;
   int meta_nt;                 // 1: metadata DMAs are non-temporal (one slab covers F: every byte is read once)
-  int* pace;                   // EXPERIMENT (VOLTRIX_FUSED_PACE, exp_fused_pace.py): zeroed int32 [8][kPaceGens][kPaceBlocks]
-                               // arrival counters, or nullptr (shipped).  The workgroups that share an XCD and a dispatch
-                               // generation wait for each other -- bounded, advisory: correctness never depends on it -- at
-                               // pace_blocks points of their column sweep, so that an XCD's 16 k resident rows sweep the
-                               // columns together (the L2-hit lever of DESIGN.md section 3.7)
+  int* pace;                   // optional: zeroed int32 [8][kPaceGens][kPaceBlocks] arrival counters (launcher).  The workgroups
+                               // that share an XCD label and a dispatch generation wait for each other -- bounded, advisory:
+                               // correctness never depends on it -- at pace_blocks points of their column sweep, so that an
+                               // XCD's 16 k resident rows sweep the columns together (the L2-hit lever)
   int pace_blocks;
 };
 constexpr int kPaceGens = 8, kPaceBlocks = 64;
 
 template <class T>
 static __global__ __launch_bounds__(T::THREADS) void spmm_fused_kernel(const FusedArgs<T> a) {
-  constexpr int FS = T::FS, DP = T::DP, MSP = T::MSP, DR = T::DR, MSR = T::MSR, RB = T::RB;
-  constexpr int ROW_BYTES = T::ROW_BYTES, KSTEP_BYTES = T::KSTEP_BYTES, DPW = T::DPW, HALF_BYTES = T::HALF_BYTES;
+  constexpr int DP = T::DP, MSP = T::MSP, DR = T::DR, MSR = T::MSR, RB = T::RB, FS = T::FS;
+  constexpr int ROW_BYTES = T::ROW_BYTES, KSTEP_BYTES = T::KSTEP_BYTES, DPW = T::DPW, STAGE_BYTES = T::STAGE_BYTES;
   constexpr int RPD = T::ROWS_PER_DMA, LPR = T::LANES_PER_ROW, SLOTS = T::SLOTS, NDMA_R = T::NDMA_R;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -191,8 +233,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_fused_kernel(const Fus
   const int ks0 = a.panel_ptr[panel];
   const int nks = (VOLTRIX_FUSED_DIAG & 2) ? 0 : a.panel_ptr[panel + 1] - ks0;
   const int rec0 = a.wave_ptr[panel * T::WAVES + wave];
-  const int nrec = (VOLTRIX_FUSED_DIAG & 1) ? 0 : a.wave_ptr[panel * T::WAVES + wave + 1] - rec0;
-  const int H = 2 * nrec;      // residual half-steps of this wave
+  const int H = (VOLTRIX_FUSED_DIAG & 1) ? 0 : a.wave_ptr[panel * T::WAVES + wave + 1] - rec0;   // residual stages of this wave
 
   float4_t acc[RB][SLOTS];
 #pragma unroll
@@ -203,7 +244,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_fused_kernel(const Fus
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_ptr)smem;
   const unsigned data_p = lds0;
   const unsigned meta_p = lds0 + T::OFF_META_P + (unsigned)wave * (MSP * T::META_P_BYTES);
-  const unsigned ring_r = lds0 + T::OFF_RING_R + (unsigned)wave * (DR * HALF_BYTES);
+  const unsigned ring_r = lds0 + T::OFF_RING_R + (unsigned)wave * (DR * STAGE_BYTES);
   const unsigned meta_r = lds0 + T::OFF_META_R + (unsigned)wave * (MSR * kRecordBytes);
 
   const unsigned row_bytes = (unsigned)F * 2u;
@@ -225,22 +266,26 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_fused_kernel(const Fus
     unsigned long long cb = (unsigned long long)((const char*)a.input + (long long)col * 2);
     asm volatile("" : "+v"(cb));
     cbase_p[d] = (const char*)cb;
-    hr_off_p[d] = 256 + 4 * r;
+    hr_off_p[d] = 512 + 4 * r;
   }
-  const uint32_t* const bits_base = a.panel_bits + ((long long)ks0 * T::WAVES + wave) * kWave;
+  // adjacency words of plan waves 2 wave, 2 wave + 1 (the plan is laid out for 8 waves x 4 row blocks)
+  const uint32_t* const bits_base = a.panel_bits + ((long long)ks0 * kFusedPlanWaves + 2 * wave) * kWave;
   const int* const cols_base = a.panel_cols + (long long)ks0 * kStageK;
-  auto issue_meta_p = [&](const int s, const int ms) {   // k-step s < nks: 2 operations
+  auto issue_meta_p = [&](const int s, const int ms) {   // k-step s < nks: 3 operations
     const unsigned dst = meta_p + (unsigned)ms * T::META_P_BYTES;
     int ml = lane;
     asm volatile("" : "+v"(ml));
+    const uint32_t* const bsrc = bits_base + (long long)s * (kFusedPlanWaves * kWave) + ml;
     if (a.meta_nt) {
-      dma_b32_nt(bits_base + (long long)s * (T::WAVES * kWave) + ml, dst);
-      dma_b32_nt(cols_base + (long long)s * kStageK + ml, dst + 256);
+      dma_b32_nt(bsrc, dst);
+      dma_b32_nt(bsrc + kWave, dst + 256);
+      dma_b32_nt(cols_base + (long long)s * kStageK + ml, dst + 512);
     } else {
-      dma_b32(bits_base + (long long)s * (T::WAVES * kWave) + ml, dst);
-      dma_b32(cols_base + (long long)s * kStageK + ml, dst + 256);
+      dma_b32(bsrc, dst);
+      dma_b32(bsrc + kWave, dst + 256);
+      dma_b32(cols_base + (long long)s * kStageK + ml, dst + 512);
     }
-    nops += 2;
+    nops += 3;
   };
   auto issue_rows_p = [&](const int ms, const int ds) {   // DPW operations
     const unsigned mslot = meta_p + (unsigned)ms * T::META_P_BYTES;
@@ -253,51 +298,55 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_fused_kernel(const Fus
     for (int d = 0; d < DPW; ++d) dma_b128(cbase_p[d] + (unsigned long long)hrow[d] * row_bytes, dst + d * 1024);
     nops += DPW;
   };
-  // transposed B reads of the panel ring (as spmm_panel_kernel)
-  const int trow_p = 8 * g + q4;
-  const int tr_z_p = slot_swizzle<SLOTS>(trow_p);
-  unsigned rd_off_p = trow_p * ROW_BYTES + 8 * p4 + (tr_z_p << 5);
-  int tr_delta_p[3];
+  // transposed B reads (both rings hold the same 32-row image: spmm_kernels.hpp "LDS image")
+  const int trow = 8 * g + q4;
+  const int tr_z = slot_swizzle<SLOTS>(trow);
+  unsigned rd_off = trow * ROW_BYTES + 8 * p4 + (tr_z << 5);
+  int tr_delta[3];
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
-    tr_delta_p[b] = ((tr_z_p >> b) & 1) ? -(32 << b) : (32 << b);
-    asm volatile("" : "+v"(tr_delta_p[b]));
+    tr_delta[b] = ((tr_z >> b) & 1) ? -(32 << b) : (32 << b);
+    asm volatile("" : "+v"(tr_delta[b]));
   }
-  asm volatile("" : "+v"(rd_off_p));
+  asm volatile("" : "+v"(rd_off));
+  // 2 SLOTS asynchronous LDS reads; the fragments are assembled by the caller AFTER its lgkmcnt wait
+  auto read_b_fragments = [&](const unsigned slot_base, uint2_t (&blo)[SLOTS], uint2_t (&bhi)[SLOTS]) {
+    unsigned taddr[SLOTS];
+    taddr[0] = slot_base + rd_off;
+#pragma unroll
+    for (int b = 0; (1 << b) < SLOTS; ++b)
+#pragma unroll
+      for (int s = (1 << b); s < (2 << b) && s < SLOTS; ++s) taddr[s] = taddr[s - (1 << b)] + tr_delta[b];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      blo[s] = lds_read_tr16_b64<0>(taddr[s]);
+      bhi[s] = lds_read_tr16_b64<4 * ROW_BYTES>(taddr[s]);
+    }
+  };
 
   // ======================================================= residual half: lane constants, issue helpers ===========
-  // row DMA i of a half-stage writes LDS rows i * RPD + lane / LPR; the lane's 16 bytes come from column chunk
-  // (lane % LPR) of that row of B, slot-swizzled on the source
-  const char* cbase_r[NDMA_R];
+  // row DMA i of a stage writes LDS rows i * RPD + lane / LPR; the lane's 16 bytes come from column chunk (lane % LPR) of that
+  // row of B, slot-swizzled on the source.  DMAs i and i + 4 (FS = 128) differ by 16 rows: same swizzle, same base pointer.
+  constexpr int NBASE = (NDMA_R == 8 && RPD == 4) ? 4 : NDMA_R;
+  static_assert(NBASE == NDMA_R || slot_swizzle<SLOTS>(4 * RPD + 1) == slot_swizzle<SLOTS>(1), "period of the row swizzle");
+  const char* cbase_r[NBASE];
 #pragma unroll
-  for (int i = 0; i < NDMA_R; ++i) {
+  for (int i = 0; i < NBASE; ++i) {
     const int r = i * RPD + lane / LPR;
     const int c = lane % LPR;
-    int col = fs0 + (((c >> 1) ^ half_swizzle<SLOTS>(r)) * 16) + (c & 1) * 8;
+    int col = fs0 + (((c >> 1) ^ slot_swizzle<SLOTS>(r)) * 16) + (c & 1) * 8;
     col = col < F ? col : fs0;
-    unsigned long long cb = (unsigned long long)((const char*)a.input + (long long)col * 2);
+    unsigned long long cb = (unsigned long long)((const char*)a.input + ((long long)col * 2 - (i & 3) * 1024));
     asm volatile("" : "+v"(cb));
     cbase_r[i] = (const char*)cb;
   }
-  const unsigned id_off_r = 4 * (lane / LPR);   // + 64 * half + 4 * RPD * i: the lane's row of DMA i inside the record
-  // A fragment of v_mfma_f32_16x16x16: lane (R, g) holds row R, condensed columns 4g .. 4g + 3 of the half-stage =
-  // TC block 2 half + (g >> 1), columns 4 (g & 1) ..: nibble R & 7 of bitmap word 4 block + (R >> 3) + 2 (g & 1)
-  const unsigned aw_off_r = 128 + 4 * (4 * (g >> 1) + (R >> 3) + 2 * (g & 1));   // + 32 * half
+  const unsigned id_off_r = 4 * (lane / LPR);   // + 4 RPD i: the lane's row of DMA i inside the record
+  // A fragment: lane (R, g) holds row R of TC block g: nibble R & 7 of bitmap words 4 g + (R >> 3) and 4 g + 2 + (R >> 3)
+  const unsigned aw_off_r = 128 + 4 * (4 * g + (R >> 3));
   const unsigned a_shift = 4 * (R & 7);
-  // transposed B reads: lane (g, q, p) supplies row 4g + q, bytes 8p .. of logical slot s
-  const int trow_r = 4 * g + q4;
-  const int tr_z_r = half_swizzle<SLOTS>(trow_r);
-  unsigned rd_off_r = trow_r * ROW_BYTES + 8 * p4 + (tr_z_r << 5);
-  int tr_delta_r[3];
-#pragma unroll
-  for (int b = 0; b < 3; ++b) {
-    tr_delta_r[b] = ((tr_z_r >> b) & 1) ? -(32 << b) : (32 << b);
-    asm volatile("" : "+v"(tr_delta_r[b]));
-  }
-  asm volatile("" : "+v"(rd_off_r));
 
   const uint32_t* const rec_base = a.records + (long long)rec0 * kRecordWords;
-  auto issue_record = [&](const int s, const int ms) {    // record s < nrec: 1 operation
+  auto issue_record = [&](const int s, const int ms) {    // record s < H: 1 operation
     int ml = lane;
     asm volatile("" : "+v"(ml));
     const uint32_t* const src = rec_base + (long long)s * kRecordWords + ml;
@@ -307,33 +356,39 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_fused_kernel(const Fus
       dma_b32(src, meta_r + (unsigned)ms * kRecordBytes);
     nops += 1;
   };
-  // rows of half-stage (record in slot ms, half hh) into ring slot rs; ids[] = the lane's rows, read from the record
-  auto read_ids = [&](const int ms, const int hh, unsigned (&ids)[NDMA_R]) {
-    const unsigned base = meta_r + (unsigned)ms * kRecordBytes + id_off_r + 64u * (unsigned)hh;
-#pragma unroll
-    for (int i = 0; i < NDMA_R; ++i) ids[i] = lds_read_b32(base + 4 * RPD * i);
+  auto read_ids = [&](const int ms, int (&ids)[NDMA_R]) {   // the lane's rows of B for the NDMA_R DMAs of the record in slot ms
+    lds_read_b32_strided<4 * RPD>(meta_r + (unsigned)ms * kRecordBytes + id_off_r, ids, std::make_integer_sequence<int, NDMA_R>{});
   };
-  auto fold_ids = [&](unsigned (&ids)[NDMA_R]) {
-    if (VOLTRIX_FUSED_DIAG & 4) {
+  auto issue_stage = [&](const int rs, const int (&ids)[NDMA_R]) {   // NDMA_R operations
+    const unsigned dst = ring_r + (unsigned)rs * STAGE_BYTES;
+    auto piece = [&](auto kc, int ib) {           // DMA number ib + K of the stage, K = 0 .. 3 sharing one M0
+      constexpr int K = decltype(kc)::value;
+      if constexpr (K < NDMA_R) {
+        const int i = ib + K;
+        unsigned hrow = (unsigned)ids[i];
+        if (VOLTRIX_FUSED_DIAG & 4) hrow &= 1023u;
+        const char* src = cbase_r[i % NBASE] + (unsigned long long)hrow * row_bytes;
+        __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(uintptr_t)(dst + ib * 1024), 16, K * 1024, 0);
+      }
+    };
 #pragma unroll
-      for (int i = 0; i < NDMA_R; ++i) ids[i] &= 1023u;
+    for (int ib = 0; ib < NDMA_R; ib += 4) {
+      piece(std::integral_constant<int, 0>{}, ib);
+      piece(std::integral_constant<int, 1>{}, ib);
+      piece(std::integral_constant<int, 2>{}, ib);
+      piece(std::integral_constant<int, 3>{}, ib);
     }
-  };
-  auto issue_half = [&](const int rs, const unsigned (&ids)[NDMA_R]) {   // NDMA_R operations
-    const unsigned dst = ring_r + (unsigned)rs * HALF_BYTES;
-#pragma unroll
-    for (int i = 0; i < NDMA_R; ++i) dma_b128(cbase_r[i] + (unsigned long long)ids[i] * row_bytes, dst + i * 1024);
     nops += NDMA_R;
   };
 
   // ======================================================= prologue ===============================================
-  // panel: metadata of k-steps 0 .. DP-2; residual: records 0 .. 2; then the first rows of both rings
+  // panel: metadata of k-steps 0 .. DP-2; residual: records 0 .. 2 DR - 1; then the first rows of both rings
 #pragma unroll
   for (int s = 0; s < DP - 1; ++s)
     if (s < nks) issue_meta_p(s, s % MSP);
 #pragma unroll
-  for (int s = 0; s < 3; ++s)
-    if (s < nrec) issue_record(s, s % MSR);
+  for (int s = 0; s < 2 * DR; ++s)
+    if (s < H) issue_record(s, s % MSR);
   wait_vmcnt<0>();
   __builtin_amdgcn_sched_barrier(0);
 
@@ -344,105 +399,97 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_fused_kernel(const Fus
     if (s + DP - 1 < nks) issue_meta_p(s + DP - 1, (s + DP - 1) % MSP);
     mark_p[s] = nops;
   }
-  int mark_r[DR];       // mark_r[i]: nops after the refill that filled the half-stage consumed i steps from now
+  int mark_r[DR];       // mark_r[i]: nops after the refill that filled the stage consumed i steps from now
 #pragma unroll
   for (int h0 = 0; h0 < DR; ++h0) {
     if (h0 < H) {
-      unsigned ids[NDMA_R];
-      read_ids((h0 >> 1) % MSR, h0 & 1, ids);
+      int ids[NDMA_R];
+      read_ids(h0 % MSR, ids);
       wait_lgkmcnt0();
-      fold_ids(ids);
-      issue_half(h0, ids);
+      issue_stage(h0, ids);
     }
     mark_r[h0] = nops;
   }
 
-  // ======================================================= one residual half-step =================================
-  int h = 0;            // next half-step
+  // ======================================================= one residual step = one whole stage ====================
+  // Invariant at the top of step h: the rows of stages h .. h + DR - 1 and the records up to h + 2 DR - 1 are issued (as far as
+  // they exist), and every record r was issued BEFORE the rows of stage r - DR -- so waiting for the rows of stage h (the
+  // oldest thing this step needs) also covers the record of stage h + DR, whose rows this step issues.  Step h therefore
+  // issues, in this order, record h + 2 DR (into the slot record h - 2 left two steps ago) and then the rows of stage h + DR
+  // (into the ring slot it has just read).
+  int h = 0;            // next stage
   int rs_h = 0;         // h % DR
-  int ms_h = 0;         // (h >> 1) % MSR
-  int hh_h = 0;         // h & 1
+  int ms_h = 0;         // h % MSR
   auto resid_step = [&]() {
-    wait_vm(nops - mark_r[0]);                 // rows of half-stage h (and every record fetched before them)
+    wait_vm(nops - mark_r[0]);
     const unsigned rec = meta_r + (unsigned)ms_h * kRecordBytes;
     const unsigned jw = lds_read_b32(rec + 4 * kRecordBlockWord);
-    const unsigned aword = lds_read_b32(rec + aw_off_r + 32u * (unsigned)hh_h);
+    const unsigned wlo = lds_read_b32(rec + aw_off_r);
+    const unsigned whi = lds_read_b32(rec + aw_off_r + 8);
     const bool refill = h + DR < H;            // wave-uniform
-    // half-stage h + 3: record (h + 3) >> 1 = s + 1 (h even) or s + 2 (h odd), half (h + 3) & 1
-    const int ms_n = (ms_h + 1 + hh_h) % MSR;
-    unsigned ids[NDMA_R];
-    if (refill) read_ids(ms_n, hh_h ^ 1, ids);
-    unsigned taddr[SLOTS];
-    taddr[0] = ring_r + (unsigned)rs_h * HALF_BYTES + rd_off_r;
-#pragma unroll
-    for (int b = 0; (1 << b) < SLOTS; ++b)
-#pragma unroll
-      for (int s = (1 << b); s < (2 << b) && s < SLOTS; ++s) taddr[s] = taddr[s - (1 << b)] + tr_delta_r[b];
-    uint2_t bf[SLOTS];
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) bf[s] = lds_read_tr16_b64<0>(taddr[s]);
+    int ids[NDMA_R];
+    read_ids((ms_h + DR) % MSR, ids);          // unconditional (a conditional read makes the compiler zero-fill ids[] every step;
+                                               // past the end the slot holds an older record: finite ids, never used)
+    uint2_t blo[SLOTS], bhi[SLOTS];
+    read_b_fragments(ring_r + (unsigned)rs_h * STAGE_BYTES, blo, bhi);
     wait_lgkmcnt0();
-    // the record three ahead (once per record, on its first half), then the rows of half-stage h + 3 into the slot just read
-    if (hh_h == 0 && (h >> 1) + 3 < nrec) issue_record((h >> 1) + 3, (ms_h + 3) % MSR);
-    if (refill) {
-      fold_ids(ids);
-      issue_half(rs_h, ids);
-    }
+    if (h + 2 * DR < H) issue_record(h + 2 * DR, (ms_h + 2 * DR) % MSR);
+    if (refill) issue_stage(rs_h, ids);
 #pragma unroll
     for (int i = 0; i < DR - 1; ++i) mark_r[i] = mark_r[i + 1];
     mark_r[DR - 1] = nops;
 
-    const half4_t afrag = nibble_to_half4_x2((aword >> a_shift) & 0xFu);
-    const int j = __builtin_amdgcn_readfirstlane((int)jw) & 3;
-    // The row block is run-time data, the accumulators are registers: a wave-uniform switch picks the set.  The MFMAs are
-    // inline asm with the accumulator tied in place ("+v"): with the builtin, hipcc wrote each case's results to fresh
-    // registers and re-joined the four paths by copying all 128 accumulator registers every half-step (1.3 us per
-    // half-step and wave instead of 0.2).  Hazards: the eight MFMAs of a case touch eight different accumulators, and the
-    // next reader of any of them (the next k-step's MFMAs, a later half-step, the epilogue) is hundreds of cycles away,
-    // behind at least one s_waitcnt -- no software wait states are needed around the block.
-    // slots in groups of four (FS = 32: the two slots twice -- the second pair of accumulators / fragments is a scratch copy)
+    const half8_t afrag = nibbles_to_half8_x2((wlo >> a_shift) & 0xFu, (whi >> a_shift) & 0xFu);
+    const int j = __builtin_amdgcn_readfirstlane((int)jw) & 7;
+    uint4_t bq[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) bq[s] = uint4_t{blo[s][0], blo[s][1], bhi[s][0], bhi[s][1]};
     if constexpr (SLOTS >= 4) {
 #pragma unroll
       for (int s0 = 0; s0 < SLOTS; s0 += 4) {
-        float4_t(&c0)[4] = reinterpret_cast<float4_t(&)[4]>(acc[0][s0]);
-        float4_t(&c1)[4] = reinterpret_cast<float4_t(&)[4]>(acc[1][s0]);
-        float4_t(&c2)[4] = reinterpret_cast<float4_t(&)[4]>(acc[2][s0]);
-        float4_t(&c3)[4] = reinterpret_cast<float4_t(&)[4]>(acc[3][s0]);
-        const uint2_t(&bq)[4] = reinterpret_cast<const uint2_t(&)[4]>(bf[s0]);
-        mfma16_select4<T::BF16>(c0, c1, c2, c3, afrag, bq, j);
-      }
-    } else {
-      float4_t c[4][4];
-      uint2_t bq[4] = {bf[0], bf[1], bf[0], bf[1]};
+        float4_t c[8][4];
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) c[jj][i] = acc[jj][s0 + i];
+        const uint4_t b4[4] = {bq[s0], bq[s0 + 1], bq[s0 + 2], bq[s0 + 3]};
+        mfma_select8<T::BF16>(c, afrag, b4, j);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[jj][s0 + i] = c[jj][i];
+      }
+    } else {   // FS = 32: two slots; the second pair of every row is a scratch copy
+      float4_t c[8][4];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
         c[jj][0] = acc[jj][0];
         c[jj][1] = acc[jj][1];
         c[jj][2] = c[jj][3] = float4_t{0.f, 0.f, 0.f, 0.f};
       }
-      mfma16_select4<T::BF16>(c[0], c[1], c[2], c[3], afrag, bq, j);
+      const uint4_t b4[4] = {bq[0], bq[1], bq[0], bq[1]};
+      mfma_select8<T::BF16>(c, afrag, b4, j);
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
+      for (int jj = 0; jj < 8; ++jj) {
         acc[jj][0] = c[jj][0];
         acc[jj][1] = c[jj][1];
       }
     }
     ++h;
     rs_h = rs_h + 1 == DR ? 0 : rs_h + 1;
-    ms_h = hh_h ? (ms_h + 1 == MSR ? 0 : ms_h + 1) : ms_h;
-    hh_h ^= 1;
+    ms_h = ms_h + 1 == MSR ? 0 : ms_h + 1;
   };
 
-  // ======================================================= panel loop: one k-step + this wave's share of half-steps ==
+  // ======================================================= panel loop: one k-step + this wave's share of stages ====
   if (nks > 0) {
-    // half-steps spread evenly over the k-steps: q_t = base (+ 1 whenever the remainder accumulator wraps)
+    // stages spread evenly over the k-steps: q_t = base (+ 1 whenever the remainder accumulator wraps)
     const int q_base = H / nks, q_rem = H - q_base * nks;
     int q_err = 0;
     int ds_t = 0, ms_t = 0;                               // k-step t
     int ds_r = (DP - 1) % DP, ms_r = (DP - 1) % MSP;      // k-step t + DP - 1 (rows issued this iteration)
     int ms_m = (2 * DP - 2) % MSP;                        // k-step t + 2 DP - 2 (metadata issued this iteration)
-    // pacing (experiment): this workgroup's cohort = the workgroups of its XCD label in its dispatch generation (32 per XCD
-    // fit at one per CU); sync point b sits at iteration ceil(b nks / blocks)
+    // pacing: this workgroup's cohort = the workgroups of its XCD label in its dispatch generation (32 per XCD fit at one per
+    // CU); sync point b sits at iteration ceil(b nks / blocks)
     const int pace_gen = (int)(blockIdx.x / kNumXcd) / 32;
     const int pace_members = pos_end - (xcd * a.panels_per_xcd + 32 * pace_gen) < 32
                                  ? pos_end - (xcd * a.panels_per_xcd + 32 * pace_gen) : 32;
@@ -452,7 +499,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_fused_kernel(const Fus
         if (wave == 0 && lane == 0) {
           int* const cnt = a.pace + ((xcd * kPaceGens + pace_gen) * kPaceBlocks + pace_b);
           __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          for (int spin = 0; spin < 64; ++spin) {             // bounded: at most 64 polls (~0.1 ms), then go on regardless
+          for (int spin = 0; spin < 64; ++spin) {             // bounded: at most 64 polls, then go on regardless
             if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= pace_members) break;
             __builtin_amdgcn_s_sleep(8);
           }
@@ -474,9 +521,8 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_fused_kernel(const Fus
       for (int i = 0; i < DP - 2; ++i) mark_p[i] = mark_p[i + 1];
       mark_p[DP - 2] = nops;
 
-      // this iteration's half-steps: half of them before the k-step's matrix work, half after it, so that the wave comes
-      // back to its residual ring twice per k-step (a ring slot can only be refilled when its half-stage is consumed; all
-      // half-steps behind the k-step left the ring idle for most of the iteration: 2.67 ms against 1.35 ms for the pair)
+      // this iteration's stages: half of them before the k-step's matrix work, half after it, so that the wave comes back
+      // to its residual ring twice per k-step (a ring slot can only be refilled when its stage is consumed)
       int q = q_base;
       q_err += q_rem;
       if (q_err >= nks) {
@@ -487,39 +533,25 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_fused_kernel(const Fus
       for (int s = 0; s < q_pre && h < H; ++s) resid_step();
 
       const unsigned mt = meta_p + (unsigned)ms_t * T::META_P_BYTES;
-      const unsigned dt = data_p + (unsigned)ds_t * KSTEP_BYTES + rd_off_p;
+      const unsigned dt = data_p + (unsigned)ds_t * KSTEP_BYTES;
       ds_t = ds_t + 1 == DP ? 0 : ds_t + 1;
       ds_r = ds_r + 1 == DP ? 0 : ds_r + 1;
       ms_t = ms_t + 1 == MSP ? 0 : ms_t + 1;
       ms_r = ms_r + 1 == MSP ? 0 : ms_r + 1;
       ms_m = ms_m + 1 == MSP ? 0 : ms_m + 1;
       {
-        const unsigned aw = lds_read_b32(mt + 4 * lane);
-        unsigned taddr[SLOTS];
-        taddr[0] = dt;
-#pragma unroll
-        for (int b = 0; (1 << b) < SLOTS; ++b)
-#pragma unroll
-          for (int s = (1 << b); s < (2 << b) && s < SLOTS; ++s) taddr[s] = taddr[s - (1 << b)] + tr_delta_p[b];
+        const unsigned aw0 = lds_read_b32(mt + 4 * lane);            // row blocks 0 .. 3 (plan wave 2 wave)
+        const unsigned aw1 = lds_read_b32(mt + 256 + 4 * lane);      // row blocks 4 .. 7 (plan wave 2 wave + 1)
         uint2_t blo[SLOTS], bhi[SLOTS];
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-          blo[s] = lds_read_tr16_b64<0>(taddr[s]);
-          bhi[s] = lds_read_tr16_b64<4 * ROW_BYTES>(taddr[s]);
-        }
+        read_b_fragments(dt, blo, bhi);
         wait_lgkmcnt0();
+        uint4_t bq[SLOTS];
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) bq[s] = uint4_t{blo[s][0], blo[s][1], bhi[s][0], bhi[s][1]};
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
-          const half8_t afrag = adjacency_to_half8_x2(aw, 4 * j);
-#pragma unroll
-          for (int s = 0; s < SLOTS; ++s) {
-            const uint4_t bq = {blo[s][0], blo[s][1], bhi[s][0], bhi[s][1]};
-            if constexpr (T::BF16)
-              acc[j][s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, afrag),
-                                                                  __builtin_bit_cast(bf16x8_t, bq), acc[j][s], 0, 0, 0);
-            else
-              acc[j][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, __builtin_bit_cast(half8_t, bq), acc[j][s], 0, 0, 0);
-          }
+          const half8_t afrag = adjacency_to_half8_x2(j < 4 ? aw0 : aw1, 4 * (j & 3));
+          mfma_block<T::BF16>(acc[j], afrag, bq);
         }
       }
       for (int s = q_pre; s < q && h < H; ++s) resid_step();
@@ -528,6 +560,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_fused_kernel(const Fus
   // ======================================================= what is left of the residual (no barriers) ==============
   while (h < H) resid_step();
   wait_vmcnt<0>();  // nothing of this wave may still be writing LDS when the workgroup's LDS is released
+  asm volatile("s_nop 15\n s_nop 15" ::: "memory");   // the last MFMAs' results -> the epilogue's accumulator reads
 
   // ======================================================= epilogue: C written once, plain stores ====================
   const float oscale = kAScaleInv * (a.out_scale ? *a.out_scale : 1.0f);
@@ -547,12 +580,12 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_fused_kernel(const Fus
 }
 
 // Host launcher.  The plan arrays are padded as the builders pad them: panel_cols by 2 k-steps, panel_bits by one k-step,
-// records by one record.
+// records by one record.  pace_blocks: sync points per column sweep between the workgroups of an XCD (0 / 1: none).
 template <class T>
 inline int launch_spmm_fused(const int* panel_ptr, const int* panel_cols, const uint32_t* panel_bits,
                              const int* panel_order, const int* wave_ptr, const uint32_t* records, int num_nodes,
                              int embedding_dim, const void* input, float* output, const float* out_scale,
-                             hipStream_t stream, int pace_blocks = 0 /* sync points per column sweep (0: none) */) {
+                             hipStream_t stream, int pace_blocks = 0) {
   if (num_nodes < 0 || embedding_dim < 0) return kErrBadShape;
   if (num_nodes == 0 || embedding_dim == 0) return kOk;
   if (embedding_dim % 8 != 0 || ((uintptr_t)input & 15) || ((uintptr_t)records & 15)) return kErrBadShape;

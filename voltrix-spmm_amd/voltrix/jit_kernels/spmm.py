@@ -170,16 +170,18 @@ def _tile_space(embedding_dim: int, elem_bytes: int):
 
 # ---- the bounded sweep (round 4) ----------------------------------------------------------------------
 SAMPLE_MIN_WINDOWS = 1 << 14     # below this many windows the sweep times the whole handle
-SAMPLE_CHUNKS = 4                # contiguous window ranges of the sample, spread over the handle
+SAMPLE_CHUNKS = 2                # contiguous window ranges of the sample (at 1/4 and 3/4 of the handle)
 SAMPLE_FRACTION = 16             # 1 / this of the windows in all
 
 
 def sample_ranges(num_windows: int):
     """Window ranges ``[(w0, w1)]`` the sweep times its candidates on: the whole handle when it is small, else
     ``SAMPLE_CHUNKS`` contiguous ranges centred at (2 k + 1) / (2 SAMPLE_CHUNKS) of the windows, 1 / ``SAMPLE_FRACTION`` of
-    them in all.  A contiguous range of a block-format handle is itself a handle (``blk_offsets[w0 : w1 + 1]`` holds absolute
-    TC-block offsets into the same ``hspa_packed`` / ``hind``), so a sample launch is the SAME kernel with a shifted
-    pointer, fewer rows and its own schedule arrays: nothing is copied."""
+    them in all (few, long launches: a launch's drained tail is what distorts a sample -- four ranges of 1/64 ranked the
+    power-law graph's tiles 4 % off, profiles/r04/experiment_tuner_sample_powerlaw_v1.log).  A contiguous range of a
+    block-format handle is itself a handle (``blk_offsets[w0 : w1 + 1]`` holds absolute TC-block offsets into the same
+    ``hspa_packed`` / ``hind``), so a sample launch is the SAME kernel with a shifted pointer, fewer rows and its own schedule
+    arrays: nothing is copied."""
     if num_windows <= SAMPLE_MIN_WINDOWS:
         return [(0, num_windows)]
     size = max(SAMPLE_MIN_WINDOWS // (2 * SAMPLE_CHUNKS), num_windows // (SAMPLE_FRACTION * SAMPLE_CHUNKS))
@@ -191,18 +193,15 @@ def sample_ranges(num_windows: int):
     return out
 
 
-def sweep_stages(space, best=None):
-    """The two stages of the bounded sweep.  Stage 1 (``best`` None): one candidate per tile SHAPE (FS, DEPTH, WAVES), each
-    with the most robust schedule its operand type has -- the unit table for 16-bit operands (balanced on every graph
-    measured: tails 0.7-1.7 %), the chunk-512 balance schedule for fp32 ones -- so that shapes are compared on equal terms.
-    Stage 2: the other schedules of the winning shape (natural order, balance chunks 512 / 2048, two units per wave; chunk 128
-    never won a sweep and is left to ``VOLTRIX_TUNE_SPACE=full``).  default space: 8 + 4 = 12 candidates instead of 44."""
+def sweep_stages(space, best=None, stage_no=0):
+    """The stages of the bounded sweep (<= 12 candidates of the default space's 44).
+    Stage 0: one candidate per (FS, WAVES) at the SHALLOWEST ring, each with the most robust schedule its operand type has --
+    the unit table for 16-bit operands (balanced on every graph measured: tails 0.7-1.7 %), the chunk-512 balance schedule
+    for fp32 ones -- so that shapes are compared on equal terms.  Stage 1: the other schedules of the winning shape (natural
+    order, balance chunks 512 / 2048, two units per wave; chunk 128 never won a sweep and is left to
+    ``VOLTRIX_TUNE_SPACE=full``).  Stage 2: the winner at the other ring depths."""
     def shape(p):
-        return (p["FS"], p["DEPTH"], p["WAVES"], p["EB"])
-
-    shapes = {}
-    for p in space:
-        shapes.setdefault(shape(p), []).append(p)
+        return (p["FS"], p["WAVES"], p["EB"])
 
     def robust(points):
         for pref in (SCHED_UNITS, 2, 0):
@@ -212,15 +211,41 @@ def sweep_stages(space, best=None):
         return points[0]
 
     if best is None:
-        return [robust(points) for points in shapes.values()]
-    points = shapes[shape(best)]
-    first = robust(points)
-    return [p for p in points if p is not first and p["SCHED"] != 1]
+        shapes = {}
+        for p in space:
+            shapes.setdefault(shape(p), []).append(p)
+        out = []
+        for points in shapes.values():
+            depth = min(p["DEPTH"] for p in points)
+            out.append(robust([p for p in points if p["DEPTH"] == depth]))
+        return out
+    if stage_no == 1:
+        return [p for p in space if shape(p) == shape(best) and p["DEPTH"] == best["DEPTH"] and p["SCHED"] not in (best["SCHED"], 1)]
+    if stage_no == 2:
+        return [p for p in space if shape(p) == shape(best) and p["SCHED"] == best["SCHED"] and p["DEPTH"] != best["DEPTH"]]
+    return []
 
 
 def sweep_budget_s(step_s: float) -> float:
     """Wall-clock cap of one sweep: max(2 s, 20 x the full-size step)."""
     return max(2.0, 20.0 * step_s)
+
+
+def sweep_bench(fn) -> float:
+    """Milliseconds per run of ``fn`` for the sweep: median of 3 batches of 4 back-to-back runs, one event pair per batch, after
+    one warm-up (a host sync after every single launch lets the clocks drop between launches and reads 10-15 % high on
+    MI355X; the reference's per-run cache flush, utils.py:277-281, prices a cold cache no steady-state caller sees)."""
+    fn()
+    times = []
+    for _ in range(3):
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        for _ in range(4):
+            fn()
+        end.record()
+        end.synchronize()
+        times.append(start.elapsed_time(end) / 4)
+    return sorted(times)[1]
 
 
 def window_order(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, num_nodes: int, sched: int = 1) -> torch.Tensor:
@@ -512,6 +537,7 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
             template=template,
             args=tune_args,
             kernel_tag="spmm",
+            bench=sweep_bench,
             bucket_keys=lambda: graph_bucket_keys(blk_offsets, num_nodes, keys),
             use_store=use_store,
             sample_args=sample_args,

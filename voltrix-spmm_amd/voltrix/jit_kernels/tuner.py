@@ -132,9 +132,9 @@ class JITTuner:
         bucket's choice and runs no sweep: one build (a cache hit when the kernel exists on disk), no launch at all (the
         caller's first real launch validates it; ``use_store=False`` after such a launch failed).
         ``sample_args`` (called only when a sweep runs) -> ``(list of argument tuples, fraction)``: every candidate is run and
-        timed on those launches instead of ``args`` (``fraction`` of the full work, for the budget).  ``stages(space, best)``
-        -> the candidates of the first stage (``best`` None) / of the second stage (``best`` = the first stage's winner);
-        None = every point of ``space``.  ``budget_s(estimated full-size step in seconds)`` -> wall-clock cap of the sweep."""
+        timed on those launches instead of ``args`` (``fraction`` of the full work, for the budget).  ``stages(space, best,
+        stage_no)`` -> the candidates of stage 0 (``best`` None) and of every later stage given the best point so far (an
+        empty list ends the sweep); None = every point of ``space``.  ``budget_s(estimated full-size step in seconds)`` -> wall-clock cap of the sweep."""
         keys = {k: keys[k] for k in sorted(keys.keys())}
         signature = (name, f"{keys}")
         if signature in self.tuned:
@@ -201,7 +201,7 @@ class JITTuner:
         timed = []
         stage_points = list(space) if (stages is None or len(space) <= 1) else list(stages(space, None))
         num_built = 0
-        for stage_no in range(2):
+        for stage_no in range(4):
             kernels = build_all(stage_points)
             num_built += len(kernels)
             for runtime, tuned_keys in kernels:
@@ -229,10 +229,12 @@ class JITTuner:
                     best_runtime, best_time, best_keys = runtime, elapsed, tuned_keys
                 if _debug():
                     print(f"Tuned JIT kernel {name} with keys {keys} and tuned keys {tuned_keys} has time {elapsed}")
-            if stages is None or len(space) <= 1 or best_keys is None or stage_no == 1:
+            if stages is None or len(space) <= 1 or best_keys is None:
+                break
+            if deadline is not None and time.perf_counter() > deadline:
                 break
             done = [tk for _, tk in timed]
-            stage_points = [tk for tk in stages(space, best_keys) if tk not in done]
+            stage_points = [tk for tk in stages(space, best_keys, stage_no + 1) if tk not in done]
             if not stage_points:
                 break
         kernels = [None] * num_built

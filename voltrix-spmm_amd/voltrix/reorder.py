@@ -378,8 +378,16 @@ def permute_rows_csr(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int
 
 
 # ---- method="auto": candidates judged by the format's own statistics, identity kept unless one clearly pays (round 4) ------
-AUTO_MIN_GAIN = 0.03           # a candidate must cut the format's gather estimate by this much ...
-AUTO_MAX_PANEL_FACTOR = 2.0    # ... without piling the shared columns of hub rows into a few very long panels
+AUTO_MIN_GAIN = 0.03           # a candidate must cut the estimated step by this much
+# the estimate: the longer of (a) the gather volume at the chip's rate -- score x 0.21 ns, calibrated on the headline graph
+# (score 6.45 M -> 1.35 ms) -- and (b) the panel kernel's critical path, the plan's LONGEST panel at ~1 us per k-step (one
+# workgroup owns a panel from start to end: the breadth-first order's hub panel of 5,547 k-steps runs 5.7 ms, whatever the
+# other 454 panels do).  profiles/r04/experiment_reorder_auto.log
+AUTO_MS_PER_SCORE = 2.1e-7
+AUTO_MS_PER_PANEL_KSTEP = 1.0e-3
+AUTO_MIN_MEAN_DEGREE = 64      # below this mean degree no candidate is tried: 16 rows x 50 edges over millions of columns share no
+                               # column whatever their order (products-like: 15.44 / 15.53 / 15.52 M TC blocks natural / shuffled /
+                               # reordered), and the two searches cost 0.47 s there
 
 
 def order_statistics(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None) -> dict:
@@ -424,21 +432,26 @@ def order_statistics(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int
     two_level = plan_ok and big and share >= hybrid.min_shared_fraction()
     return {"tc_blocks": int(blocks), "shared_fraction": share, "ksteps": int(ksteps), "longest_panel_ksteps": int(longest),
             "two_level": bool(two_level), "ids_outside_universe": int(outside),
-            "score": float(blocks) * (1.0 - 0.9 * share) if two_level else float(blocks)}
+            "score": float(blocks) * (1.0 - 0.9 * share) if two_level else float(blocks),
+            "estimated_ms": max(AUTO_MS_PER_SCORE * (float(blocks) * (1.0 - 0.9 * share) if two_level else float(blocks)),
+                                AUTO_MS_PER_PANEL_KSTEP * float(longest) if two_level else 0.0)}
 
 
 def auto_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
                      candidates=("bfs", "spectral"), info: dict = None):
     """The safe default: every candidate order is judged by ``order_statistics`` of the row-permuted CSR
-    against the order the caller's rows already have, and the IDENTITY is kept unless a candidate cuts the score by
-    ``AUTO_MIN_GAIN`` (3 %: what fewer TC blocks or more shared edges are worth) without the hub pile-up a degenerate
-    breadth-first order produces (its level order turns into a degree sort on graphs with a background of random edges: the
-    plan's longest panel then holds the shared columns of 512 hub rows and the panel kernel's tail triples the step --
-    5.7 ms against 1.78 ms on the label-shuffled reddit-like graph).  Deterministic: statistics of the
-    format, no timing.  Returns ``(perm or None, name)``; None = keep the caller's order."""
+    against the order the caller's rows already have, and the IDENTITY is kept unless a candidate cuts the ESTIMATED step by
+    ``AUTO_MIN_GAIN`` (3 %).  The estimate is the longer of the gather volume (fewer TC blocks, more shared edges) and the panel
+    kernel's critical path: a degenerate breadth-first order (its levels turn into a degree sort on graphs with a background of
+    random edges) piles the shared columns of 512 hub rows into one panel whose workgroup then runs alone -- 5.7 ms against
+    1.78 ms on the label-shuffled reddit-like graph although it has FEWER TC blocks and MORE shared edges (DESIGN.md section
+    3.4).  Deterministic: statistics of the format, no timing.  Returns ``(perm or None, name)``; None = keep the caller's
+    order."""
     report = {"identity": order_statistics(indptr, indices, num_nodes, num_cols)}
     base = report["identity"]
-    best, best_name, best_score = None, "identity", base["score"]
+    best, best_name, best_ms = None, "identity", base["estimated_ms"]
+    if indices.numel() < AUTO_MIN_MEAN_DEGREE * max(1, num_nodes):
+        candidates = ()
     for name in candidates:
         if name == "bfs":
             perm = bfs_permutation(indptr, indices, num_nodes, num_cols)
@@ -453,14 +466,11 @@ def auto_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int
         p_indptr, p_indices = permute_rows_csr(indptr, indices, num_nodes, perm)
         st = order_statistics(p_indptr, p_indices, num_nodes, num_cols)
         del p_indptr, p_indices
-        per_panel = st["ksteps"] / max(1, (num_nodes + 511) // 512)
-        st["balanced"] = (not st["two_level"]) or st["longest_panel_ksteps"] <= max(
-            AUTO_MAX_PANEL_FACTOR * base["longest_panel_ksteps"], 4.0 * per_panel, 64)
-        st["accepted"] = bool(st["balanced"] and st["score"] <= (1.0 - AUTO_MIN_GAIN) * base["score"]
-                              and st["score"] < best_score)
+        st["accepted"] = bool(st["estimated_ms"] <= (1.0 - AUTO_MIN_GAIN) * base["estimated_ms"]
+                              and st["estimated_ms"] < best_ms)
         report[name] = st
         if st["accepted"]:
-            best, best_name, best_score = perm, name, st["score"]
+            best, best_name, best_ms = perm, name, st["estimated_ms"]
     if info is not None:
         info.update(report=report, picked=best_name)
     return best, best_name
