@@ -53,6 +53,9 @@ def parse_args():
                          "window: VOLTRIX_HYBRID=0; two-level: VOLTRIX_HYBRID=1 (side-car whenever the plan is not empty)")
     ap.add_argument("--tune", default="default", choices=["default", "full", "none"],
                     help="VOLTRIX_TUNE_SPACE of the first call's tile / schedule sweep")
+    ap.add_argument("--no-tuned-defaults", action="store_true",
+                    help="measure the first call OFF the shipped buckets: VOLTRIX_TUNED_DEFAULTS=0 and an empty store of "
+                         "choices, so the bounded sweep (tuner.py) runs; its cost is first_call_ms / tuner.sweep_seconds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-formats", action="store_true",
                     help="skip the untimed comparison runs (window format alone, cold-cache timing)")
@@ -244,6 +247,10 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     os.environ["VOLTRIX_TUNE_SPACE"] = args.tune
+    if args.no_tuned_defaults:
+        import tempfile
+        os.environ["VOLTRIX_TUNED_DEFAULTS"] = "0"
+        os.environ["VOLTRIX_TUNED_STORE"] = os.path.join(tempfile.mkdtemp(prefix="voltrix_bench_"), f"tuned_rank{rank}.json")
     if args.format != "auto":
         os.environ["VOLTRIX_HYBRID"] = "0" if args.format == "window" else "1"
         os.environ.setdefault("VOLTRIX_HYBRID_MIN_SHARE", "0")

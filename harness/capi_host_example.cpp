@@ -100,7 +100,7 @@ static UnitTable build_unit_table(const Handle& h, int n, hipStream_t s) {
   UnitTable t{};
   void* ws = dev_alloc<char>((size_t)voltrix_unit_table_workspace_bytes(n));
   int* d_header = dev_alloc<int>(8);
-  RC_OK(voltrix_launch_unit_table_count(h.blk_offsets, n, /*max_stages=*/0, ws, d_header, s, &rc_));
+  RC_OK(voltrix_launch_unit_table_count(h.blk_offsets, n, /*max_stages=*/0, /*xcd_ptr=*/nullptr, ws, d_header, s, &rc_));
   HIP_OK(hipMemcpyAsync(t.header, d_header, sizeof(t.header), hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   const int num_units = t.header[0], num_cuts = t.header[1], top = t.header[5];
@@ -108,8 +108,8 @@ static UnitTable build_unit_table(const Handle& h, int n, hipStream_t s) {
   t.cuts = dev_alloc<int>(4 * (size_t)num_cuts);
   t.unit_ptr = dev_alloc<int>(9);
   void* fill_ws = dev_alloc<char>((size_t)voltrix_unit_table_fill_workspace_bytes(num_units));
-  RC_OK(voltrix_launch_unit_table_fill(h.blk_offsets, n, ws, fill_ws, num_units, num_cuts, top, t.units, t.unit_ptr,
-                                       t.cuts, s, &rc_));
+  RC_OK(voltrix_launch_unit_table_fill(h.blk_offsets, n, /*xcd_ptr=*/nullptr, ws, fill_ws, num_units, num_cuts, top, t.units,
+                                       t.unit_ptr, t.cuts, s, &rc_));
   HIP_OK(hipStreamSynchronize(s));
   HIP_OK(hipFree(ws));
   HIP_OK(hipFree(fill_ws));
@@ -210,7 +210,9 @@ int main(int argc, char** argv) {
   int* panel_order = dev_alloc<int>(num_panels);
   RC_OK(voltrix_launch_panel_plan_fill(d_indptr, d_indices, n, n, e, waves, row_blocks, tau, plan_ws, panel_ptr,
                                        resid_indptr, ksteps, resid_indices, panel_cols, panel_bits, s_main, &rc_));
-  RC_OK(voltrix_launch_panel_order(panel_ptr, num_panels, /*group=*/1, panel_order, s_main, &rc_));
+  // xcd_ptr = nullptr everywhere in this example: XCD ranges of equal panel / window COUNTS.  Ranges of equal work (what
+  // voltrix/hybrid.py::balance_xcd_ranges computes from panel_ptr and the residual's blk_offsets) are a speed matter only.
+  RC_OK(voltrix_launch_panel_order(panel_ptr, num_panels, /*group=*/1, /*xcd_ptr=*/nullptr, panel_order, s_main, &rc_));
   const Handle hr = preprocess(resid_indptr, resid_indices, n, n, resid_edges, s_main);
   const UnitTable tr = build_unit_table(hr, n, s_main);
   float* partials_r = dev_alloc<float>((size_t)std::max(1, tr.header[2]) * 16 * f);
@@ -221,7 +223,8 @@ int main(int argc, char** argv) {
   HIP_OK(hipMemsetAsync(d_c, 0, (size_t)n * f * sizeof(float), s_main));
   HIP_OK(hipEventRecord(fork, s_main));
   HIP_OK(hipStreamWaitEvent(s_side, fork, 0));
-  RC_OK(voltrix_launch_spmm_panel_f16(panel_ptr, panel_cols, panel_bits, panel_order, n, f, d_b, /*input_rows=*/n, d_c,
+  RC_OK(voltrix_launch_spmm_panel_f16(panel_ptr, panel_cols, panel_bits, panel_order, /*xcd_ptr=*/nullptr, 0, n, f, d_b,
+                                      /*input_rows=*/n, d_c,
                                       /*accumulate=*/2, /*fs=*/128, /*depth=*/3, waves, row_blocks, /*ksteps=*/1,
                                       VOLTRIX_SLAB_AUTO, /*out_scale=*/nullptr, s_side, &rc_));
   HIP_OK(hipEventRecord(join, s_side));
@@ -248,7 +251,8 @@ int main(int argc, char** argv) {
                                           &rc_));
   HIP_OK(hipMemsetAsync(d_c, 0xFF, (size_t)n * f * sizeof(float), s_main));  // NaN pattern: every element must be written
   const int fused_fs = f <= 32 ? 32 : (f <= 64 ? 64 : 128);
-  RC_OK(voltrix_launch_spmm_fused_f16(panel_ptr, panel_cols, panel_bits, panel_order, wave_ptr, records, n, f, d_b, d_c,
+  RC_OK(voltrix_launch_spmm_fused_f16(panel_ptr, panel_cols, panel_bits, panel_order, /*xcd_ptr=*/nullptr, 0, wave_ptr, records,
+                                      n, f, d_b, d_c,
                                       fused_fs, /*depth=*/fused_fs == 128 ? 3 : 4, /*pace_blocks=*/0, /*out_scale=*/nullptr,
                                       s_main, &rc_));
   HIP_OK(hipStreamSynchronize(s_main));

@@ -175,15 +175,19 @@ void voltrix_launch_combine_partials(void* cuts, int num_cuts, void* partials, v
  *    float[num_slots * 16 * embedding_dim] and voltrix_unit_table_fill_workspace_bytes(U) bytes of fill workspace)
  *   phase 2  voltrix_launch_unit_table_fill: writes units, unit_ptr, cuts (every element); same workspace, untouched since
  *            phase 1; num_units / num_cuts / top as read from the header.
- * The table depends on blk_offsets only (ties between units of equal length are broken by window, then unit index), so a
- * handle always gets the same table and the SpMM the same bits. */
+ * xcd_ptr: NULL, or device int32[9] = first window of every XCD's range (xcd_ptr[0] = 0, xcd_ptr[8] = ceil(num_nodes / 16),
+ * non-decreasing; the same array in both phases): ranges of equal WORK instead of equal window counts, for graphs whose
+ * stages per row vary along the rows (communities); a two-level host passes 32 x the panel kernel's xcd_ptr so that both
+ * kernels keep a panel's rows on one XCD.  Speed only: the SpMM gives the same bits with any ranges.
+ * The table depends on blk_offsets (and xcd_ptr) only (ties between units of equal length are broken by window, then unit
+ * index), so a handle always gets the same table and the SpMM the same bits. */
 int64_t voltrix_unit_table_workspace_bytes(int num_nodes);
 int64_t voltrix_unit_table_fill_workspace_bytes(int64_t num_units);
-void voltrix_launch_unit_table_count(void* blk_offsets, int num_nodes, int max_stages, void* workspace, void* header,
-                                     void* stream, int* return_code);
-void voltrix_launch_unit_table_fill(void* blk_offsets, int num_nodes, void* workspace, void* fill_workspace, int num_units,
-                                    int num_cuts, int top, void* units, void* unit_ptr, void* cuts, void* stream,
-                                    int* return_code);
+void voltrix_launch_unit_table_count(void* blk_offsets, int num_nodes, int max_stages, void* xcd_ptr, void* workspace,
+                                     void* header, void* stream, int* return_code);
+void voltrix_launch_unit_table_fill(void* blk_offsets, int num_nodes, void* xcd_ptr, void* workspace, void* fill_workspace,
+                                    int num_units, int num_cuts, int top, void* units, void* unit_ptr, void* cuts,
+                                    void* stream, int* return_code);
 
 /* "Balance" schedule for a handle: order_out int32[W] (device) lists the windows of every XCD range, inside chunks of
  * `chunk` (1..4096) consecutive windows, by descending TC-block count, so that co-resident waves sweep their sorted
@@ -212,16 +216,20 @@ void voltrix_launch_window_order(void* blk_offsets, int num_nodes, int chunk, vo
  * launched -- -1 (VOLTRIX_SLAB_AUTO) one launch per 256-byte group of column slabs when such a group of `input`
  * (input_rows x 256 bytes) fits the 256 MiB Infinity Cache, else one grid over all slabs; 0 always one grid; 1 always the
  * launches.  Same bits either way.
+ * xcd_ptr / max_panels_per_xcd: NULL / 0, or device int32[9] = first launch POSITION of every XCD's range (xcd_ptr[8] =
+ * NP) and the length of the longest range (sizes the grid): ranges of equal work instead of ceil(NP / 8) positions each
+ * (graphs with community structure: the k-steps per panel vary by community); panel_order must have been built with the same
+ * xcd_ptr.  Speed only.
  * MEMORY REQUIREMENT of the atomic forms (accumulate == 2 here, atomic_out != 0 in voltrix_launch_spmm_*_sched): they use the
  * hardware's no-return global_atomic_add_f32, which is only defined on ordinary (coarse-grained) device memory -- hipMalloc,
  * torch's allocator.  On fine-grained or host-mapped output (hipHostMalloc, hipMallocManaged with fine-grained coherence) the
  * adds can be lost silently: give such outputs a device-memory staging buffer, or use accumulate 0 / 1. */
-void voltrix_launch_spmm_panel_f16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order,
-                                   int num_nodes, int embedding_dim, void* input, int64_t input_rows, void* output,
+void voltrix_launch_spmm_panel_f16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order, void* xcd_ptr,
+                                   int max_panels_per_xcd, int num_nodes, int embedding_dim, void* input, int64_t input_rows, void* output,
                                    int accumulate, int fs, int depth, int waves, int row_blocks, int ksteps,
                                    int slab_policy, void* out_scale, void* stream, int* return_code);
-void voltrix_launch_spmm_panel_bf16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order,
-                                    int num_nodes, int embedding_dim, void* input, int64_t input_rows, void* output,
+void voltrix_launch_spmm_panel_bf16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order, void* xcd_ptr,
+                                    int max_panels_per_xcd, int num_nodes, int embedding_dim, void* input, int64_t input_rows, void* output,
                                     int accumulate, int fs, int depth, int waves, int row_blocks, int ksteps,
                                     int slab_policy, void* out_scale, void* stream, int* return_code);
 
@@ -241,13 +249,13 @@ void voltrix_launch_spmm_panel_bf16(void* panel_ptr, void* panel_cols, void* pan
  * pace_blocks: 0 / 1 = none; n > 1 (one column slab only) = the workgroups that share an XCD and a dispatch generation wait
  * for each other at n points of their column sweep (bounded polls on counters the library keeps: advisory, the result never
  * depends on it) so that an XCD's resident rows sweep the sorted columns together and share gathered rows through its L2.
- * input / out_scale as for voltrix_launch_spmm_panel_f16. */
-void voltrix_launch_spmm_fused_f16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order,
-                                   void* wave_ptr, void* records, int num_nodes, int embedding_dim, void* input,
+ * input / out_scale / xcd_ptr / max_panels_per_xcd as for voltrix_launch_spmm_panel_f16. */
+void voltrix_launch_spmm_fused_f16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order, void* xcd_ptr,
+                                   int max_panels_per_xcd, void* wave_ptr, void* records, int num_nodes, int embedding_dim, void* input,
                                    void* output, int fs, int depth, int pace_blocks, void* out_scale, void* stream,
                                    int* return_code);
-void voltrix_launch_spmm_fused_bf16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order,
-                                    void* wave_ptr, void* records, int num_nodes, int embedding_dim, void* input,
+void voltrix_launch_spmm_fused_bf16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order, void* xcd_ptr,
+                                    int max_panels_per_xcd, void* wave_ptr, void* records, int num_nodes, int embedding_dim, void* input,
                                     void* output, int fs, int depth, int pace_blocks, void* out_scale, void* stream,
                                    int* return_code);
 
@@ -288,11 +296,11 @@ void voltrix_launch_panel_plan_fill(void* node_pointer, void* edge_list, int num
                                     void* panel_cols, void* panel_bits, void* stream, int* return_code);
 
 /* `panel_order` of the panel launches: order_out int32[num_panels] (device), position -> panel; inside every XCD's range of
- * ceil(num_panels / 8) positions, groups of `group` consecutive panels (neighbours share their band columns: side by side
+ * positions (xcd_ptr int32[9] on the device, or NULL: ceil(num_panels / 8) each), groups of `group` consecutive panels (neighbours share their band columns: side by side
  * they share gathered rows through L2), the groups with the most k-steps first (ties by index), natural order inside a
  * group; group = 1: plain longest-first (what the Python host uses: groups of 4 gained 3 % on the bare kernel pair, nothing
  * through the operator).  Speed only. */
-void voltrix_launch_panel_order(void* panel_ptr, int num_panels, int group, void* order_out, void* stream,
+void voltrix_launch_panel_order(void* panel_ptr, int num_panels, int group, void* xcd_ptr, void* order_out, void* stream,
                                 int* return_code);
 
 /* Default tile for a feature width; is_f16 selects the operand type.  Always succeeds. */

@@ -349,3 +349,55 @@ def test_side_car_follows_copies_only_when_told_and_survives_save_load(cuda_devi
             voltrix.spmm(*unknown, num_nodes=n, num_edges=e, feat=feat)
     assert len([w for w in caught if "copy_side_car" in str(w.message)]) == 1
     voltrix.sidecar._WARNED[0] = False
+
+
+def test_xcd_ranges_of_equal_work_give_the_same_bits(cuda_device, monkeypatch):
+    """Round 4: both kernels of the two-level step take their XCD ranges from the work (hybrid.balance_xcd_ranges) instead
+    of NP / 8 panels each.  A block-model graph (communities of very different sizes: the busiest eighth of the rows holds
+    well above 1/8 of the work): the ranges differ from the equal-count ones, their work is balanced, and the result --
+    window pair and one-launch form -- has the same bits as with equal-count ranges (the order of a row's sums is unchanged:
+    ranges only decide WHICH CU runs a panel)."""
+    import numpy as np
+
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    monkeypatch.setenv("VOLTRIX_FUSED", "1")
+    indptr, indices, _ = synth_graphs.generate("reddit_sbm", device="cuda", scale=0.25)
+    n = indptr.numel() - 1
+    two = voltrix.csr_preprocess_hybrid(indptr.cpu(), indices.cpu(), n)
+    two.hash_tag = "xcd_balanced"
+    plan = two.plan
+    assert plan.xcd_ptr is not None and two.window_xcd_ptr is not None and two.fused is not None
+    xp = plan.xcd_ptr.cpu().numpy()
+    assert xp[0] == 0 and xp[8] == plan.num_panels and (np.diff(xp) >= 0).all() and plan.max_panels_per_xcd == np.diff(xp).max()
+    equal = np.minimum(np.arange(9) * ((plan.num_panels + 7) // 8), plan.num_panels)
+    assert (xp != equal).any()
+    ksteps = np.diff(plan.panel_ptr.cpu().numpy())
+    nst = (np.diff(two.blk_offsets.cpu().numpy().astype(np.int64)) + 3) // 4
+    nst = np.concatenate([nst, np.zeros(plan.num_panels * 32 - nst.size, np.int64)]).reshape(plan.num_panels, 32).sum(1)
+    work = hybrid.KSTEP_COST_IN_STAGES * ksteps + nst
+
+    def busiest(ptr):
+        per = np.array([work[ptr[x]:ptr[x + 1]].sum() for x in range(8)])
+        return per.max() / per.mean()
+
+    assert busiest(xp) < min(1.12, busiest(equal) - 0.05), (busiest(xp), busiest(equal))   # 114 panels: 14 per XCD
+    assert (two.window_xcd_ptr.cpu().numpy() == np.minimum(xp.astype(np.int64) * 32, (n + 15) // 16)).all()
+    order = plan.panel_order.cpu().numpy()
+    for x in range(8):
+        assert sorted(order[xp[x]:xp[x + 1]]) == list(range(xp[x], xp[x + 1]))
+
+    feat = torch.randn(n, 128, device=cuda_device).half()
+    balanced = voltrix.spmm_two_level(two, feat).clone()
+    monkeypatch.setenv("VOLTRIX_FUSED", "0")
+    balanced_pair = voltrix.spmm_two_level(two, feat).clone()
+    saved = (plan.xcd_ptr, plan.max_panels_per_xcd, plan.panel_order, two.window_xcd_ptr)
+    plan.xcd_ptr, plan.max_panels_per_xcd, two.window_xcd_ptr = None, 0, None
+    plan.panel_order = hybrid.longest_first_order(plan.panel_ptr)
+    two.hash_tag = "xcd_equal_counts"
+    assert torch.equal(voltrix.spmm_two_level(two, feat), balanced_pair)
+    monkeypatch.setenv("VOLTRIX_FUSED", "1")
+    assert torch.equal(voltrix.spmm_two_level(two, feat), balanced)
+    plan.xcd_ptr, plan.max_panels_per_xcd, plan.panel_order, two.window_xcd_ptr = saved
+    ref = torch.sparse.mm(torch.sparse_csr_tensor(indptr.long(), indices.long(), torch.ones(indices.numel(), device="cuda"),
+                                                  size=(n, n)), feat.float())
+    assert float((balanced - ref).norm() / ref.norm()) < 1e-3 and float((balanced_pair - ref).norm() / ref.norm()) < 1e-3

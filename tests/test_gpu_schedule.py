@@ -65,10 +65,64 @@ def test_workspace_sizes_and_bad_arguments(cuda_device):
     assert lib.voltrix_unit_table_fill_workspace_bytes(ctypes.c_int64(16565)) > 5 * 4 * 16565
     rc = ctypes.c_int(-1)
     z = ctypes.c_void_p(0)
-    lib.voltrix_launch_unit_table_count(z, ctypes.c_int(-1), ctypes.c_int(0), z, z, z, ctypes.byref(rc))
+    lib.voltrix_launch_unit_table_count(z, ctypes.c_int(-1), ctypes.c_int(0), z, z, z, z, ctypes.byref(rc))
     assert rc.value == 1
-    lib.voltrix_launch_unit_table_count(z, ctypes.c_int(64), ctypes.c_int(0), z, z, z, ctypes.byref(rc))
+    lib.voltrix_launch_unit_table_count(z, ctypes.c_int(64), ctypes.c_int(0), z, z, z, z, ctypes.byref(rc))
     assert rc.value == 1   # no header
+
+
+@pytest.mark.parametrize("name,scale", [("reddit_sbm", 0.1), ("reddit_like", 0.05), ("powerlaw_4m", 0.01)])
+@pytest.mark.parametrize("max_stages", [None, 3, 37])
+def test_unit_table_over_ranges_of_equal_work(cuda_device, name, scale, max_stages):
+    """Round 4: XCD ranges given as data (xcd_ptr, first window of every range) instead of W / 8 windows each.  The native
+    builder and the torch restatement agree element by element; every stage is still in exactly one unit; a window's XCD is
+    the range that holds it; and the ranges balanced_xcd_windows draws hold about equal stages."""
+    from voltrix.schedule import balanced_xcd_windows
+
+    indptr, indices, _ = synth_graphs.generate(name, device="cuda", scale=scale)
+    n = indptr.numel() - 1
+    blk_offsets = voltrix.csr_fused_preprocess_kernel(indptr, indices, n)[0]
+    w_total = (n + 15) // 16
+    for xcd_ptr in (balanced_xcd_windows(blk_offsets, n), balanced_xcd_windows(blk_offsets, n, align=32),
+                    torch.tensor([0, 0, 5, 5, w_total // 2, w_total // 2, w_total - 1, w_total, w_total], dtype=torch.int32,
+                                 device="cuda")):      # empty ranges, a range of one window
+        assert int(xcd_ptr[0]) == 0 and int(xcd_ptr[8]) == w_total and bool((xcd_ptr[1:] >= xcd_ptr[:-1]).all())
+        native = unit_table(blk_offsets, n, max_stages, xcd_ptr=xcd_ptr)
+        ref = unit_table_torch(blk_offsets, n, max_stages, xcd_ptr=xcd_ptr)
+        _same(native, ref)
+        units = native.units.cpu().numpy().astype(np.int64)
+        nst = (np.diff(blk_offsets.cpu().numpy().astype(np.int64)) + 3) // 4
+        w, j, k = units[:, 0], units[:, 1], units[:, 2]
+        length = (nst[w] - j + k - 1) // k
+        assert (np.bincount(w, weights=length, minlength=nst.size) == nst).all()
+        ptr, xp = native.unit_ptr.cpu().numpy(), xcd_ptr.cpu().numpy()
+        for x in range(8):
+            seg = slice(ptr[x], ptr[x + 1])
+            assert ((w[seg] >= xp[x]) & (w[seg] < xp[x + 1])).all() and (np.diff(length[seg]) <= 0).all()
+    bal = balanced_xcd_windows(blk_offsets, n).cpu().numpy()
+    per = np.add.reduceat(nst, bal[:8].clip(max=w_total - 1)) if w_total else np.zeros(8)
+    assert per.max() <= 1.05 * per.mean() + nst.max()
+
+
+def test_panel_order_over_ranges_of_equal_work(cuda_device):
+    from voltrix.hybrid import longest_first_order
+    from voltrix.schedule import split_equal_work
+
+    for num_panels in (16, 37, 455, 4100):
+        g = torch.Generator().manual_seed(num_panels)
+        nks = torch.randint(0, 50, (num_panels,), generator=g) * (torch.arange(num_panels) % 7 == 0).long() * 9 + \
+            torch.randint(0, 6, (num_panels,), generator=g)
+        panel_ptr = torch.zeros(num_panels + 1, dtype=torch.int32)
+        panel_ptr[1:] = nks.cumsum(0)
+        xcd_ptr = split_equal_work(nks)
+        native = longest_first_order(panel_ptr.cuda(), 1, xcd_ptr.cuda())
+        ref = longest_first_order(panel_ptr, 1, xcd_ptr)
+        assert native.is_cuda and torch.equal(native.cpu(), ref)
+        xp = xcd_ptr.tolist()
+        for x in range(8):       # positions [xp[x], xp[x+1]) hold exactly the panels xp[x] .. xp[x+1]-1, longest first
+            seg = ref[xp[x]:xp[x + 1]].long()
+            assert torch.equal(torch.sort(seg).values, torch.arange(xp[x], xp[x + 1]))
+            assert bool((nks[seg][1:] <= nks[seg][:-1]).all())
 
 
 @pytest.mark.parametrize("group", [1, 4, 7])

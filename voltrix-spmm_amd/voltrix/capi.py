@@ -210,10 +210,11 @@ def launch_combine_partials(table, partials_ptr, output_ptr, num_nodes, embeddin
     return rc.value
 
 
-def build_unit_table(blk_offsets, num_nodes: int, max_stages: int = 0, stream=None):
+def build_unit_table(blk_offsets, num_nodes: int, max_stages: int = 0, stream=None, xcd_ptr=None):
     """The handle's unit table through the library's two-phase builder (voltrix/unit_table.hpp): returns
     ``(units int32 [U, 4], unit_ptr int32 [9], cuts int32 [C, 4], header)`` with ``header`` = the eight ints of phase 1
-    as a Python list (num_units, num_cuts, num_slots, max_units_per_xcd, max_stages, top, 0, 0).  One host sync."""
+    as a Python list (num_units, num_cuts, num_slots, max_units_per_xcd, max_stages, top, 0, 0).  ``xcd_ptr``: None (equal
+    window ranges per XCD) or a device int32 [9] tensor of first windows (ranges of equal work).  One host sync."""
     import torch
 
     dev = blk_offsets.device
@@ -222,7 +223,8 @@ def build_unit_table(blk_offsets, num_nodes: int, max_stages: int = 0, stream=No
                             dtype=torch.uint8, device=dev)
     header = torch.empty(8, dtype=torch.int32, device=dev)
     rc = ctypes.c_int(-1)
-    lib().voltrix_launch_unit_table_count(_ptr(blk_offsets), ctypes.c_int(num_nodes), ctypes.c_int(int(max_stages)),
+    xp = ctypes.c_void_p(xcd_ptr.data_ptr() if xcd_ptr is not None else 0)
+    lib().voltrix_launch_unit_table_count(_ptr(blk_offsets), ctypes.c_int(num_nodes), ctypes.c_int(int(max_stages)), xp,
                                           _ptr(workspace), _ptr(header), ctypes.c_void_p(stream), ctypes.byref(rc))
     check(rc.value, "voltrix_launch_unit_table_count")
     head = [int(v) for v in header.tolist()]   # the sync
@@ -232,7 +234,7 @@ def build_unit_table(blk_offsets, num_nodes: int, max_stages: int = 0, stream=No
     unit_ptr = torch.empty(9, dtype=torch.int32, device=dev)
     fill_ws = torch.empty(max(16, int(lib().voltrix_unit_table_fill_workspace_bytes(ctypes.c_int64(num_units)))),
                           dtype=torch.uint8, device=dev)
-    lib().voltrix_launch_unit_table_fill(_ptr(blk_offsets), ctypes.c_int(num_nodes), _ptr(workspace), _ptr(fill_ws),
+    lib().voltrix_launch_unit_table_fill(_ptr(blk_offsets), ctypes.c_int(num_nodes), xp, _ptr(workspace), _ptr(fill_ws),
                                          ctypes.c_int(num_units), ctypes.c_int(num_cuts), ctypes.c_int(top), _ptr(units),
                                          _ptr(unit_ptr), _ptr(cuts), ctypes.c_void_p(stream), ctypes.byref(rc))
     check(rc.value, "voltrix_launch_unit_table_fill")
@@ -262,8 +264,10 @@ def launch_spmm_panel(plan, input_ptr, output_ptr, embedding_dim, accumulate, bf
     rc = ctypes.c_int(-1)
     fn = lib().voltrix_launch_spmm_panel_bf16 if bf16 else lib().voltrix_launch_spmm_panel_f16
     order = plan.panel_order.data_ptr() if plan.panel_order is not None else 0
+    xcd_ptr = getattr(plan, "xcd_ptr", None)
     fn(_ptr(plan.panel_ptr), _ptr(plan.panel_cols), _ptr(plan.panel_bits), ctypes.c_void_p(order),
-       ctypes.c_int(plan.num_nodes), ctypes.c_int(embedding_dim), ctypes.c_void_p(input_ptr), ctypes.c_int64(input_rows),
+       ctypes.c_void_p(xcd_ptr.data_ptr() if xcd_ptr is not None else 0),
+       ctypes.c_int(plan.max_panels_per_xcd if xcd_ptr is not None else 0), ctypes.c_int(plan.num_nodes), ctypes.c_int(embedding_dim), ctypes.c_void_p(input_ptr), ctypes.c_int64(input_rows),
        ctypes.c_void_p(output_ptr), ctypes.c_int(int(accumulate)), ctypes.c_int(tile[0]), ctypes.c_int(tile[1]),
        ctypes.c_int(plan.waves), ctypes.c_int(plan.row_blocks), ctypes.c_int(tile[2]), ctypes.c_int(slab_policy),
        ctypes.c_void_p(out_scale), ctypes.c_void_p(stream), ctypes.byref(rc))
@@ -278,7 +282,10 @@ def launch_spmm_fused(plan, fused, input_ptr, output_ptr, embedding_dim, bf16, t
     rc = ctypes.c_int(-1)
     fn = lib().voltrix_launch_spmm_fused_bf16 if bf16 else lib().voltrix_launch_spmm_fused_f16
     order = plan.panel_order.data_ptr() if plan.panel_order is not None else 0
-    fn(_ptr(plan.panel_ptr), _ptr(plan.panel_cols), _ptr(plan.panel_bits), ctypes.c_void_p(order), _ptr(fused.wave_ptr),
+    xcd_ptr = getattr(plan, "xcd_ptr", None)
+    fn(_ptr(plan.panel_ptr), _ptr(plan.panel_cols), _ptr(plan.panel_bits), ctypes.c_void_p(order),
+       ctypes.c_void_p(xcd_ptr.data_ptr() if xcd_ptr is not None else 0),
+       ctypes.c_int(plan.max_panels_per_xcd if xcd_ptr is not None else 0), _ptr(fused.wave_ptr),
        _ptr(fused.records), ctypes.c_int(plan.num_nodes), ctypes.c_int(embedding_dim), ctypes.c_void_p(input_ptr),
        ctypes.c_void_p(output_ptr), ctypes.c_int(tile[0]), ctypes.c_int(tile[1]), ctypes.c_int(int(pace_blocks)),
        ctypes.c_void_p(out_scale), ctypes.c_void_p(stream), ctypes.byref(rc))
@@ -318,9 +325,10 @@ def build_fused_records(blk_offsets, hspa_packed, hind, num_nodes: int, stream=N
     return wave_ptr, records, num_records
 
 
-def launch_panel_order(panel_ptr, num_panels: int, order_out, stream, group: int = 1) -> None:
+def launch_panel_order(panel_ptr, num_panels: int, order_out, stream, group: int = 1, xcd_ptr=None) -> None:
     rc = ctypes.c_int(-1)
-    lib().voltrix_launch_panel_order(_ptr(panel_ptr), ctypes.c_int(num_panels), ctypes.c_int(group), _ptr(order_out),
+    lib().voltrix_launch_panel_order(_ptr(panel_ptr), ctypes.c_int(num_panels), ctypes.c_int(group),
+                                     ctypes.c_void_p(xcd_ptr.data_ptr() if xcd_ptr is not None else 0), _ptr(order_out),
                                      ctypes.c_void_p(stream), ctypes.byref(rc))
     check(rc.value, "voltrix_launch_panel_order")
 

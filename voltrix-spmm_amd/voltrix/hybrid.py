@@ -53,6 +53,8 @@ class PanelPlan:
     num_ksteps: int
     num_shared_edges: int
     num_resid_edges: int
+    xcd_ptr: torch.Tensor = None      # int32 [9] or None: XCD x owns the launch positions [xcd_ptr[x], xcd_ptr[x + 1]) -- ranges of
+    max_panels_per_xcd: int = 0       # equal WORK (balance_xcd_ranges); None: ranges of ceil(NP / 8) positions
 
     @property
     def panel_rows(self) -> int:
@@ -76,6 +78,7 @@ class TwoLevelHandle:
     num_edges: int               # of the whole matrix (shared + residual)
     hash_tag: str = None         # tuner key of the residual launches (like hspa_packed.hash_tag in the reference)
     fused: "FusedRecords" = None  # the residual re-packed for the one-launch kernel (spmm_fused_kernels.hpp), or None
+    window_xcd_ptr: torch.Tensor = None   # int32 [9]: the residual's unit table uses the panel kernel's XCD ranges (x 32 windows)
     format_choice: dict = dataclasses.field(default_factory=dict)   # (width, dtype) -> "two-level" | "window" (voltrix.spmm, auto mode)
 
     @property
@@ -220,7 +223,43 @@ def empty_plan(num_nodes, waves, row_blocks, tau, device, num_edges):
                      num_shared_edges=0, num_resid_edges=num_edges)
 
 
-def longest_first_order(panel_ptr: torch.Tensor, group: int = 1) -> torch.Tensor:
+# a k-step of the panel kernel costs about this many residual stages of the window kernel (reddit-like pair, each kernel
+# alone: 182.6 k k-steps in 0.70 ms, 1.59 M stages in 0.92 ms -- 0.98 us against 0.148 us per CU)
+KSTEP_COST_IN_STAGES = 6.6
+
+
+def balance_xcd_ranges(two: "TwoLevelHandle") -> None:
+    """Round 4: the XCD ranges of BOTH kernels of the two-level step from the work, not from the row count.  Every XCD used
+    to own NP / 8 consecutive panels (and the residual's windows of the same rows); on graphs whose rows are statistically
+    alike that is an equal split of the work (reddit-like: +- 2 %), on graphs with community structure it is not -- a panel
+    inside a 17 k-node community carries 540 k-steps, one inside a 900-node community 30: the busiest XCD of the reddit-size
+    block model held 1.57 x the mean (profiles/r04).  Work of panel p = KSTEP_COST_IN_STAGES x its k-steps + the residual
+    stages of its 32 windows; boundaries where the prefix sum crosses x / 8 of the total; the plan's launch order is rebuilt
+    longest-first inside the new ranges and the residual handle's unit table takes the same ranges (x 32 windows: a panel's
+    rows stay on one XCD for both kernels).  Speed only -- same bits with any ranges.  One tiny host read (the longest range
+    sizes the panel kernel's grid)."""
+    from .schedule import split_equal_work
+
+    plan = two.plan
+    if plan.num_ksteps == 0 or plan.num_panels < 2 * 8:
+        return
+    dev = plan.panel_ptr.device
+    windows_per_panel = plan.panel_rows // 16
+    num_windows = (two.num_nodes + 15) // 16
+    nst = ((two.blk_offsets[1:num_windows + 1] - two.blk_offsets[:num_windows]).to(torch.int64) + 3) // 4
+    pad = plan.num_panels * windows_per_panel - num_windows
+    per_panel = torch.cat([nst, torch.zeros(pad, dtype=torch.int64, device=dev)]).view(plan.num_panels, windows_per_panel).sum(1)
+    ksteps = (plan.panel_ptr[1:] - plan.panel_ptr[:-1]).to(torch.float64)
+    work = (KSTEP_COST_IN_STAGES * ksteps + per_panel.to(torch.float64)).round().to(torch.int64)
+    xcd_ptr = split_equal_work(work)
+    ranges = (xcd_ptr[1:] - xcd_ptr[:-1])
+    plan.xcd_ptr = xcd_ptr
+    plan.max_panels_per_xcd = int(ranges.max())                 # the host read
+    plan.panel_order = longest_first_order(plan.panel_ptr, xcd_ptr=xcd_ptr)
+    two.window_xcd_ptr = (xcd_ptr.to(torch.int64) * windows_per_panel).clamp(max=num_windows).to(torch.int32)
+
+
+def longest_first_order(panel_ptr: torch.Tensor, group: int = 1, xcd_ptr: torch.Tensor = None) -> torch.Tensor:
     """Launch order of the panel kernel: int32 [NP], position -> panel; inside every XCD's contiguous range of positions
     (spmm_panel_kernel: blockIdx % 8 picks the range) GROUPS of ``group`` consecutive panels, the groups with the most k-steps
     first, the panels of a group in their natural order; ``group`` = 1 (shipped): plain longest-first.  455 workgroups on
@@ -235,11 +274,16 @@ def longest_first_order(panel_ptr: torch.Tensor, group: int = 1) -> torch.Tensor
         return torch.zeros(0, dtype=torch.int32, device=panel_ptr.device)
     if panel_ptr.is_cuda:   # the library's kernel (panel_plan.hpp::panel_order_kernel; same order, checked by the tests)
         order = torch.empty(num_panels, dtype=torch.int32, device=panel_ptr.device)
-        capi.launch_panel_order(panel_ptr, num_panels, order, torch.cuda.current_stream().cuda_stream, group)
+        capi.launch_panel_order(panel_ptr, num_panels, order, torch.cuda.current_stream().cuda_stream, group, xcd_ptr)
         return order
     nks = (panel_ptr[1:] - panel_ptr[:-1]).to(torch.int64)
     per_xcd = (num_panels + 7) // 8
     idx = torch.arange(num_panels, device=panel_ptr.device)
+    if xcd_ptr is not None:          # ranges of equal work: XCD of a panel, and its first position
+        assert group == 1
+        xcd = torch.searchsorted(xcd_ptr.to(torch.int64)[1:8].contiguous(), idx, right=True)
+        top = int(nks.max())
+        return torch.argsort(xcd * (top + 1) + (top - nks), stable=True).to(torch.int32)
     xcd = idx // per_xcd
     gid = xcd * (per_xcd // group + 2) + (idx - xcd * per_xcd) // group
     gsum = torch.zeros(int(gid.max()) + 1, dtype=torch.int64, device=panel_ptr.device).index_add_(0, gid, nks)
@@ -481,11 +525,17 @@ def launch_fused(plan: PanelPlan, fused: FusedRecords, feat: torch.Tensor, outpu
 
 def min_shared_fraction() -> float:
     """Fraction of the edges that must sit in shared columns for ``csr_preprocess`` to attach the two-level side-car
-    (``VOLTRIX_HYBRID_MIN_SHARE``).  Default 0.4 in ``auto`` mode -- the measured break-even lies between the reddit-like
-    graph (55 % shared: two-level 1.38 ms, window format 1.87 ms) and its uniform-column variant (29 % shared: 2.20 vs
-    1.73 ms), profiles/r02/bench_reddit_uniform_f128_operator.json -- and 0.2 when the side-car is forced
-    (``VOLTRIX_HYBRID=1``) or the first call is allowed to time both forms (``VOLTRIX_HYBRID=tune``)."""
-    default = "0.4" if hybrid_mode() == "auto" else "0.2"
+    (``VOLTRIX_HYBRID_MIN_SHARE``).  Default 0.38 in ``auto`` mode, from the measured curve over seven reddit-size graphs
+    whose local half of the column mixture goes from 0 to 65 % of the edges (profiles/r04/experiment_share_curve.log; two-level
+    time / window-format time at F = 128):
+
+        share   0.293  0.339  0.389  0.437  0.492  0.554  0.662
+        ratio   1.076  1.049  0.974  0.877  0.776  0.705  0.577
+
+    -- the forms break even at a share of 0.365 (rounds 2-3: 0.4, "between" the two points measured then, 0.29 and 0.55); 0.2
+    when the side-car is forced (``VOLTRIX_HYBRID=1``) or the first call is allowed to time both forms
+    (``VOLTRIX_HYBRID=tune``)."""
+    default = "0.38" if hybrid_mode() == "auto" else "0.2"
     return float(os.getenv("VOLTRIX_HYBRID_MIN_SHARE", default))
 
 

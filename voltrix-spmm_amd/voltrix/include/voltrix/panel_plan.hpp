@@ -313,12 +313,21 @@ static __global__ __launch_bounds__(kPlanThreads) void panel_plan_fill_kernel(
 // small: N / 512).  Measured on the reddit-like pair with two units per wave on the residual: groups of 4 1.282 ms,
 // plain longest-first 1.323 ms, natural order 1.294 ms (profiles/r02/experiment_panel_groups.log) -- but no gain through
 // the operator (profiles/r02/bench_ab_panel_group.txt), so hosts pass group = 1.
+// xcd_ptr (round 4): int32[9], first position of every XCD's range (xcd_ptr[8] = NP), or NULL = ranges of ceil(NP / 8)
+// positions: ranges of equal WORK for graphs whose k-steps per panel vary by community (voltrix/hybrid.py::xcd_partition).
 static __global__ __launch_bounds__(256) void panel_order_kernel(const int* __restrict__ panel_ptr, const int num_panels,
                                                                  const int per_xcd, const int group,
+                                                                 const int* __restrict__ xcd_ptr,
                                                                  int* __restrict__ order_out) {
   for (int p = blockIdx.x * 256 + threadIdx.x; p < num_panels; p += gridDim.x * 256) {
-    const int lo = (p / per_xcd) * per_xcd;
-    const int hi = lo + per_xcd < num_panels ? lo + per_xcd : num_panels;
+    int lo = (p / per_xcd) * per_xcd;
+    int hi = lo + per_xcd < num_panels ? lo + per_xcd : num_panels;
+    if (xcd_ptr != nullptr) {
+      int x = 0;
+      for (int i = 1; i < kNumXcd; ++i) x += p >= xcd_ptr[i] ? 1 : 0;
+      lo = xcd_ptr[x];
+      hi = xcd_ptr[x + 1];
+    }
     const int my_group = (p - lo) / group;
     const int g0 = lo + my_group * group, g1 = g0 + group < hi ? g0 + group : hi;
     const int mine = panel_ptr[g1] - panel_ptr[g0];      // k-steps of my group
@@ -332,12 +341,13 @@ static __global__ __launch_bounds__(256) void panel_order_kernel(const int* __re
   }
 }
 
-inline int panel_order(const int* panel_ptr, int num_panels, int group, int* order_out, hipStream_t stream) {
+inline int panel_order(const int* panel_ptr, int num_panels, int group, int* order_out, hipStream_t stream,
+                       const int* xcd_ptr = nullptr) {
   if (num_panels < 0 || group < 1) return kErrBadShape;
   if (num_panels == 0) return kOk;
   const int per_xcd = (num_panels + kNumXcd - 1) / kNumXcd;
   hipLaunchKernelGGL(panel_order_kernel, dim3((num_panels + 255) / 256), dim3(256), 0, stream, panel_ptr, num_panels,
-                     per_xcd, group, order_out);
+                     per_xcd, group, xcd_ptr, order_out);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

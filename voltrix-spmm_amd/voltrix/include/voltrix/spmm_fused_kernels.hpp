@@ -193,6 +193,7 @@ struct FusedArgs {
   const int* panel_cols;       // [32 * (S + 2)]
   const uint32_t* panel_bits;  // [(S + 1) * 8 * 64]   (the plan's 8 x 4 layout)
   const int* panel_order;      // optional: launch position -> panel (longest first); nullptr = natural
+  const int* xcd_ptr;          // optional int32[9]: XCD x owns the launch positions [xcd_ptr[x], xcd_ptr[x + 1]) (PanelArgs::xcd_ptr)
   const int* wave_ptr;         // [4 NP + 1]: first residual stage record of (panel, wave)
   const uint32_t* records;     // [R + 1][64]
   const in_t* input;
@@ -223,8 +224,10 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_fused_kernel(const Fus
 
   // XCD x = blockIdx.x % 8 owns a contiguous range of launch positions (as spmm_panel_kernel)
   const int xcd = blockIdx.x % kNumXcd;
-  const int pos = xcd * a.panels_per_xcd + (int)(blockIdx.x / kNumXcd);
-  const int pos_end = (xcd + 1) * a.panels_per_xcd < a.num_panels ? (xcd + 1) * a.panels_per_xcd : a.num_panels;
+  const int pos0 = a.xcd_ptr ? a.xcd_ptr[xcd] : xcd * a.panels_per_xcd;
+  const int pos = pos0 + (int)(blockIdx.x / kNumXcd);
+  const int pos_end = a.xcd_ptr ? a.xcd_ptr[xcd + 1]
+                                : ((xcd + 1) * a.panels_per_xcd < a.num_panels ? (xcd + 1) * a.panels_per_xcd : a.num_panels);
   if (pos >= pos_end) return;  // workgroup-uniform
   const int panel = a.panel_order ? a.panel_order[pos] : pos;
   const int fs0 = blockIdx.y * FS;
@@ -491,8 +494,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_fused_kernel(const Fus
     // pacing: this workgroup's cohort = the workgroups of its XCD label in its dispatch generation (32 per XCD fit at one per
     // CU); sync point b sits at iteration ceil(b nks / blocks)
     const int pace_gen = (int)(blockIdx.x / kNumXcd) / 32;
-    const int pace_members = pos_end - (xcd * a.panels_per_xcd + 32 * pace_gen) < 32
-                                 ? pos_end - (xcd * a.panels_per_xcd + 32 * pace_gen) : 32;
+    const int pace_members = pos_end - (pos0 + 32 * pace_gen) < 32 ? pos_end - (pos0 + 32 * pace_gen) : 32;
     int pace_b = 1, pace_next = a.pace ? (nks + a.pace_blocks - 1) / a.pace_blocks : 0x7FFFFFFF;
     for (int t = 0; t < nks; ++t) {
       if (a.pace && t == pace_next && blockIdx.y == 0 && pace_gen < kPaceGens) {   // workgroup-uniform
@@ -585,7 +587,8 @@ template <class T>
 inline int launch_spmm_fused(const int* panel_ptr, const int* panel_cols, const uint32_t* panel_bits,
                              const int* panel_order, const int* wave_ptr, const uint32_t* records, int num_nodes,
                              int embedding_dim, const void* input, float* output, const float* out_scale,
-                             hipStream_t stream, int pace_blocks = 0) {
+                             hipStream_t stream, int pace_blocks = 0, const int* xcd_ptr = nullptr,
+                             int max_panels_per_xcd = 0) {
   if (num_nodes < 0 || embedding_dim < 0) return kErrBadShape;
   if (num_nodes == 0 || embedding_dim == 0) return kOk;
   if (embedding_dim % 8 != 0 || ((uintptr_t)input & 15) || ((uintptr_t)records & 15)) return kErrBadShape;
@@ -602,6 +605,12 @@ inline int launch_spmm_fused(const int* panel_ptr, const int* panel_cols, const 
   a.num_nodes = num_nodes;
   a.num_panels = (num_nodes + kFusedPanelRows - 1) / kFusedPanelRows;
   a.panels_per_xcd = (a.num_panels + kNumXcd - 1) / kNumXcd;
+  a.xcd_ptr = nullptr;
+  if (xcd_ptr != nullptr) {
+    if (max_panels_per_xcd < 1 || max_panels_per_xcd > a.num_panels) return kErrBadShape;
+    a.xcd_ptr = xcd_ptr;
+    a.panels_per_xcd = max_panels_per_xcd;
+  }
   a.F = embedding_dim;
   const int slabs = (embedding_dim + T::FS - 1) / T::FS;
   a.meta_nt = slabs == 1;

@@ -105,6 +105,8 @@ struct PanelArgs {
   const int* panel_cols;       // [32 * (S + 2)]
   const uint32_t* panel_bits;  // [(S + 1) * WAVES * 64]
   const int* panel_order;      // optional: launch position -> panel (longest first); nullptr = natural
+  const int* xcd_ptr;          // optional int32[9]: XCD x owns the launch positions [xcd_ptr[x], xcd_ptr[x + 1]) (ranges of equal
+                               // work, hybrid.py::xcd_partition); nullptr: ranges of panels_per_xcd positions each
   const in_t* input;
   float* output;
   const float* out_scale;      // optional device scalar (see SpmmArgs::out_scale)
@@ -131,8 +133,9 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
   // XCD x = blockIdx.x % 8 owns a contiguous range of launch positions: neighbouring panels share most of their
   // columns (band / community structure), so they should share an L2.
   const int xcd = blockIdx.x % kNumXcd;
-  const int pos = xcd * a.panels_per_xcd + (int)(blockIdx.x / kNumXcd);
-  const int pos_end = (xcd + 1) * a.panels_per_xcd < a.num_panels ? (xcd + 1) * a.panels_per_xcd : a.num_panels;
+  const int pos = (a.xcd_ptr ? a.xcd_ptr[xcd] : xcd * a.panels_per_xcd) + (int)(blockIdx.x / kNumXcd);
+  const int pos_end = a.xcd_ptr ? a.xcd_ptr[xcd + 1]
+                                : ((xcd + 1) * a.panels_per_xcd < a.num_panels ? (xcd + 1) * a.panels_per_xcd : a.num_panels);
   if (pos >= pos_end) return;  // workgroup-uniform
   const int panel = a.panel_order ? a.panel_order[pos] : pos;
   const int fs0 = (a.slab_first + blockIdx.y) * FS;
@@ -363,7 +366,8 @@ inline int launch_spmm_panel(const int* panel_ptr, const int* panel_cols, const 
                              int accumulate, const float* out_scale, hipStream_t stream, int slab_first = 0,
                              int slab_count = 0 /* as launch_spmm_tc16: > 0 = that window of slabs in one launch */,
                              long long input_rows = 0 /* rows of the dense operand (0: num_nodes) */,
-                             int slab_policy = kSlabAuto) {
+                             int slab_policy = kSlabAuto, const int* xcd_ptr = nullptr /* device int32[9] */,
+                             int max_panels_per_xcd = 0 /* longest range of xcd_ptr (sizes the grid) */) {
   if (num_nodes < 0 || embedding_dim < 0 || accumulate < 0 || accumulate > 2) return kErrBadShape;
   if (num_nodes == 0 || embedding_dim == 0) return kOk;
   if (embedding_dim % 8 != 0 || ((uintptr_t)input & 15)) return kErrBadShape;
@@ -378,6 +382,12 @@ inline int launch_spmm_panel(const int* panel_ptr, const int* panel_cols, const 
   a.num_nodes = num_nodes;
   a.num_panels = (num_nodes + T::PANEL_ROWS - 1) / T::PANEL_ROWS;
   a.panels_per_xcd = (a.num_panels + kNumXcd - 1) / kNumXcd;
+  a.xcd_ptr = nullptr;
+  if (xcd_ptr != nullptr) {
+    if (max_panels_per_xcd < 1 || max_panels_per_xcd > a.num_panels) return kErrBadShape;
+    a.xcd_ptr = xcd_ptr;
+    a.panels_per_xcd = max_panels_per_xcd;      // sizes the grid; the kernel reads its range from xcd_ptr
+  }
   a.F = embedding_dim;
   a.accumulate = accumulate;
   const int total_slabs = (embedding_dim + T::FS - 1) / T::FS;
@@ -388,7 +398,8 @@ inline int launch_spmm_panel(const int* panel_ptr, const int* panel_cols, const 
     for (int s = 0; s < total_slabs; s += group) {
       const int rc = launch_spmm_panel<T>(panel_ptr, panel_cols, panel_bits, panel_order, num_nodes, embedding_dim, input,
                                           output, accumulate, out_scale, stream, s,
-                                          total_slabs - s < group ? total_slabs - s : group);
+                                          total_slabs - s < group ? total_slabs - s : group, input_rows, slab_policy, xcd_ptr,
+                                          max_panels_per_xcd);
       if (rc != kOk) return rc;
     }
     return kOk;

@@ -5,8 +5,11 @@
 //   * a window of nst stages (a stage = 4 TC blocks = one MFMA K step) longer than L stages is cut into
 //     k = ceil(nst / L) interleaved units, unit j = stages j, j + k, j + 2k, ...  (length ceil((nst - j) / k));
 //   * L = max(8, floor(1.5 x the lower median of nst)) unless the caller gives one;
-//   * units int32[U][4] = {window, j, k, slot}: the units of XCD x's window range [x wpx, (x + 1) wpx), wpx = ceil(W / 8),
-//     back to back, LONGEST FIRST (ties: window, then j -- a stable order, so the table is a function of the handle);
+//   * units int32[U][4] = {window, j, k, slot}: the units of XCD x's window range, back to back, LONGEST FIRST (ties: window,
+//     then j -- a stable order, so the table is a function of the handle).  The ranges: [x wpx, (x + 1) wpx), wpx =
+//     ceil(W / 8), or -- round 4 -- the caller's xcd_ptr int32[9] (first window of every range; xcd_ptr[8] = W): ranges of
+//     equal WORK instead of equal window counts (graphs with community structure: the k-steps / stages per row vary by
+//     community, an equal-rows split left one XCD with 1.57 x the mean work on the reddit-size block model);
 //     slot = index of the unit's partial tile (cut windows: consecutive slots in unit order) or -1;
 //   * unit_ptr int32[9] = first unit of every XCD's range; cuts int32[C][4] = {window, first slot, k, 0} per cut window.
 // Two phases around the one host sync the caller needs anyway (U and C size the outputs):
@@ -116,6 +119,14 @@ inline long long unit_table_fill_workspace_bytes(long long num_units) {
 __device__ __forceinline__ int ut_stages(const int* __restrict__ blk_offsets, const int w) {
   return (blk_offsets[w + 1] - blk_offsets[w] + kTcbPerStage - 1) / kTcbPerStage;
 }
+// XCD range of window w: the caller's boundaries (xcd_ptr[x] <= w < xcd_ptr[x + 1]) or the equal split
+__device__ __forceinline__ int ut_xcd_of(const int* __restrict__ xcd_ptr, const int windows_per_xcd, const int w) {
+  if (xcd_ptr == nullptr) return w / windows_per_xcd;
+  int x = 0;
+#pragma unroll
+  for (int i = 1; i < kNumXcd; ++i) x += w >= xcd_ptr[i] ? 1 : 0;
+  return x;
+}
 
 static __global__ __launch_bounds__(256) void ut_hist_kernel(const int* __restrict__ blk_offsets, const int num_windows,
                                                              int* __restrict__ hist) {
@@ -169,7 +180,8 @@ static __global__ __launch_bounds__(1024) void ut_median_kernel(const int* __res
 }
 
 static __global__ __launch_bounds__(256) void ut_cut_kernel(const int* __restrict__ blk_offsets, const int num_windows,
-                                                            const int windows_per_xcd, int* __restrict__ stats,
+                                                            const int windows_per_xcd, const int* __restrict__ xcd_ptr,
+                                                            int* __restrict__ stats,
                                                             int* __restrict__ k_out, int* __restrict__ kcut_out,
                                                             int* __restrict__ cutflag_out) {
   const int L = stats[0];
@@ -181,7 +193,7 @@ static __global__ __launch_bounds__(256) void ut_cut_kernel(const int* __restric
     kcut_out[w] = k > 1 ? k : 0;
     cutflag_out[w] = k > 1 ? 1 : 0;
     atomicMax(&stats[1], (nst + k - 1) / k);   // top: the longest unit (unit 0 of its window)
-    atomicAdd(&stats[8 + w / windows_per_xcd], k);
+    atomicAdd(&stats[8 + ut_xcd_of(xcd_ptr, windows_per_xcd, w)], k);
   }
 }
 
@@ -217,7 +229,7 @@ inline int unit_table_check(int num_nodes) {
 
 // Phase 1: header[8] <- {U, C, slots, max units per XCD, L, top, 0, 0}.  max_stages <= 0: the default bound.
 inline int unit_table_count(const int* blk_offsets, int num_nodes, int max_stages, void* workspace, int* header,
-                            hipStream_t stream) {
+                            hipStream_t stream, const int* xcd_ptr = nullptr /* device int32[9] or NULL: equal split */) {
   if (int rc = unit_table_check(num_nodes)) return rc;
   if (((uintptr_t)workspace & 15) || header == nullptr) return kErrBadShape;
   if (hipMemsetAsync(header, 0, kUtHeaderInts * sizeof(int), stream) != hipSuccess) return kErrLaunch;
@@ -229,7 +241,7 @@ inline int unit_table_count(const int* blk_offsets, int num_nodes, int max_stage
   if (max_stages <= 0) hipLaunchKernelGGL(ut_hist_kernel, dim3(grid), dim3(256), 0, stream, blk_offsets, W, ws.hist);
   hipLaunchKernelGGL(ut_median_kernel, dim3(1), dim3(1024), 0, stream, ws.hist, W, max_stages, ws.stats);
   const int wpx = (W + kNumXcd - 1) / kNumXcd;
-  hipLaunchKernelGGL(ut_cut_kernel, dim3(grid), dim3(256), 0, stream, blk_offsets, W, wpx, ws.stats, ws.k, ws.kcut,
+  hipLaunchKernelGGL(ut_cut_kernel, dim3(grid), dim3(256), 0, stream, blk_offsets, W, wpx, xcd_ptr, ws.stats, ws.k, ws.kcut,
                      ws.cutflag);
   if (int rc = ut_exclusive_scan(ws.k, W, ws.chunk_sums, ws.first, stream)) return rc;
   if (int rc = ut_exclusive_scan(ws.kcut, W, ws.chunk_sums, ws.slot_first, stream)) return rc;
@@ -241,7 +253,8 @@ inline int unit_table_count(const int* blk_offsets, int num_nodes, int max_stage
 
 // one thread per window: its units' sort keys, and the cut record of a cut window
 static __global__ __launch_bounds__(256) void ut_emit_kernel(const int* __restrict__ blk_offsets, const int num_windows,
-                                                             const int windows_per_xcd, const int* __restrict__ stats,
+                                                             const int windows_per_xcd, const int* __restrict__ xcd_ptr,
+                                                             const int* __restrict__ stats,
                                                              const int* __restrict__ k_in, const int* __restrict__ first,
                                                              const int* __restrict__ slot_first,
                                                              const int* __restrict__ cut_pos,
@@ -252,7 +265,7 @@ static __global__ __launch_bounds__(256) void ut_emit_kernel(const int* __restri
     const int nst = ut_stages(blk_offsets, w);
     const int k = k_in[w];
     const int u0 = first[w];
-    const uint32_t group = (uint32_t)(w / windows_per_xcd) * (uint32_t)(top + 1);
+    const uint32_t group = (uint32_t)ut_xcd_of(xcd_ptr, windows_per_xcd, w) * (uint32_t)(top + 1);
     for (int j = 0; j < k; ++j) {
       const int length = (nst - j + k - 1) / k;
       unit_window[u0 + j] = w;
@@ -291,7 +304,8 @@ static __global__ void ut_ptr_kernel(const int* __restrict__ stats, int* __restr
 // Phase 2 (same workspace, untouched since phase 1; num_units / num_cuts / top = the header the caller read).
 // units int32[U][4], unit_ptr int32[9], cuts int32[C][4]: every element is written.
 inline int unit_table_fill(const int* blk_offsets, int num_nodes, void* workspace, void* fill_workspace, int num_units,
-                           int num_cuts, int top, int* units, int* unit_ptr, int* cuts, hipStream_t stream) {
+                           int num_cuts, int top, int* units, int* unit_ptr, int* cuts, hipStream_t stream,
+                           const int* xcd_ptr = nullptr /* the same boundaries as in phase 1 */) {
   if (int rc = unit_table_check(num_nodes)) return rc;
   if (((uintptr_t)workspace & 15) || ((uintptr_t)fill_workspace & 15) || num_units < 0 || num_cuts < 0 || top < 0)
     return kErrBadShape;
@@ -303,7 +317,7 @@ inline int unit_table_fill(const int* blk_offsets, int num_nodes, void* workspac
   const UtFillWorkspace fw = ut_fill_workspace(fill_workspace, num_units);
   const int wpx = (W + kNumXcd - 1) / kNumXcd;
   const int grid = (W + 255) / 256 < 4096 ? (W + 255) / 256 : 4096;
-  hipLaunchKernelGGL(ut_emit_kernel, dim3(grid), dim3(256), 0, stream, blk_offsets, W, wpx, ws.stats, ws.k, ws.first,
+  hipLaunchKernelGGL(ut_emit_kernel, dim3(grid), dim3(256), 0, stream, blk_offsets, W, wpx, xcd_ptr, ws.stats, ws.k, ws.first,
                      ws.slot_first, ws.cut_pos, fw.unit_window, fw.keys_in, fw.vals_in, reinterpret_cast<int4*>(cuts));
   // stable sort by (XCD, top - length): 3 bits of XCD above the bits of top
   int bits = 1;

@@ -308,21 +308,25 @@ def arg_defs_for(dtype):
     )
 
 
-def handle_unit_table(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, num_nodes: int, pairs: bool = False):
+def handle_unit_table(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, num_nodes: int, pairs: bool = False,
+                      xcd_ptr: torch.Tensor = None):
     """The handle's unit table (voltrix.schedule.unit_table; default length bound, or 1.25 x the median for the paired
-    launch), built once on the GPU and cached on the ``hspa_packed`` tensor object."""
+    launch), built once on the GPU and cached on the ``hspa_packed`` tensor object.  XCD ranges: the caller's ``xcd_ptr``
+    (the two-level step: the panel kernel's ranges) or, round 4, ranges of equal STAGES instead of equal window counts
+    (``schedule.balanced_xcd_windows``: graphs whose rows are not statistically alike)."""
     attr = "_voltrix_unit_table_pairs" if pairs else "_voltrix_unit_table"
     cache = getattr(hspa_packed, attr, None)
-    key = (blk_offsets.data_ptr(), num_nodes)
+    key = (blk_offsets.data_ptr(), num_nodes, xcd_ptr.data_ptr() if xcd_ptr is not None else 0)
     if isinstance(cache, tuple) and cache[0] == key:
         return cache[1]
-    from ..schedule import default_max_stages, unit_table
+    from ..schedule import balanced_xcd_windows, default_max_stages, unit_table
 
+    ranges = xcd_ptr if xcd_ptr is not None else balanced_xcd_windows(blk_offsets, num_nodes)
     if pairs:
         median_x_1_5 = default_max_stages(blk_offsets, num_nodes)
-        table = unit_table(blk_offsets, num_nodes, max(8, int(PAIR_UNIT_FACTOR * median_x_1_5 / 1.5)))
+        table = unit_table(blk_offsets, num_nodes, max(8, int(PAIR_UNIT_FACTOR * median_x_1_5 / 1.5)), xcd_ptr=ranges)
     else:
-        table = unit_table(blk_offsets, num_nodes)
+        table = unit_table(blk_offsets, num_nodes, xcd_ptr=ranges)
     try:
         setattr(hspa_packed, attr, (key, table))
     except AttributeError:
@@ -406,7 +410,7 @@ class PendingCombine:
 
 
 def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_dim, input, output, out_scale=None,
-                atomic_out=False, beside_panel=False, defer_combine=False, row_map=None, values=None):
+                atomic_out=False, beside_panel=False, defer_combine=False, row_map=None, values=None, xcd_ptr=None):
     """Extensions over the reference wrapper (all default to its behaviour):
     ``out_scale``      float32 device tensor whose first element multiplies every output element (the power-of-two
                        written by ``capi.launch_cast_f32_f16_scaled``); default 1.
@@ -419,6 +423,8 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
                        handles of a row-permuted CSR (voltrix/reorder.py) write the product through it.
     ``values``         weighted SpMM (voltrix/weighted.py): the value plane [T, 16, 8] of ``input``'s 16-bit dtype that
                        replaces the bitmaps as the A operand.
+    ``xcd_ptr``        int32 [9] device tensor: first window of every XCD's range for the unit-table schedules (the two-level
+                       step passes the panel kernel's ranges); default: ranges of equal stages.
     """
     assert blk_offsets.is_cuda and blk_offsets.dtype == torch.int32
     assert hspa_packed.is_cuda and hspa_packed.dtype == torch.uint32
@@ -456,7 +462,7 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
     else:
         want = lambda sched: any(p["SCHED"] == sched for p in space)           # noqa: E731
     if want(SCHED_UNITS):
-        table = handle_unit_table(blk_offsets, hspa_packed, num_nodes)
+        table = handle_unit_table(blk_offsets, hspa_packed, num_nodes, xcd_ptr=xcd_ptr)
         partials = torch.empty(max(1, table.num_slots) * 16 * embedding_dim, dtype=torch.float32, device=input.device)
         units, unit_ptr, cuts = table.units, table.unit_ptr, table.cuts
         max_units, num_cuts = table.max_units_per_xcd, table.num_cuts
@@ -465,7 +471,7 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
         units = unit_ptr = cuts = blk_offsets   # never dereferenced (no SCHED 4 point will run)
         max_units = num_cuts = 0
     if want(SCHED_PAIRS):
-        table_p = handle_unit_table(blk_offsets, hspa_packed, num_nodes, pairs=True)
+        table_p = handle_unit_table(blk_offsets, hspa_packed, num_nodes, pairs=True, xcd_ptr=xcd_ptr)
         partials_p = torch.empty(max(1, table_p.num_slots) * 16 * embedding_dim, dtype=torch.float32, device=input.device)
     else:
         table_p, partials_p = None, out_scale

@@ -429,7 +429,9 @@ def order_statistics(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int
     share = (nnz - resid) / max(1, nnz) if plan_ok else 0.0
     big = (nnz >= hybrid.AUTO_MIN_EDGES and num_nodes >= hybrid.AUTO_MIN_ROWS
            and nnz >= hybrid.AUTO_MIN_MEAN_DEGREE * max(1, num_nodes))
-    two_level = plan_ok and big and share >= hybrid.min_shared_fraction()
+    mode = hybrid.hybrid_mode()       # the decision csr_preprocess_device will make for this order (spmm/spmm.py)
+    two_level = (plan_ok and ksteps > 0 and (mode == "on" or (mode in ("auto", "tune") and big))
+                 and share >= hybrid.min_shared_fraction())
     return {"tc_blocks": int(blocks), "shared_fraction": share, "ksteps": int(ksteps), "longest_panel_ksteps": int(longest),
             "two_level": bool(two_level), "ids_outside_universe": int(outside),
             "score": float(blocks) * (1.0 - 0.9 * share) if two_level else float(blocks),

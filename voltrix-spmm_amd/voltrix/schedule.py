@@ -54,21 +54,64 @@ def default_max_stages(blk_offsets: torch.Tensor, num_nodes: int) -> int:
     return max(8, int(1.5 * float(nst.float().median())))
 
 
-def unit_table(blk_offsets: torch.Tensor, num_nodes: int, max_stages: int = None, chunk: int = None) -> UnitTable:
+def balanced_xcd_windows(blk_offsets: torch.Tensor, num_nodes: int, align: int = 1) -> torch.Tensor:
+    """int32 [9] on the handle's device: first window of every XCD's range such that the eight ranges hold about the same
+    number of STAGES (the window kernel's work), boundaries on multiples of ``align`` windows.  The equal-windows split the
+    kernels default to is the same thing on graphs whose rows are statistically alike (the reddit-like stand-in: +- 2 %); on
+    graphs with community structure it is not (a reddit-size block model: 1.57 x the mean on the busiest XCD).  Depends on
+    blk_offsets only: deterministic."""
+    dev = blk_offsets.device
+    num_windows = (num_nodes + 15) // 16
+    out = torch.zeros(NUM_XCD + 1, dtype=torch.int64, device=dev)
+    if num_windows == 0:
+        return out.to(torch.int32)
+    nst = ((blk_offsets[1:num_windows + 1] - blk_offsets[:num_windows]).to(torch.int64) + 3) // 4
+    return split_equal_work(nst, align)
+
+
+def split_equal_work(work: torch.Tensor, align: int = 1) -> torch.Tensor:
+    """int32 [9]: boundaries b[0] = 0 <= b[1] <= ... <= b[8] = len(work) (multiples of ``align`` inside) such that the eight
+    ranges of ``work`` (non-negative int64 per item) have about equal sums: b[x] = the index whose prefix sum is NEAREST to
+    x / 8 of the total (the item that crosses the target goes to the side that leaves the smaller error), rounded up to
+    ``align``."""
+    dev = work.device
+    n = work.numel()
+    prefix = torch.cumsum(work.to(torch.int64), 0)
+    total = int(prefix[-1]) if n else 0
+    out = torch.zeros(NUM_XCD + 1, dtype=torch.int64, device=dev)
+    out[NUM_XCD] = n
+    if total > 0:
+        targets = torch.tensor([(total * x + NUM_XCD - 1) // NUM_XCD for x in range(1, NUM_XCD)], dtype=torch.int64, device=dev)
+        hi = (torch.searchsorted(prefix, targets, right=False) + 1).clamp(max=n)   # items before the boundary, crossing one in
+        over = prefix[hi - 1] - targets
+        under = targets - torch.where(hi >= 2, prefix[(hi - 2).clamp(min=0)], torch.zeros_like(targets))
+        cut = torch.where(under < over, hi - 1, hi)
+        cut = ((cut + align - 1) // align * align).clamp(max=n)
+        out[1:NUM_XCD] = torch.cummax(cut, 0).values
+    else:
+        per = (n + NUM_XCD - 1) // NUM_XCD
+        out[1:NUM_XCD] = torch.arange(1, NUM_XCD, device=dev).mul(per).clamp(max=n)
+    return out.to(torch.int32)
+
+
+def unit_table(blk_offsets: torch.Tensor, num_nodes: int, max_stages: int = None, chunk: int = None,
+               xcd_ptr: torch.Tensor = None) -> UnitTable:
     """The handle's unit table (layout and rules: :func:`unit_table_torch`).  Built by the library's two-phase device
     builder (``voltrix/unit_table.hpp`` through ``capi.build_unit_table`` -- the same entry points a C host binds);
     the chunked listing (experiments) and CPU tensors go through the torch-tensor restatement, which the tests also use
     to check the native table element by element."""
     if chunk is not None or not blk_offsets.is_cuda:
-        return unit_table_torch(blk_offsets, num_nodes, max_stages, chunk)
+        return unit_table_torch(blk_offsets, num_nodes, max_stages, chunk, xcd_ptr)
     from . import capi
 
-    units, unit_ptr, cuts, head = capi.build_unit_table(blk_offsets, num_nodes, 0 if max_stages is None else max_stages)
+    units, unit_ptr, cuts, head = capi.build_unit_table(blk_offsets, num_nodes, 0 if max_stages is None else max_stages,
+                                                        xcd_ptr=xcd_ptr)
     return UnitTable(units, unit_ptr, cuts, head[3], head[0], head[1], head[2], head[4] if num_nodes > 0 else
                      (1 if max_stages is None else max_stages))
 
 
-def unit_table_torch(blk_offsets: torch.Tensor, num_nodes: int, max_stages: int = None, chunk: int = None) -> UnitTable:
+def unit_table_torch(blk_offsets: torch.Tensor, num_nodes: int, max_stages: int = None, chunk: int = None,
+                     xcd_ptr: torch.Tensor = None) -> UnitTable:
     """Cut every window of more than ``max_stages`` stages (a stage = 4 TC blocks = one MFMA K step) into
     ``k = ceil(stages / max_stages)`` interleaved units -- unit j runs the stages j, j + k, j + 2k, ... -- so that every
     unit sweeps the window's whole (sorted) column range with at most ``max_stages`` stages.  Units of one XCD's window
@@ -99,7 +142,11 @@ def unit_table_torch(blk_offsets: torch.Tensor, num_nodes: int, max_stages: int 
     slot_first = torch.cumsum(k_cut, 0) - k_cut
     slot = torch.where(cut[w], slot_first[w] + j, torch.full_like(w, -1))
     wpx = (num_windows + NUM_XCD - 1) // NUM_XCD
-    xcd = w // wpx
+    if xcd_ptr is not None:      # ranges of equal work (balanced_xcd_windows): XCD of window w = ranges whose start is <= w
+        assert chunk is None
+        xcd = torch.searchsorted(xcd_ptr.to(torch.int64)[1:NUM_XCD].contiguous(), w, right=True)
+    else:
+        xcd = w // wpx
     group = xcd if chunk is None else xcd * (wpx // max(1, chunk) + 2) + (w - xcd * wpx) // max(1, chunk)
     top = int(length.max())
     order = torch.argsort(group * (top + 1) + (top - length), stable=True)

@@ -98,11 +98,12 @@ def save_handle(path: str, handle, num_nodes: int) -> None:
         blob["two_level"] = {
             "residual": [t.detach().cpu() for t in (two.blk_offsets, two.hspa_packed.view(torch.int32), two.hind)],
             "plan_tensors": {k: (getattr(plan, k).detach().cpu().view(torch.int32) if getattr(plan, k) is not None else None)
-                             for k in ("panel_ptr", "panel_cols", "panel_bits", "panel_order")},
+                             for k in ("panel_ptr", "panel_cols", "panel_bits", "panel_order", "xcd_ptr")},
             "plan_scalars": {f.name: getattr(plan, f.name) for f in dataclasses.fields(plan)
                              if not isinstance(getattr(plan, f.name), torch.Tensor) and getattr(plan, f.name) is not None
                              or f.name in ("num_nodes", "waves", "row_blocks", "tau", "num_ksteps", "num_shared_edges",
-                                           "num_resid_edges")},
+                                           "num_resid_edges", "max_panels_per_xcd")},
+            "window_xcd_ptr": two.window_xcd_ptr.cpu() if two.window_xcd_ptr is not None else None,
             "num_nodes": two.num_nodes, "num_edges": two.num_edges, "hash_tag": two.hash_tag,
             "format_choice": dict(two.format_choice),
             "fused": None if two.fused is None else {"wave_ptr": two.fused.wave_ptr.cpu(),
@@ -129,11 +130,13 @@ def load_handle(path: str, device: Optional[torch.device] = None):
         pt = {k: (v.to(device) if v is not None else None) for k, v in tl["plan_tensors"].items()}
         pt["panel_bits"] = pt["panel_bits"].view(torch.uint32)
         scalars = {k: tl["plan_scalars"][k] for k in ("num_nodes", "waves", "row_blocks", "tau", "num_ksteps",
-                                                       "num_shared_edges", "num_resid_edges")}
+                                                       "num_shared_edges", "num_resid_edges", "max_panels_per_xcd")}
         plan = hybrid.PanelPlan(**pt, **scalars)
         r0, r1, r2 = (t.to(device) for t in tl["residual"])
         two = hybrid.TwoLevelHandle(r0, r1.view(torch.uint32), r2, plan, tl["num_nodes"], tl["num_edges"],
                                     hash_tag=tl["hash_tag"], format_choice=dict(tl["format_choice"]))
+        if tl.get("window_xcd_ptr") is not None:
+            two.window_xcd_ptr = tl["window_xcd_ptr"].to(device)
         if tl["fused"] is not None:
             two.fused = hybrid.FusedRecords(tl["fused"]["wave_ptr"].to(device),
                                             tl["fused"]["records"].to(device).view(torch.uint32), tl["fused"]["num_records"])

@@ -121,6 +121,7 @@ def _build_two_level(indptr_d, indices_d, num_nodes, num_cols, waves=hybrid.DEFA
     pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(resid_indptr, resid_indices, num_nodes, num_cols,
                                                                  path=preprocess_mode()[1])
     two = hybrid.TwoLevelHandle(pointer1, hspa_packed, hind, plan, num_nodes, int(indices_d.numel()))
+    hybrid.balance_xcd_ranges(two)
     _attach_fused(two)
     return two
 
@@ -151,6 +152,7 @@ def csr_preprocess_hybrid(indptr: torch.Tensor, indices: torch.Tensor, num_nodes
     pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(resid_indptr, resid_indices, num_nodes, num_cols,
                                                                  path=preprocess_mode()[1])
     two = hybrid.TwoLevelHandle(pointer1, hspa_packed, hind, plan, num_nodes, int(indices.numel()))
+    hybrid.balance_xcd_ranges(two)
     _attach_fused(two)
     return two
 
@@ -263,7 +265,7 @@ def _run_two_level(two, operand, output, out_scale, tag_source=None, concurrent=
         return spmm_kernel(two.blk_offsets, resid, two.hind, num_nodes=two.num_nodes,
                            num_edges=two.plan.num_resid_edges, embedding_dim=operand.shape[1], input=operand,
                            output=output, out_scale=out_scale, atomic_out=atomic,
-                           beside_panel=two.plan.num_ksteps > 0, defer_combine=True)
+                           beside_panel=two.plan.num_ksteps > 0, defer_combine=True, xcd_ptr=two.window_xcd_ptr)
 
     hybrid.run_two_level(two.plan, operand, output, run_window, out_scale=out_scale, concurrent=concurrent)
 
