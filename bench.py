@@ -598,10 +598,16 @@ def main():
                    "join": "atomic",
                    "panel_rows": two.plan.panel_rows, "tau": two.plan.tau,
                    "shared_edge_fraction_rank0": two.plan.num_shared_edges / max(1, local_nnz),
-                   "panel_ksteps_rank0": two.plan.num_ksteps, "residual_tc_blocks_rank0": resid_blocks}
+                   "panel_ksteps_rank0": two.plan.num_ksteps, "residual_tc_blocks_rank0": resid_blocks,
+                   # round 4: the schedules of the step (data, not timing): XCD ranges of equal work, long panels in pieces
+                   "xcd_ranges": "equal work" if two.plan.xcd_ptr is not None else "equal counts",
+                   "panel_pieces": None if two.plan.parts is None else {
+                       "bound_ksteps": two.plan.parts.cap, "pieces": two.plan.parts.num_parts,
+                       "cut_panels": two.plan.parts.num_cuts, "partial_tiles": two.plan.parts.num_slots}}
             kernels = ("memset(C) ; spmm_panel_kernel || "
                        + ("spmm_tc16_pair_kernel" if point.get("SCHED") == SCHED_PAIRS else "spmm_tc16_kernel")
-                       + " ; combine_partials_kernel")
+                       + " ; combine_partials_kernel"
+                       + (" ; combine_panel_partials_kernel" if two.plan.parts is not None and two.plan.parts.num_slots else ""))
         else:
             gather_bytes = 8 * total_blocks * num_feats * in_bytes  # rows gathered from L2 / Infinity Cache / HBM
             fmt = {"format": "window (the reference's block format)"}

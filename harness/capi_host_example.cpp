@@ -235,6 +235,49 @@ int main(int argc, char** argv) {
   HIP_OK(hipStreamSynchronize(s_main));
   const double err_two_level = max_rel_err(to_host(d_c, (size_t)n * f));
 
+  // ---- 2b. the same step with the panel kernel over PIECES of panels (round 4): a piece table built on the host from
+  // ---- panel_ptr -- here every panel of two or more k-steps is cut in two, so the combine path runs on any graph; the
+  // ---- product's rule (voltrix/hybrid.py::panel_parts) cuts only panels longer than a CU's fair share of the k-steps.
+  // ---- Pieces of a cut panel STORE to partial tiles; combine_panel_partials adds them to C in slot order after the join. ----
+  std::vector<int> h_panel_ptr(num_panels + 1);
+  HIP_OK(hipMemcpy(h_panel_ptr.data(), panel_ptr, (num_panels + 1) * sizeof(int), hipMemcpyDeviceToHost));
+  std::vector<int> h_parts, h_pcuts;
+  int slots = 0;
+  for (int p = 0; p < num_panels; ++p) {   // launch order: natural (XCD ranges of ceil(pieces / 8) positions each)
+    const int nks = h_panel_ptr[p + 1] - h_panel_ptr[p];
+    if (nks >= 2) {
+      const int first = nks / 2;
+      h_pcuts.insert(h_pcuts.end(), {p, slots, 2, 0});
+      h_parts.insert(h_parts.end(), {p, 0, first, slots});
+      h_parts.insert(h_parts.end(), {p, first, nks - first, slots + 1});
+      slots += 2;
+    } else {
+      h_parts.insert(h_parts.end(), {p, 0, nks, -1});
+    }
+  }
+  const int num_parts = (int)h_parts.size() / 4, num_pcuts = (int)h_pcuts.size() / 4;
+  int* parts = dev_alloc<int>(h_parts.size());
+  int* pcuts = dev_alloc<int>(std::max<size_t>(h_pcuts.size(), 4));
+  float* panel_partials = dev_alloc<float>((size_t)std::max(1, slots) * panel_rows * f);
+  HIP_OK(hipMemcpy(parts, h_parts.data(), h_parts.size() * sizeof(int), hipMemcpyHostToDevice));
+  if (num_pcuts) HIP_OK(hipMemcpy(pcuts, h_pcuts.data(), h_pcuts.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_OK(hipMemsetAsync(d_c, 0, (size_t)n * f * sizeof(float), s_main));
+  HIP_OK(hipEventRecord(fork, s_main));
+  HIP_OK(hipStreamWaitEvent(s_side, fork, 0));
+  RC_OK(voltrix_launch_spmm_panel_parts_f16(panel_ptr, panel_cols, panel_bits, parts, num_parts, /*xcd_ptr=*/nullptr, 0,
+                                            panel_partials, n, f, d_b, /*input_rows=*/n, d_c, /*accumulate=*/2, /*fs=*/128,
+                                            /*depth=*/3, waves, row_blocks, /*ksteps=*/1, VOLTRIX_SLAB_AUTO, nullptr, s_side,
+                                            &rc_));
+  HIP_OK(hipEventRecord(join, s_side));
+  window_spmm(hr, tr, n, resid_edges, f, d_b, d_c, /*atomic_out=*/1, partials_r, s_main);
+  HIP_OK(hipStreamWaitEvent(s_main, join, 0));
+  RC_OK(voltrix_launch_combine_partials(tr.cuts, tr.header[1], partials_r, d_c, n, f, /*accumulate=*/1, nullptr, s_main,
+                                        &rc_));
+  RC_OK(voltrix_launch_combine_panel_partials(pcuts, num_pcuts, panel_partials, d_c, n, f, panel_rows, /*accumulate=*/1,
+                                              s_main, &rc_));
+  HIP_OK(hipStreamSynchronize(s_main));
+  const double err_pieces = max_rel_err(to_host(d_c, (size_t)n * f));
+
   // ---- 3. the same two-level product as ONE launch: stage records of the residual handle, then spmm_fused (plain stores:
   // ---- no zero fill, no second stream, no combine pass; the residual handle itself is no longer needed afterwards) ----------
   int fused_waves = 0, fused_row_blocks = 0;
@@ -329,12 +372,14 @@ int main(int argc, char** argv) {
   const bool order_ok = order == cpu_order;
 
   std::printf("N=%d nnz=%lld F=%d | window format: %d TC blocks, %d units (%d cut windows), rel err %.3e | two-level: %d "
-              "k-steps, %d residual edges (%d units), rel err %.3e | one launch: %d stage records, rel err %.3e\n",
+              "k-steps, %d residual edges (%d units), rel err %.3e | panels in %d pieces (%d cut): rel err %.3e | one launch: %d "
+              "stage records, rel err %.3e\n",
               n, (long long)e, f, h.total_blocks, t.header[0], t.header[1], err_window, ksteps, resid_edges, tr.header[0],
-              err_two_level, num_records, err_fused);
+              err_two_level, num_parts, num_pcuts, err_pieces, num_records, err_fused);
   std::printf("Cuthill-McKee search from row %d: %d rows in %d levels, order %s the CPU search\n", start, cm_nodes, cm_levels,
               order_ok ? "equals" : "DIFFERS FROM");
-  const bool ok = err_window < 1e-5 && err_two_level < 1e-5 && err_fused < 1e-5 && std::isfinite(err_window) &&
-                  std::isfinite(err_two_level) && std::isfinite(err_fused) && order_ok;
+  const bool ok = err_window < 1e-5 && err_two_level < 1e-5 && err_fused < 1e-5 && err_pieces < 1e-5 &&
+                  std::isfinite(err_window) && std::isfinite(err_two_level) && std::isfinite(err_fused) &&
+                  std::isfinite(err_pieces) && order_ok;
   return ok ? 0 : 1;
 }

@@ -30,7 +30,7 @@ def main():
     two_level = fmt.startswith("two-level")
     pair = "two units per wave" in (tile.get("schedule") or "")
     tile_sig = f"SpmmTile<{tile['fs']}, {tile['depth']}, {tile['waves']},"
-    wanted = {("spmm_tc16_pair_kernel" if pair else "spmm_tc16_kernel<"): tile_sig, "combine_partials_kernel": "",
+    wanted = {("spmm_tc16_pair_kernel" if pair else "spmm_tc16_kernel<"): tile_sig, "combine_partials_kernel": "", "combine_panel_partials_kernel": "" if two_level else None,
               "spmm_panel_kernel": "" if two_level else None, "FillFunctor<float>": "" if two_level else None,
               "spmm_fused_kernel": ""}
 

@@ -233,6 +233,30 @@ void voltrix_launch_spmm_panel_bf16(void* panel_ptr, void* panel_cols, void* pan
                                     int accumulate, int fs, int depth, int waves, int row_blocks, int ksteps,
                                     int slab_policy, void* out_scale, void* stream, int* return_code);
 
+/* The same kernel over PARTS of panels (round 4; voltrix/hybrid.py::panel_parts builds the table, no reference counterpart).
+ * A panel's k-step list is walked by ONE workgroup, so the longest panel is a critical path (a panel inside a dense
+ * community carries 5-20 x the k-steps of the median panel).  parts int32 [num_parts][4] = {panel, first k-step inside the
+ * panel, k-steps, slot} replaces panel_order: launch position -> a piece of at most a bounded number of k-steps.  slot < 0:
+ * the panel is whole and its tile goes to `output` per `accumulate`, exactly as above.  slot >= 0: the panel is cut; every
+ * piece STORES its tile to partials[slot] (float32 [slots][16 waves row_blocks][embedding_dim], per-call scratch) and
+ * voltrix_launch_combine_panel_partials -- on the same stream, after this launch (and, for accumulate == 2, after the window
+ * kernel has been joined) -- adds the pieces to `output` in slot order: a fixed order, whatever the pieces' timing.
+ * xcd_ptr / max_parts_per_xcd as above, over part positions (NULL / 0: ranges of ceil(num_parts / 8)).
+ *   cuts int32 [num_cuts][4] = {panel, first slot, pieces, 0};  panel_rows = 16 waves row_blocks;  accumulate 0: output rows
+ *   of the cut panels = the sum; != 0: added onto output (plain read-add-store). */
+void voltrix_launch_spmm_panel_parts_f16(void* panel_ptr, void* panel_cols, void* panel_bits, void* parts, int num_parts,
+                                         void* xcd_ptr, int max_parts_per_xcd, void* partials, int num_nodes, int embedding_dim,
+                                         void* input, int64_t input_rows, void* output, int accumulate, int fs, int depth,
+                                         int waves, int row_blocks, int ksteps, int slab_policy, void* out_scale, void* stream,
+                                         int* return_code);
+void voltrix_launch_spmm_panel_parts_bf16(void* panel_ptr, void* panel_cols, void* panel_bits, void* parts, int num_parts,
+                                          void* xcd_ptr, int max_parts_per_xcd, void* partials, int num_nodes, int embedding_dim,
+                                          void* input, int64_t input_rows, void* output, int accumulate, int fs, int depth,
+                                          int waves, int row_blocks, int ksteps, int slab_policy, void* out_scale, void* stream,
+                                          int* return_code);
+void voltrix_launch_combine_panel_partials(void* cuts, int num_cuts, void* partials, void* output, int num_nodes,
+                                           int embedding_dim, int panel_rows, int accumulate, void* stream, int* return_code);
+
 /* The two-level format in ONE launch (spmm_fused_kernels.hpp; round 3, rebuilt in round 4).  One 256-thread workgroup per
  * 512-row panel -- four waves, one per SIMD, eight 16-row blocks each; the plan keeps its waves = 8 x row_blocks = 4 layout --
  * computes the whole product for its rows: the shared columns from the panel plan (arrays as for

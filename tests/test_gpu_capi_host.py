@@ -33,3 +33,4 @@ def test_cpp_host_runs_both_formats_through_the_c_abi(cuda_device, host_binary, 
                           timeout=300)
     assert proc.returncode == 0, (proc.returncode, proc.stdout[-2000:], proc.stderr[-2000:])
     assert "rel err" in proc.stdout and "order equals the CPU search" in proc.stdout
+    assert "panels in" in proc.stdout and "pieces" in proc.stdout      # step 2b: voltrix_launch_spmm_panel_parts_f16 + combine

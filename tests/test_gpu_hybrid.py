@@ -401,3 +401,91 @@ def test_xcd_ranges_of_equal_work_give_the_same_bits(cuda_device, monkeypatch):
     ref = torch.sparse.mm(torch.sparse_csr_tensor(indptr.long(), indices.long(), torch.ones(indices.numel(), device="cuda"),
                                                   size=(n, n)), feat.float())
     assert float((balanced - ref).norm() / ref.norm()) < 1e-3 and float((balanced_pair - ref).norm() / ref.norm()) < 1e-3
+
+
+@pytest.mark.parametrize("waves,rb,tile,feat_dim", [(8, 4, (128, 3, 1), 128), (8, 4, (128, 3, 1), 264), (4, 4, (64, 4, 1), 64),
+                                                    (8, 4, (64, 4, 2), 40), (8, 2, (128, 4, 1), 128)])
+@pytest.mark.parametrize("cap", [1, 3, 1000])
+def test_panel_kernel_in_pieces(cuda_device, waves, rb, tile, feat_dim, cap):
+    """Round 4: the panel kernel over PIECES of panels (PanelArgs::parts) -- cut panels leave partial tiles that
+    combine_panel_partials adds in slot order.  Small integers: the same bits as one workgroup per panel in all three output
+    modes (every partial sum is an integer below 2^24, so the order of the pieces cannot show).  Random data: within the
+    stated bound of the oracle, and the same bits run to run.  cap = 1: every k-step its own piece; 1000: nothing is cut
+    (table without slots); several column slabs (F = 264), two k-steps per ring slot, the N % panel tail."""
+    n = 1100
+    indptr, indices = _random_csr(n, 90, seed=waves + rb + feat_dim)
+    _, _, plan = hybrid.build_panel_plan(torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda(), n, None, waves,
+                                         rb, 2)
+    shared = oracle_np.panel_to_edges(plan.panel_ptr.cpu().numpy(), plan.panel_cols.cpu().numpy(),
+                                      plan.panel_bits.view(torch.int32).cpu().numpy().view(np.uint32), n, waves, rb)
+    s_indptr, s_indices = _edges_to_csr(shared, n)
+    torch.manual_seed(feat_dim + cap)
+    ints = torch.randint(-3, 4, (n, feat_dim), device=cuda_device).half()
+    prior = torch.randint(-50, 50, (n, feat_dim), device=cuda_device).float()
+
+    def run(feat, accumulate):
+        out = prior.clone() if accumulate else torch.full((n, feat_dim), float("nan"), device=cuda_device)
+        hybrid.launch_panel(plan, feat, out, accumulate=accumulate, tile=tile)
+        return out
+
+    whole = {acc: run(ints, acc) for acc in (0, 1, 2)}
+    plan.parts = hybrid.panel_parts(plan.panel_ptr, cap)
+    assert (plan.parts.num_slots > 0) == (cap < 1000) and plan.parts.num_parts >= plan.num_panels
+    for acc in (0, 1, 2):
+        assert torch.equal(run(ints, acc), whole[acc]), acc
+    feat = torch.randn(n, feat_dim).half()
+    out = run(feat.cuda(), 0)
+    _assert_close(out, s_indptr, s_indices, feat.float(), n, "fp16")
+    assert torch.equal(run(feat.cuda(), 0), out)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    out_side = torch.full((n, feat_dim), float("nan"), device=cuda_device)
+    hybrid.launch_panel(plan, feat.cuda(), out_side, accumulate=0, tile=tile, stream=side.cuda_stream)   # combine on that stream too
+    side.synchronize()
+    assert torch.equal(out_side, out)
+
+
+def test_two_level_operator_with_pieces(cuda_device, monkeypatch, tmp_path):
+    """The operator with a part table on the plan (forced: the test graph's panels are short): window pair + atomic join +
+    both combine passes, one-stream form, graph capture, save / load.  Integers: bit-equal to the table-free plan."""
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    indptr, indices, _ = synth_graphs.generate("reddit_sbm", device="cuda", scale=0.1)
+    n = indptr.numel() - 1
+    two = voltrix.csr_preprocess_hybrid(indptr.cpu(), indices.cpu(), n)
+    two.hash_tag = "pieces"
+    plan = two.plan
+    assert plan.num_ksteps > 0
+    ints = torch.randint(-3, 4, (n, 128), device=cuda_device).half()
+    plan.parts = None
+    ref = voltrix.spmm_two_level(two, ints).clone()
+    ref_one_stream = voltrix.spmm_two_level(two, ints, concurrent=False).clone()
+    assert torch.equal(ref, ref_one_stream)
+    cap = max(1, int(torch.diff(plan.panel_ptr).max()) // 3)
+    plan.parts = hybrid.panel_parts(plan.panel_ptr, cap, plan.xcd_ptr)
+    assert plan.parts.num_cuts > 0
+    assert torch.equal(voltrix.spmm_two_level(two, ints), ref)
+    assert torch.equal(voltrix.spmm_two_level(two, ints, concurrent=False), ref)
+    feat = torch.randn(n, 128, device=cuda_device).half()
+    out = voltrix.spmm_two_level(two, feat).clone()
+    _assert_close(out, indptr.cpu().numpy(), indices.cpu().numpy(), feat.float().cpu(), n, "fp16")
+    assert torch.equal(voltrix.spmm_two_level(two, feat), out)            # run to run
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    static_in = feat.clone()
+    with torch.cuda.graph(graph):
+        static_out = voltrix.spmm_two_level(two, static_in)
+    static_in.copy_(ints)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, ref)
+    path = str(tmp_path / "handle.pt")          # the part table travels as its bound and is rebuilt on load
+    monkeypatch.setenv("VOLTRIX_HYBRID", "1")
+    handle = voltrix.csr_preprocess(indptr.cpu(), indices.cpu(), n)
+    side = voltrix.two_level_of(handle[1])
+    side.plan.parts = hybrid.panel_parts(side.plan.panel_ptr, cap, side.plan.xcd_ptr)
+    voltrix.save_handle(path, handle, n)
+    loaded = voltrix.load_handle(path)
+    lp = voltrix.two_level_of(loaded[1]).plan.parts
+    assert lp is not None and lp.cap == cap and torch.equal(lp.parts, side.plan.parts.parts) and torch.equal(lp.cuts, side.plan.parts.cuts)
+    loaded[1].hash_tag = "pieces_loaded"
+    assert torch.equal(voltrix.spmm(*loaded, num_nodes=n, num_edges=indices.numel(), feat=ints), ref)

@@ -72,3 +72,48 @@ def test_plan_scaled_reddit_like_shares_the_band():
     _, _, plan = hybrid.build_panel_plan_torch(indptr, indices, n, None, 8, 4, 3)
     assert plan.num_shared_edges + plan.num_resid_edges == indices.numel()
     assert plan.num_shared_edges > 0.3 * indices.numel()
+
+
+@pytest.mark.parametrize("cap", [1, 7, 64, 10 ** 6])
+@pytest.mark.parametrize("num_panels", [1, 9, 200])
+def test_panel_part_table(num_panels, cap):
+    """Round 4: the panel kernel's launch table in pieces of at most ``cap`` k-steps (hybrid.panel_parts).  Every k-step of
+    every panel is in exactly one piece; pieces of a cut panel are contiguous, in order, nearly equal, and take consecutive
+    slots; whole panels keep slot -1 (panels without k-steps stay in the table: store mode writes their zero rows); every XCD
+    range lists its own panels' pieces longest first."""
+    from voltrix import hybrid
+    from voltrix.schedule import split_equal_work
+
+    g = torch.Generator().manual_seed(num_panels + cap)
+    nks = torch.randint(0, 40, (num_panels,), generator=g) * (torch.arange(num_panels) % 5 == 0).long() * 11 + \
+        torch.randint(0, 9, (num_panels,), generator=g)
+    panel_ptr = torch.zeros(num_panels + 1, dtype=torch.int32)
+    panel_ptr[1:] = nks.cumsum(0)
+    for xcd_ptr in (None, split_equal_work(nks)):
+        t = hybrid.panel_parts(panel_ptr, cap, xcd_ptr)
+        parts, cuts = t.parts.numpy().astype(np.int64), t.cuts.numpy().astype(np.int64)
+        assert t.num_parts == len(parts) >= num_panels and t.num_cuts == len(cuts) and t.cap == cap
+        assert (parts[:, 2] <= cap).all() and (parts[:, 2] >= 0).all()
+        covered = [np.zeros(int(x), np.int64) for x in nks]
+        for p, b, n, _ in parts:
+            covered[p][b:b + n] += 1
+        assert all((c == 1).all() for c in covered)
+        slots = 0
+        for p, first, pieces, _ in cuts:
+            assert first == slots and pieces == -(-int(nks[p]) // cap) >= 2
+            mine = parts[parts[:, 0] == p]
+            mine = mine[np.argsort(mine[:, 3])]
+            assert (mine[:, 3] == first + np.arange(pieces)).all()
+            assert (mine[:, 1] == np.concatenate([[0], np.cumsum(mine[:, 2])[:-1]])).all()      # contiguous, in slot order
+            assert mine[:, 2].max() - mine[:, 2].min() <= 1
+            slots += pieces
+        assert slots == t.num_slots == int((parts[:, 3] >= 0).sum())
+        whole = parts[parts[:, 3] < 0]
+        assert sorted(whole[:, 0]) == sorted(set(range(num_panels)) - set(cuts[:, 0]))
+        xp = t.xcd_ptr.numpy()
+        assert xp[0] == 0 and xp[8] == t.num_parts and t.max_parts_per_xcd == np.diff(xp).max()
+        panel_xcd = (np.searchsorted(xcd_ptr.numpy()[1:8], np.arange(num_panels), side="right") if xcd_ptr is not None
+                     else np.arange(num_panels) // max(1, (num_panels + 7) // 8))
+        for x in range(8):
+            seg = parts[xp[x]:xp[x + 1]]
+            assert (panel_xcd[seg[:, 0]] == x).all() and (np.diff(seg[:, 2]) <= 0).all()

@@ -20,12 +20,13 @@ template <bool BF16>
 int dispatch(int fs, int depth, int waves, int rb, int ks, const int* panel_ptr, const int* panel_cols,
              const uint32_t* panel_bits, const int* panel_order, int num_nodes, int embedding_dim, const void* input,
              float* output, int accumulate, const float* out_scale, hipStream_t stream, int64_t input_rows,
-             int slab_policy, const int* xcd_ptr, int max_panels_per_xcd) {
+             int slab_policy, const int* xcd_ptr, int max_panels_per_xcd, const int* parts = nullptr, int num_parts = 0,
+             float* partials = nullptr) {
 #define X(FS, D, W, RB, KS)                                                                                          \
   if (fs == FS && depth == D && waves == W && rb == RB && ks == KS)                                                  \
     return voltrix::launch_spmm_panel<voltrix::PanelTile<FS, D, W, RB, KS, BF16>>(                                   \
         panel_ptr, panel_cols, panel_bits, panel_order, num_nodes, embedding_dim, input, output, accumulate, out_scale, \
-        stream, 0, 0, input_rows, slab_policy, xcd_ptr, max_panels_per_xcd);
+        stream, 0, 0, input_rows, slab_policy, xcd_ptr, max_panels_per_xcd, parts, num_parts, partials);
   VOLTRIX_PANEL_SPACE(X)
 #undef X
   return voltrix::kErrBadConfig;
@@ -57,6 +58,44 @@ void voltrix_launch_spmm_panel_bf16(void* panel_ptr, void* panel_cols, void* pan
                                 static_cast<float*>(output), accumulate, static_cast<const float*>(out_scale),
                                 static_cast<hipStream_t>(stream), input_rows, slab_policy,
                                 static_cast<const int*>(xcd_ptr), max_panels_per_xcd);
+}
+
+void voltrix_launch_spmm_panel_parts_f16(void* panel_ptr, void* panel_cols, void* panel_bits, void* parts, int num_parts,
+                                         void* xcd_ptr, int max_parts_per_xcd, void* partials, int num_nodes, int embedding_dim,
+                                         void* input, int64_t input_rows, void* output, int accumulate, int fs, int depth,
+                                         int waves, int row_blocks, int ksteps, int slab_policy, void* out_scale, void* stream,
+                                         int* return_code) {
+  *return_code = parts == nullptr ? voltrix::kErrBadShape
+                                  : dispatch<false>(fs, depth, waves, row_blocks, ksteps, static_cast<const int*>(panel_ptr),
+                                                    static_cast<const int*>(panel_cols), static_cast<const uint32_t*>(panel_bits),
+                                                    nullptr, num_nodes, embedding_dim, input, static_cast<float*>(output),
+                                                    accumulate, static_cast<const float*>(out_scale),
+                                                    static_cast<hipStream_t>(stream), input_rows, slab_policy,
+                                                    static_cast<const int*>(xcd_ptr), max_parts_per_xcd,
+                                                    static_cast<const int*>(parts), num_parts, static_cast<float*>(partials));
+}
+
+void voltrix_launch_spmm_panel_parts_bf16(void* panel_ptr, void* panel_cols, void* panel_bits, void* parts, int num_parts,
+                                          void* xcd_ptr, int max_parts_per_xcd, void* partials, int num_nodes, int embedding_dim,
+                                          void* input, int64_t input_rows, void* output, int accumulate, int fs, int depth,
+                                          int waves, int row_blocks, int ksteps, int slab_policy, void* out_scale, void* stream,
+                                          int* return_code) {
+  *return_code = parts == nullptr ? voltrix::kErrBadShape
+                                  : dispatch<true>(fs, depth, waves, row_blocks, ksteps, static_cast<const int*>(panel_ptr),
+                                                   static_cast<const int*>(panel_cols), static_cast<const uint32_t*>(panel_bits),
+                                                   nullptr, num_nodes, embedding_dim, input, static_cast<float*>(output),
+                                                   accumulate, static_cast<const float*>(out_scale),
+                                                   static_cast<hipStream_t>(stream), input_rows, slab_policy,
+                                                   static_cast<const int*>(xcd_ptr), max_parts_per_xcd,
+                                                   static_cast<const int*>(parts), num_parts, static_cast<float*>(partials));
+}
+
+void voltrix_launch_combine_panel_partials(void* cuts, int num_cuts, void* partials, void* output, int num_nodes,
+                                           int embedding_dim, int panel_rows, int accumulate, void* stream, int* return_code) {
+  *return_code = voltrix::launch_combine_panel_partials(static_cast<const int*>(cuts), num_cuts,
+                                                        static_cast<const float*>(partials), static_cast<float*>(output),
+                                                        num_nodes, embedding_dim, panel_rows, accumulate,
+                                                        static_cast<hipStream_t>(stream));
 }
 
 void voltrix_launch_panel_order(void* panel_ptr, int num_panels, int group, void* xcd_ptr, void* order_out, void* stream,

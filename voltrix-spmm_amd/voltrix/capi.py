@@ -34,6 +34,9 @@ SYMBOLS = (
     "voltrix_launch_combine_partials",
     "voltrix_launch_spmm_panel_f16",
     "voltrix_launch_spmm_panel_bf16",
+    "voltrix_launch_spmm_panel_parts_f16",
+    "voltrix_launch_spmm_panel_parts_bf16",
+    "voltrix_launch_combine_panel_partials",
     "voltrix_launch_spmm_fused_f16",
     "voltrix_launch_spmm_fused_bf16",
     "voltrix_fused_panel_geometry",
@@ -258,10 +261,22 @@ def launch_spmm_f32_as_f16(blk_offsets, hspa_packed, hind, num_nodes, num_edges,
 
 
 def launch_spmm_panel(plan, input_ptr, output_ptr, embedding_dim, accumulate, bf16, tile, out_scale, stream,
-                      input_rows: int = 0, slab_policy: int = SLAB_AUTO) -> int:
+                      input_rows: int = 0, slab_policy: int = SLAB_AUTO, partials_ptr: int = 0) -> int:
     """Panel kernel (shared-column half of the two-level format); ``plan`` = voltrix.hybrid.PanelPlan, ``tile`` =
-    (fs, depth, ksteps); ``input_rows`` = rows of the dense operand (0: the plan's rows).  Returns the return code."""
+    (fs, depth, ksteps); ``input_rows`` = rows of the dense operand (0: the plan's rows).  A plan with a part table
+    (``plan.parts``) goes through ``voltrix_launch_spmm_panel_parts_*`` with ``partials_ptr`` = the call's partial-tile
+    buffer.  Returns the return code."""
     rc = ctypes.c_int(-1)
+    parts = getattr(plan, "parts", None)
+    if parts is not None:
+        fn = lib().voltrix_launch_spmm_panel_parts_bf16 if bf16 else lib().voltrix_launch_spmm_panel_parts_f16
+        fn(_ptr(plan.panel_ptr), _ptr(plan.panel_cols), _ptr(plan.panel_bits), _ptr(parts.parts), ctypes.c_int(parts.num_parts),
+           _ptr(parts.xcd_ptr), ctypes.c_int(parts.max_parts_per_xcd), ctypes.c_void_p(partials_ptr),
+           ctypes.c_int(plan.num_nodes), ctypes.c_int(embedding_dim), ctypes.c_void_p(input_ptr), ctypes.c_int64(input_rows),
+           ctypes.c_void_p(output_ptr), ctypes.c_int(int(accumulate)), ctypes.c_int(tile[0]), ctypes.c_int(tile[1]),
+           ctypes.c_int(plan.waves), ctypes.c_int(plan.row_blocks), ctypes.c_int(tile[2]), ctypes.c_int(slab_policy),
+           ctypes.c_void_p(out_scale), ctypes.c_void_p(stream), ctypes.byref(rc))
+        return rc.value
     fn = lib().voltrix_launch_spmm_panel_bf16 if bf16 else lib().voltrix_launch_spmm_panel_f16
     order = plan.panel_order.data_ptr() if plan.panel_order is not None else 0
     xcd_ptr = getattr(plan, "xcd_ptr", None)
@@ -271,6 +286,17 @@ def launch_spmm_panel(plan, input_ptr, output_ptr, embedding_dim, accumulate, bf
        ctypes.c_void_p(output_ptr), ctypes.c_int(int(accumulate)), ctypes.c_int(tile[0]), ctypes.c_int(tile[1]),
        ctypes.c_int(plan.waves), ctypes.c_int(plan.row_blocks), ctypes.c_int(tile[2]), ctypes.c_int(slab_policy),
        ctypes.c_void_p(out_scale), ctypes.c_void_p(stream), ctypes.byref(rc))
+    return rc.value
+
+
+def launch_combine_panel_partials(parts, partials_ptr, output_ptr, num_nodes, embedding_dim, panel_rows, accumulate,
+                                  stream) -> int:
+    """``output (+)= `` the partial tiles of the cut panels, pieces in slot order (``parts`` = voltrix.hybrid.PanelParts)."""
+    rc = ctypes.c_int(-1)
+    lib().voltrix_launch_combine_panel_partials(_ptr(parts.cuts), ctypes.c_int(parts.num_cuts), ctypes.c_void_p(partials_ptr),
+                                                ctypes.c_void_p(output_ptr), ctypes.c_int(num_nodes),
+                                                ctypes.c_int(embedding_dim), ctypes.c_int(panel_rows),
+                                                ctypes.c_int(int(accumulate)), ctypes.c_void_p(stream), ctypes.byref(rc))
     return rc.value
 
 

@@ -41,6 +41,19 @@ FUSED_ROW_BLOCKS = 8
 
 
 @dataclasses.dataclass
+class PanelParts:
+    """Launch table of the panel kernel in PIECES of bounded length (``panel_parts``; spmm_panel_kernels.hpp, PanelArgs::parts)."""
+    parts: torch.Tensor       # int32 [P, 4]: panel, first k-step inside the panel, k-steps, slot (-1: the panel is whole)
+    cuts: torch.Tensor        # int32 [C, 4]: panel, first slot, pieces, 0 -- one row per cut panel
+    xcd_ptr: torch.Tensor     # int32 [9]: XCD x owns the positions [xcd_ptr[x], xcd_ptr[x + 1]) of ``parts``, longest first
+    max_parts_per_xcd: int
+    num_parts: int
+    num_cuts: int
+    num_slots: int            # partial tiles ([panel rows][F] fp32 each) a call needs
+    cap: int                  # no piece is longer than this many k-steps
+
+
+@dataclasses.dataclass
 class PanelPlan:
     panel_ptr: torch.Tensor      # int32 [NP+1]
     panel_cols: torch.Tensor     # int32 [32 * (S + 2)]
@@ -55,6 +68,7 @@ class PanelPlan:
     num_resid_edges: int
     xcd_ptr: torch.Tensor = None      # int32 [9] or None: XCD x owns the launch positions [xcd_ptr[x], xcd_ptr[x + 1]) -- ranges of
     max_panels_per_xcd: int = 0       # equal WORK (balance_xcd_ranges); None: ranges of ceil(NP / 8) positions
+    parts: PanelParts = None          # long panels cut into pieces of bounded length (panel_parts), or None: one workgroup per panel
 
     @property
     def panel_rows(self) -> int:
@@ -257,6 +271,62 @@ def balance_xcd_ranges(two: "TwoLevelHandle") -> None:
     plan.max_panels_per_xcd = int(ranges.max())                 # the host read
     plan.panel_order = longest_first_order(plan.panel_ptr, xcd_ptr=xcd_ptr)
     two.window_xcd_ptr = (xcd_ptr.to(torch.int64) * windows_per_panel).clamp(max=num_windows).to(torch.int32)
+    cap = default_part_cap(plan.num_ksteps)
+    if PANEL_PART_FACTOR > 0 and int(ksteps.max()) > cap:      # a second host read; pieces only where a panel is too long
+        plan.parts = panel_parts(plan.panel_ptr, cap, xcd_ptr)
+
+
+# A panel's k-steps are walked by ONE workgroup: panels longer than this multiple of a CU's fair share of the k-steps
+# (S / 256) are cut.  Measured on MI355X (profiles/r04/experiment_panel_parts.log, experiment_schedule_ab.log; DESIGN.md
+# section 3.3), step in ms without the table -> 1.0 / 0.75 / 0.5: block model 1.236 -> 1.055 / 1.039 / 1.154, block model
+# shuffled + spectral order 1.275 -> 1.173 / 1.176, reddit-like shuffled + spectral order 1.427 -> 1.433 / 1.457 (65 panels
+# cut for nothing), headline graph 1.353 -> 1.357 / 1.362 (0 / 2 panels cut).  Shorter pieces balance better, but every piece of
+# a cut panel writes and re-reads a 256-KiB tile and the combine pass runs after the join: 1.0 cuts only the panels that ARE
+# the critical path.
+PANEL_PART_FACTOR = 1.0
+NUM_CUS = 256
+
+
+def default_part_cap(num_ksteps: int) -> int:
+    return max(32, int(PANEL_PART_FACTOR * num_ksteps / NUM_CUS))
+
+
+def panel_parts(panel_ptr: torch.Tensor, cap: int, panel_xcd_ptr: torch.Tensor = None) -> PanelParts:
+    """Cut every panel of more than ``cap`` k-steps into ``k = ceil(k-steps / cap)`` CONTIGUOUS pieces of nearly equal length
+    (the panel's columns are sorted: a piece sweeps a contiguous column range).  Pieces are listed per XCD range (the panel's
+    range: ``panel_xcd_ptr`` in panel units, or NP / 8 panels each), longest first.  The pieces of a cut panel take
+    consecutive partial-tile slots in k-step order and ``combine_panel_partials`` adds them in that order: a fixed
+    summation order whatever the pieces' timing.  Whole panels keep slot -1 (their tile goes straight to C, as without
+    the table).  Torch tensor ops on ``panel_ptr``'s device (plumbing, once per handle; one host read for the sizes)."""
+    assert cap >= 1
+    dev = panel_ptr.device
+    num_panels = panel_ptr.numel() - 1
+    nks = (panel_ptr[1:] - panel_ptr[:-1]).to(torch.int64)
+    k = torch.clamp((nks + cap - 1) // cap, min=1)
+    p = torch.repeat_interleave(torch.arange(num_panels, dtype=torch.int64, device=dev), k)
+    first = torch.cumsum(k, 0) - k
+    j = torch.arange(p.numel(), dtype=torch.int64, device=dev) - first[p]
+    base, rem = nks[p] // k[p], nks[p] % k[p]
+    length = base + (j < rem).to(torch.int64)
+    begin = j * base + torch.minimum(j, rem)
+    cut = k > 1
+    k_cut = torch.where(cut, k, torch.zeros_like(k))
+    slot_first = torch.cumsum(k_cut, 0) - k_cut
+    slot = torch.where(cut[p], slot_first[p] + j, torch.full_like(p, -1))
+    if panel_xcd_ptr is not None:
+        xcd = torch.searchsorted(panel_xcd_ptr.to(torch.int64)[1:8].contiguous(), p, right=True)
+    else:
+        xcd = p // max(1, (num_panels + 7) // 8)
+    top = int(length.max()) if p.numel() else 0
+    order = torch.argsort(xcd * (top + 1) + (top - length), stable=True)
+    parts = torch.stack([p[order], begin[order], length[order], slot[order]], dim=1).to(torch.int32).contiguous()
+    counts = torch.bincount(xcd, minlength=8)
+    xcd_ptr = torch.zeros(9, dtype=torch.int64, device=dev)
+    xcd_ptr[1:] = torch.cumsum(counts, 0)
+    cp = torch.nonzero(cut).flatten()
+    cuts = torch.stack([cp, slot_first[cp], k[cp], torch.zeros_like(cp)], dim=1).to(torch.int32).contiguous()
+    return PanelParts(parts, cuts, xcd_ptr.to(torch.int32), int(counts.max()) if p.numel() else 0, int(p.numel()),
+                      int(cp.numel()), int(k_cut.sum()), cap)
 
 
 def longest_first_order(panel_ptr: torch.Tensor, group: int = 1, xcd_ptr: torch.Tensor = None) -> torch.Tensor:
@@ -454,18 +524,42 @@ def run_two_level(plan: PanelPlan, operand: torch.Tensor, output: torch.Tensor, 
     fork = torch.cuda.Event()
     fork.record(main)
     side.wait_event(fork)                        # operand / out_scale / the zero fill were produced on `main`
-    launch_panel(plan, operand, output, accumulate=2, out_scale=out_scale, tile=tile, stream=side.cuda_stream)
+    pending_panel = launch_panel(plan, operand, output, accumulate=2, out_scale=out_scale, tile=tile,
+                                 stream=side.cuda_stream, defer_combine=True)
     join = torch.cuda.Event()
     join.record(side)
     pending = run_window(True)
     main.wait_event(join)
     finish(pending)                              # adds onto rows that now hold the panel kernel's part, complete
+    finish(pending_panel)                        # pieces of cut panels, in slot order (both kernels are done with C)
+
+
+class PendingPanelCombine:
+    """The partial tiles of cut panels, still to be added to C (``launch_panel(..., defer_combine=True)``)."""
+
+    def __init__(self, plan, partials, output, num_feats, accumulate):
+        self.plan, self.partials, self.output, self.num_feats, self.accumulate = plan, partials, output, num_feats, accumulate
+
+    def run(self, raw_stream: int = None):
+        """On the current stream (bracketed for a KernelTimer), or on the raw HIP stream handle given."""
+        from .utils import timed_launch
+
+        current = torch.cuda.current_stream()
+        with timed_launch("combine_panel_partials", current) if raw_stream is None else contextlib.nullcontext():
+            rc = capi.launch_combine_panel_partials(self.plan.parts, self.partials.data_ptr(), self.output.data_ptr(),
+                                                    self.plan.num_nodes, self.num_feats, self.plan.panel_rows,
+                                                    self.accumulate, current.cuda_stream if raw_stream is None else raw_stream)
+        capi.check(rc, "voltrix_launch_combine_panel_partials")
+        self.partials = None
 
 
 def launch_panel(plan: PanelPlan, feat: torch.Tensor, output: torch.Tensor, accumulate, out_scale=None,
-                 tile=None, stream=None, slab_policy: int = None) -> None:
+                 tile=None, stream=None, slab_policy: int = None, defer_combine: bool = False):
     """``output (+)= A_shared @ feat`` for fp16 / bfloat16 ``feat`` [*, F] and float32 ``output`` [N, F].
-    ``accumulate``: 0 / False store, 1 / True read-add-store, 2 float atomics (include/voltrix_capi.h)."""
+    ``accumulate``: 0 / False store, 1 / True read-add-store, 2 float atomics (include/voltrix_capi.h).
+    Plans with a part table (``plan.parts``): cut panels leave partial tiles that a combine pass adds to ``output`` in
+    fixed order -- right after the launch on the same stream, or, with ``defer_combine``, by the returned
+    ``PendingPanelCombine`` (the atomic join runs it after both kernels are done)."""
     assert feat.is_cuda and feat.is_contiguous() and feat.dtype in (torch.float16, torch.bfloat16)
     assert output.is_cuda and output.is_contiguous() and output.dtype == torch.float32
     f = feat.shape[1]
@@ -477,10 +571,22 @@ def launch_panel(plan: PanelPlan, feat: torch.Tensor, output: torch.Tensor, accu
         from .jit_kernels import spmm as _spmm_wrapper    # the one place the operator's slab policy lives (tests flip it)
 
         slab_policy = _spmm_wrapper.SLAB_POLICY
+    parts = plan.parts
+    partials = None
+    if parts is not None and parts.num_slots > 0:
+        partials = torch.empty(parts.num_slots * plan.panel_rows * f, dtype=torch.float32, device=feat.device)
     rc = capi.launch_spmm_panel(plan, feat.data_ptr(), output.data_ptr(), f, int(accumulate),
                                 feat.dtype == torch.bfloat16, tile, out_scale.data_ptr() if out_scale is not None else 0,
-                                stream, input_rows=feat.shape[0], slab_policy=slab_policy)
+                                stream, input_rows=feat.shape[0], slab_policy=slab_policy,
+                                partials_ptr=partials.data_ptr() if partials is not None else 0)
     capi.check(rc, "voltrix_launch_spmm_panel")
+    if partials is None:
+        return None
+    pending = PendingPanelCombine(plan, partials, output, f, 1 if int(accumulate) else 0)
+    if defer_combine:
+        return pending
+    pending.run(None if stream == torch.cuda.current_stream().cuda_stream else stream)
+    return None
 
 
 # fused kernel tile per feature width: (fs, depth of the shared panel ring)

@@ -58,6 +58,7 @@ typedef uint16_t bfloat16_bits;  // bfloat16 storage type of the dense operand (
 typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
 typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+typedef int int4_t __attribute__((ext_vector_type(4)));
 
 using gas_ptr = const void __attribute__((address_space(1)))*;
 using lds_ptr = void __attribute__((address_space(3)))*;

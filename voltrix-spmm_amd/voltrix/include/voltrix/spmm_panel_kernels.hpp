@@ -106,7 +106,13 @@ struct PanelArgs {
   const uint32_t* panel_bits;  // [(S + 1) * WAVES * 64]
   const int* panel_order;      // optional: launch position -> panel (longest first); nullptr = natural
   const int* xcd_ptr;          // optional int32[9]: XCD x owns the launch positions [xcd_ptr[x], xcd_ptr[x + 1]) (ranges of equal
-                               // work, hybrid.py::xcd_partition); nullptr: ranges of panels_per_xcd positions each
+                               // work, hybrid.py::balance_xcd_ranges); nullptr: ranges of panels_per_xcd positions each
+  const int* parts;            // optional int32 [num_panels = number of PARTS][4] = {panel, first k-step inside the panel, k-steps,
+                               // slot}: launch position -> a bounded piece of a panel's k-step list (hybrid.py::panel_parts; replaces
+                               // panel_order).  slot < 0: the panel is whole, its tile goes to C per `accumulate`; slot >= 0: the
+                               // panel is cut, this piece's tile is STORED to partials[slot] and combine_panel_partials_kernel
+                               // adds the pieces to C in slot order -- a fixed order whatever the pieces' timing
+  float* partials;             // [slots][PANEL_ROWS][F] fp32 (per-call scratch; only with parts)
   const in_t* input;
   float* output;
   const float* out_scale;      // optional device scalar (see SpmmArgs::out_scale)
@@ -137,15 +143,24 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
   const int pos_end = a.xcd_ptr ? a.xcd_ptr[xcd + 1]
                                 : ((xcd + 1) * a.panels_per_xcd < a.num_panels ? (xcd + 1) * a.panels_per_xcd : a.num_panels);
   if (pos >= pos_end) return;  // workgroup-uniform
-  const int panel = a.panel_order ? a.panel_order[pos] : pos;
+  int panel, ks0, nks, slot = -1;
+  if (a.parts) {               // kernel-uniform
+    const int4_t part = *reinterpret_cast<const int4_t*>(a.parts + 4 * (long long)pos);
+    panel = part[0];
+    ks0 = a.panel_ptr[panel] + part[1];
+    nks = part[2];
+    slot = part[3];
+  } else {
+    panel = a.panel_order ? a.panel_order[pos] : pos;
+    ks0 = a.panel_ptr[panel];
+    nks = a.panel_ptr[panel + 1] - ks0;
+  }
   const int fs0 = (a.slab_first + blockIdx.y) * FS;
   const int F = a.F;
   const int lane = threadIdx.x & (kWave - 1);
 
-  const int ks0 = a.panel_ptr[panel];
-  const int nks = a.panel_ptr[panel + 1] - ks0;
   const int ngroups = (nks + KS - 1) / KS;
-  if (ngroups == 0 && a.accumulate) return;  // workgroup-uniform: nothing to add
+  if (ngroups == 0 && a.accumulate && slot < 0) return;  // workgroup-uniform: nothing to add
 
   float4_t acc[RB][SLOTS];
 #pragma unroll
@@ -319,8 +334,22 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
 
   // ---- epilogue: D[row = 4*(lane>>4) + i][col = lane & 15] per (row block, 16-column slot) ------------------------
   const float oscale = kAScaleInv * (a.out_scale ? *a.out_scale : 1.0f);
-  const int prow0 = panel * T::PANEL_ROWS + wave * (RB * 16) + 4 * (lane >> 4);
   const int ocol0 = fs0 + (lane & 15);
+  if (slot >= 0) {   // a piece of a cut panel: its tile goes to the partial slot, whole (rows past num_nodes hold zeros)
+    float* const tile = a.partials + (long long)slot * T::PANEL_ROWS * F;
+    const int trow0 = wave * (RB * 16) + 4 * (lane >> 4);
+#pragma unroll
+    for (int j = 0; j < RB; ++j)
+#pragma unroll
+      for (int s = 0; s < SLOTS; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int col = ocol0 + 16 * s;
+          if (col < F) tile[(long long)(trow0 + 16 * j + i) * F + col] = acc[j][s][i] * oscale;
+        }
+    return;
+  }
+  const int prow0 = panel * T::PANEL_ROWS + wave * (RB * 16) + 4 * (lane >> 4);
   if (a.accumulate == 2) {
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
@@ -358,6 +387,39 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
   }
 }
 
+// Cut panels (PanelArgs::parts): C (+)= the pieces' tiles, summed in slot order.  One workgroup per (cut, 16 rows); a thread
+// per float4 of the row, strided.  cuts int32 [C][4] = {panel, first slot, pieces, 0}.  HBM-bound, and small: only panels
+// longer than the bound are cut.
+static __global__ __launch_bounds__(256) void combine_panel_partials_kernel(const int* __restrict__ cuts,
+                                                                            const float* __restrict__ partials,
+                                                                            float* __restrict__ output, int num_nodes, int F,
+                                                                            int panel_rows, int accumulate) {
+  const int4_t cut = *reinterpret_cast<const int4_t*>(cuts + 4 * (long long)blockIdx.x);
+  const int panel = cut[0], first = cut[1], pieces = cut[2];
+  const int f4 = F / 4;
+  const long long tile = (long long)panel_rows * F;
+  for (int e = threadIdx.x; e < 16 * f4; e += 256) {
+    const int r = blockIdx.y * 16 + e / f4, c = 4 * (e % f4);
+    const long long row = (long long)panel * panel_rows + r;
+    if (row >= num_nodes) continue;
+    const float* src = partials + (long long)first * tile + (long long)r * F + c;
+    float4_t sum = *reinterpret_cast<const float4_t*>(src);
+    for (int j = 1; j < pieces; ++j) sum += *reinterpret_cast<const float4_t*>(src + j * tile);
+    float4_t* dst = reinterpret_cast<float4_t*>(output + row * F + c);
+    *dst = accumulate ? *dst + sum : sum;
+  }
+}
+
+inline int launch_combine_panel_partials(const int* cuts, int num_cuts, const float* partials, float* output, int num_nodes,
+                                         int embedding_dim, int panel_rows, int accumulate, hipStream_t stream) {
+  if (num_cuts < 0 || num_nodes < 0 || embedding_dim < 0 || panel_rows < 16 || panel_rows % 16 != 0) return kErrBadShape;
+  if (num_cuts == 0 || num_nodes == 0 || embedding_dim == 0) return kOk;
+  if (embedding_dim % 4 != 0 || cuts == nullptr || partials == nullptr || output == nullptr) return kErrBadShape;
+  hipLaunchKernelGGL(combine_panel_partials_kernel, dim3((unsigned)num_cuts, (unsigned)(panel_rows / 16)), dim3(256), 0, stream,
+                     cuts, partials, output, num_nodes, embedding_dim, panel_rows, accumulate);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
 // Host launcher.  The plan arrays must be padded as the builder pads them: panel_cols by 2 k-steps (64 ints) and
 // panel_bits by one k-step beyond S = panel_ptr[NP] (the metadata DMAs fetch 64 column ids at a time).
 template <class T>
@@ -367,8 +429,11 @@ inline int launch_spmm_panel(const int* panel_ptr, const int* panel_cols, const 
                              int slab_count = 0 /* as launch_spmm_tc16: > 0 = that window of slabs in one launch */,
                              long long input_rows = 0 /* rows of the dense operand (0: num_nodes) */,
                              int slab_policy = kSlabAuto, const int* xcd_ptr = nullptr /* device int32[9] */,
-                             int max_panels_per_xcd = 0 /* longest range of xcd_ptr (sizes the grid) */) {
+                             int max_panels_per_xcd = 0 /* longest range of xcd_ptr (sizes the grid) */,
+                             const int* parts = nullptr /* device int32[num_parts][4]: replaces panel_order */, int num_parts = 0,
+                             float* partials = nullptr) {
   if (num_nodes < 0 || embedding_dim < 0 || accumulate < 0 || accumulate > 2) return kErrBadShape;
+  if (parts != nullptr && num_parts < 1) return kErrBadShape;   // partials: required when any part carries a slot
   if (num_nodes == 0 || embedding_dim == 0) return kOk;
   if (embedding_dim % 8 != 0 || ((uintptr_t)input & 15)) return kErrBadShape;
   PanelArgs<T> a;
@@ -381,6 +446,9 @@ inline int launch_spmm_panel(const int* panel_ptr, const int* panel_cols, const 
   a.out_scale = out_scale;
   a.num_nodes = num_nodes;
   a.num_panels = (num_nodes + T::PANEL_ROWS - 1) / T::PANEL_ROWS;
+  a.parts = parts;
+  a.partials = partials;
+  if (parts != nullptr) a.num_panels = num_parts;    // launch positions are parts
   a.panels_per_xcd = (a.num_panels + kNumXcd - 1) / kNumXcd;
   a.xcd_ptr = nullptr;
   if (xcd_ptr != nullptr) {
@@ -399,7 +467,7 @@ inline int launch_spmm_panel(const int* panel_ptr, const int* panel_cols, const 
       const int rc = launch_spmm_panel<T>(panel_ptr, panel_cols, panel_bits, panel_order, num_nodes, embedding_dim, input,
                                           output, accumulate, out_scale, stream, s,
                                           total_slabs - s < group ? total_slabs - s : group, input_rows, slab_policy, xcd_ptr,
-                                          max_panels_per_xcd);
+                                          max_panels_per_xcd, parts, num_parts, partials);
       if (rc != kOk) return rc;
     }
     return kOk;

@@ -202,7 +202,10 @@ class JITTuner:
         stage_points = list(space) if (stages is None or len(space) <= 1) else list(stages(space, None))
         num_built = 0
         for stage_no in range(4):
+            t_build = time.perf_counter()
             kernels = build_all(stage_points)
+            if deadline is not None:     # the budget bounds TIMING: hipcc builds of a cold cache do not eat it (the same stages,
+                deadline += time.perf_counter() - t_build    # hence the same choice, whether or not the kernels were on disk)
             num_built += len(kernels)
             for runtime, tuned_keys in kernels:
                 if len(space) > 1:

@@ -379,12 +379,22 @@ def permute_rows_csr(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int
 
 # ---- method="auto": candidates judged by the format's own statistics, identity kept unless one clearly pays (round 4) ------
 AUTO_MIN_GAIN = 0.03           # a candidate must cut the estimated step by this much
-# the estimate: the longer of (a) the gather volume at the chip's rate -- score x 0.21 ns, calibrated on the headline graph
-# (score 6.45 M -> 1.35 ms) -- and (b) the panel kernel's critical path, the plan's LONGEST panel at ~1 us per k-step (one
-# workgroup owns a panel from start to end: the breadth-first order's hub panel of 5,547 k-steps runs 5.7 ms, whatever the
-# other 454 panels do).  profiles/r04/experiment_reorder_auto.log
-AUTO_MS_PER_SCORE = 2.1e-7
-AUTO_MS_PER_PANEL_KSTEP = 1.0e-3
+# subspace steps of the spectral candidate: 8 give the same order quality as 16 on both reddit-size stand-ins (TC blocks 12.749 M
+# / 12.749 M, k-steps 224.6 k / 224.3 k; block model 10.348 M / 10.339 M) at 68 instead of 95 ms (profiles/r04/experiment_spectral_cost.log)
+AUTO_SPECTRAL_ITERATIONS = 8
+# The estimate (ms, F = 128 16-bit on MI355X; only RATIOS between orders of one graph are used).  Window format: TC blocks x
+# 0.14 us (14.11 M -> 1.78 ms shuffled, 12.86 M -> 1.90 natural, 11.05 M -> 1.45 block model).  Two-level: the longest of
+#   (a) the residual's gathers beside the panel kernel: residual edges / 8 (one edge per gathered row: TC blocks) x 0.21 us
+#       (6.36 M -> 1.30 ms, 3.76 M -> 0.89),
+#   (b) the panel kernel's k-steps per CU x 1.8 us beside the window kernel (713 -> 1.28 ms, 525 -> 0.96),
+#   (c) its critical path: the longest PIECE (hybrid.panel_parts cuts panels at default_part_cap) x 2 us per k-step -- without
+#       pieces the breadth-first order's hub panel of 5,547 k-steps ran 5.7 ms whatever the other 454 panels did,
+# plus 0.05 ms of zero fill and combine passes.  profiles/r04/experiment_reorder_auto*.log, experiment_panel_parts.log
+AUTO_MS_PER_WINDOW_BLOCK = 1.4e-7
+AUTO_MS_PER_RESIDUAL_BLOCK = 2.1e-7
+AUTO_MS_PER_KSTEP_PER_CU = 1.8e-3
+AUTO_MS_PER_PANEL_KSTEP = 2.0e-3
+AUTO_MS_JOIN = 0.05
 AUTO_MIN_MEAN_DEGREE = 64      # below this mean degree no candidate is tried: 16 rows x 50 edges over millions of columns share no
                                # column whatever their order (products-like: 15.44 / 15.53 / 15.52 M TC blocks natural / shuffled /
                                # reordered), and the two searches cost 0.47 s there
@@ -393,9 +403,8 @@ AUTO_MIN_MEAN_DEGREE = 64      # below this mean degree no candidate is tried: 1
 def order_statistics(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None) -> dict:
     """What a row order does to the block format, from the COUNT phases of the two preprocess builders only (no handle is
     built): TC blocks of the window format, the fraction of the edges in columns that >= tau rows of a 512-row panel share,
-    the panel plan's k-steps in all and in its longest panel, and ``score`` -- an estimate of the rows of B one product gathers:
-    TC blocks x (1 - 0.9 x shared fraction) when the two-level side-car would be built (a shared edge costs about a tenth of
-    a residual one), the TC blocks alone otherwise.  One host sync."""
+    the panel plan's k-steps in all and in its longest panel, the residual's edges, whether ``csr_preprocess`` would build the
+    two-level side-car for this order, and ``estimated_ms`` -- the step by the model above.  One host sync."""
     from . import capi, hybrid
 
     dev = indptr.device
@@ -432,11 +441,15 @@ def order_statistics(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int
     mode = hybrid.hybrid_mode()       # the decision csr_preprocess_device will make for this order (spmm/spmm.py)
     two_level = (plan_ok and ksteps > 0 and (mode == "on" or (mode in ("auto", "tune") and big))
                  and share >= hybrid.min_shared_fraction())
+    if two_level:
+        piece = min(int(longest), hybrid.default_part_cap(int(ksteps))) if hybrid.PANEL_PART_FACTOR > 0 else int(longest)
+        estimate = AUTO_MS_JOIN + max(AUTO_MS_PER_RESIDUAL_BLOCK * resid / 8.0,
+                                      AUTO_MS_PER_KSTEP_PER_CU * ksteps / hybrid.NUM_CUS, AUTO_MS_PER_PANEL_KSTEP * piece)
+    else:
+        estimate = AUTO_MS_PER_WINDOW_BLOCK * float(blocks)
     return {"tc_blocks": int(blocks), "shared_fraction": share, "ksteps": int(ksteps), "longest_panel_ksteps": int(longest),
-            "two_level": bool(two_level), "ids_outside_universe": int(outside),
-            "score": float(blocks) * (1.0 - 0.9 * share) if two_level else float(blocks),
-            "estimated_ms": max(AUTO_MS_PER_SCORE * (float(blocks) * (1.0 - 0.9 * share) if two_level else float(blocks)),
-                                AUTO_MS_PER_PANEL_KSTEP * float(longest) if two_level else 0.0)}
+            "two_level": bool(two_level), "ids_outside_universe": int(outside), "residual_edges": int(resid) if plan_ok else nnz,
+            "estimated_ms": estimate}
 
 
 def auto_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
@@ -460,7 +473,7 @@ def auto_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int
         elif name == "spectral":
             if num_nodes < 4 * 8192:        # a one-dimensional embedding of a few thousand rows regroups nothing a window sees
                 continue
-            perm = spectral_permutation(indptr, indices, num_nodes, num_cols, iterations=12)
+            perm = spectral_permutation(indptr, indices, num_nodes, num_cols, iterations=AUTO_SPECTRAL_ITERATIONS)
         elif name == "degree":
             perm = degree_permutation_device(indptr, num_nodes)
         else:

@@ -99,8 +99,9 @@ def save_handle(path: str, handle, num_nodes: int) -> None:
             "residual": [t.detach().cpu() for t in (two.blk_offsets, two.hspa_packed.view(torch.int32), two.hind)],
             "plan_tensors": {k: (getattr(plan, k).detach().cpu().view(torch.int32) if getattr(plan, k) is not None else None)
                              for k in ("panel_ptr", "panel_cols", "panel_bits", "panel_order", "xcd_ptr")},
+            "parts_cap": plan.parts.cap if plan.parts is not None else None,   # the part table is rebuilt from this on load
             "plan_scalars": {f.name: getattr(plan, f.name) for f in dataclasses.fields(plan)
-                             if not isinstance(getattr(plan, f.name), torch.Tensor) and getattr(plan, f.name) is not None
+                             if isinstance(getattr(plan, f.name), (int, float, str, bool))
                              or f.name in ("num_nodes", "waves", "row_blocks", "tau", "num_ksteps", "num_shared_edges",
                                            "num_resid_edges", "max_panels_per_xcd")},
             "window_xcd_ptr": two.window_xcd_ptr.cpu() if two.window_xcd_ptr is not None else None,
@@ -132,6 +133,8 @@ def load_handle(path: str, device: Optional[torch.device] = None):
         scalars = {k: tl["plan_scalars"][k] for k in ("num_nodes", "waves", "row_blocks", "tau", "num_ksteps",
                                                        "num_shared_edges", "num_resid_edges", "max_panels_per_xcd")}
         plan = hybrid.PanelPlan(**pt, **scalars)
+        if tl.get("parts_cap") is not None:
+            plan.parts = hybrid.panel_parts(plan.panel_ptr, tl["parts_cap"], plan.xcd_ptr)
         r0, r1, r2 = (t.to(device) for t in tl["residual"])
         two = hybrid.TwoLevelHandle(r0, r1.view(torch.uint32), r2, plan, tl["num_nodes"], tl["num_edges"],
                                     hash_tag=tl["hash_tag"], format_choice=dict(tl["format_choice"]))
