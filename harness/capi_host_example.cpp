@@ -96,11 +96,11 @@ struct UnitTable {
   int header[8];
 };
 
-static UnitTable build_unit_table(const Handle& h, int n, hipStream_t s) {
+static UnitTable build_unit_table(const Handle& h, int n, hipStream_t s, int* xcd_ptr = nullptr /* device int32[9] */) {
   UnitTable t{};
   void* ws = dev_alloc<char>((size_t)voltrix_unit_table_workspace_bytes(n));
   int* d_header = dev_alloc<int>(8);
-  RC_OK(voltrix_launch_unit_table_count(h.blk_offsets, n, /*max_stages=*/0, /*xcd_ptr=*/nullptr, ws, d_header, s, &rc_));
+  RC_OK(voltrix_launch_unit_table_count(h.blk_offsets, n, /*max_stages=*/0, xcd_ptr, ws, d_header, s, &rc_));
   HIP_OK(hipMemcpyAsync(t.header, d_header, sizeof(t.header), hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   const int num_units = t.header[0], num_cuts = t.header[1], top = t.header[5];
@@ -108,8 +108,8 @@ static UnitTable build_unit_table(const Handle& h, int n, hipStream_t s) {
   t.cuts = dev_alloc<int>(4 * (size_t)num_cuts);
   t.unit_ptr = dev_alloc<int>(9);
   void* fill_ws = dev_alloc<char>((size_t)voltrix_unit_table_fill_workspace_bytes(num_units));
-  RC_OK(voltrix_launch_unit_table_fill(h.blk_offsets, n, /*xcd_ptr=*/nullptr, ws, fill_ws, num_units, num_cuts, top, t.units,
-                                       t.unit_ptr, t.cuts, s, &rc_));
+  RC_OK(voltrix_launch_unit_table_fill(h.blk_offsets, n, xcd_ptr, ws, fill_ws, num_units, num_cuts, top, t.units, t.unit_ptr,
+                                       t.cuts, s, &rc_));
   HIP_OK(hipStreamSynchronize(s));
   HIP_OK(hipFree(ws));
   HIP_OK(hipFree(fill_ws));
@@ -235,43 +235,42 @@ int main(int argc, char** argv) {
   HIP_OK(hipStreamSynchronize(s_main));
   const double err_two_level = max_rel_err(to_host(d_c, (size_t)n * f));
 
-  // ---- 2b. the same step with the panel kernel over PIECES of panels (round 4): a piece table built on the host from
-  // ---- panel_ptr -- here every panel of two or more k-steps is cut in two, so the combine path runs on any graph; the
-  // ---- product's rule (voltrix/hybrid.py::panel_parts) cuts only panels longer than a CU's fair share of the k-steps.
-  // ---- Pieces of a cut panel STORE to partial tiles; combine_panel_partials adds them to C in slot order after the join. ----
-  std::vector<int> h_panel_ptr(num_panels + 1);
-  HIP_OK(hipMemcpy(h_panel_ptr.data(), panel_ptr, (num_panels + 1) * sizeof(int), hipMemcpyDeviceToHost));
-  std::vector<int> h_parts, h_pcuts;
-  int slots = 0;
-  for (int p = 0; p < num_panels; ++p) {   // launch order: natural (XCD ranges of ceil(pieces / 8) positions each)
-    const int nks = h_panel_ptr[p + 1] - h_panel_ptr[p];
-    if (nks >= 2) {
-      const int first = nks / 2;
-      h_pcuts.insert(h_pcuts.end(), {p, slots, 2, 0});
-      h_parts.insert(h_parts.end(), {p, 0, first, slots});
-      h_parts.insert(h_parts.end(), {p, first, nks - first, slots + 1});
-      slots += 2;
-    } else {
-      h_parts.insert(h_parts.end(), {p, 0, nks, -1});
-    }
-  }
-  const int num_parts = (int)h_parts.size() / 4, num_pcuts = (int)h_pcuts.size() / 4;
-  int* parts = dev_alloc<int>(h_parts.size());
-  int* pcuts = dev_alloc<int>(std::max<size_t>(h_pcuts.size(), 4));
+  // ---- 2b. the same step under the round-4 schedules, every table built by the library: XCD ranges of equal work for both
+  // ---- kernels (panel work = 6.6 x k-steps + residual stages), the residual's unit table over those ranges, and the panel
+  // ---- kernel over PIECES of at most `cap` k-steps -- the product cuts panels longer than a CU's fair share (S / 256); a small
+  // ---- cap here, so that the combine path runs on any graph.  Pieces of a cut panel STORE to partial tiles;
+  // ---- combine_panel_partials adds them to C in slot order after the join. ------------------------------------------------
+  int* xcd_ptr = dev_alloc<int>(9);
+  int* window_xcd_ptr = dev_alloc<int>(9);
+  RC_OK(voltrix_launch_xcd_ranges_of_panels(panel_ptr, hr.blk_offsets, n, panel_rows, /*kstep_cost_x10=*/66, xcd_ptr,
+                                            window_xcd_ptr, s_main, &rc_));
+  const UnitTable tr2 = build_unit_table(hr, n, s_main, window_xcd_ptr);
+  float* partials_r2 = dev_alloc<float>((size_t)std::max(1, tr2.header[2]) * 16 * f);
+  const int cap = 4;
+  void* parts_ws = dev_alloc<char>((size_t)voltrix_panel_parts_workspace_bytes(num_panels));
+  int* d_parts_header = dev_alloc<int>(8);
+  RC_OK(voltrix_launch_panel_parts_count(panel_ptr, num_panels, cap, xcd_ptr, parts_ws, d_parts_header, s_main, &rc_));
+  int parts_header[8];
+  HIP_OK(hipMemcpyAsync(parts_header, d_parts_header, sizeof(parts_header), hipMemcpyDeviceToHost, s_main));
+  HIP_OK(hipStreamSynchronize(s_main));
+  const int num_parts = parts_header[0], num_pcuts = parts_header[1], slots = parts_header[2], max_parts = parts_header[3];
+  int* parts = dev_alloc<int>(4 * (size_t)std::max(1, num_parts));
+  int* part_xcd_ptr = dev_alloc<int>(9);
+  int* pcuts = dev_alloc<int>(4 * (size_t)std::max(1, num_pcuts));
   float* panel_partials = dev_alloc<float>((size_t)std::max(1, slots) * panel_rows * f);
-  HIP_OK(hipMemcpy(parts, h_parts.data(), h_parts.size() * sizeof(int), hipMemcpyHostToDevice));
-  if (num_pcuts) HIP_OK(hipMemcpy(pcuts, h_pcuts.data(), h_pcuts.size() * sizeof(int), hipMemcpyHostToDevice));
+  RC_OK(voltrix_launch_panel_parts_fill(panel_ptr, num_panels, cap, xcd_ptr, parts_ws, parts, part_xcd_ptr, pcuts, s_main,
+                                        &rc_));
   HIP_OK(hipMemsetAsync(d_c, 0, (size_t)n * f * sizeof(float), s_main));
   HIP_OK(hipEventRecord(fork, s_main));
   HIP_OK(hipStreamWaitEvent(s_side, fork, 0));
-  RC_OK(voltrix_launch_spmm_panel_parts_f16(panel_ptr, panel_cols, panel_bits, parts, num_parts, /*xcd_ptr=*/nullptr, 0,
+  RC_OK(voltrix_launch_spmm_panel_parts_f16(panel_ptr, panel_cols, panel_bits, parts, num_parts, part_xcd_ptr, max_parts,
                                             panel_partials, n, f, d_b, /*input_rows=*/n, d_c, /*accumulate=*/2, /*fs=*/128,
                                             /*depth=*/3, waves, row_blocks, /*ksteps=*/1, VOLTRIX_SLAB_AUTO, nullptr, s_side,
                                             &rc_));
   HIP_OK(hipEventRecord(join, s_side));
-  window_spmm(hr, tr, n, resid_edges, f, d_b, d_c, /*atomic_out=*/1, partials_r, s_main);
+  window_spmm(hr, tr2, n, resid_edges, f, d_b, d_c, /*atomic_out=*/1, partials_r2, s_main);
   HIP_OK(hipStreamWaitEvent(s_main, join, 0));
-  RC_OK(voltrix_launch_combine_partials(tr.cuts, tr.header[1], partials_r, d_c, n, f, /*accumulate=*/1, nullptr, s_main,
+  RC_OK(voltrix_launch_combine_partials(tr2.cuts, tr2.header[1], partials_r2, d_c, n, f, /*accumulate=*/1, nullptr, s_main,
                                         &rc_));
   RC_OK(voltrix_launch_combine_panel_partials(pcuts, num_pcuts, panel_partials, d_c, n, f, panel_rows, /*accumulate=*/1,
                                               s_main, &rc_));

@@ -257,6 +257,33 @@ void voltrix_launch_spmm_panel_parts_bf16(void* panel_ptr, void* panel_cols, voi
 void voltrix_launch_combine_panel_partials(void* cuts, int num_cuts, void* partials, void* output, int num_nodes,
                                            int embedding_dim, int panel_rows, int accumulate, void* stream, int* return_code);
 
+/* Builders of the two schedules above, on the device (round 4; voltrix/schedule_tables.hpp; the Python host's
+ * voltrix/schedule.py::split_equal_work and voltrix/hybrid.py::panel_parts are their torch-tensor restatements).
+ * XCD ranges: xcd_ptr int32[9] <- b[0] = 0 <= ... <= b[8] = n such that the eight ranges of the items' work have about equal
+ * sums (boundary = the index whose prefix sum is nearest to ceil(total x / 8), rounded up to `align`; total 0: ceil(n / 8)
+ * items each).  _of_work: work int32[num_items]; _of_windows: the stages of a handle's windows (work of window w =
+ * ceil(TC blocks / 4)), n = ceil(num_nodes / 16); _of_panels: work of panel p = round(kstep_cost_x10 / 10 x its k-steps) +
+ * the stages of its panel_rows / 16 windows in resid_blk_offsets (the Python host passes 66: a k-step costs a CU about 6.6
+ * residual stages), and window_xcd_ptr int32[9] (or NULL) <- the same ranges in windows, for the residual's unit table.
+ * One workgroup each; stream-ordered, no host read. */
+void voltrix_launch_xcd_ranges_of_work(void* work, int num_items, int align, void* xcd_ptr, void* stream, int* return_code);
+void voltrix_launch_xcd_ranges_of_windows(void* blk_offsets, int num_nodes, int align, void* xcd_ptr, void* stream,
+                                          int* return_code);
+void voltrix_launch_xcd_ranges_of_panels(void* panel_ptr, void* resid_blk_offsets, int num_nodes, int panel_rows,
+                                         int kstep_cost_x10, void* xcd_ptr, void* window_xcd_ptr, void* stream,
+                                         int* return_code);
+/* Piece table, two phases around the host read that sizes it.  count: header int32[8] <- {pieces, cut panels, partial-tile
+ * slots, pieces in the longest XCD range, cap, 0, 0, 0}; fill (same panel_ptr / cap / panel_xcd_ptr / workspace, untouched in
+ * between): parts int32[pieces][4], part_xcd_ptr int32[9], cuts int32[max(1, cut panels)][4] as described above -- panels
+ * of more than `cap` k-steps in ceil(k-steps / cap) contiguous pieces of nearly equal length; per XCD range (panel_xcd_ptr in
+ * panel units, or NULL = ceil(num_panels / 8) panels each) longest first, ties by (panel, piece).  workspace: 16-byte aligned,
+ * voltrix_panel_parts_workspace_bytes(num_panels) bytes. */
+int64_t voltrix_panel_parts_workspace_bytes(int num_panels);
+void voltrix_launch_panel_parts_count(void* panel_ptr, int num_panels, int cap, void* panel_xcd_ptr, void* workspace,
+                                      void* header, void* stream, int* return_code);
+void voltrix_launch_panel_parts_fill(void* panel_ptr, int num_panels, int cap, void* panel_xcd_ptr, void* workspace,
+                                     void* parts, void* part_xcd_ptr, void* cuts, void* stream, int* return_code);
+
 /* The two-level format in ONE launch (spmm_fused_kernels.hpp; round 3, rebuilt in round 4).  One 256-thread workgroup per
  * 512-row panel -- four waves, one per SIMD, eight 16-row blocks each; the plan keeps its waves = 8 x row_blocks = 4 layout --
  * computes the whole product for its rows: the shared columns from the panel plan (arrays as for

@@ -374,7 +374,7 @@ def test_xcd_ranges_of_equal_work_give_the_same_bits(cuda_device, monkeypatch):
     ksteps = np.diff(plan.panel_ptr.cpu().numpy())
     nst = (np.diff(two.blk_offsets.cpu().numpy().astype(np.int64)) + 3) // 4
     nst = np.concatenate([nst, np.zeros(plan.num_panels * 32 - nst.size, np.int64)]).reshape(plan.num_panels, 32).sum(1)
-    work = hybrid.KSTEP_COST_IN_STAGES * ksteps + nst
+    work = hybrid.KSTEP_COST_X10 / 10 * ksteps + nst
 
     def busiest(ptr):
         per = np.array([work[ptr[x]:ptr[x + 1]].sum() for x in range(8)])

@@ -182,3 +182,70 @@ def test_two_units_per_wave_give_the_same_bits(cuda_device, kind, name, scale, n
     windows_with_nan = torch.zeros((n + 15) // 16, dtype=torch.bool, device="cuda")
     windows_with_nan[(deg0.nonzero().flatten() // 16)] = True
     assert not nan_rows[~windows_with_nan.repeat_interleave(16)[:n]].any()   # NaN stays inside the windows that gather row 0
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 455, 5000, 1 << 20])
+def test_native_xcd_ranges_equal_the_torch_restatement(cuda_device, n):
+    """voltrix_launch_xcd_ranges_of_work / _of_windows / _of_panels (schedule_tables.hpp) against schedule.split_equal_work and
+    hybrid.xcd_ranges_of_panels_torch, element by element: skewed work, zeros, every alignment, the all-zero case (equal
+    counts), fewer items than XCDs, a million items (every thread of the one workgroup owns a chunk)."""
+    from voltrix import hybrid
+    from voltrix.schedule import split_equal_work
+
+    g = torch.Generator().manual_seed(n + 1)
+    for kind in ("skewed", "ones", "zeros", "one hot"):
+        work = {"skewed": (torch.rand(n, generator=g) ** 6 * 5000).to(torch.int32) * (torch.rand(n, generator=g) < 0.7),
+                "ones": torch.ones(n, dtype=torch.int32), "zeros": torch.zeros(n, dtype=torch.int32),
+                "one hot": torch.zeros(n, dtype=torch.int32)}[kind].to(torch.int32)
+        if kind == "one hot" and n:
+            work[n // 3] = 7
+        for align in (1, 4, 32):
+            native = capi.xcd_ranges_of_work(work.cuda(), align)
+            ref = split_equal_work(work.to(torch.int64), align)
+            assert torch.equal(native.cpu(), ref), (kind, align, native.tolist(), ref.tolist())
+    # windows of a handle: stages = ceil(TC blocks / 4)
+    counts = torch.randint(1, 90, (n,), generator=g) * (torch.rand(n, generator=g) < 0.8) + 1
+    blk = torch.zeros(n + 1, dtype=torch.int32)
+    blk[1:] = counts.cumsum(0)
+    num_nodes = max(0, 16 * n - 5)
+    for align in (1, 32):
+        native = capi.xcd_ranges_of_windows(blk.cuda(), num_nodes, align)
+        ref = split_equal_work((counts.to(torch.int64) + 3) // 4, align) if n else torch.zeros(9, dtype=torch.int32)
+        assert torch.equal(native.cpu(), ref), (align, native.tolist(), ref.tolist())
+    # panels: 32 windows each (the last one partial), k-steps per panel, cost 6.6 and a cost with exact halves (2.5)
+    num_panels = (num_nodes + 511) // 512
+    if num_panels:
+        nks = torch.randint(0, 300, (num_panels,), generator=g) * (torch.rand(num_panels, generator=g) < 0.5)
+        panel_ptr = torch.zeros(num_panels + 1, dtype=torch.int32)
+        panel_ptr[1:] = nks.cumsum(0)
+        for cost in (66, 25, 0):
+            native = capi.xcd_ranges_of_panels(panel_ptr.cuda(), blk.cuda(), num_nodes, 512, cost)
+            ref = hybrid.xcd_ranges_of_panels_torch(panel_ptr, blk, num_nodes, 512, cost)
+            assert torch.equal(native[0].cpu(), ref[0]) and torch.equal(native[1].cpu(), ref[1]), cost
+
+
+@pytest.mark.parametrize("cap", [1, 7, 64, 10 ** 6])
+@pytest.mark.parametrize("num_panels", [1, 9, 200, 4100])
+def test_native_piece_table_equals_the_torch_restatement(cuda_device, num_panels, cap):
+    """voltrix_launch_panel_parts_count / _fill against hybrid.panel_parts_torch: every array, element by element (the order
+    inside an XCD range is longest first, ties by (panel, piece): a function of panel_ptr alone), with and without ranges of
+    equal work, panels without k-steps, many equal lengths."""
+    from voltrix import hybrid
+    from voltrix.schedule import split_equal_work
+
+    if cap == 1 and num_panels > 1000:
+        pytest.skip("every k-step its own piece on thousands of panels: a table nobody builds")
+    g = torch.Generator().manual_seed(num_panels + cap)
+    nks = torch.randint(0, 40, (num_panels,), generator=g) * (torch.arange(num_panels) % 5 == 0).long() * 11 + \
+        torch.randint(0, 9, (num_panels,), generator=g)
+    panel_ptr = torch.zeros(num_panels + 1, dtype=torch.int32)
+    panel_ptr[1:] = nks.cumsum(0)
+    for xcd_ptr in (None, split_equal_work(nks), torch.tensor([0, 0, 0, num_panels // 2, num_panels // 2, num_panels, num_panels,
+                                                                 num_panels, num_panels], dtype=torch.int32)):
+        native = hybrid.panel_parts(panel_ptr.cuda(), cap, xcd_ptr.cuda() if xcd_ptr is not None else None)
+        ref = hybrid.panel_parts_torch(panel_ptr, cap, xcd_ptr)
+        assert (native.num_parts, native.num_cuts, native.num_slots, native.max_parts_per_xcd, native.cap) == \
+            (ref.num_parts, ref.num_cuts, ref.num_slots, ref.max_parts_per_xcd, ref.cap)
+        assert torch.equal(native.xcd_ptr.cpu(), ref.xcd_ptr)
+        assert torch.equal(native.cuts.cpu(), ref.cuts)
+        assert torch.equal(native.parts.cpu(), ref.parts)

@@ -1,7 +1,9 @@
 // libvoltrix_hip.so -- schedule builders (include/voltrix_capi.h): the window kernel's unit table, built on the device
-// from the handle's blk_offsets (no reference counterpart).
+// from the handle's blk_offsets (no reference counterpart); round 4: the XCD ranges of equal work and
+// the panel kernel's piece table (schedule_tables.hpp).
 #include <hip/hip_runtime.h>
 
+#include "voltrix/schedule_tables.hpp"
 #include "voltrix/unit_table.hpp"
 #include "voltrix_capi.h"
 
@@ -27,6 +29,42 @@ void voltrix_launch_unit_table_fill(void* blk_offsets, int num_nodes, void* xcd_
                                           num_units, num_cuts, top, static_cast<int*>(units), static_cast<int*>(unit_ptr),
                                           static_cast<int*>(cuts), static_cast<hipStream_t>(stream),
                                           static_cast<const int*>(xcd_ptr));
+}
+
+void voltrix_launch_xcd_ranges_of_work(void* work, int num_items, int align, void* xcd_ptr, void* stream, int* return_code) {
+  *return_code = voltrix::xcd_ranges_of_work(static_cast<const int*>(work), num_items, align, static_cast<int*>(xcd_ptr),
+                                             static_cast<hipStream_t>(stream));
+}
+
+void voltrix_launch_xcd_ranges_of_windows(void* blk_offsets, int num_nodes, int align, void* xcd_ptr, void* stream,
+                                          int* return_code) {
+  *return_code = voltrix::xcd_ranges_of_windows(static_cast<const int*>(blk_offsets), num_nodes, align,
+                                                static_cast<int*>(xcd_ptr), static_cast<hipStream_t>(stream));
+}
+
+void voltrix_launch_xcd_ranges_of_panels(void* panel_ptr, void* resid_blk_offsets, int num_nodes, int panel_rows,
+                                         int kstep_cost_x10, void* xcd_ptr, void* window_xcd_ptr, void* stream,
+                                         int* return_code) {
+  *return_code = voltrix::xcd_ranges_of_panels(static_cast<const int*>(panel_ptr), static_cast<const int*>(resid_blk_offsets),
+                                               num_nodes, panel_rows, kstep_cost_x10, static_cast<int*>(xcd_ptr),
+                                               static_cast<int*>(window_xcd_ptr), static_cast<hipStream_t>(stream));
+}
+
+int64_t voltrix_panel_parts_workspace_bytes(int num_panels) { return voltrix::panel_parts_workspace_bytes(num_panels); }
+
+void voltrix_launch_panel_parts_count(void* panel_ptr, int num_panels, int cap, void* panel_xcd_ptr, void* workspace,
+                                      void* header, void* stream, int* return_code) {
+  *return_code = voltrix::panel_parts_count(static_cast<const int*>(panel_ptr), num_panels, cap,
+                                            static_cast<const int*>(panel_xcd_ptr), workspace, static_cast<int*>(header),
+                                            static_cast<hipStream_t>(stream));
+}
+
+void voltrix_launch_panel_parts_fill(void* panel_ptr, int num_panels, int cap, void* panel_xcd_ptr, void* workspace,
+                                     void* parts, void* part_xcd_ptr, void* cuts, void* stream, int* return_code) {
+  *return_code = voltrix::panel_parts_fill(static_cast<const int*>(panel_ptr), num_panels, cap,
+                                           static_cast<const int*>(panel_xcd_ptr), workspace, static_cast<int*>(parts),
+                                           static_cast<int*>(part_xcd_ptr), static_cast<int*>(cuts),
+                                           static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -37,6 +37,12 @@ SYMBOLS = (
     "voltrix_launch_spmm_panel_parts_f16",
     "voltrix_launch_spmm_panel_parts_bf16",
     "voltrix_launch_combine_panel_partials",
+    "voltrix_launch_xcd_ranges_of_work",
+    "voltrix_launch_xcd_ranges_of_windows",
+    "voltrix_launch_xcd_ranges_of_panels",
+    "voltrix_panel_parts_workspace_bytes",
+    "voltrix_launch_panel_parts_count",
+    "voltrix_launch_panel_parts_fill",
     "voltrix_launch_spmm_fused_f16",
     "voltrix_launch_spmm_fused_bf16",
     "voltrix_fused_panel_geometry",
@@ -242,6 +248,77 @@ def build_unit_table(blk_offsets, num_nodes: int, max_stages: int = 0, stream=No
                                          _ptr(unit_ptr), _ptr(cuts), ctypes.c_void_p(stream), ctypes.byref(rc))
     check(rc.value, "voltrix_launch_unit_table_fill")
     return units, unit_ptr, cuts, head
+
+
+def xcd_ranges_of_work(work, align: int = 1, stream=None):
+    """int32 [9] on ``work``'s device: eight ranges of the int32 items ``work`` with about equal sums
+    (voltrix/schedule_tables.hpp; voltrix/schedule.py::split_equal_work is the restatement).  Stream-ordered."""
+    import torch
+
+    out = torch.empty(9, dtype=torch.int32, device=work.device)
+    rc = ctypes.c_int(-1)
+    stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    lib().voltrix_launch_xcd_ranges_of_work(_ptr(work), ctypes.c_int(work.numel()), ctypes.c_int(int(align)), _ptr(out),
+                                            ctypes.c_void_p(stream), ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_xcd_ranges_of_work")
+    return out
+
+
+def xcd_ranges_of_windows(blk_offsets, num_nodes: int, align: int = 1, stream=None):
+    """int32 [9]: first window of every XCD's range, ranges of equal STAGES of the handle ``blk_offsets``."""
+    import torch
+
+    out = torch.empty(9, dtype=torch.int32, device=blk_offsets.device)
+    rc = ctypes.c_int(-1)
+    stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    lib().voltrix_launch_xcd_ranges_of_windows(_ptr(blk_offsets), ctypes.c_int(num_nodes), ctypes.c_int(int(align)), _ptr(out),
+                                               ctypes.c_void_p(stream), ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_xcd_ranges_of_windows")
+    return out
+
+
+def xcd_ranges_of_panels(panel_ptr, resid_blk_offsets, num_nodes: int, panel_rows: int, kstep_cost_x10: int, stream=None):
+    """``(xcd_ptr, window_xcd_ptr)`` int32 [9] each: ranges of panels with equal work (``kstep_cost_x10 / 10`` x k-steps +
+    residual stages) and the same ranges counted in windows."""
+    import torch
+
+    dev = panel_ptr.device
+    out, out_w = torch.empty(9, dtype=torch.int32, device=dev), torch.empty(9, dtype=torch.int32, device=dev)
+    rc = ctypes.c_int(-1)
+    stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    lib().voltrix_launch_xcd_ranges_of_panels(_ptr(panel_ptr), _ptr(resid_blk_offsets), ctypes.c_int(num_nodes),
+                                              ctypes.c_int(panel_rows), ctypes.c_int(int(kstep_cost_x10)), _ptr(out),
+                                              _ptr(out_w), ctypes.c_void_p(stream), ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_xcd_ranges_of_panels")
+    return out, out_w
+
+
+def build_panel_parts(panel_ptr, cap: int, panel_xcd_ptr=None, stream=None):
+    """The panel kernel's piece table through the library's two-phase builder (voltrix/schedule_tables.hpp): returns
+    ``(parts int32 [P, 4], part_xcd_ptr int32 [9], cuts int32 [C, 4], header)`` with ``header`` = (pieces, cut panels,
+    slots, pieces of the longest XCD range, cap, 0, 0, 0) as a Python list.  One host sync."""
+    import torch
+
+    dev = panel_ptr.device
+    num_panels = panel_ptr.numel() - 1
+    stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    workspace = torch.empty(max(16, int(lib().voltrix_panel_parts_workspace_bytes(ctypes.c_int(num_panels)))),
+                            dtype=torch.uint8, device=dev)
+    header = torch.empty(8, dtype=torch.int32, device=dev)
+    rc = ctypes.c_int(-1)
+    xp = ctypes.c_void_p(panel_xcd_ptr.data_ptr() if panel_xcd_ptr is not None else 0)
+    lib().voltrix_launch_panel_parts_count(_ptr(panel_ptr), ctypes.c_int(num_panels), ctypes.c_int(int(cap)), xp,
+                                           _ptr(workspace), _ptr(header), ctypes.c_void_p(stream), ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_panel_parts_count")
+    head = [int(v) for v in header.tolist()]   # the sync
+    parts = torch.empty((head[0], 4), dtype=torch.int32, device=dev)
+    cuts = torch.empty((max(1, head[1]), 4), dtype=torch.int32, device=dev)
+    part_xcd_ptr = torch.empty(9, dtype=torch.int32, device=dev)
+    lib().voltrix_launch_panel_parts_fill(_ptr(panel_ptr), ctypes.c_int(num_panels), ctypes.c_int(int(cap)), xp,
+                                          _ptr(workspace), _ptr(parts), _ptr(part_xcd_ptr), _ptr(cuts),
+                                          ctypes.c_void_p(stream), ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_panel_parts_fill")
+    return parts, part_xcd_ptr, cuts[:head[1]], head
 
 
 def spmm_f32_workspace_bytes(input_rows: int, embedding_dim: int) -> int:

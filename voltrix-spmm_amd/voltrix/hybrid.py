@@ -240,6 +240,7 @@ def empty_plan(num_nodes, waves, row_blocks, tau, device, num_edges):
 # a k-step of the panel kernel costs about this many residual stages of the window kernel (reddit-like pair, each kernel
 # alone: 182.6 k k-steps in 0.70 ms, 1.59 M stages in 0.92 ms -- 0.98 us against 0.148 us per CU)
 KSTEP_COST_IN_STAGES = 6.6
+KSTEP_COST_X10 = 66      # the same figure in tenths: the builders work in integers
 
 
 def balance_xcd_ranges(two: "TwoLevelHandle") -> None:
@@ -252,28 +253,44 @@ def balance_xcd_ranges(two: "TwoLevelHandle") -> None:
     longest-first inside the new ranges and the residual handle's unit table takes the same ranges (x 32 windows: a panel's
     rows stay on one XCD for both kernels).  Speed only -- same bits with any ranges.  One tiny host read (the longest range
     sizes the panel kernel's grid)."""
-    from .schedule import split_equal_work
-
     plan = two.plan
     if plan.num_ksteps == 0 or plan.num_panels < 2 * 8:
         return
-    dev = plan.panel_ptr.device
-    windows_per_panel = plan.panel_rows // 16
-    num_windows = (two.num_nodes + 15) // 16
-    nst = ((two.blk_offsets[1:num_windows + 1] - two.blk_offsets[:num_windows]).to(torch.int64) + 3) // 4
-    pad = plan.num_panels * windows_per_panel - num_windows
-    per_panel = torch.cat([nst, torch.zeros(pad, dtype=torch.int64, device=dev)]).view(plan.num_panels, windows_per_panel).sum(1)
-    ksteps = (plan.panel_ptr[1:] - plan.panel_ptr[:-1]).to(torch.float64)
-    work = (KSTEP_COST_IN_STAGES * ksteps + per_panel.to(torch.float64)).round().to(torch.int64)
-    xcd_ptr = split_equal_work(work)
-    ranges = (xcd_ptr[1:] - xcd_ptr[:-1])
+    if plan.panel_ptr.is_cuda:      # the library's builder (schedule_tables.hpp: the entry point a C host binds)
+        xcd_ptr, two.window_xcd_ptr = capi.xcd_ranges_of_panels(plan.panel_ptr, two.blk_offsets, two.num_nodes, plan.panel_rows,
+                                                                KSTEP_COST_X10)
+    else:
+        xcd_ptr, two.window_xcd_ptr = xcd_ranges_of_panels_torch(plan.panel_ptr, two.blk_offsets, two.num_nodes,
+                                                                 plan.panel_rows, KSTEP_COST_X10)
+    longest_range, longest_panel = torch.stack([(xcd_ptr[1:] - xcd_ptr[:-1]).max(),
+                                                (plan.panel_ptr[1:] - plan.panel_ptr[:-1]).max()]).tolist()   # the host read
     plan.xcd_ptr = xcd_ptr
-    plan.max_panels_per_xcd = int(ranges.max())                 # the host read
+    plan.max_panels_per_xcd = int(longest_range)
     plan.panel_order = longest_first_order(plan.panel_ptr, xcd_ptr=xcd_ptr)
-    two.window_xcd_ptr = (xcd_ptr.to(torch.int64) * windows_per_panel).clamp(max=num_windows).to(torch.int32)
     cap = default_part_cap(plan.num_ksteps)
-    if PANEL_PART_FACTOR > 0 and int(ksteps.max()) > cap:      # a second host read; pieces only where a panel is too long
+    if PANEL_PART_FACTOR > 0 and longest_panel > cap:          # pieces only where a panel is too long
         plan.parts = panel_parts(plan.panel_ptr, cap, xcd_ptr)
+
+
+def xcd_ranges_of_panels_torch(panel_ptr: torch.Tensor, resid_blk_offsets: torch.Tensor, num_nodes: int, panel_rows: int,
+                               kstep_cost_x10: int):
+    """Torch-tensor restatement of ``voltrix_launch_xcd_ranges_of_panels`` (tests compare them): ``(xcd_ptr,
+    window_xcd_ptr)``.  Work of a panel = round-half-even(k-steps x cost / 10) + the stages of its windows, integers
+    throughout."""
+    from .schedule import split_equal_work
+
+    dev = panel_ptr.device
+    num_panels = panel_ptr.numel() - 1
+    windows_per_panel = panel_rows // 16
+    num_windows = (num_nodes + 15) // 16
+    nst = ((resid_blk_offsets[1:num_windows + 1] - resid_blk_offsets[:num_windows]).to(torch.int64) + 3) // 4
+    pad = num_panels * windows_per_panel - num_windows
+    stages = torch.cat([nst, torch.zeros(pad, dtype=torch.int64, device=dev)]).view(num_panels, windows_per_panel).sum(1)
+    tenths = (panel_ptr[1:] - panel_ptr[:-1]).to(torch.int64) * kstep_cost_x10
+    q, r = tenths // 10, tenths % 10
+    q = q + ((r > 5) | ((r == 5) & (q % 2 == 1))).to(torch.int64)
+    xcd_ptr = split_equal_work(q + stages)
+    return xcd_ptr, (xcd_ptr.to(torch.int64) * windows_per_panel).clamp(max=num_windows).to(torch.int32)
 
 
 # A panel's k-steps are walked by ONE workgroup: panels longer than this multiple of a CU's fair share of the k-steps
@@ -292,6 +309,18 @@ def default_part_cap(num_ksteps: int) -> int:
 
 
 def panel_parts(panel_ptr: torch.Tensor, cap: int, panel_xcd_ptr: torch.Tensor = None) -> PanelParts:
+    """The panel kernel's piece table (layout and rules: :func:`panel_parts_torch`).  Built by the library's two-phase
+    device builder (``voltrix/schedule_tables.hpp`` through ``capi.build_panel_parts`` -- the entry points a C host binds);
+    CPU tensors go through the torch-tensor restatement, which the tests also use to check the native table element by
+    element."""
+    if not panel_ptr.is_cuda:
+        return panel_parts_torch(panel_ptr, cap, panel_xcd_ptr)
+    assert cap >= 1
+    parts, part_xcd_ptr, cuts, head = capi.build_panel_parts(panel_ptr, cap, panel_xcd_ptr)
+    return PanelParts(parts, cuts, part_xcd_ptr, head[3], head[0], head[1], head[2], cap)
+
+
+def panel_parts_torch(panel_ptr: torch.Tensor, cap: int, panel_xcd_ptr: torch.Tensor = None) -> PanelParts:
     """Cut every panel of more than ``cap`` k-steps into ``k = ceil(k-steps / cap)`` CONTIGUOUS pieces of nearly equal length
     (the panel's columns are sorted: a piece sweeps a contiguous column range).  Pieces are listed per XCD range (the panel's
     range: ``panel_xcd_ptr`` in panel units, or NP / 8 panels each), longest first.  The pieces of a cut panel take

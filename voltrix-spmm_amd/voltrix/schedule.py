@@ -65,6 +65,10 @@ def balanced_xcd_windows(blk_offsets: torch.Tensor, num_nodes: int, align: int =
     out = torch.zeros(NUM_XCD + 1, dtype=torch.int64, device=dev)
     if num_windows == 0:
         return out.to(torch.int32)
+    if blk_offsets.is_cuda:      # the library's builder (voltrix/schedule_tables.hpp); the lines below are its restatement
+        from . import capi
+
+        return capi.xcd_ranges_of_windows(blk_offsets, num_nodes, align)
     nst = ((blk_offsets[1:num_windows + 1] - blk_offsets[:num_windows]).to(torch.int64) + 3) // 4
     return split_equal_work(nst, align)
 
