@@ -1061,11 +1061,25 @@ inline int cast_f32_to_f16(const float* src, _Float16* dst, long long n, hipStre
 // epilogue through SpmmArgs::out_scale) moves the operand's largest magnitude to [2^14, 2^15) and keeps the 10-bit
 // mantissa (= TF32's) for everything within 2^-28 of it.  All on the stream, no host sync.  Inf / NaN operands:
 // scale 1 (they propagate as in fp32).  scale[1] is scratch (max |src| bits).
+// One atomic per WORKGROUP, and only when it can raise the maximum: round 4 measured the per-wave atomicMax of the first
+// version (16 k atomics onto one address, serialised in L2) at 0.18 ms of a 0.23 ms cast at F = 128
+// (profiles/r04/experiment_cast.log) -- the whole fixed cost of the fp32-input path.
 static __global__ __launch_bounds__(256) void amax_abs_f32_kernel(const float* __restrict__ src, const long long n4,
                                                            unsigned* __restrict__ amax_bits) {
+  __shared__ unsigned wave_max[256 / kWave];
   const long long stride = (long long)gridDim.x * blockDim.x;
   unsigned m = 0u;  // |x| as bits: non-negative floats order like unsigned integers (NaN > Inf > finite)
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + stride < n4; i += 2 * stride) {          // two independent 16-byte loads in flight per thread
+    const uint4 x = reinterpret_cast<const uint4*>(src)[i];
+    const uint4 y = reinterpret_cast<const uint4*>(src)[i + stride];
+    const unsigned a = x.x & 0x7FFFFFFFu, b = x.y & 0x7FFFFFFFu, c = x.z & 0x7FFFFFFFu, d = x.w & 0x7FFFFFFFu;
+    const unsigned e = y.x & 0x7FFFFFFFu, f = y.y & 0x7FFFFFFFu, g = y.z & 0x7FFFFFFFu, h = y.w & 0x7FFFFFFFu;
+    const unsigned ab = a > b ? a : b, cd = c > d ? c : d, ef = e > f ? e : f, gh = g > h ? g : h;
+    const unsigned abcd = ab > cd ? ab : cd, efgh = ef > gh ? ef : gh, all = abcd > efgh ? abcd : efgh;
+    m = m > all ? m : all;
+  }
+  for (; i < n4; i += stride) {
     const uint4 x = reinterpret_cast<const uint4*>(src)[i];
     const unsigned a = x.x & 0x7FFFFFFFu, b = x.y & 0x7FFFFFFFu, c = x.z & 0x7FFFFFFFu, d = x.w & 0x7FFFFFFFu;
     const unsigned ab = a > b ? a : b, cd = c > d ? c : d, abcd = ab > cd ? ab : cd;
@@ -1076,7 +1090,14 @@ static __global__ __launch_bounds__(256) void amax_abs_f32_kernel(const float* _
     const unsigned o = (unsigned)__shfl_xor((int)m, off, kWave);
     m = m > o ? m : o;
   }
-  if ((threadIdx.x & (kWave - 1)) == 0 && m != 0u) atomicMax(amax_bits, m);
+  if ((threadIdx.x & (kWave - 1)) == 0) wave_max[threadIdx.x / kWave] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < 256 / kWave; ++w) m = m > wave_max[w] ? m : wave_max[w];
+    // a stale (smaller) read only costs an atomic that changes nothing
+    if (m > __hip_atomic_load(amax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_bits, m);
+  }
 }
 
 __device__ __forceinline__ int operand_scale_exponent(const unsigned amax_bits) {
