@@ -635,7 +635,7 @@ FUSED_PACE_BLOCKS = 0
 def fused_enabled() -> bool:
     """``VOLTRIX_FUSED=1``: run the two-level product as ONE launch (spmm_fused_kernel: plain stores, no zero fill, no
     atomics, no second stream, one fixed summation order) instead of the panel kernel beside the window kernel with the
-    atomic join.  Off by default: measured on the reddit-like graph the one-launch kernel takes 2.0 ms against 1.35 ms for
+    atomic join.  Off by default: measured on the reddit-like graph the one-launch kernel takes 2.0-2.1 ms against 1.35 ms for
     the pair (profiles/r03/experiment_fused_*.log) -- it stays as the form for hosts that want a
     single stream-ordered launch and run-to-run identical bits."""
     return os.getenv("VOLTRIX_FUSED", "0") in ("1", "on")
