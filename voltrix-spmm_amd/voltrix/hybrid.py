@@ -712,9 +712,12 @@ def hybrid_mode() -> str:
 # panel kernel needs columns that several rows of a 512-row panel share)
 AUTO_MIN_EDGES = 1 << 22
 AUTO_MIN_MEAN_DEGREE = 64
-# ... and one panel workgroup (512 rows) per CU at the very least: below that the panel kernel cannot fill the chip
-# (measured on a 46 k-row banded graph: 0.29 ms with the side-car, 0.24 ms in the window format)
-AUTO_MIN_ROWS = 256 * DEFAULT_WAVES * DEFAULT_ROW_BLOCKS * 16
+# ... and enough rows for the panel kernel to fill the chip.  Rounds 2-3: one 512-row panel per CU (131 k rows).  With panels in
+# pieces (round 4) a plan of ~220 panels launches ~400 workgroups, and the measured break-even moved down
+# (profiles/r04/experiment_small_graphs.log, window format -> side-car, ms): 116 k rows 0.810 -> 0.749 (reddit-like), 0.664 ->
+# 0.471 (block model) -- whole panels: 1.026 / 0.568 --; 58 k rows 0.411 -> 0.553, 0.301 -> 0.370; 29 k rows 0.228 -> 0.322.
+# Interpolated break-even 83-106 k rows.
+AUTO_MIN_ROWS = 110_000
 
 
 def handle_bytes(tensors) -> int:
