@@ -557,7 +557,7 @@ def run_two_level(plan: PanelPlan, operand: torch.Tensor, output: torch.Tensor, 
                                  stream=side.cuda_stream, defer_combine=True)
     join = torch.cuda.Event()
     join.record(side)
-    pending = run_window(True)
+    pending = run_window(True)     # (enqueueing the window kernel first changes nothing: 1.374 vs 1.376 ms, profiles/r04)
     main.wait_event(join)
     finish(pending)                              # adds onto rows that now hold the panel kernel's part, complete
     finish(pending_panel)                        # pieces of cut panels, in slot order (both kernels are done with C)
