@@ -52,13 +52,18 @@ def test_bucket_miss_first_call_is_bounded(tmp_path, workload, feat):
     """a graph of a bucket the store does not know (shipped defaults off, empty store) pays ONE bounded
     sweep on its first call -- <= 12 candidates per kernel (tile shapes, then the winner's schedules), timed on a 1/16 sample of
     the handle, capped at max(2 s, 20 steps) -- instead of 44 candidates x 11 full-size launches (round 3: 60 s on the power-law
-    graph, 39 s on the papers-like one).  BASELINE configs 3-5 at their stated sizes; the JIT kernels are in the in-tree
-    cache, so no compile time is in the figure (asserted)."""
-    out = tmp_path / "sweep.json"
-    run = subprocess.run([sys.executable, os.path.join(REPO, "tests", "tuner_sweep_worker.py"), str(tmp_path / "tuned.json"),
-                          workload, str(feat), str(out)], capture_output=True, text=True, timeout=900)
-    assert run.returncode == 0, run.stderr[-3000:]
-    st = json.load(open(out))
+    graph, 39 s on the papers-like one).  BASELINE configs 3-5 at their stated sizes.  No compile time is in the figure
+    (asserted): the JIT kernels come from the in-tree cache; on a tree without it the first run only fills the cache and a
+    second run, with a fresh store, is the one measured."""
+    for attempt in range(2):
+        out = tmp_path / f"sweep{attempt}.json"
+        run = subprocess.run([sys.executable, os.path.join(REPO, "tests", "tuner_sweep_worker.py"),
+                              str(tmp_path / f"tuned{attempt}.json"), workload, str(feat), str(out)], capture_output=True,
+                             text=True, timeout=900)
+        assert run.returncode == 0, run.stderr[-3000:]
+        st = json.load(open(out))
+        if st["jit"]["compiled"] == 0:
+            break
     kernels = 2 if st["two_level"] else 1        # reddit-like: the residual's window kernel is tuned beside the panel kernel
     assert st["tuner"]["sweeps"] >= 1 and st["tuner"]["bucket_hits"] == 0 and st["tuner"]["stored_hits"] == 0, st
     assert st["tuner"]["timed_candidates"] <= 12 * st["tuner"]["sweeps"], st
