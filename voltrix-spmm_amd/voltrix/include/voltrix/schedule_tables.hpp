@@ -23,6 +23,7 @@
 namespace voltrix {
 
 constexpr int kSplitThreads = 1024;
+constexpr int kSplitUnroll = 8;      // 64-item steps a wave loads before it sums them (memory-level parallelism of the walk)
 
 // work of item i: a functor over the raw arrays, so that windows and panels need no materialised work array
 struct WorkOfArray {
@@ -54,50 +55,97 @@ struct WorkOfPanels {    // round(kstep_cost x k-steps + stages of the panel's w
   }
 };
 
-// One workgroup: every thread owns a contiguous chunk of the items.  Pass 1: chunk sums -> exclusive prefix over the threads
-// (LDS, thread 0: 1024 adds) -> total and the seven targets.  Pass 2: every thread walks its chunk again; the chunk that holds
-// the first index whose prefix reaches a target writes that boundary.  Thread 0 rounds, clamps and makes the list monotone.
+// One workgroup of 16 waves; every WAVE owns a contiguous sixteenth of the items and walks it 64 items per step, lane l
+// taking item base + l (coalesced 256-byte loads; a thread-contiguous walk would keep 1024 cache lines alive at once).
+// Pass 1: per-wave sums -> exclusive prefix over the waves (thread 0: 16 adds) -> total and the seven targets.
+// Pass 2: the wave whose range holds the first index whose prefix reaches a target walks it again with a wave-wide inclusive
+// scan per step; the lane at the crossing writes the boundary.  Thread 0 rounds, clamps and makes the list monotone.
+// Measured (one CU, latency-bound by design -- the table is built once per handle): 14.6 k windows 0.02 ms, 1 M 0.38 ms,
+// 6.95 M (the papers-like graph) 4.7 ms.
+__device__ __forceinline__ long long wave_inclusive_scan(long long v, const int lane) {
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const long long o = __shfl_up(v, off, kWave);
+    if (lane >= off) v += o;
+  }
+  return v;
+}
+
 template <class Work>
 static __global__ __launch_bounds__(kSplitThreads) void split_equal_work_kernel(const Work work, const int n, const int align,
                                                                                int* __restrict__ xcd_ptr) {
-  __shared__ long long chunk_sum[kSplitThreads + 1];
+  constexpr int kWaves = kSplitThreads / kWave;
+  __shared__ long long wave_sum[kWaves + 1];
   __shared__ long long target[kNumXcd];
   __shared__ int cut[kNumXcd + 1];
-  const int t = threadIdx.x;
-  const int per = (n + kSplitThreads - 1) / kSplitThreads;
-  const int i0 = t * per < n ? t * per : n;
-  const int i1 = i0 + per < n ? i0 + per : n;
+  const int t = threadIdx.x, wave = t / kWave, lane = t % kWave;
+  const long long per = ((long long)(n + kWaves - 1) / kWaves + kWave - 1) / kWave * kWave;   // a multiple of 64
+  const int i0 = (int)(wave * per < n ? wave * per : n);
+  const int i1 = (int)(i0 + per < n ? i0 + per : n);
   long long s = 0;
-  for (int i = i0; i < i1; ++i) s += work(i);
-  chunk_sum[t] = s;
+  for (int base = i0; base < i1; base += kWave * kSplitUnroll) {     // kSplitUnroll independent loads in flight per lane
+    long long v[kSplitUnroll];
+#pragma unroll
+    for (int u = 0; u < kSplitUnroll; ++u) {
+      const int i = base + u * kWave + lane;
+      v[u] = i < i1 ? work(i) : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < kSplitUnroll; ++u) s += v[u];
+  }
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, kWave);
+  if (lane == 0) wave_sum[wave] = s;
   if (t < kNumXcd + 1) cut[t] = t == kNumXcd ? n : 0;
   __syncthreads();
   if (t == 0) {
     long long run = 0;
-    for (int k = 0; k < kSplitThreads; ++k) {
-      const long long v = chunk_sum[k];
-      chunk_sum[k] = run;
+    for (int k = 0; k < kWaves; ++k) {
+      const long long v = wave_sum[k];
+      wave_sum[k] = run;
       run += v;
     }
-    chunk_sum[kSplitThreads] = run;
+    wave_sum[kWaves] = run;
     for (int x = 1; x < kNumXcd; ++x) target[x] = (run * x + kNumXcd - 1) / kNumXcd;
   }
   __syncthreads();
-  const long long total = chunk_sum[kSplitThreads];
+  const long long total = wave_sum[kWaves];
   if (total > 0) {
-    const long long before = chunk_sum[t], after = t + 1 < kSplitThreads ? chunk_sum[t + 1] : total;
-    for (int x = 1; x < kNumXcd; ++x) {
+    const long long before = wave_sum[wave], after = wave_sum[wave + 1];
+    for (int x = 1; x < kNumXcd; ++x) {           // wave-uniform
       const long long tg = target[x];
-      if (!(before < tg && tg <= after)) continue;      // the first index whose prefix reaches tg is not in this chunk
-      long long prev = before;
-      for (int i = i0; i < i1; ++i) {
-        const long long cur = prev + work(i);
-        if (cur >= tg) {
-          const long long under = tg - prev, over = cur - tg;
-          cut[x] = under < over ? i : i + 1;             // items before the boundary
-          break;
+      if (!(before < tg && tg <= after)) continue;   // the first index whose prefix reaches tg is not in this wave's range
+      long long run = before;
+      bool found = false;
+      for (int base = i0; base < i1 && !found; base += kWave * kSplitUnroll) {   // wave-uniform
+        long long v[kSplitUnroll], group = 0;
+#pragma unroll
+        for (int u = 0; u < kSplitUnroll; ++u) {
+          const int i = base + u * kWave + lane;
+          v[u] = i < i1 ? work(i) : 0;
+          group += v[u];
         }
-        prev = cur;
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) group += __shfl_xor(group, off, kWave);
+        if (run + group < tg) {          // the crossing is not in these kSplitUnroll x 64 items
+          run += group;
+          continue;
+        }
+#pragma unroll
+        for (int u = 0; u < kSplitUnroll; ++u) {
+          if (found) continue;
+          const int i = base + u * kWave + lane;
+          const long long cur = run + wave_inclusive_scan(v[u], lane);
+          const unsigned long long hits = __ballot(i < i1 && cur >= tg);
+          if (hits) {
+            if (lane == __ffsll((long long)hits) - 1) {
+              const long long under = tg - (cur - v[u]), over = cur - tg;
+              cut[x] = under < over ? i : i + 1;         // items before the boundary
+            }
+            found = true;
+          }
+          run = __shfl(cur, kWave - 1, kWave);
+        }
       }
     }
   }
