@@ -172,6 +172,19 @@ def test_two_level_reddit_like_full_size(cuda_device, monkeypatch):
     a = run(x)
     b = _window_runner(win, n, e, f, capi.default_tile(f, True))(x)
     assert torch.equal(a, b)
+    # round 4: the schedules of the step at full size -- XCD ranges of equal work came with the handle; panels in pieces of at
+    # most 100 k-steps (the product's bound, S / 256 = 713, cuts none of this graph's panels): 2,000-odd pieces, every panel
+    # cut, partial tiles summed in slot order -- the same bits on integers, and the size-independent properties again
+    from voltrix import hybrid
+
+    plan = two.plan
+    assert plan.xcd_ptr is not None and two.window_xcd_ptr is not None and plan.parts is None
+    plan.parts = hybrid.panel_parts(plan.panel_ptr, 100, plan.xcd_ptr)
+    assert plan.parts.num_cuts > 400 and plan.parts.num_parts > 1800
+    assert int(plan.parts.parts[:, 2].sum()) == plan.num_ksteps and int(plan.parts.parts[:, 2].max()) <= 100
+    assert torch.equal(run(x), a)
+    _check_properties(run, indptr, indices, n, f)
+    plan.parts = None
 
 
 def test_format_policy_is_decided_in_csr_preprocess_at_full_size(cuda_device, monkeypatch):
