@@ -489,3 +489,36 @@ def test_two_level_operator_with_pieces(cuda_device, monkeypatch, tmp_path):
     assert lp is not None and lp.cap == cap and torch.equal(lp.parts, side.plan.parts.parts) and torch.equal(lp.cuts, side.plan.parts.cuts)
     loaded[1].hash_tag = "pieces_loaded"
     assert torch.equal(voltrix.spmm(*loaded, num_nodes=n, num_edges=indices.numel(), feat=ints), ref)
+
+
+def test_slim_handle_runs_on_the_side_car_alone_and_refuses_the_window_paths(cuda_device, monkeypatch):
+    """voltrix.slim_handle: after the side-car has been built the reference tensors of the whole matrix can be dropped -- the
+    operator gives the same bits from the 4-element stand-ins (reddit-like headline: 617 MB freed), and refuses the paths
+    that would need the dropped TC blocks instead of reading four elements as a handle."""
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    monkeypatch.setenv("VOLTRIX_HYBRID", "1")
+    indptr, indices, _ = synth_graphs.generate("reddit_like", scale=0.02)
+    n, e = indptr.numel() - 1, indices.numel()
+    handle = voltrix.csr_preprocess(indptr, indices, n)
+    handle[1].hash_tag = "slim_test"
+    assert voltrix.two_level_of(handle[1]) is not None
+    feat = torch.randn(n, 128, device=cuda_device).half()
+    ref = voltrix.spmm(*handle, num_nodes=n, num_edges=e, feat=feat).clone()
+    before = sum(t.numel() * t.element_size() for t in handle)
+    slim = voltrix.slim_handle(handle)
+    assert slim[0] is handle[0] and slim[1].numel() == 4 and slim[2].numel() == 4
+    assert sum(t.numel() * t.element_size() for t in slim) < before / 10
+    del handle
+    assert torch.equal(voltrix.spmm(*slim, num_nodes=n, num_edges=e, feat=feat), ref)
+    _assert_close(ref, indptr.numpy(), indices.numpy(), feat.float().cpu(), n, "fp16")
+    monkeypatch.setenv("VOLTRIX_HYBRID", "0")
+    with pytest.raises(AssertionError, match="slimmed"):
+        voltrix.spmm(*slim, num_nodes=n, num_edges=e, feat=feat)
+    monkeypatch.setenv("VOLTRIX_HYBRID", "1")
+    monkeypatch.setenv("VOLTRIX_FP32_MODE", "exact")
+    with pytest.raises(AssertionError, match="slimmed"):
+        voltrix.spmm(*slim, num_nodes=n, num_edges=e, feat=feat.float())
+    monkeypatch.delenv("VOLTRIX_FP32_MODE")
+    monkeypatch.setenv("VOLTRIX_HYBRID", "0")                         # a handle without a side-car is returned unchanged
+    no_side_car = voltrix.csr_preprocess(indptr, indices, n)
+    assert voltrix.slim_handle(no_side_car)[1] is no_side_car[1]

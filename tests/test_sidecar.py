@@ -47,3 +47,28 @@ def test_unknown_big_handle_warns_once():
         sidecar.warn_if_unknown(t, 300000, 1 << 25, 1 << 22, 131072, 64)
     assert len(caught) == 1 and "copy_side_car" in str(caught[0].message)
     sidecar._WARNED[0] = False
+
+
+def test_slim_handle_keeps_the_side_car_and_marks_the_stand_ins():
+    """voltrix.slim_handle (round 4, opt-in): a handle with a side-car is replaced by 4-element stand-ins that carry it (and
+    the tag); a handle without one is returned as it is; the mark dies with the stand-in's storage."""
+    import gc
+
+    from voltrix import sidecar
+
+    blk = torch.zeros(3, dtype=torch.int32)
+    packed, hind = torch.zeros(400, dtype=torch.int32), torch.zeros(800, dtype=torch.int32)
+    assert sidecar.slim_handle((blk, packed, hind)) == (blk, packed, hind)          # nothing recorded: unchanged
+    sidecar.register(packed, None)
+    assert sidecar.slim_handle((blk, packed, hind))[1] is packed                   # decided: window format -> unchanged
+    marker = object()
+    sidecar.register(packed, marker)
+    packed.hash_tag = "tagged"
+    b2, p2, h2 = sidecar.slim_handle((blk, packed, hind))
+    assert b2 is blk and p2.numel() == 4 and h2.numel() == 4 and p2.dtype == packed.dtype and h2.dtype == hind.dtype
+    assert sidecar.lookup(p2) == (True, marker) and p2.hash_tag == "tagged"
+    assert sidecar.is_slim(p2) and sidecar.is_slim(p2.view(torch.int32)) and not sidecar.is_slim(packed)
+    key = sidecar._key(p2)[0]
+    del p2, b2, h2
+    gc.collect()
+    assert key not in sidecar._SLIM and key not in sidecar._ENTRIES

@@ -11,7 +11,7 @@ from .spmm import *  # noqa: F401,F403
 from .spmm import (BLK_H, BLK_W, csr_preprocess, csr_preprocess_device, csr_preprocess_hybrid, spmm, spmm_two_level,
                    two_level_of)
 from .hybrid import TwoLevelHandle
-from .sidecar import copy_side_car, load_handle, save_handle
+from .sidecar import copy_side_car, load_handle, save_handle, slim_handle
 from .reorder import ReorderedHandle, csr_preprocess_reordered, spmm_reordered
 from .weighted import WeightedHandle, csr_preprocess_weighted, spmm_weighted
 from .graphed import GraphedSpMM

@@ -27,6 +27,7 @@ import torch
 
 _LOCK = threading.Lock()
 _ENTRIES = {}          # key -> TwoLevelHandle, or None = "csr_preprocess decided for the window format"
+_SLIM = set()          # keys of stand-in handles (slim_handle): nothing but the side-car is left of them
 _WARNED = [False]
 
 
@@ -48,6 +49,7 @@ def register(hspa_packed: torch.Tensor, two) -> None:
 def _drop(key) -> None:
     with _LOCK:
         _ENTRIES.pop(key, None)
+        _SLIM.discard(key)
 
 
 def lookup(hspa_packed: torch.Tensor):
@@ -81,6 +83,35 @@ def warn_if_unknown(hspa_packed: torch.Tensor, num_nodes: int, num_edges: int, m
         "reloaded file?), so the two-level side-car, if one was built, is not attached to it and the product runs in the "
         "window format.  Use voltrix.copy_side_car(original_hspa_packed, copy) after copying a handle, or "
         "voltrix.save_handle / voltrix.load_handle to move one between processes.", stacklevel=3)
+
+
+def slim_handle(handle):
+    """Opt-in, for hosts short of memory: once ``csr_preprocess`` has decided for the two-level form, the reference handle of
+    the WHOLE matrix is only the key the side-car hangs on -- ``voltrix.spmm`` never reads its TC blocks again (617 MB on the
+    headline graph next to a 703 MB side-car).  Returns ``(blk_offsets, stub, stub)`` with 4-element stand-ins for
+    ``hspa_packed`` and ``hind`` that carry the side-car (and the hash tag); drop the original tuple to free the memory.
+    What is given up: the window-format paths of THIS handle -- ``VOLTRIX_HYBRID=0``, ``VOLTRIX_FP32_MODE=exact``, a direct
+    ``spmm_kernel`` call, the C-ABI -- which ``voltrix.spmm`` then refuses instead of running on four elements.  A handle
+    without a side-car is returned unchanged."""
+    blk_offsets, hspa_packed, hind = handle
+    known, two = lookup(hspa_packed)
+    if not known or two is None:
+        return handle
+    stub_packed = torch.zeros(4, dtype=hspa_packed.dtype, device=hspa_packed.device)
+    stub_hind = torch.zeros(4, dtype=hind.dtype, device=hind.device)
+    if getattr(hspa_packed, "hash_tag", None) is not None:
+        stub_packed.hash_tag = hspa_packed.hash_tag
+    register(stub_packed, two)
+    with _LOCK:
+        _SLIM.add(_key(stub_packed)[0])
+    return blk_offsets, stub_packed, stub_hind
+
+
+def is_slim(hspa_packed: torch.Tensor) -> bool:
+    """Whether this memory is a stand-in made by ``slim_handle`` (the window-format paths must refuse it)."""
+    key, _ = _key(hspa_packed)
+    with _LOCK:
+        return key in _SLIM
 
 
 # ---- moving a handle (and its side-car) between processes ---------------------------------------------------------------

@@ -206,8 +206,11 @@ def spmm(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tenso
         _run_two_level(two, operand, output, out_scale, tag_source=hspa_packed)
 
     if two is None or exact or two.num_nodes != num_nodes or mode == "off":
+        assert not sidecar.is_slim(hspa_packed), \
+            "this handle was slimmed (voltrix.slim_handle): only its two-level side-car is left, the window-format paths " \
+            "(VOLTRIX_HYBRID=0, VOLTRIX_FP32_MODE=exact) need the full reference handle"
         window()
-    elif mode != "tune":
+    elif mode != "tune" or sidecar.is_slim(hspa_packed):
         two_level()   # csr_preprocess decided (auto) or the caller did (VOLTRIX_HYBRID=1): stream-ordered, capturable
     else:   # opt-in: the first call for this (width, dtype) times both forms and keeps the faster (host sync!)
         key = (padded, str(operand.dtype))
