@@ -20,6 +20,8 @@ os.environ["VOLTRIX_HYBRID"] = "1"
 # and without the metadata DMAs those are whatever LDS held -- a variant with 16 alone faulted (out-of-bounds gathers)
 VARIANTS = {"full": 0, "no_mfma": 1, "no_rows": 2, "no_frag_reads": 8, "no_mfma_no_frag_reads": 9,
             "no_rows_no_meta": 18, "no_mfma_no_rows": 3, "no_mfma_no_rows_no_meta": 19, "only_loop_control": 31}
+# (The metadata-once-per-workgroup form was A/B'd against the per-wave form through this harness before the latter was deleted:
+# profiles/r04/experiment_meta_ab.log.)
 if os.environ.get("EXP_ONLY"):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["EXP_ONLY"].split(",")}
 

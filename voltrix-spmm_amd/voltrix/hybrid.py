@@ -497,8 +497,9 @@ def build_panel_plan_torch(indptr: torch.Tensor, indices: torch.Tensor, num_node
 
 
 # panel kernel tile per feature width: (fs, depth, ks); waves / row_blocks come from the plan.  Depth 3 at FS = 128 keeps
-# the workgroup at 44 KB of LDS and 183 registers, so that it fits on a CU NEXT TO a (128, 3, 4) window-kernel
-# workgroup (103 KB, 136 registers) -- the two kernels overlap when they run on two streams.
+# the workgroup at 36 KB of LDS and 176 registers, so that it fits on a CU NEXT TO a (128, 3, 4) pair window-kernel
+# workgroup (103 KB, 160 registers: 2 x 176 + 160 = 512, tests/test_register_budget.py) -- the two kernels overlap when they
+# run on two streams.
 def default_panel_tile(embedding_dim: int, waves: int, row_blocks: int = DEFAULT_ROW_BLOCKS):
     if embedding_dim <= 32:
         return (32, 6, 2)

@@ -198,6 +198,9 @@ __device__ __forceinline__ void dma_b32(const void* src, unsigned lds_byte_addr)
 __device__ __forceinline__ void dma_b32_nt(const void* src, unsigned lds_byte_addr) {
   __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(uintptr_t)lds_byte_addr, 4, 0, 2);
 }
+__device__ __forceinline__ void dma_b128_nt(const void* src, unsigned lds_byte_addr) {
+  __builtin_amdgcn_global_load_lds((gas_ptr)src, (lds_ptr)(uintptr_t)lds_byte_addr, 16, 0, 2);
+}
 
 // Slot swizzle: LDS row r keeps logical 32-byte slot s at physical slot s ^ slot_swizzle(r).  One transposed read
 // touches, per 32-lane half, rows {8g+q, 8g'+q : q<4} (+4 for the second read); this makes their 8 x 32 B land on

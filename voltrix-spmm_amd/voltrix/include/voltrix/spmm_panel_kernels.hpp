@@ -20,13 +20,13 @@
 // Per k-step the workgroup gathers 32 rows of B ONCE (8 KiB at FS = 128; LDS-DMA, every wave issues its share) and each
 // wave multiplies it into RB 16-row blocks: RB * FS/16 v_mfma_f32_16x16x32_f16 per 2 * FS/16 transposed LDS reads.  The
 // ring is shared, so there is one raw s_barrier per step: counted vmcnt wait -> barrier -> reads (cdna_hip_programming.md
-// "Pipelining across barriers"); the metadata (this wave's 256 B of adjacency bits, the step's 32 rows) is fetched by
-// wave-private LDS-DMAs a ring ahead, as in spmm_tc16_kernel.
+// "Pipelining across barriers"); the metadata (every wave's 256 B of adjacency bits, the step's 32 rows) is fetched once per
+// workgroup into a shared slot a ring ahead (PanelTile: three DMAs per k-step, issued by waves 0 .. 2).
 //
 // Bound: matrix cores (16 rows x 32 columns per MFMA at the panel's density), with 1/16 .. 1/32 of the window kernel's
 // gather traffic per covered edge.  Being MFMA-bound is what makes it a good neighbour: on a second stream it overlaps the
-// gather-bound window kernel on the same CUs (183 VGPRs x 2 waves per SIMD + 44 KB of LDS at DEPTH 3 leave room for a
-// (128, 3, 4) window workgroup).  The structured-sparse MFMAs were measured and are NOT used: they make this kernel
+// gather-bound window kernel on the same CUs (176 VGPRs x 2 waves per SIMD + 36 KB of LDS at DEPTH 3 leave exactly the 160
+// registers and more than the 103 KB a (128, 3, 4) pair window workgroup needs: tests/test_register_budget.py).  The structured-sparse MFMAs were measured and are NOT used: they make this kernel
 // faster alone and the pair slower (harness/experiments/smfmac_prototype/README.md).
 //
 // Inline-asm note: every LDS read here is asynchronous asm whose outputs are all consumed after the lgkmcnt wait.  A read
@@ -37,11 +37,13 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "voltrix/spmm_kernels.hpp"
 
 // Diagnostic builds only (-DVOLTRIX_EXPERIMENTAL, traits.hpp; harness/experiments/panel_diag.py, exp_corun_diag.py): bit 0 skips the MFMAs, bit 1 the row DMAs,
-// bit 2 the barrier, bit 3 the fragment reads, bit 4 the metadata DMAs of the loop.  Results are wrong by design; shipped kernels use 0.
+// bit 2 the barrier, bit 3 the fragment reads, bit 4 the metadata DMAs of the loop (bit 4 ONLY with bit 1: the row gathers take
+// their row ids from the metadata slots).  Results are wrong by design; shipped kernels use 0.
 #ifndef VOLTRIX_PANEL_DIAG
 #define VOLTRIX_PANEL_DIAG 0
 #endif
@@ -74,13 +76,22 @@ struct PanelTile {
   static constexpr int ROWS_PER_DMA = 1024 / ROW_BYTES;
   static constexpr int LANES_PER_ROW = ROW_BYTES / 16;
   static constexpr int SLOTS = FS / 16;
-  // wave-private metadata slot: KS x 64 adjacency words, then 64 column ids (32 * KS used)
-  static constexpr int META_BYTES = KS * 256 + 256;
+  // Metadata slot, shared by the workgroup (round 4; rounds 2-3: one slot per wave, every wave fetching its own 256 B of words
+  // and its own copy of the SAME ids -- 16 small DMAs per k-step at 8 waves; now 3): the adjacency words of ALL waves for the
+  // group's KS k-steps (word (k, wave v, lane L) at ((k WAVES + v) 64 + L) 4, as in panel_bits), then the 64 column ids.
+  // The words come as 1-KiB dwordx4 DMAs issued by waves 0 .. NBITS_DMA - 1, the ids as one DMA of wave NBITS_DMA; the ring's
+  // barrier per k-step makes them visible (a group's metadata lands D - 1 steps before its rows are issued).  Measured
+  // (profiles/r04/experiment_meta_ab.log): headline step unchanged (the panel kernel gains what the window kernel loses),
+  // block model -3.5 % (the panel kernel is its critical path), 8 KiB less LDS.
+  static constexpr int BITS_BYTES = KS * WAVES * 256;
+  static constexpr int META_BYTES = BITS_BYTES + 256;
   static constexpr int META_SLOTS = 2 * DEPTH - 1;
-  static constexpr int NMETA = KS + 1;                             // metadata DMAs per wave and step
-  static constexpr int VM_PER_STEP = DPW + NMETA;
+  static constexpr int NBITS_DMA = BITS_BYTES / 1024;
+  static_assert(BITS_BYTES % 1024 == 0 && NBITS_DMA + 1 <= WAVES, "metadata DMA roles");
+  static constexpr int VM_PER_STEP = DPW + 1;                      // of waves 0 .. NBITS_DMA (one metadata DMA per step)
+  static constexpr int VM_PER_STEP_PLAIN = DPW;                    // of the other waves
   static constexpr int DATA_LDS = DEPTH * STAGE_BYTES;
-  static constexpr int BLOCK_LDS = DATA_LDS + WAVES * META_SLOTS * META_BYTES;
+  static constexpr int BLOCK_LDS = DATA_LDS + META_SLOTS * META_BYTES;
   static_assert(BLOCK_LDS <= 160 * 1024, "LDS per CU");
   static_assert(VM_PER_STEP * (DEPTH - 2) <= 63, "vmcnt is a 6-bit counter on gfx9");
 };
@@ -169,7 +180,8 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
     for (int s = 0; s < SLOTS; ++s) acc[j][s] = float4_t{0.f, 0.f, 0.f, 0.f};
 
   const unsigned data0 = (unsigned)(uintptr_t)(lds_ptr)smem;
-  const unsigned meta0 = data0 + T::DATA_LDS + (unsigned)wave * (MS * T::META_BYTES);
+  const unsigned meta0 = data0 + T::DATA_LDS;
+  const bool meta_wave = wave <= T::NBITS_DMA;   // waves 0 .. NBITS_DMA - 1 fetch the words, wave NBITS_DMA the column ids
 
   if (ngroups > 0) {
     // ---- lane constants ---------------------------------------------------------------------------------------
@@ -186,13 +198,12 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
       unsigned long long cb = (unsigned long long)((const char*)a.input + (long long)col * 2);
       asm volatile("" : "+v"(cb));
       cbase[d] = (const char*)cb;
-      hr_off[d] = KS * 256 + 4 * r;
+      hr_off[d] = T::BITS_BYTES + 4 * r;
     }
     // metadata DMAs of k-step group s (clamped to the panel's last group: the pipeline issues a static number of DMAs)
     // wave-uniform bases (scalar registers); the lane offset is added at each DMA from an opaque copy of the lane id, so
     // that no 64-bit per-lane pointer stays live across the k-step loop (4 VGPRs fewer: 179 of the 184 that fit beside a
     // window-kernel workgroup)
-    const uint32_t* const bits_base = a.panel_bits + ((long long)ks0 * T::WAVES + wave) * kWave;
     const int* const cols_base = a.panel_cols + (long long)ks0 * kStageK;
     // ring positions are carried counters (ms = group % MS, ds = group % D), never a division: the k-step loop issued
     // 66 scalar instructions per step when they were computed with %
@@ -201,16 +212,12 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
       const unsigned dst = meta0 + (unsigned)ms * T::META_BYTES;
       int ml = lane;
       asm volatile("" : "+v"(ml));
-      if (a.meta_nt) {   // workgroup-uniform
-#pragma unroll
-        for (int k = 0; k < KS; ++k)
-          dma_b32_nt(bits_base + (long long)(sc * KS + k) * (T::WAVES * kWave) + ml, dst + 256 * k);
-        dma_b32_nt(cols_base + (long long)sc * (KS * kStageK) + ml, dst + 256 * KS);
-      } else {
-#pragma unroll
-        for (int k = 0; k < KS; ++k)
-          dma_b32(bits_base + (long long)(sc * KS + k) * (T::WAVES * kWave) + ml, dst + 256 * k);
-        dma_b32(cols_base + (long long)sc * (KS * kStageK) + ml, dst + 256 * KS);
+      if (wave < T::NBITS_DMA) {            // wave-uniform: 1 KiB of the group's KS x WAVES x 256 bytes of words
+        const char* src = (const char*)(a.panel_bits + (long long)(ks0 + sc * KS) * (T::WAVES * kWave)) + wave * 1024 + ml * 16;
+        if (a.meta_nt) dma_b128_nt(src, dst + wave * 1024); else dma_b128(src, dst + wave * 1024);
+      } else if (wave == T::NBITS_DMA) {
+        const int* src = cols_base + (long long)sc * (KS * kStageK) + ml;
+        if (a.meta_nt) dma_b32_nt(src, dst + T::BITS_BYTES); else dma_b32(src, dst + T::BITS_BYTES);
       }
     };
     auto issue_rows = [&](int ms, int ds) {
@@ -229,6 +236,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
 #pragma unroll
     for (int s = 0; s < D - 1; ++s) issue_meta(s, s % MS);
     wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();           // the other waves' metadata DMAs have landed too
 #pragma unroll
     for (int s = 0; s < D - 1; ++s) {
       issue_rows(s % MS, s % D);            // groups past the panel's end re-gather its last group (static DMA count)
@@ -258,18 +266,23 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
       // rows of group t (issued D-1 steps ago) and the metadata of group t+D-1 must have landed; the D-2 younger
       // steps may stay in flight.  Steps past ngroups-D+1 issue nothing.
       const int young = ngroups - 1 - t;
-      if (young >= D - 2) {
-        wait_vmcnt<T::VM_PER_STEP*(D - 2)>();
-      } else {
-        switch (young) {
-          case 0: wait_vmcnt<0>(); break;
-          case 1: wait_vmcnt<T::VM_PER_STEP * 1>(); break;
-          case 2: wait_vmcnt<T::VM_PER_STEP * 2>(); break;
-          case 3: wait_vmcnt<T::VM_PER_STEP * 3>(); break;
-          case 4: wait_vmcnt<T::VM_PER_STEP * 4>(); break;
-          default: wait_vmcnt<T::VM_PER_STEP * 5>(); break;
+      auto wait_steps = [&](auto per_step) {     // per_step: this wave's vector-memory operations per step (a constant)
+        constexpr int VM = decltype(per_step)::value;
+        if (young >= D - 2) {
+          wait_vmcnt<VM*(D - 2)>();
+        } else {
+          switch (young) {
+            case 0: wait_vmcnt<0>(); break;
+            case 1: wait_vmcnt<VM * 1>(); break;
+            case 2: wait_vmcnt<VM * 2>(); break;
+            case 3: wait_vmcnt<VM * 3>(); break;
+            case 4: wait_vmcnt<VM * 4>(); break;
+            default: wait_vmcnt<VM * 5>(); break;
+          }
         }
-      }
+      };
+      if (meta_wave) wait_steps(std::integral_constant<int, T::VM_PER_STEP>{});
+      else wait_steps(std::integral_constant<int, T::VM_PER_STEP_PLAIN>{});
       if (!(VOLTRIX_PANEL_DIAG & 4))
         __builtin_amdgcn_s_barrier();  // every wave's share of group t has landed; everyone is done reading group t-1
       __builtin_amdgcn_sched_barrier(0);
@@ -289,7 +302,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
 #pragma unroll
       for (int k = 0; k < KS; ++k) {
         if (t * KS + k < nks) {      // workgroup-uniform
-          const unsigned aw = lds_read_b32(mt + 256 * k + 4 * lane);
+          const unsigned aw = lds_read_b32(mt + 256 * (k * T::WAVES + wave) + 4 * lane);
           unsigned taddr[SLOTS];
           taddr[0] = dt + k * T::KSTEP_BYTES;
 #pragma unroll
