@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""The reference's own evaluation set in ONE process: 12 graphs (bench/plot.py:8) x feature widths (bench_all.py:21: 256, 512,
+1024; plus north_star's 32 and 128) x methods {hipSPARSE, Voltrix (fp32 inputs, as the reference feeds them), Voltrix-fp16}.
+
+    python harness/eval_set.py [--datasets amazon0505,DD,...] [--feature_dims 32,128,256,512,1024]
+                               [--output_file results.csv] [--jsonl eval.jsonl] [--scale 1.0] [--reorder]
+
+``harness/bench_all.py`` is the file-based form of the same sweep (one process per cell, as bench/bench_all.py:62-172); this
+driver generates every stand-in once (``synth_graphs.EVALUATION_SET``: datasets.zip is unreachable offline), preprocesses it
+once and loops over widths and methods in-process -- 12 x 5 x 3 cells in minutes instead of an hour of process start-ups.
+Two timings per cell:
+  * ``Time (ms)`` of results.csv = the reference's protocol (bm_voltrix.py:36: ``GPU_bench(spmm, iters=10, warmup=10,
+    kernel_name="spmm")`` -- every call after a cache flush, its own event pair), in the reference's CSV schema
+    (bench_all.py:75);
+  * the jsonl line adds the steady-state time (median of batches of back-to-back calls: bench.py's protocol), the HBM-roofline
+    fraction of the algorithmic bytes 4 (nnz + N + 1) + N F (s_in + 4), launches per call, the first call's
+    wall time, the handle's TC blocks / stages (= gathered bytes) and the tile the tuner picked.
+``--reorder`` adds Reorder=Y rows: the library's symmetric relabelling (csr_preprocess_reordered(..., relabel=True)), features
+permuted outside the timed call, as bench_all.py:120-129 runs Voltrix on ``<name>.reorder.npz``.
+Bench infrastructure, not part of the product.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "voltrix-spmm_amd")):
+    sys.path.insert(0, p)
+os.environ.setdefault("VOLTRIX_CACHE_DIR", os.path.join(REPO, "voltrix-spmm_amd", ".jit_cache"))
+
+import torch  # noqa: E402
+
+import synth_graphs  # noqa: E402
+import voltrix  # noqa: E402
+from voltrix.utils import GPU_bench, KernelTimer, calc_diff  # noqa: E402
+
+HBM_PEAK = 8.0e12
+
+
+def steady_ms(fn, iters=7, warm=3, batch=10):
+    for _ in range(warm):
+        fn()
+    times = []
+    for _ in range(iters):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(batch):
+            fn()
+        e.record()
+        e.synchronize()
+        times.append(s.elapsed_time(e) / batch)
+    return sorted(times)[len(times) // 2]
+
+
+def launches_per_call(fn):
+    with KernelTimer() as timer:
+        fn()
+    got = timer.summary()
+    return {k: v[0] for k, v in got.items()}
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--datasets", default=",".join(synth_graphs.EVALUATION_SET))
+    ap.add_argument("--feature_dims", default="32,128,256,512,1024")
+    ap.add_argument("--methods", default="hipSPARSE,Voltrix,Voltrix-fp16")
+    ap.add_argument("--output_file", default="results.csv")
+    ap.add_argument("--jsonl", default="eval_set.jsonl")
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--reorder", action="store_true")
+    ap.add_argument("--check", action="store_true", help="compare every Voltrix cell's output with hipSPARSE's (calc_diff)")
+    args = ap.parse_args(argv)
+    dev = torch.device("cuda", 0)
+    dims = [int(d) for d in args.feature_dims.split(",")]
+    methods = args.methods.split(",")
+    with open(args.output_file, "w") as f:
+        f.write("Method,Dataset,FeatDim,Reorder,Time (ms)\n")
+    jl = open(args.jsonl, "w")
+
+    def record(method, name, dim, mark, ms, extra):
+        with open(args.output_file, "a") as f:
+            f.write(f"{method},{name},{dim},{mark},{ms:.4f}\n")
+        line = dict(method=method, dataset=name, feat=dim, reorder=mark, ref_protocol_ms=ms, **extra)
+        jl.write(json.dumps(line) + "\n")
+        jl.flush()
+        rf = extra.get("hbm_roofline_frac")
+        print(f"{method:13s} {name:14s} F={dim:<5d} reorder={mark} flush {ms:9.4f} ms  steady {extra.get('steady_ms', float('nan')):9.4f} ms"
+              + (f"  roofline {100 * rf:5.1f} %" if rf is not None else ""), flush=True)
+
+    for name in args.datasets.split(","):
+        standin = synth_graphs.EVALUATION_SET.get(name, name)
+        indptr, indices, _ = synth_graphs.generate(standin, device=dev, scale=args.scale)
+        n, nnz = indptr.numel() - 1, indices.numel()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        handle = voltrix.csr_preprocess_device(indptr, indices, n)
+        torch.cuda.synchronize()
+        prep_ms = (time.perf_counter() - t0) * 1e3
+        handle[1].hash_tag = f"eval/{standin}/{args.scale}"
+        blocks = int(handle[0][-1])
+        nblk = (handle[0][1:] - handle[0][:-1])
+        stages = int(((nblk + 3) // 4).sum())
+        two = voltrix.two_level_of(handle[1])
+        variants = [("N", handle, None)]
+        if args.reorder:
+            t0 = time.perf_counter()
+            rh = voltrix.csr_preprocess_reordered(indptr.cpu(), indices.cpu(), n, method="auto", relabel=True)
+            torch.cuda.synchronize()
+            reorder_ms = (time.perf_counter() - t0) * 1e3
+            variants.append(("Y", rh, reorder_ms))
+        csr = None
+        if "hipSPARSE" in methods or args.check:
+            csr = torch.sparse_csr_tensor(indptr, indices, torch.ones(nnz, device=dev), size=(n, n))
+        for dim in dims:
+            torch.manual_seed(20)
+            feat32 = torch.randn(n, dim, device=dev)
+            base = None
+            if csr is not None:
+                run = lambda: csr @ feat32  # noqa: E731
+                base = run()
+                if "hipSPARSE" in methods:
+                    ms = GPU_bench(run, iters=args.iters, warmup=3, kernel_name="spmm")
+                    record("hipSPARSE", name, dim, "N", ms, dict(num_nodes=n, nnz=nnz, steady_ms=steady_ms(run, iters=3, batch=3)))
+            for method in [m for m in methods if m.startswith("Voltrix")]:
+                feat = feat32.half() if method == "Voltrix-fp16" else feat32
+                for mark, h, reorder_ms in variants:
+                    if mark == "Y":
+                        fin = voltrix.permute_features(h, feat)
+                        call = lambda: voltrix.spmm_reordered(h, fin, permuted_output=True)  # noqa: E731
+                    else:
+                        call = lambda: voltrix.spmm(*h, num_nodes=n, num_edges=nnz, feat=feat)  # noqa: E731
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    out = call()
+                    torch.cuda.synchronize()
+                    first_ms = (time.perf_counter() - t0) * 1e3
+                    ms = GPU_bench(call, iters=args.iters, warmup=10, kernel_name="spmm")
+                    st = steady_ms(call)
+                    s_in = feat.element_size()
+                    alg = synth_graphs.algorithmic_bytes(n, nnz, dim, s_in)
+                    extra = dict(num_nodes=n, nnz=nnz, steady_ms=st, first_call_ms=first_ms, preprocess_ms=prep_ms,
+                                 algorithmic_bytes=alg, hbm_roofline_frac=alg / (st * 1e-3) / HBM_PEAK,
+                                 hbm_roofline_frac_flushed=alg / (ms * 1e-3) / HBM_PEAK, gflops=2.0 * nnz * dim / st / 1e6,
+                                 tc_blocks=blocks, stages=stages, gathered_bytes=stages * 32 * dim * 2,
+                                 two_level=two is not None and mark == "N", launches=launches_per_call(call))
+                    if reorder_ms is not None:
+                        extra["reorder_ms"] = reorder_ms
+                    if args.check and base is not None and mark == "N":
+                        extra["calc_diff_vs_hipsparse"] = float(calc_diff(out, base))
+                    record(method, name, dim, mark, ms, extra)
+                    del out
+            del feat32, base
+        del handle, csr, indptr, indices, variants
+        torch.cuda.empty_cache()
+    jl.close()
+    print(f"results -> {os.path.abspath(args.output_file)}, {os.path.abspath(args.jsonl)}")
+
+
+if __name__ == "__main__":
+    main()

@@ -25,7 +25,9 @@ from typing import Optional
 
 import torch
 
-_LOCK = threading.Lock()
+# re-entrant: the storage finalizer (_drop) may run inside a garbage-collection pass that fires while this thread holds the
+# lock in lookup() / register()
+_LOCK = threading.RLock()
 _ENTRIES = {}          # key -> TwoLevelHandle, or None = "csr_preprocess decided for the window format"
 _SLIM = set()          # keys of stand-in handles (slim_handle): nothing but the side-car is left of them
 _WARNED = [False]
@@ -150,7 +152,10 @@ def load_handle(path: str, device: Optional[torch.device] = None):
     from . import hybrid
 
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    blob = torch.load(path, map_location="cpu", weights_only=False)
+    # the blob is tensors in plain containers (save_handle): the restricted unpickler is enough, a handle file from another host
+    # cannot run code here
+    blob = torch.load(path, map_location="cpu", weights_only=True)
+    assert isinstance(blob, dict), f"{path}: not a voltrix handle file"
     assert blob.get("format") == "voltrix-handle-1", f"{path}: not a voltrix handle file"
     blk_offsets, packed, hind = (t.to(device) for t in blob["handle"])
     hspa_packed = packed.view(torch.uint32)
