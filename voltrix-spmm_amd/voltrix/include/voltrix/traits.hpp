@@ -12,8 +12,8 @@
 // VOLTRIX_DIAG (spmm_kernels.hpp), VOLTRIX_PANEL_DIAG (spmm_panel_kernels.hpp), VOLTRIX_FUSED_DIAG (spmm_fused_kernels.hpp):
 // they drop parts of a kernel (results wrong by design) or add time stamps.  A product build defines none of them; a mask
 // without the gate is a build error, so no diagnostic path can slip into libvoltrix_hip.so or a JIT kernel.
-#if !defined(VOLTRIX_EXPERIMENTAL) && (defined(VOLTRIX_DIAG) || defined(VOLTRIX_PANEL_DIAG) || defined(VOLTRIX_FUSED_DIAG))
-#error "VOLTRIX_DIAG / VOLTRIX_PANEL_DIAG / VOLTRIX_FUSED_DIAG need -DVOLTRIX_EXPERIMENTAL (diagnostic builds only)"
+#if !defined(VOLTRIX_EXPERIMENTAL) && (defined(VOLTRIX_DIAG) || defined(VOLTRIX_PANEL_DIAG) || defined(VOLTRIX_FUSED_DIAG) || defined(VOLTRIX_STREAM_DIAG))
+#error "VOLTRIX_DIAG / VOLTRIX_PANEL_DIAG / VOLTRIX_FUSED_DIAG / VOLTRIX_STREAM_DIAG need -DVOLTRIX_EXPERIMENTAL (diagnostic builds only)"
 #endif
 
 #define VOLTRIX_BLK_H 16  // rows per row window          (reference traits.h:6)

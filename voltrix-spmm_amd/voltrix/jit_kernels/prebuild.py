@@ -18,7 +18,7 @@ def _spmm_arg_defs(dtype):
     return spmm.arg_defs_for(dtype)
 
 
-def jobs(feature_widths=(32, 64, 128), modes=("default", "none")):
+def jobs(feature_widths=(32, 64, 128), modes=("default", "none", "stream")):
     """(name, arg_defs, code) of every kernel the operator API can ask for with the current VOLTRIX_TUNE_SPACE."""
     out = []
     for mod in (preprocess, hmat_gem, bmat_swizzle):

@@ -35,8 +35,16 @@ def tune_space(mode: str):
         _TUNE_SPACE_OVERRIDE.reset(token)
 
 
-includes = ('"voltrix/spmm_kernels.hpp"',)
+includes = ('"voltrix/spmm_kernels.hpp"', '"voltrix/spmm_stream_kernels.hpp"')
 template = """
+if ({SCHED} == 6) {
+  __return_code = voltrix::launch_spmm_stream<voltrix::SpmmTile<{FS}, {DEPTH}, {WAVES}, {EB}, {BF16} != 0, {WEIGHTED} != 0>>(
+      hspa_packed, hind, num_nodes, embedding_dim, input, output, stream, s_units, s_runs, s_run_ptr, s_max_runs, partials_s,
+      out_scale, 0, 0, input_rows, slab_policy);
+  if (__return_code == 0 && combine_now != 0)
+    __return_code = voltrix::combine_partials(cuts_s, num_cuts_s, partials_s, output, num_nodes, embedding_dim, 0, stream, nullptr);
+  return;
+}
 __return_code = voltrix::launch_spmm_tc16<voltrix::SpmmTile<{FS}, {DEPTH}, {WAVES}, {EB}, {BF16} != 0, {WEIGHTED} != 0>>(
     blk_offsets, hspa_packed, hind,
     num_nodes, embedding_dim, input, output, stream,
@@ -68,6 +76,11 @@ SCHED_UNITS = 4
 # 1.365 -> 1.293 ms (profiles/r02/experiment_pair_units.log).  16-bit binary operand, four-wave tiles; with several column
 # slabs the launch is slab-major (slabs of 128 bytes and more) and a pair never straddles two slabs.
 SCHED_PAIRS = 5
+# SCHED 6: the window format as a STREAM of stages (spmm_stream_kernels.hpp, round 5): a wave walks a run of consecutive
+# windows through one ring that never drains at a window boundary, stores every finished window from the loop with 16-byte
+# stores, and needs neither a prologue per window nor a 4-byte-per-lane epilogue -- the kernel for the short windows of the
+# reference's low-degree evaluation graphs.  16-bit binary operand, plain stores to C (no row map, no atomics).
+SCHED_STREAM = 6
 PAIR_UNIT_FACTOR = 1.25   # x the median window length (measured: 1.0 .. 1.5 within 1 %, profiles/r02/experiment_pair_units.log)
 
 # How an operand wider than the tile's slab is launched (spmm_kernels.hpp::slab_launch_group): -1 = the library's rule (one
@@ -112,11 +125,17 @@ def _lds_bytes(fs, depth, waves, eb, weighted=False):
 TWO_LEVEL_LDS_BUDGET = 160 * 1024 - 47 * 1024   # panel workgroup: 24 KiB ring + 20 KiB metadata + slack
 
 
-def tile_space(embedding_dim: int, elem_bytes: int, bf16: bool = False, max_lds: int = None, weighted: bool = False):
+def tile_space(embedding_dim: int, elem_bytes: int, bf16: bool = False, max_lds: int = None, weighted: bool = False,
+               stream_ok: bool = True):
     """Points of the tile space worth trying for this feature width (``bf16``: the 2-byte operand is bfloat16;
     ``max_lds``: keep only tiles whose workgroup fits that many bytes of LDS; ``weighted``: the A operand is a value
     plane, 1 KiB more per metadata slot)."""
     points = tuple(dict(point, BF16=int(bf16), WEIGHTED=int(weighted)) for point in _tile_space(embedding_dim, elem_bytes))
+    if weighted or max_lds is not None or not stream_ok:   # the stream kernel: binary operand, plain stores, alone on the CU
+        points = tuple(p for p in points if p["SCHED"] != SCHED_STREAM)
+        if not points:   # VOLTRIX_TUNE_SPACE=stream on a launch the stream kernel does not serve: the default tile
+            with tune_space("none"):
+                points = tuple(dict(point, BF16=int(bf16), WEIGHTED=int(weighted)) for point in _tile_space(embedding_dim, elem_bytes))
     if weighted:
         assert elem_bytes == 2
         points = tuple(p for p in points if p["SCHED"] != SCHED_PAIRS)   # paired units: binary operand only
@@ -147,6 +166,8 @@ def _tile_space(embedding_dim: int, elem_bytes: int):
         if elem_bytes == 4:
             return ({"FS": min(fs, 64), "DEPTH": 3, "WAVES": 1, "EB": 4, "SCHED": 2},)
         return ({"FS": fs, "DEPTH": 4 if fs == 32 else 3, "WAVES": 4, "EB": 2, "SCHED": SCHED_UNITS},)
+    if mode == "stream" and elem_bytes == 2:   # the stream kernel's default point alone (tests, experiments)
+        return ({"FS": fs_fit, "DEPTH": 3 if fs_fit >= 128 else 4, "WAVES": 1, "EB": 2, "SCHED": SCHED_STREAM},)
     if mode == "full":
         fs_list = sorted({fs_fit, max(32, fs_fit // 2), min(256, fs_fit * 2) if embedding_dim > 128 else fs_fit})
         depths, waves = (2, 3, 4), (1, 2, 4)
@@ -165,6 +186,11 @@ def _tile_space(embedding_dim: int, elem_bytes: int):
                         scheds += (SCHED_PAIRS,)   # two units per wave (several slabs: slab-major order, i.e. slabs >= 128 bytes)
                     for sched in scheds:
                         space.append({"FS": fs, "DEPTH": d, "WAVES": w, "EB": elem_bytes, "SCHED": sched})
+    if elem_bytes == 2:   # stream points: the full-width slab, one or two waves per workgroup (LDS decides the waves per CU)
+        for w in (1, 2):
+            for d in (2, 3, 4):
+                if (1 + 32 * fs_fit * 2 // 1024) * (d - 1) + d * (fs_fit // 16) <= 63:   # loads + stores behind a wait
+                    space.append({"FS": fs_fit, "DEPTH": d, "WAVES": w, "EB": 2, "SCHED": SCHED_STREAM})
     return tuple(space)
 
 
@@ -201,10 +227,10 @@ def sweep_stages(space, best=None, stage_no=0):
     order, balance chunks 512 / 2048, two units per wave; chunk 128 never won a sweep and is left to
     ``VOLTRIX_TUNE_SPACE=full``).  Stage 2: the winner at the other ring depths."""
     def shape(p):
-        return (p["FS"], p["WAVES"], p["EB"])
+        return (p["FS"], p["WAVES"], p["EB"], p["SCHED"] == SCHED_STREAM)
 
     def robust(points):
-        for pref in (SCHED_UNITS, 2, 0):
+        for pref in (SCHED_STREAM, SCHED_UNITS, 2, 0):
             for p in points:
                 if p["SCHED"] == pref:
                     return p
@@ -304,6 +330,13 @@ def arg_defs_for(dtype):
         ("values", dtype),
         ("input_rows", int),
         ("slab_policy", int),
+        ("s_units", torch.int32),
+        ("s_runs", torch.int32),
+        ("s_run_ptr", torch.int32),
+        ("s_max_runs", int),
+        ("cuts_s", torch.int32),
+        ("num_cuts_s", int),
+        ("partials_s", torch.float32),
         ("stream", torch.cuda.Stream),
     )
 
@@ -329,6 +362,22 @@ def handle_unit_table(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, num_
         table = unit_table(blk_offsets, num_nodes, xcd_ptr=ranges)
     try:
         setattr(hspa_packed, attr, (key, table))
+    except AttributeError:
+        pass
+    return table
+
+
+def handle_stream_table(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tensor, num_nodes: int):
+    """The handle's stream table (voltrix.schedule.stream_tables), built once and cached on the ``hspa_packed`` tensor object."""
+    cache = getattr(hspa_packed, "_voltrix_stream_table", None)
+    key = (blk_offsets.data_ptr(), num_nodes)
+    if isinstance(cache, tuple) and cache[0] == key:
+        return cache[1]
+    from ..schedule import stream_tables
+
+    table = stream_tables(blk_offsets, hspa_packed, hind, num_nodes)
+    try:
+        hspa_packed._voltrix_stream_table = (key, table)
     except AttributeError:
         pass
     return table
@@ -445,7 +494,8 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
         assert values.is_cuda and values.dtype == input.dtype and elem_bytes == 2 and values.is_contiguous()
         assert values.numel() * 4 == hspa_packed.numel() * 128, "value plane: 128 values per TC block"
     space = tile_space(embedding_dim, elem_bytes, input.dtype == torch.bfloat16,
-                       TWO_LEVEL_LDS_BUDGET if beside_panel else None, weighted=values is not None)
+                       TWO_LEVEL_LDS_BUDGET if beside_panel else None, weighted=values is not None,
+                       stream_ok=not atomic_out and row_map is None)
     keys = {
         "feature_hash": feature_hash(hspa_packed),
         "embedding_dim": embedding_dim,
@@ -454,6 +504,8 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
         "two_level": bool(beside_panel),
         "weighted": values is not None,
     }
+    if row_map is not None:
+        keys["row_map"] = True   # a different space (no stream points): a different choice
     # unit tables / partial-tile buffers: before the choice is made, those of every schedule in the space (the sweep runs
     # them all); afterwards only the chosen schedule's
     chosen = jit_tuner.tuned_point("spmm_kernel", keys).get("SCHED") if jit_tuner.is_tuned("spmm_kernel", keys) else None
@@ -475,6 +527,11 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
         partials_p = torch.empty(max(1, table_p.num_slots) * 16 * embedding_dim, dtype=torch.float32, device=input.device)
     else:
         table_p, partials_p = None, out_scale
+    if want(SCHED_STREAM):
+        table_s = handle_stream_table(blk_offsets, hspa_packed, hind, num_nodes)
+        partials_s = torch.empty(max(1, table_s.num_slots) * 16 * embedding_dim, dtype=torch.float32, device=input.device)
+    else:
+        table_s, partials_s = None, out_scale
     needs_orders = chosen is None or chosen in ORDER_CHUNKS
 
     def order(sched):
@@ -488,7 +545,11 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
                 table_p.max_units_per_xcd if table_p is not None else 0, table_p.cuts if table_p is not None else blk_offsets,
                 table_p.num_cuts if table_p is not None else 0, partials_p, int(combine_now),
                 row_map if row_map is not None else blk_offsets, int(row_map is not None),
-                values if values is not None else input, int(input.shape[0]), int(SLAB_POLICY), torch.cuda.current_stream())
+                values if values is not None else input, int(input.shape[0]), int(SLAB_POLICY),
+                table_s.units if table_s is not None else blk_offsets, table_s.runs if table_s is not None else blk_offsets,
+                table_s.run_ptr if table_s is not None else blk_offsets, table_s.max_runs_per_xcd if table_s is not None else 0,
+                table_s.cuts if table_s is not None else blk_offsets, table_s.num_cuts if table_s is not None else 0,
+                partials_s, torch.cuda.current_stream())
 
     args = make_args(output, not defer_combine)
     # tuning runs: every candidate is timed with its COMPLETE work (the unit-table schedules with their combine pass, also
@@ -500,7 +561,7 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
     def sample_args():
         """(argument tuples of the sample launches, fraction of the handle they cover): called by the tuner only when a
         sweep really runs.  Every range gets its own schedule arrays (window orders, unit tables, partial tiles)."""
-        from ..schedule import default_max_stages, unit_table
+        from ..schedule import default_max_stages, stream_tables, unit_table
 
         num_windows = (num_nodes + 15) // 16
         ranges = sample_ranges(num_windows)
@@ -525,6 +586,10 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
                 t = unit_table(sub, n_sub, max(8, int(PAIR_UNIT_FACTOR * default_max_stages(sub, n_sub) / 1.5)))
                 a[19], a[20], a[21], a[22], a[23] = t.units, t.unit_ptr, t.max_units_per_xcd, t.cuts, t.num_cuts
                 a[24] = torch.empty(max(1, t.num_slots) * 16 * embedding_dim, dtype=torch.float32, device=input.device)
+            if want(SCHED_STREAM):
+                t = stream_tables(sub, hspa_packed, hind, n_sub, run_cost=table_s.run_cost, cut_stages=table_s.cut_stages)
+                a[31], a[32], a[33], a[34], a[35], a[36] = t.units, t.runs, t.run_ptr, t.max_runs_per_xcd, t.cuts, t.num_cuts
+                a[37] = torch.empty(max(1, t.num_slots) * 16 * embedding_dim, dtype=torch.float32, device=input.device)
             a[25] = 1                                       # combine now: the candidate's complete work
             if row_map is not None:
                 a[26] = row_map[16 * w0:16 * w1]
@@ -568,4 +633,6 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
             return PendingCombine(table, partials, output, num_nodes, embedding_dim, bool(atomic_out), row_map)
         if sched == SCHED_PAIRS and table_p is not None and table_p.num_cuts > 0:
             return PendingCombine(table_p, partials_p, output, num_nodes, embedding_dim, bool(atomic_out), row_map)
+        if sched == SCHED_STREAM and table_s is not None and table_s.num_cuts > 0:
+            return PendingCombine(table_s, partials_s, output, num_nodes, embedding_dim, False, None)
     return None

@@ -162,3 +162,105 @@ def unit_table_torch(blk_offsets: torch.Tensor, num_nodes: int, max_stages: int 
     cuts = torch.stack([cw, slot_first[cw], k[cw], torch.zeros_like(cw)], dim=1).to(torch.int32).contiguous()
     return UnitTable(units, unit_ptr.to(torch.int32), cuts, int(counts.max()), int(w.numel()), int(cw.numel()),
                      int(k_cut.sum()), max_stages)
+
+
+# ---- stream tables: the schedule of spmm_stream_kernel (short windows; voltrix/spmm_stream_kernels.hpp) ---------------------
+@dataclass
+class StreamTable:
+    """Runs of consecutive units for the stream kernel: a wave walks the stages of a run as one stream."""
+    units: torch.Tensor       # int32 [U, 8]: first TC block, end TC block of the window, TC blocks between two stages (4 x stride),
+                              #   window, partial-tile slot or -1, stages, columns of the window's last TC block that carry an
+                              #   edge (1 .. 8; 0 = a window without edges), 0 -- in window order
+    runs: torch.Tensor        # int32 [R, 4]: first unit, units (<= 64), stages, 0
+    run_ptr: torch.Tensor     # int32 [9]: the runs of every XCD (contiguous windows, equal work)
+    cuts: torch.Tensor        # int32 [C, 4]: window, first slot, units, 0 (combine_partials)
+    max_runs_per_xcd: int
+    num_runs: int
+    num_units: int
+    num_cuts: int
+    num_slots: int
+    run_cost: int
+    cut_stages: int
+
+
+STREAM_WAVE_SLOTS = 256 * 6      # waves the chip holds at the default ring depth (6 per CU)
+STREAM_RUNS_PER_SLOT = 6         # runs every wave slot gets on average: the tail of the launch is a fraction of one run
+
+
+def last_block_columns(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    """int64 [W]: how many of the 8 condensed columns of every window's LAST TC block carry an edge.  Every other block of a
+    window is full, padded ``hind`` slots are 0 and real columns ascend, so the count is 1 + the non-zero slots after the first;
+    a window without edges (one all-zero block, the reference's quirk) counts 0."""
+    num_windows = (num_nodes + 15) // 16
+    off = blk_offsets[:num_windows + 1].to(torch.int64)
+    last = off[1:] - 1
+    h = hind.view(-1, 8)[last]
+    ncl = 1 + (h[:, 1:] > 0).sum(1)
+    bits = hspa_packed.view(torch.int32).view(-1, 4)[last]
+    empty = (bits == 0).all(1)
+    return torch.where(empty, torch.zeros_like(ncl), ncl)
+
+
+def stream_tables(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tensor, num_nodes: int, run_cost: int = None,
+                  cut_stages: int = None) -> StreamTable:
+    """The handle's stream table.  A unit = a whole window, or -- windows longer than ``cut_stages`` stages -- one of its
+    ``k = ceil(stages / cut_stages)`` interleaved pieces (unit j runs the stages j, j + k, ...; partial tiles summed in unit
+    order by ``combine_partials``, exactly as in :func:`unit_table_torch`).  Units stay in WINDOW order (consecutive windows'
+    metadata and rows of C are consecutive in memory; band graphs gather overlapping rows of B).  A unit costs its stages + 1
+    (the store of its 16 rows); the eight XCD ranges hold equal cost; inside a range, a run = the units whose cost prefix falls
+    into the same bucket of ``run_cost``, so a run costs < run_cost + the cost of one unit and has <= 64 units.
+    Defaults: ``run_cost`` such that every wave slot of the chip gets about six runs (6 .. 48), ``cut_stages`` = the larger of
+    ``run_cost`` and 1.5 x the median window (graphs of long windows: one window per run, only the tail is cut).
+    Torch tensor ops on the handle's device: once per handle; depends on ``blk_offsets`` only (deterministic)."""
+    dev = blk_offsets.device
+    num_windows = (num_nodes + 15) // 16
+    z4 = torch.zeros((0, 4), dtype=torch.int32, device=dev)
+    if num_windows == 0:
+        return StreamTable(torch.zeros((0, 8), dtype=torch.int32, device=dev), z4, torch.zeros(9, dtype=torch.int32, device=dev),
+                           z4, 0, 0, 0, 0, 0, run_cost or 6, cut_stages or 8)
+    off = blk_offsets[:num_windows + 1].to(torch.int64)
+    nblk = off[1:] - off[:-1]
+    nst = (nblk + 3) // 4
+    if run_cost is None:
+        total = int(nst.sum()) + num_windows
+        run_cost = int(min(48, max(6, total // (STREAM_WAVE_SLOTS * STREAM_RUNS_PER_SLOT))))
+    assert 2 <= run_cost <= 128, "a run holds at most 64 units"
+    if cut_stages is None:
+        cut_stages = max(run_cost, default_max_stages(blk_offsets, num_nodes))
+    assert cut_stages >= 1
+    k = torch.clamp((nst + cut_stages - 1) // cut_stages, min=1)
+    w = torch.repeat_interleave(torch.arange(num_windows, dtype=torch.int64, device=dev), k)
+    first_unit_of_window = torch.cumsum(k, 0) - k
+    j = torch.arange(w.numel(), dtype=torch.int64, device=dev) - first_unit_of_window[w]
+    kk = k[w]
+    length = (nst[w] - j + kk - 1) // kk
+    cut = k > 1
+    k_cut = torch.where(cut, k, torch.zeros_like(k))
+    slot_first = torch.cumsum(k_cut, 0) - k_cut
+    slot = torch.where(cut[w], slot_first[w] + j, torch.full_like(w, -1))
+    zero = torch.zeros_like(w)
+    ncl = last_block_columns(blk_offsets, hspa_packed, hind, num_nodes)
+    units = torch.stack([off[w] + 4 * j, off[w + 1], 4 * kk, w, slot, length, ncl[w], zero], dim=1).to(torch.int32).contiguous()
+    cost = length + 1
+    ub = split_equal_work(cost).to(torch.int64)                   # unit boundaries of the XCD ranges
+    c_before = torch.cumsum(cost, 0) - cost
+    idx = torch.arange(w.numel(), dtype=torch.int64, device=dev)
+    xcd = torch.searchsorted(ub[1:NUM_XCD].contiguous(), idx, right=True)
+    base = c_before[ub[:NUM_XCD].clamp(max=w.numel() - 1)][xcd]
+    key = xcd * (int(c_before[-1]) // run_cost + 2) + (c_before - base) // run_cost
+    new_run = torch.ones_like(key, dtype=torch.bool)
+    new_run[1:] = key[1:] != key[:-1]
+    run_id = torch.cumsum(new_run.to(torch.int64), 0) - 1
+    num_runs = int(run_id[-1]) + 1
+    first = torch.nonzero(new_run).flatten()
+    count = torch.bincount(run_id, minlength=num_runs)
+    stages = torch.zeros(num_runs, dtype=torch.int64, device=dev).index_add_(0, run_id, length)
+    assert int(count.max()) <= 64
+    runs = torch.stack([first, count, stages, torch.zeros_like(first)], dim=1).to(torch.int32).contiguous()
+    run_ptr = torch.zeros(NUM_XCD + 1, dtype=torch.int64, device=dev)
+    run_ptr[1:] = torch.cumsum(torch.bincount(xcd[first], minlength=NUM_XCD), 0)
+    cw = torch.nonzero(cut).flatten()
+    cuts = torch.stack([cw, slot_first[cw], k[cw], torch.zeros_like(cw)], dim=1).to(torch.int32).contiguous()
+    per_xcd = run_ptr[1:] - run_ptr[:-1]
+    return StreamTable(units, runs, run_ptr.to(torch.int32), cuts, int(per_xcd.max()), num_runs, int(w.numel()),
+                       int(cw.numel()), int(k_cut.sum()), run_cost, cut_stages)
