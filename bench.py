@@ -60,9 +60,12 @@ def parse_args():
     ap.add_argument("--no-reference-formats", action="store_true",
                     help="skip the untimed comparison runs (window format alone, cold-cache timing)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for debugging)")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="N > 1: run all-gather and SpMM back to back on one stream (default: the all-gather of step k+1 "
-                         "runs on a second stream beside the SpMM of step k, double-buffered B)")
+    ap.add_argument("--overlap-steps", action="store_true",
+                    help="N > 1: TIME the cross-step overlapped form (the all-gather of step k+1 on a second stream beside the "
+                         "SpMM of step k, double-buffered B) -- legitimate only for INDEPENDENT products.  Default: the dependent "
+                         "step (all-gather, then the product that consumes it, then the next all-gather: layer l+1's B is layer "
+                         "l's C) is ms_per_step and the overlapped figure is reported beside it as config.step_independent_ms")
+    ap.add_argument("--no-overlap", action="store_true", help="accepted for compatibility: the dependent step is the default")
     ap.add_argument("--one-device", action="store_true",
                     help="debug: every rank uses cuda:0 (exercises the sharded path on a 1-GPU box, with --backend gloo)")
     ap.add_argument("--gather", default="auto", choices=["auto", "collective", "p2p", "rows"],
@@ -164,8 +167,9 @@ def gather_model(gather_bytes, l2_hit_frac, operand_bytes, kernel_ms):
 def choose_referenced_rows(op, vdist, local_indptr, local_indices, num_nodes, parts, feat_local, args, device):
     """--gather auto, second half: is the referenced-rows operator (only the rows of B a shard references travel) worth
     building?  Only when the shards reference < 70 % of the remote rows (MAX over ranks).  Then it is built beside the
-    all-gather operator and ONE whole step of each (exchange + product, after one warm-up step) is timed, MAX over ranks; the
-    ranks agree on every decision through all-reduces, and a rank that fails to build the candidate makes all ranks drop it."""
+    all-gather operator and the median of THREE whole steps of each (exchange + product, after two warm-up steps) decides, each
+    step MAX over ranks; the ranks agree on every decision through all-reduces.  A rank that fails to build the candidate aborts
+    the run (its peers would otherwise wait inside the builder's all-to-all)."""
     world, rank = op.world_size, op.rank
     r0, r1 = parts[rank]
     remote = local_indices[(local_indices < r0) | (local_indices >= r1)]
@@ -176,17 +180,10 @@ def choose_referenced_rows(op, vdist, local_indptr, local_indices, num_nodes, pa
     info = {"referenced_fraction_of_remote_rows": float(frac)}
     if float(frac) >= args.rows_below or args.slabs > 1:
         return info
-    ok = torch.ones(1, device=device)
-    op_rows = None
-    try:
-        op_rows = vdist.RowShardedSpMM.from_shard(local_indptr, local_indices, num_nodes, parts, mode="rows",
-                                                  exchange_at_world_1=args.force_dist)
-    except RuntimeError as exc:   # e.g. out of memory while building the request lists: every rank must drop the candidate
-        info["rows_error"] = str(exc)[:200]
-        ok.zero_()
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if float(ok) == 0.0:
-        return info
+    # from_shard(mode="rows") exchanges its request lists with two all-to-alls: a rank that failed in the middle would leave
+    # the others inside a collective it never posts.  No try / except around it -- a failure aborts the run on every rank.
+    op_rows = vdist.RowShardedSpMM.from_shard(local_indptr, local_indices, num_nodes, parts, mode="rows",
+                                              exchange_at_world_1=args.force_dist)
     num_feats = feat_local.shape[1]
 
     def whole_step(o, buf):
@@ -197,14 +194,17 @@ def choose_referenced_rows(op, vdist, local_indptr, local_indices, num_nodes, pa
         buf = o._buffer("whole", num_feats, feat_local)
         for _ in range(2):                      # first call: tile choice / unit table of this operator's handle
             whole_step(o, buf)
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        whole_step(o, buf)
-        torch.cuda.synchronize()
-        t = torch.tensor([(time.perf_counter() - t0) * 1e3], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        timings[name] = float(t)
+        samples = []
+        for _ in range(3):                      # median of three whole steps, each MAX over ranks
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            whole_step(o, buf)
+            torch.cuda.synchronize()
+            t = torch.tensor([(time.perf_counter() - t0) * 1e3], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            samples.append(float(t))
+        timings[name] = sorted(samples)[1]
     info["whole_step_ms"] = timings
     if timings["rows"] < timings["allgather"]:
         info["picked"] = "rows"
@@ -212,20 +212,48 @@ def choose_referenced_rows(op, vdist, local_indptr, local_indices, num_nodes, pa
     return info
 
 
-def measured_counters(key):
+def measured_counters(key, sources_hash):
     """PMC-derived figures of the step (profiles/traffic.json, written from rocprofv3 passes of THIS command): fabric-side
     bytes per step and the matrix-core busy fraction -- only for the exact configuration `key` names (workload, width,
-    dtype, format, tile, schedule), else None: the counters need their own profiling passes and cannot be read live."""
+    dtype, format, tile, schedule) AND only while the entry was measured on the kernel sources of this tree (its
+    ``sources_hash`` = voltrix.jit.compiler.get_kernel_sources_version(), written by harness/pmc_summarize.py): the counters
+    need their own profiling passes and cannot be read live, so an entry that predates a kernel edit is refused, not replayed.
+    -> (entry or None, why not)."""
     try:
         with open(os.path.join(REPO, "profiles", "traffic.json")) as f:
             entry = json.load(f).get("runs", {}).get(key)
-        return entry
     except (OSError, ValueError, KeyError):
-        return None
+        entry = None
+    if entry is None:
+        return None, f"none for this exact configuration ({key}): PMC passes are separate runs (profiles/)"
+    if entry.get("sources_hash") != sources_hash:
+        return None, (f"stale: the entry for {key} ({entry.get('source')}) was measured on kernel sources "
+                      f"{entry.get('sources_hash')}, this tree is {sources_hash} -- re-run harness/pmc_bench.sh")
+    return entry, None
+
+
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` (N > 1) outside torch.distributed.run: start the N ranks as FRESH child processes -- one
+    ``python -m torch.distributed.run`` with this command line -- before this process has touched the GPU, relay their output
+    (rank 0 prints the JSON line) and exit with their code.  Nothing is re-executed in place: a process that initialised the GPU
+    must never exec."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env, stdin=subprocess.DEVNULL)
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -258,7 +286,7 @@ def main():
     import voltrix
     from voltrix import dist as vdist
     from voltrix.jit_kernels import jit_tuner
-    from voltrix.jit_kernels.spmm import ORDER_CHUNKS, SCHED_PAIRS, SCHED_UNITS, slab_launches
+    from voltrix.jit_kernels.spmm import ORDER_CHUNKS, SCHED_PAIRS, SCHED_STREAM, SCHED_UNITS, slab_launches
 
     workload = args.workload or ("reddit_like" if world == 1 else "papers_like")
     config_index = {"cora_like": 0, "reddit_like": 1, "reddit_uniform": 1, "reddit_shuffled": 1, "reddit_sbm": 1,
@@ -356,17 +384,22 @@ def main():
     tuner_stats = dict(jit_tuner.stats)
 
     slab_pipeline = distributed and args.slabs > 1
-    overlap = distributed and not args.no_overlap and not slab_pipeline
+    can_overlap = distributed and not slab_pipeline
+    overlap_timed = can_overlap and args.overlap_steps       # default: the DEPENDENT step is the one that is timed
     if distributed:
         # two copies of the gather buffer: while the SpMM of step k reads one, the all-gather of step k+1 fills the other
-        bufs = [gathered, gathered.clone()] if overlap else [gathered]
-        comm_stream = torch.cuda.Stream(device=device) if overlap else main_stream
+        # (the independent-products form; the dependent step uses one buffer and one stream)
+        bufs = [gathered, gathered.clone()] if can_overlap else [gathered]
+        comm_stream = torch.cuda.Stream(device=device) if can_overlap else main_stream
         ev_gathered = [None] * len(bufs)   # all-gather into buffer b finished
         ev_consumed = [None] * len(bufs)   # SpMM that read buffer b finished
     step_no = [0]
 
-    def step(record=None):
-        """One pass of the hot path: all-gather(B) (N > 1), then the SpMM that consumes exactly that gathered B."""
+    def step(record=None, overlap=None):
+        """One pass of the hot path: all-gather(B) (N > 1), then the SpMM that consumes exactly that gathered B.
+        ``overlap`` False (the timed default): everything on the caller's stream, step k + 1 starts when step k's product is done
+        -- a chain of layers.  True: the all-gather of step k + 1 beside the product of step k (independent products)."""
+        overlap = overlap_timed if overlap is None else overlap
         if not distributed:
             if record is not None:
                 record[0].record()
@@ -380,6 +413,15 @@ def main():
             out_holder[0] = op(feat_local)
             if record is not None:
                 record[1].record()
+            return
+        if not overlap:
+            op.gather_into(bufs[0], feat_local)
+            if record is not None:
+                record[0].record()
+            spmm(bufs[0])
+            if record is not None:
+                record[1].record()
+            step_no[0] = 1
             return
         b = step_no[0] % len(bufs)
         step_no[0] += 1
@@ -428,7 +470,7 @@ def main():
     elif slab_pipeline:
         b_used = op.gather_into(bufs[0], feat_local)
     else:
-        b_used = bufs[(step_no[0] - 1) % len(bufs)]
+        b_used = bufs[(step_no[0] - 1) % len(bufs)] if overlap_timed else bufs[0]
     col_sums = b_used.float().sum(dim=1)
     col_abs = b_used.float().abs().sum(dim=1)
     want = torch.zeros(local_rows, dtype=torch.float32, device=device)
@@ -501,6 +543,9 @@ def main():
         if s == SCHED_PAIRS:
             return ("unit table (windows cut at 1.25 x the median length, longest first), two units per wave "
                     "(spmm_tc16_pair_kernel) + combine pass")
+        if s == SCHED_STREAM:
+            return ("stream of stages (spmm_stream_kernel): a wave walks a run of consecutive windows through one ring, 16-byte "
+                    "stores from the loop; windows above the cut length in interleaved units + combine pass")
         return "natural window order" if s == 0 else f"balance schedule, chunk {ORDER_CHUNKS.get(s)}"
 
     # ---- untimed comparison runs (N = 1): the window format alone, and a cold-cache timing --------------------------------
@@ -513,7 +558,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        with torch.cuda.stream(comm_stream if overlap else main_stream):
+        with torch.cuda.stream(main_stream):
             for _ in range(3):
                 op.gather_into(bufs[0], feat_local)
         torch.cuda.synchronize()
@@ -525,6 +570,28 @@ def main():
             extras["exchange_choice"] = exchange_choice   # what the warm-up measured (MAX over ranks) and what it kept
         extras["allgather_bytes_received_per_rank"] = op.exchange_bytes_received(num_feats, gathered.element_size())
         extras["local_spmm_ms"] = kernel_ms
+        if can_overlap:
+            # the other form of the step, K steps between barriers like the timed region (MAX over ranks): with the dependent
+            # step timed (default) this is what INDEPENDENT products would get from overlapping the exchange of step k + 1
+            # with the product of step k; with --overlap-steps it is the dependent chain
+            other = not overlap_timed
+            torch.cuda.synchronize()    # the two forms use the buffers from different streams: a clean hand-over
+            for _ in range(2):
+                step(overlap=other)
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step(overlap=other)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t = torch.tensor([(time.perf_counter() - t0) / args.steps * 1e3], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            torch.cuda.synchronize()
+            extras["step_independent_ms" if other else "step_dependent_ms"] = float(t)
+            extras["timed_step"] = ("dependent: all-gather(B), then the product that consumes it, on one stream; the next step "
+                                    "starts when this one's product is done" if not overlap_timed else
+                                    "independent products: the all-gather of step k + 1 beside the product of step k")
         # what the step should take on a fully connected xGMI node, to read the measured one against
         extras["predicted_ms"] = {k: round(v, 3) for k, v in vdist.predicted_step_ms(
             world, rows_padded * num_feats * gathered.element_size(), kernel_ms).items()}
@@ -611,15 +678,20 @@ def main():
         else:
             gather_bytes = 8 * total_blocks * num_feats * in_bytes  # rows gathered from L2 / Infinity Cache / HBM
             fmt = {"format": "window (the reference's block format)"}
-            kernels = ("spmm_tc16_pair_kernel" if point.get("SCHED") == SCHED_PAIRS else "spmm_tc16_kernel") + (
-                " ; combine_partials_kernel" if point.get("SCHED") in (SCHED_UNITS, SCHED_PAIRS) else "")
+            kernels = ("spmm_tc16_pair_kernel" if point.get("SCHED") == SCHED_PAIRS else
+                       ("spmm_stream_kernel" if point.get("SCHED") == SCHED_STREAM else "spmm_tc16_kernel")) + (
+                " ; combine_partials_kernel" if point.get("SCHED") in (SCHED_UNITS, SCHED_PAIRS, SCHED_STREAM) else "")
         tile_desc = {"fs": point.get("FS"), "depth": point.get("DEPTH"), "waves": point.get("WAVES"),
                      "schedule": sched_name(point),
                      # wide operands: one launch per 256-byte group of column slabs (spmm_kernels.hpp::slab_launch_group)
                      "launches_per_step": slab_launches(num_feats, point.get("FS") or 128, in_bytes, num_nodes)}
         counter_key = (f"{workload}|F{num_feats}|{args.dtype}|{'two-level' if used_two else 'window'}|"
                        f"{point.get('FS')},{point.get('DEPTH')},{point.get('WAVES')}|sched{point.get('SCHED')}")
-        counters = measured_counters(counter_key) if (world == 1 and args.scale == 1.0) else None
+        from voltrix.jit.compiler import get_kernel_sources_version
+
+        sources_hash = get_kernel_sources_version()
+        counters, why_not = (measured_counters(counter_key, sources_hash) if (world == 1 and args.scale == 1.0)
+                             else (None, "counters are kept for the full-size single-GPU configurations only"))
         line = {
             "metric": "spmm_gflops",
             "value": flop / (ms_per_step * 1e-3) / 1e9,
@@ -643,7 +715,7 @@ def main():
                 "sparse_format": fmt,
                 "parallelism": f"row-window shards x{world}" + (
                     " (every rank generates its own shard) + RCCL all-gather(B) per step"
-                    + (" (overlapped with the previous step's SpMM)" if overlap else "")
+                    + (" (overlapped with the previous step's SpMM)" if overlap_timed else " (dependent: gather, then product)")
                     + (f"; exchange: {gather_mode}" + (" (chosen by the warm-up's measurement)" if args.gather == "auto" else "")
                        + (f", {args.slabs} feature slabs pipelined" if slab_pipeline else ""))
                     if distributed else ""),
@@ -659,8 +731,8 @@ def main():
                 "traffic": counters["traffic_bytes"] if counters else None,
                 "mfma_busy_frac": counters.get("mfma_busy_frac") if counters else None,
                 "l2_hit_frac": counters.get("l2_hit_frac") if counters else None,
-                "counters_from": counters.get("source") if counters else
-                f"none for this exact configuration ({counter_key}): PMC passes are separate runs (profiles/)",
+                "counters_from": counters.get("source") if counters else why_not,
+                "kernel_sources_hash": sources_hash,
                 "kernel": kernels + " (HIP events on the launch stream around the operator call)",
                 "kernel_ms": kernel_ms, "kernels_ms": kernels_ms, "algorithmic_bytes": alg_bytes,
                 "gather_bytes": gather_bytes, "gather_gbs": gather_bytes / (kernel_ms * 1e-3) / 1e9,

@@ -34,6 +34,8 @@ import torch  # noqa: E402
 
 import synth_graphs  # noqa: E402
 import voltrix  # noqa: E402
+from voltrix.jit_kernels import jit_tuner  # noqa: E402
+from voltrix.jit_kernels.spmm import feature_hash  # noqa: E402
 from voltrix.utils import GPU_bench, KernelTimer, calc_diff  # noqa: E402
 
 HBM_PEAK = 8.0e12
@@ -52,6 +54,12 @@ def steady_ms(fn, iters=7, warm=3, batch=10):
         e.synchronize()
         times.append(s.elapsed_time(e) / batch)
     return sorted(times)[len(times) // 2]
+
+
+def tuned_point(hspa_packed, f, two_level, dev):
+    keys = {"feature_hash": feature_hash(hspa_packed), "embedding_dim": f, "dtype": str(torch.float16),
+            "device": torch.cuda.get_device_name(dev), "two_level": bool(two_level), "weighted": False}
+    return dict(jit_tuner.tuned_point("spmm_kernel", keys))
 
 
 def launches_per_call(fn):
@@ -145,7 +153,10 @@ def main(argv=None):
                                  algorithmic_bytes=alg, hbm_roofline_frac=alg / (st * 1e-3) / HBM_PEAK,
                                  hbm_roofline_frac_flushed=alg / (ms * 1e-3) / HBM_PEAK, gflops=2.0 * nnz * dim / st / 1e6,
                                  tc_blocks=blocks, stages=stages, gathered_bytes=stages * 32 * dim * 2,
-                                 two_level=two is not None and mark == "N", launches=launches_per_call(call))
+                                 two_level=two is not None and mark == "N", launches=launches_per_call(call),
+                                 tile=tuned_point(two.hspa_packed if (two is not None and mark == "N") else h[1],
+                                                  (dim + 7) // 8 * 8, two is not None and mark == "N", dev) if mark == "N" else None,
+                                 tuner=dict(jit_tuner.stats))
                     if reorder_ms is not None:
                         extra["reorder_ms"] = reorder_ms
                     if args.check and base is not None and mark == "N":

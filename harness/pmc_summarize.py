@@ -88,9 +88,11 @@ def main():
              "mfma_busy_frac": step["mfma"] / max(1.0, step["busy"] / 8 * 1024),
              "kernels_serialised_ms": step["ms"], "bench_ms_per_step_under_profiler": bench["ms_per_step"],
              "fabric_TBps_at_serialised_time": traffic / max(1e-9, step["ms"] * 1e-3) / 1e12,
-             "source": args.source or args.dir}
+             "source": args.source or args.dir,
+             # the kernel sources the counters were measured on (bench.py replays the entry only while they match the tree)
+             "sources_hash": bench["roofline"].get("kernel_sources_hash")}
     key = (f"{cfg['workload'].split(':')[0]}|F{cfg['feat']}|{bench['dtype']}|{'two-level' if two_level else 'window'}|"
-           f"{tile['fs']},{tile['depth']},{tile['waves']}|sched{5 if pair else ('4' if 'unit table' in tile['schedule'] else ('0' if 'natural' in tile['schedule'] else '?'))}")
+           f"{tile['fs']},{tile['depth']},{tile['waves']}|sched{5 if pair else (6 if 'stream' in tile['schedule'] else ('4' if 'unit table' in tile['schedule'] else ('0' if 'natural' in tile['schedule'] else '?')))}")
     out.append(f"per step [{key}]: " + json.dumps(entry))
     open(os.path.join(args.dir, "summary_step.txt"), "w").write("\n".join(out) + "\n")
     json.dump({key: entry}, open(os.path.join(args.dir, "traffic_entry.json"), "w"), indent=1)

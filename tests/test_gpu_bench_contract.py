@@ -40,3 +40,26 @@ def test_bench_line_carries_the_contract(tmp_path):
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["unit"] == "GFLOP/s"
     assert isinstance(cpu["sample"], str) and cfg["rowsum_check_max_rel_err"] < 1e-4
     assert cfg["tile"]["launches_per_step"] == 1 and cfg["first_call_ms"] > 0
+
+
+def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
+    """``python bench.py --gpus 2`` outside torch.distributed.run spawns its two ranks as child processes (before touching the
+    GPU) and relays rank 0's ONE line; the timed step is the dependent one (gather, then the product that consumes it), the
+    overlapped figure rides beside it.  Two gloo ranks on the one GPU of the box."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["VOLTRIX_TUNE_SPACE"] = "none"
+    run = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device",
+                          "--scale", "0.01", "--workload", "reddit_like", "--steps", "3", "--warmup", "1", "--tune", "none",
+                          "--gather", "collective"], capture_output=True, text=True, env=env, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "strong"
+    for key in ("allgather_ms", "local_spmm_ms", "predicted_ms", "step_independent_ms", "timed_step"):
+        assert key in cfg, key
+    assert cfg["timed_step"].startswith("dependent") and cfg["rowsum_check_max_rel_err"] < 1e-4
+    assert cfg["allgather_ms"] > 0 and cfg["local_spmm_ms"] > 0 and cfg["step_independent_ms"] > 0
+    # the dependent step cannot be shorter than its two halves one after the other allow
+    assert line["ms_per_step"] >= 0.5 * max(cfg["allgather_ms"], cfg["local_spmm_ms"])

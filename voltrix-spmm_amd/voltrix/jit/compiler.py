@@ -84,6 +84,25 @@ def get_repo_version() -> str:
 
 
 @functools.lru_cache(maxsize=None)
+def get_kernel_sources_version() -> str:
+    """md5 over EVERY device source of the package -- all headers under ``include/voltrix`` (JIT-reachable or not: the panel,
+    plan and table kernels live in the ahead-of-time library) and the library's ``csrc/*``.  Measurements that cannot be
+    repeated live (the PMC passes behind ``profiles/traffic.json``) carry it, and ``bench.py`` replays them only while it
+    matches the tree (round 5)."""
+    root = get_jit_include_dir()
+    files = [os.path.join(root, PROJECT_NAME_ABBR_LOWER, f) for f in sorted(os.listdir(os.path.join(root, PROJECT_NAME_ABBR_LOWER)))]
+    csrc = os.path.normpath(os.path.join(root, "..", "..", "csrc"))
+    if os.path.isdir(csrc):
+        files += [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".hpp", ".h"))]
+    md5 = hashlib.md5()
+    for path in files:
+        if os.path.isfile(path):
+            with open(path, "rb") as f:
+                md5.update(f.read())
+    return md5.hexdigest()[0:12]
+
+
+@functools.lru_cache(maxsize=None)
 def get_hipcc_compiler() -> Tuple[str, str]:
     """(path, version) of the first usable hipcc: $VOLTRIX_HIPCC_COMPILER, $VOLTRIX_NVCC_COMPILER (legacy name),
     $ROCM_PATH/bin/hipcc, /opt/rocm/bin/hipcc (reference get_nvcc_compiler, compiler.py:62-81)."""

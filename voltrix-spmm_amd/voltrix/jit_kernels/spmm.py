@@ -200,17 +200,30 @@ SAMPLE_CHUNKS = 2                # contiguous window ranges of the sample (at 1/
 SAMPLE_FRACTION = 16             # 1 / this of the windows in all
 
 
-def sample_ranges(num_windows: int):
+SAMPLE_MIN_STAGES = 1 << 19      # a sample launch must fill the chip for a while: at least this many stages (4 TC blocks each)
+
+
+def sample_ranges(num_windows: int, total_blocks: int = None):
     """Window ranges ``[(w0, w1)]`` the sweep times its candidates on: the whole handle when it is small, else
     ``SAMPLE_CHUNKS`` contiguous ranges centred at (2 k + 1) / (2 SAMPLE_CHUNKS) of the windows, 1 / ``SAMPLE_FRACTION`` of
     them in all (few, long launches: a launch's drained tail is what distorts a sample -- four ranges of 1/64 ranked the
     power-law graph's tiles 4 % off, profiles/r04/experiment_tuner_sample_powerlaw_v1.log).  A contiguous range of a
     block-format handle is itself a handle (``blk_offsets[w0 : w1 + 1]`` holds absolute TC-block offsets into the same
     ``hspa_packed`` / ``hind``), so a sample launch is the SAME kernel with a shifted pointer, fewer rows and its own schedule
-    arrays: nothing is copied."""
+    arrays: nothing is copied.  Round 5: the sample is sized by WORK, not by windows -- on the low-degree graphs of the
+    reference's evaluation set a window is one or two stages, 1/16 of the windows is a launch of a few microseconds, and such a
+    sample ranked the kernels by their launch latency (the stream kernel, 1.7 x faster on the whole graph, lost it): with
+    ``total_blocks`` given, the ranges hold at least ``SAMPLE_MIN_STAGES`` stages (the whole handle when it has fewer)."""
     if num_windows <= SAMPLE_MIN_WINDOWS:
         return [(0, num_windows)]
     size = max(SAMPLE_MIN_WINDOWS // (2 * SAMPLE_CHUNKS), num_windows // (SAMPLE_FRACTION * SAMPLE_CHUNKS))
+    if total_blocks is not None:
+        stages = max(1, total_blocks // 4)
+        if stages <= SAMPLE_MIN_STAGES:
+            return [(0, num_windows)]
+        size = max(size, -(-num_windows * SAMPLE_MIN_STAGES // (stages * SAMPLE_CHUNKS)))
+        if size * SAMPLE_CHUNKS * 2 > num_windows:
+            return [(0, num_windows)]
     out = []
     for k in range(SAMPLE_CHUNKS):
         centre = (2 * k + 1) * num_windows // (2 * SAMPLE_CHUNKS)
@@ -564,7 +577,7 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
         from ..schedule import default_max_stages, stream_tables, unit_table
 
         num_windows = (num_nodes + 15) // 16
-        ranges = sample_ranges(num_windows)
+        ranges = sample_ranges(num_windows, int(blk_offsets[num_windows]))
         if len(ranges) == 1 and ranges[0] == (0, num_windows):
             return [tune_args], 1.0
         out_full = tune_args[7]
@@ -587,7 +600,7 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
                 a[19], a[20], a[21], a[22], a[23] = t.units, t.unit_ptr, t.max_units_per_xcd, t.cuts, t.num_cuts
                 a[24] = torch.empty(max(1, t.num_slots) * 16 * embedding_dim, dtype=torch.float32, device=input.device)
             if want(SCHED_STREAM):
-                t = stream_tables(sub, hspa_packed, hind, n_sub, run_cost=table_s.run_cost, cut_stages=table_s.cut_stages)
+                t = stream_tables(sub, hspa_packed, hind, n_sub, cut_stages=table_s.cut_stages)   # run cost: the sample's own
                 a[31], a[32], a[33], a[34], a[35], a[36] = t.units, t.runs, t.run_ptr, t.max_runs_per_xcd, t.cuts, t.num_cuts
                 a[37] = torch.empty(max(1, t.num_slots) * 16 * embedding_dim, dtype=torch.float32, device=input.device)
             a[25] = 1                                       # combine now: the candidate's complete work
