@@ -28,7 +28,7 @@ def test_spmm_kernel_asserts_like_reference():
 
 
 def test_tile_space_is_valid_and_bounded(monkeypatch):
-    for mode, lo, hi in (("default", 16, 68), ("full", 36, 220), ("none", 1, 1)):
+    for mode, lo, hi in (("default", 16, 74), ("full", 36, 226), ("none", 1, 1), ("stream", 1, 1)):
         monkeypatch.setenv("VOLTRIX_TUNE_SPACE", mode)
         for f in (16, 32, 64, 128, 512):
             for eb in (2, 4):
@@ -36,8 +36,15 @@ def test_tile_space_is_valid_and_bounded(monkeypatch):
                 assert lo <= len(space) <= hi, (mode, f, eb, len(space))
                 for p in space:
                     assert spmm_mod._lds_bytes(p["FS"], p["DEPTH"], p["WAVES"], p["EB"]) <= 160 * 1024
-                    assert p["EB"] == eb and p["FS"] in (32, 64, 128, 256) and p["SCHED"] in ((0, 1, 2, 3, 4, 5) if eb == 2 else (0, 1, 2, 3))
+                    assert p["EB"] == eb and p["FS"] in (32, 64, 128, 256) and p["SCHED"] in ((0, 1, 2, 3, 4, 5, 6) if eb == 2 else (0, 1, 2, 3))
                     assert p["SCHED"] != 5 or (p["WAVES"] == 4 and (p["FS"] >= 64 or f <= p["FS"]))   # paired units
+                    if p["SCHED"] == 6:   # stream points: loads + stores behind a counted wait fit the 6-bit vmcnt
+                        ndma, slots = 32 * p["FS"] * 2 // 1024, p["FS"] // 16
+                        assert p["WAVES"] in (1, 2) and (1 + ndma) * (p["DEPTH"] - 1) + p["DEPTH"] * slots <= 63
+                # the stream kernel serves plain stores of a binary 16-bit operand only
+                for kw in (dict(weighted=True), dict(max_lds=spmm_mod.TWO_LEVEL_LDS_BUDGET), dict(stream_ok=False)):
+                    if eb == 2:
+                        assert all(p["SCHED"] != 6 for p in spmm_mod.tile_space(f, eb, **kw)), (mode, f, kw)
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
     # the single default point = the ahead-of-time library's default tile + the unit-table schedule
     assert spmm_mod.tile_space(128, 2) == ({"FS": 128, "DEPTH": 3, "WAVES": 4, "EB": 2, "SCHED": 4, "BF16": 0, "WEIGHTED": 0},)

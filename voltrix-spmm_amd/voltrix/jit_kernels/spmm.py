@@ -159,6 +159,8 @@ def tile_space(embedding_dim: int, elem_bytes: int, bf16: bool = False, max_lds:
 
 def _tile_space(embedding_dim: int, elem_bytes: int):
     mode = tune_space_mode()
+    if mode == "stream" and elem_bytes != 2:   # the stream kernel's own mode: operands it does not serve take the default tile
+        mode = "none"
     fs_max = 128
     fs_fit = 32 if embedding_dim <= 32 else (64 if embedding_dim <= 64 else fs_max)
     if mode == "none":  # the ahead-of-time library's default tile (csrc/capi_common.hpp::default_tile) + unit table
