@@ -46,7 +46,7 @@ def main(argv=None):
     ap.add_argument("--synthetic", default=None, help="comma list of NAME[:scale] (synth_graphs) instead of a folder")
     ap.add_argument("--feature_dims", default=",".join(map(str, FEATURE_DIMS)))
     ap.add_argument("--methods", default="hipSPARSE,Voltrix")
-    ap.add_argument("--reorder_method", default="spectral", choices=["spectral", "bfs", "rcm"],
+    ap.add_argument("--reorder_method", default="auto", choices=["auto", "spectral", "bfs", "rcm"],
                     help="how a missing <name>.reorder.npz is produced")
     ap.add_argument("--output_file", default="results.csv")
     ap.add_argument("--append", action="store_true")

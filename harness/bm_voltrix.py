@@ -33,7 +33,9 @@ def main(argv=None):
                          "torch.sparse.mm on the CPU")
     ap.add_argument("--reorder", action="store_true",
                     help="with --npz NAME.npz: run on NAME.reorder.npz, the externally reordered file the reference's protocol "
-                         "expects beside it (bench/graph_gen.py:42-45; written by `graph_gen.py --write_reorder`), and mark the "
+                         "expects beside it (bench/graph_gen.py:42-45; written by `graph_gen.py --write_reorder`) -- or, when "
+                         "there is no such file, on the library's own symmetric reorder of NAME.npz "
+                         "(csr_preprocess_reordered(..., relabel=True)) -- and mark the "
                          "results.csv row Reorder=True")
     ap.add_argument("--num_feats", type=int, default=128)
     ap.add_argument("--seed", type=int, default=20)
@@ -45,8 +47,8 @@ def main(argv=None):
         from harness.graph_gen import load_graph
 
         path = args.npz[:-4] + ".reorder.npz" if args.reorder else args.npz
-        assert os.path.exists(path), f"{path} not found" + (" (graph_gen.py --write_reorder writes it)" if args.reorder else "")
-        ip, ix = load_graph(path)
+        in_library = args.reorder and not os.path.exists(path)   # no reordered twin on disk: the library relabels (below)
+        ip, ix = load_graph(args.npz if in_library else path)
         indptr, indices = torch.from_numpy(ip), torch.from_numpy(ix)
         n = indptr.numel() - 1
         torch.manual_seed(args.seed)
@@ -61,13 +63,27 @@ def main(argv=None):
         weight = torch.tensor(np.fromfile(f("feat.csv"), dtype=np.float32)).cuda().view(n, -1)
     if args.fp16:
         weight = weight.half()
-    blk_ofs, hspa_packed, hind = voltrix.csr_preprocess(indptr, indices, n)
-    hspa_packed.hash_tag = f"{args.dataset}{'.reorder' if args.reorder else ''}_{n}_{indices.numel()}"
+    if args.npz and in_library:
+        # the library's symmetric reorder (P A P^T, candidates judged by voltrix.reorder.auto_permutation): B goes in in the
+        # new order, C comes out in it -- the permutations are outside the timed call, as when the reference reads a reordered
+        # file -- and the result is put back only for the comparison with the baseline
+        rh = voltrix.csr_preprocess_reordered(indptr, indices, n, method="auto", relabel=True)
+        rh.hspa_packed.hash_tag = f"{args.dataset}.reorder_{n}_{indices.numel()}"
+        weight_in = voltrix.permute_features(rh, weight)
 
-    def spmm():
-        return voltrix.spmm(blk_ofs, hspa_packed, hind, num_nodes=n, num_edges=indices.numel(), feat=weight)
+        def spmm():
+            return voltrix.spmm_reordered(rh, weight_in)
 
-    o = spmm().detach().cpu()
+        o = voltrix.unpermute_output(rh, spmm()).detach().cpu()
+        print(f"[Voltrix] reorder: {rh.method}")
+    else:
+        blk_ofs, hspa_packed, hind = voltrix.csr_preprocess(indptr, indices, n)
+        hspa_packed.hash_tag = f"{args.dataset}{'.reorder' if args.reorder else ''}_{n}_{indices.numel()}"
+
+        def spmm():
+            return voltrix.spmm(blk_ofs, hspa_packed, hind, num_nodes=n, num_edges=indices.numel(), feat=weight)
+
+        o = spmm().detach().cpu()
     if o_base is None:
         o_base = torch.tensor(np.fromfile(f("output_base.csv"), dtype=np.float32).reshape(*o.shape))
     print(f"difference rate: {calc_diff(o, o_base) * 100:.3f}%")

@@ -137,7 +137,7 @@ def main(argv=None):
                 for mark, h, reorder_ms in variants:
                     if mark == "Y":
                         fin = voltrix.permute_features(h, feat)
-                        call = lambda: voltrix.spmm_reordered(h, fin, permuted_output=True)  # noqa: E731
+                        call = lambda: voltrix.spmm_reordered(h, fin)  # noqa: E731  (B and C in the new order)
                     else:
                         call = lambda: voltrix.spmm(*h, num_nodes=n, num_edges=nnz, feat=feat)  # noqa: E731
                     torch.cuda.synchronize()

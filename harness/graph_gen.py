@@ -114,23 +114,26 @@ def load_graph(path):
 
 def write_reorder_npz(path, method):
     """NAME.npz -> NAME.reorder.npz: nodes relabelled so that position k of the order becomes node k (rows AND columns, as
-    the reference's externally reordered files are)."""
+    the reference's externally reordered files are).  The relabelled CSR is the library's own (``voltrix.reorder.relabel_csr``,
+    what ``csr_preprocess_reordered(..., relabel=True)`` runs on); ``method`` "auto" = that call's default, candidates judged
+    with B's address locality, the caller's order kept when nothing pays."""
     sys.path.insert(0, os.path.join(REPO, "voltrix-spmm_amd"))
     from voltrix import reorder
 
     indptr, indices = load_npz(path)
     n = len(indptr) - 1
+    ip, ix = torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda()
     if method == "rcm":
-        perm = reorder.rcm_permutation(indptr, indices, n)
+        perm = torch.from_numpy(np.ascontiguousarray(reorder.rcm_permutation(indptr, indices, n))).cuda().long()
+    elif method == "auto":
+        perm, _ = reorder.auto_permutation(ip, ix, n, relabel=True)
+        perm = torch.arange(n, device="cuda") if perm is None else perm
     else:
-        ip, ix = torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda()
-        fn = reorder.spectral_permutation if method == "spectral" else reorder.bfs_permutation
-        perm = fn(ip, ix, n).cpu().numpy()
-    label = np.empty(n, dtype=np.int64)
-    label[perm] = np.arange(n)
-    rows = np.repeat(np.arange(n), np.diff(indptr))
+        perm = (reorder.spectral_permutation if method == "spectral" else reorder.bfs_permutation)(ip, ix, n)
+    r_indptr, r_indices = reorder.relabel_csr(ip, ix, n, perm)
+    rows = np.repeat(np.arange(n), np.diff(r_indptr.cpu().numpy()))
     out = path[:-4] + ".reorder.npz"
-    np.savez(out, src_li=label[rows], dst_li=label[indices], num_nodes=n)
+    np.savez(out, src_li=rows, dst_li=r_indices.cpu().numpy().astype(np.int64), num_nodes=n)
     return out
 
 
@@ -145,7 +148,7 @@ def main(argv=None):
     ap.add_argument("--out_dir", default=".")
     ap.add_argument("--only_dense", action="store_true", help="only feat.csv / output_base.csv (reference flag)")
     ap.add_argument("--mtx", action="store_true", help="also write data.mtx")
-    ap.add_argument("--write_reorder", default=None, choices=["spectral", "bfs", "rcm"],
+    ap.add_argument("--write_reorder", default=None, choices=["auto", "spectral", "bfs", "rcm"],
                     help="with --npz NAME.npz: also write NAME.reorder.npz -- the graph with its nodes relabelled (P A P^T, "
                          "TC-GNN edge-list layout) by voltrix.reorder's spectral / bfs order (GPU) or scipy's RCM (host): the "
                          "file the reference's protocol reads with --reorder (bench/graph_gen.py:42-45)")

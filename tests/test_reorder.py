@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import synth_graphs
-from oracle import oracle_c, oracle_np
+from oracle import oracle_c, oracle_np, torch_ref
 from voltrix import reorder
 
 
@@ -256,3 +256,59 @@ def test_auto_reorder_is_never_worse_than_no_reorder(cuda_device, graph, scale, 
            for k, v in info["report"].items()})
     assert t_auto <= 1.05 * t_plain + 0.01, (t_auto, t_plain, info["picked"],
                                              {k: (v["estimated_ms"], v["longest_panel_ksteps"]) for k, v in info["report"].items()})
+
+
+# ---- round 5: the symmetric form, P A P^T (what the reference's <name>.reorder.npz files hold, bench/graph_gen.py:42-45) -----
+def test_relabel_csr_is_p_a_pt_and_local_fraction_sees_the_labels(monkeypatch):
+    import scipy.sparse as sp
+
+    from voltrix.reorder import local_fraction, locality_factor, relabel_csr
+
+    monkeypatch.setattr(reorder, "LOCAL_RADIUS", 1200)      # the graph below has 4.7 k nodes and a band of +- 1.2 k
+
+    indptr, indices, _ = synth_graphs.generate("reddit_like", scale=0.02)
+    n = indptr.numel() - 1
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(3))
+    r_indptr, r_indices = relabel_csr(indptr, indices, n, perm)
+    a = sp.csr_matrix((np.ones(indices.numel()), indices.numpy(), indptr.numpy()), shape=(n, n))
+    b = sp.csr_matrix((np.ones(r_indices.numel()), r_indices.numpy(), r_indptr.numpy()), shape=(n, n))
+    p = perm.numpy()
+    assert (a[p][:, p] != b).nnz == 0 and b.has_sorted_indices
+    # half of the stand-in's edges sit in a band around the row; a random relabelling scatters them, the inverse brings them back
+    label = torch.empty(n, dtype=torch.int64)
+    label[perm] = torch.arange(n)
+    natural, scattered = local_fraction(indptr, indices, n), local_fraction(indptr, indices, n, label)
+    assert natural > 0.6 and scattered < natural - 0.15
+    assert abs(local_fraction(r_indptr, r_indices, n) - scattered) < 1e-6
+    assert locality_factor(1.0) < locality_factor(0.5) == 1.0 < locality_factor(0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["given", "bfs", "auto"])
+def test_relabelled_handle_is_the_operator_on_p_a_pt(cuda_device, method, monkeypatch):
+    """B goes in in the new order (permute_features), C comes out in it; ``unpermute=True`` gives the product of the caller's
+    graph.  Oracle: torch.sparse.mm on the relabelled CSR and on the original one."""
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    import voltrix
+    from voltrix.reorder import relabel_csr
+
+    indptr, indices, _ = synth_graphs.generate("reddit_shuffled", scale=0.05)
+    n, e = indptr.numel() - 1, indices.numel()
+    given = torch.randperm(n, generator=torch.Generator().manual_seed(9))
+    info = {}
+    h = voltrix.csr_preprocess_reordered(indptr, indices, n, method=given if method == "given" else method, relabel=True,
+                                         info=info)
+    assert h.row_map is None and h.relabelled == (not h.method.endswith("identity"))
+    torch.manual_seed(1)
+    feat = torch.randint(-3, 4, (n, 64)).half()
+    fin = voltrix.permute_features(h, feat.cuda())
+    out_new = voltrix.spmm_reordered(h, fin, hash_tag=f"relabel/{method}")
+    out_old = voltrix.spmm_reordered(h, fin, unpermute=True)
+    ref_old = torch_ref.spmm(indptr.numpy(), indices.numpy(), feat.float(), n)
+    assert torch.equal(out_old.cpu(), ref_old)                       # integers: exact
+    perm = h.perm.cpu()
+    r_indptr, r_indices = relabel_csr(indptr, indices, n, perm)
+    ref_new = torch_ref.spmm(r_indptr.numpy(), r_indices.numpy(), feat[perm].float(), n)
+    assert torch.equal(out_new.cpu(), ref_new) and torch.equal(out_new.cpu(), ref_old[perm])
+    if method == "auto":     # judged with B's address locality: every report line carries the local fraction
+        assert all("local_fraction" in v for v in info["report"].values())

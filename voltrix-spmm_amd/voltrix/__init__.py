@@ -12,7 +12,7 @@ from .spmm import (BLK_H, BLK_W, csr_preprocess, csr_preprocess_device, csr_prep
                    two_level_of)
 from .hybrid import TwoLevelHandle
 from .sidecar import copy_side_car, load_handle, save_handle, slim_handle
-from .reorder import ReorderedHandle, csr_preprocess_reordered, spmm_reordered
+from .reorder import ReorderedHandle, csr_preprocess_reordered, permute_features, spmm_reordered, unpermute_output
 from .weighted import WeightedHandle, csr_preprocess_weighted, spmm_weighted
 from .graphed import GraphedSpMM
 from . import autograd, hybrid, jit, sidecar, utils

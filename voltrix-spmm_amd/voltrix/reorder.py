@@ -377,6 +377,47 @@ def permute_rows_csr(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int
     return new_indptr.to(torch.int32), new_indices.contiguous()
 
 
+def relabel_csr(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, perm: torch.Tensor):
+    """CSR of ``P A P^T`` for the order ``perm`` (position k holds old node perm[k]): rows regrouped AND column ids relabelled
+    with the same permutation, rows sorted -- what the reference's externally reordered ``<name>.reorder.npz`` files hold
+    (bench/graph_gen.py:42-45).  int32, on the input's device; one 64-bit sort of the edge keys."""
+    dev = indptr.device
+    label = torch.empty(num_nodes, dtype=torch.int64, device=dev)
+    label[perm] = torch.arange(num_nodes, dtype=torch.int64, device=dev)      # old node -> new node
+    p_indptr, p_indices = permute_rows_csr(indptr, indices, num_nodes, perm)
+    deg = (p_indptr[1:] - p_indptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(num_nodes, dtype=torch.int64, device=dev), deg)
+    keys = torch.sort(rows * num_nodes + label[p_indices.long()]).values
+    del rows
+    new_indices = (keys % num_nodes).to(torch.int32)
+    return p_indptr, new_indices.contiguous()
+
+
+# B's address locality (round 5).  Rows of B referenced within LOCAL_RADIUS of the referencing row stay in the XCD's 4 MiB L2
+# while its window range sweeps them (4 MiB / 256-byte rows = 16 k rows, shared by the range's co-resident windows); the others
+# come from the Infinity Cache or HBM at about half the rate (MI355X_MICROARCH.md "Indexed rows": 66-73 vs 33.5 GB/s per CU).
+# The block-count estimate below was fitted on graphs whose edges are half local (reddit-like), so a candidate's estimate is
+# scaled by gather_cost(its local fraction) / gather_cost(0.5).  Only orders that RELABEL the columns can change the fraction.
+LOCAL_RADIUS = 4096
+LOCAL_RATE, FAR_RATE, LOCAL_REFERENCE = 70.0, 33.5, 0.5
+
+
+def local_fraction(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, label: torch.Tensor = None) -> float:
+    """Fraction of the edges whose column lies within LOCAL_RADIUS of its row (``label``: in the labels of a candidate order,
+    old node -> new node).  One pass over the edges; one host read."""
+    deg = (indptr[1:] - indptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(num_nodes, dtype=torch.int64, device=indptr.device), deg)
+    cols = indices.long()
+    if label is not None:
+        rows, cols = label[rows], label[cols]
+    return float(((rows - cols).abs() <= LOCAL_RADIUS).float().mean()) if cols.numel() else 1.0
+
+
+def locality_factor(local: float) -> float:
+    cost = lambda x: x / LOCAL_RATE + (1.0 - x) / FAR_RATE      # noqa: E731
+    return cost(local) / cost(LOCAL_REFERENCE)
+
+
 # ---- method="auto": candidates judged by the format's own statistics, identity kept unless one clearly pays (round 4) ------
 AUTO_MIN_GAIN = 0.03           # a candidate must cut the estimated step by this much
 # subspace steps of the spectral candidate: 8 give the same order quality as 16 on both reddit-size stand-ins (TC blocks 12.749 M
@@ -453,7 +494,7 @@ def order_statistics(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int
 
 
 def auto_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
-                     candidates=("bfs", "spectral"), info: dict = None):
+                     candidates=("bfs", "spectral"), info: dict = None, relabel: bool = False):
     """The safe default: every candidate order is judged by ``order_statistics`` of the row-permuted CSR
     against the order the caller's rows already have, and the IDENTITY is kept unless a candidate cuts the ESTIMATED step by
     ``AUTO_MIN_GAIN`` (3 %).  The estimate is the longer of the gather volume (fewer TC blocks, more shared edges) and the panel
@@ -461,11 +502,17 @@ def auto_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int
     random edges) piles the shared columns of 512 hub rows into one panel whose workgroup then runs alone -- 5.7 ms against
     1.78 ms on the label-shuffled reddit-like graph although it has FEWER TC blocks and MORE shared edges (DESIGN.md section
     3.4).  Deterministic: statistics of the format, no timing.  Returns ``(perm or None, name)``; None = keep the caller's
-    order."""
+    order.  ``relabel`` (round 5): the candidates are judged as SYMMETRIC relabellings ``P A P^T`` -- the estimate of every
+    order, the caller's included, is scaled by what its share of local edges does to the gather rate (``locality_factor``), the
+    one effect a row-only order cannot have -- and the mean-degree guard is lifted: at low degree the order does not change the
+    block count, but where B's rows sit in memory is all that is left to win."""
     report = {"identity": order_statistics(indptr, indices, num_nodes, num_cols)}
     base = report["identity"]
+    if relabel:
+        base["local_fraction"] = local_fraction(indptr, indices, num_nodes)
+        base["estimated_ms"] *= locality_factor(base["local_fraction"])
     best, best_name, best_ms = None, "identity", base["estimated_ms"]
-    if indices.numel() < AUTO_MIN_MEAN_DEGREE * max(1, num_nodes):
+    if indices.numel() < AUTO_MIN_MEAN_DEGREE * max(1, num_nodes) and not relabel:
         candidates = ()
     for name in candidates:
         if name == "bfs":
@@ -479,8 +526,14 @@ def auto_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int
         else:
             raise ValueError(f"unknown candidate order {name!r}")
         p_indptr, p_indices = permute_rows_csr(indptr, indices, num_nodes, perm)
-        st = order_statistics(p_indptr, p_indices, num_nodes, num_cols)
+        st = order_statistics(p_indptr, p_indices, num_nodes, num_cols)     # block counts do not depend on the column labels
         del p_indptr, p_indices
+        if relabel:
+            label = torch.empty(num_nodes, dtype=torch.int64, device=indptr.device)
+            label[perm] = torch.arange(num_nodes, dtype=torch.int64, device=indptr.device)
+            st["local_fraction"] = local_fraction(indptr, indices, num_nodes, label)
+            st["estimated_ms"] *= locality_factor(st["local_fraction"])
+            del label
         st["accepted"] = bool(st["estimated_ms"] <= (1.0 - AUTO_MIN_GAIN) * base["estimated_ms"]
                               and st["estimated_ms"] < best_ms)
         report[name] = st
@@ -503,20 +556,29 @@ class ReorderedHandle:
     num_nodes: int
     num_edges: int
     method: str
+    relabelled: bool = False     # True: the handle is that of P A P^T (columns relabelled too): B and C live in the NEW order
 
 
 def csr_preprocess_reordered(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
-                             method="auto", info: dict = None) -> ReorderedHandle:
+                             method="auto", info: dict = None, relabel: bool = False) -> ReorderedHandle:
     """CSR (CPU or CUDA int32) -> handle of the row-reordered matrix for ``spmm_reordered``.  ``method``: "auto" (default,
     round 4: the breadth-first and the spectral order are tried and judged by the format's own statistics; the caller's order
     is KEPT unless one of them clearly pays -- never worse than no reorder, ``auto_permutation``), "bfs" (Cuthill-McKee
     levels), "spectral" (Fiedler order of the row co-occurrence matrix, computed with the SpMM kernels: the one that survives a
     background of random edges), "degree", "identity", or an explicit permutation tensor (position k holds row perm[k]).
-    ``info``: dict that receives the statistics ``auto`` decided on."""
+    ``info``: dict that receives the statistics ``auto`` decided on.
+
+    ``relabel=True`` (round 5; square adjacency): the SYMMETRIC form ``P A P^T`` -- the columns are relabelled with the row
+    permutation, exactly what the reference benchmarks on (``<name>.reorder.npz``, bench/graph_gen.py:42-45,
+    bench_all.py:120-129).  The handle then describes the relabelled matrix: ``spmm_reordered`` takes B in the NEW order
+    (``permute_features(handle, feat)``, once per feature matrix) and returns C in the new order (``unpermute=True`` puts the
+    rows back).  Only this form restores the address locality of B (a row-only order cannot: products-like 4.4 ms natural, 4.9
+    shuffled, 5.7 row-reordered); ``auto`` judges the candidates with that term and tries them at any mean degree."""
     assert indptr.dtype == torch.int32 and indices.dtype == torch.int32 and indptr.numel() == num_nodes + 1
+    assert not relabel or num_cols in (None, num_nodes), "relabel=True relabels rows and columns alike: a square adjacency"
     indptr_d, indices_d = indptr.contiguous().cuda(), indices.contiguous().cuda()
     if method == "auto":
-        perm, name = auto_permutation(indptr_d, indices_d, num_nodes, num_cols, info=info)
+        perm, name = auto_permutation(indptr_d, indices_d, num_nodes, num_cols, info=info, relabel=relabel)
         if perm is None:
             perm, name = torch.arange(num_nodes, device=indptr_d.device), "auto:identity"
         else:
@@ -536,6 +598,8 @@ def csr_preprocess_reordered(indptr: torch.Tensor, indices: torch.Tensor, num_no
         raise ValueError(f"unknown reorder method {method!r}")
     if name.endswith("identity"):
         p_indptr, p_indices = indptr_d, indices_d
+    elif relabel:
+        p_indptr, p_indices = relabel_csr(indptr_d, indices_d, num_nodes, perm)
     else:
         p_indptr, p_indices = permute_rows_csr(indptr_d, indices_d, num_nodes, perm)
     # the operator's own preprocess: the reference handle of A[perm, :] and, when the (reordered!) graph pays for it, the
@@ -546,15 +610,31 @@ def csr_preprocess_reordered(indptr: torch.Tensor, indices: torch.Tensor, num_no
     pointer1, hspa_packed, hind = csr_preprocess_device(p_indptr, p_indices, num_nodes, num_cols)
     padded = 16 * ((num_nodes + 15) // 16)
     row_map = None
-    if not name.endswith("identity"):       # the identity order needs no map: the kernels write C in place
+    if not name.endswith("identity") and not relabel:   # the identity order and relabelled handles need no map: C is written in place
         row_map = torch.full((padded,), -1, dtype=torch.int32, device=indptr_d.device)
         row_map[:num_nodes] = perm.to(torch.int32)
-    return ReorderedHandle(pointer1, hspa_packed, hind, row_map, perm, num_nodes, int(indices.numel()), name)
+    return ReorderedHandle(pointer1, hspa_packed, hind, row_map, perm, num_nodes, int(indices.numel()), name,
+                           relabelled=bool(relabel) and not name.endswith("identity"))
 
 
-def spmm_reordered(handle: ReorderedHandle, feat: torch.Tensor, hash_tag: str = None) -> torch.Tensor:
-    """``csr(ones) @ feat`` in the ORIGINAL row order for a ``ReorderedHandle``: float32 [num_nodes, F] on the current
-    stream; ``feat`` as for ``voltrix.spmm`` (it is gathered as it is: column ids were never relabelled)."""
+def permute_features(handle: ReorderedHandle, feat: torch.Tensor) -> torch.Tensor:
+    """``feat`` (rows in the caller's node order) -> the rows in the order of a relabelled handle: row k = old row perm[k].  Once
+    per feature matrix, outside the product (the reference's protocol reads features for the reordered file the same way)."""
+    assert isinstance(handle, ReorderedHandle) and feat.shape[0] == handle.num_nodes
+    return feat.index_select(0, handle.perm.to(feat.device)) if handle.relabelled else feat
+
+
+def unpermute_output(handle: ReorderedHandle, out: torch.Tensor) -> torch.Tensor:
+    """C of a relabelled handle (rows in the new order) -> rows in the caller's node order."""
+    return torch.empty_like(out).index_copy_(0, handle.perm.to(out.device), out) if handle.relabelled else out
+
+
+def spmm_reordered(handle: ReorderedHandle, feat: torch.Tensor, hash_tag: str = None, unpermute: bool = False) -> torch.Tensor:
+    """``csr(ones) @ feat`` for a ``ReorderedHandle``: float32 [num_nodes, F] on the current stream.
+    Row-only handles (``relabel=False``): ``feat`` as for ``voltrix.spmm`` (it is gathered as it is: column ids were never
+    relabelled), the result in the ORIGINAL row order.  Relabelled handles: ``feat`` in the NEW order (``permute_features``),
+    the result in the new order too -- the plain operator on ``P A P^T``, every kernel and format of it -- unless
+    ``unpermute``."""
     from .jit_kernels import spmm_kernel
     from .spmm.spmm import _operand
 
@@ -564,9 +644,10 @@ def spmm_reordered(handle: ReorderedHandle, feat: torch.Tensor, hash_tag: str = 
     num_feats = feat.shape[1]
     from .spmm.spmm import spmm, two_level_of
 
-    if handle.row_map is None:       # identity order (method "auto" kept the caller's rows): the plain operator
-        return spmm(handle.blk_offsets, handle.hspa_packed, handle.hind, num_nodes=handle.num_nodes,
-                    num_edges=handle.num_edges, feat=feat)
+    if handle.row_map is None:       # identity order (method "auto" kept the caller's rows) or a relabelled handle: the plain operator
+        out = spmm(handle.blk_offsets, handle.hspa_packed, handle.hind, num_nodes=handle.num_nodes,
+                   num_edges=handle.num_edges, feat=feat)
+        return unpermute_output(handle, out) if (unpermute and handle.relabelled) else out
     if two_level_of(handle.hspa_packed) is not None:
         # two-level side-car on the reordered rows: the panel kernel writes its panel's rows in place, so the product comes
         # out in the handle's row order and one indexed copy (N x F x 4 bytes each way) puts the rows back
