@@ -189,6 +189,44 @@ void voltrix_launch_unit_table_fill(void* blk_offsets, int num_nodes, void* xcd_
                                     int num_units, int num_cuts, int top, void* units, void* unit_ptr, void* cuts,
                                     void* stream, int* return_code);
 
+/* Stream kernel (round 5; spmm_stream_kernels.hpp): the window format walked as a STREAM OF STAGES -- the kernel for graphs of
+ * short windows (the reference's low-degree evaluation graphs, bench/plot.py:8).  Replaces the reference's one-CTA-per-window
+ * dispatch (voltrix_spmm_forward_cuda, spmm_kernels.cuh:2003-2113, grids :2028,2058,2089) for them: a wave owns a RUN of
+ * consecutive units (whole windows; a long window's interleaved pieces), one LDS ring that never drains at a window boundary,
+ * every finished window stored from the loop with 16-byte stores.  16-bit binary operand, plain stores (every row of the output
+ * is written; cut windows go through `partials` and voltrix_launch_combine_partials with accumulate = 0, row_map = NULL).
+ *   tables      built by the library from the handle's three tensors, two phases around the host reads that size the outputs:
+ *     voltrix_launch_stream_table_count: header int32[8] (device) = {num_units U, cut windows C, partial-tile slots, bound on
+ *       the number of runs, run_cost, cut_stages, 0, 0}.  run_cost <= 0: clamp((stages + windows) / 9216, 6, 48) (six runs per
+ *       wave slot of the chip); cut_stages <= 0: max(run_cost, max(8, 1.5 x median stages per window)).  run_cost <= 128.
+ *       workspace: voltrix_stream_table_workspace_bytes(num_nodes) bytes, device, 16-byte aligned.
+ *     (caller reads the header; allocates units int32[U][8], cuts int32[C][4], runs int32[bound][4], run_ptr int32[9],
+ *      header2 int32[4], partials float[slots * 16 * embedding_dim], voltrix_stream_table_fill_workspace_bytes(U) bytes)
+ *     voltrix_launch_stream_table_fill: writes them all; header2 = {runs R, max runs per XCD, 0, 0} (the launch's
+ *       max_runs_per_xcd); same workspace, untouched since phase 1; run_cost as read from the header.
+ *     units[u] = {first TC block, end TC block of the window, 4 x stride, window, partial-tile slot or -1, stages, columns of the
+ *     window's last TC block that carry an edge (0: a window without edges), 0}; runs[r] = {first unit, units (<= 64), stages,
+ *     0}; run_ptr[x] .. run_ptr[x + 1] = the runs of XCD x (contiguous windows, equal cost).  The tables depend on the handle
+ *     only: a handle always gets the same tables and the product the same bits.
+ *   tile        (fs, depth, waves): fs 32 | 64 | 128 (the slab: embedding_dim <= 32 | <= 64 | wider), depth 2..4, waves 1 | 2;
+ *               fs = 0 selects the default (fs by width, depth 2, waves 1).
+ *   input_rows  rows of the dense operand (0: num_nodes); decides 32- or 64-bit row addressing and the slab launches. */
+int64_t voltrix_stream_table_workspace_bytes(int num_nodes);
+int64_t voltrix_stream_table_fill_workspace_bytes(int64_t num_units);
+void voltrix_launch_stream_table_count(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int run_cost,
+                                       int cut_stages, void* workspace, void* header, void* stream, int* return_code);
+void voltrix_launch_stream_table_fill(void* blk_offsets, int num_nodes, void* workspace, void* fill_workspace, int num_units,
+                                      int num_cuts, int run_bound, int run_cost, void* units, void* cuts, void* runs,
+                                      void* run_ptr, void* header2, void* stream, int* return_code);
+void voltrix_launch_spmm_stream_f16(void* hspa_packed, void* hind, int num_nodes, int embedding_dim, void* input,
+                                    int64_t input_rows, void* output, void* units, void* runs, void* run_ptr,
+                                    int max_runs_per_xcd, void* partials, void* out_scale, int fs, int depth, int waves,
+                                    int slab_policy, void* stream, int* return_code);
+void voltrix_launch_spmm_stream_bf16(void* hspa_packed, void* hind, int num_nodes, int embedding_dim, void* input,
+                                     int64_t input_rows, void* output, void* units, void* runs, void* run_ptr,
+                                     int max_runs_per_xcd, void* partials, void* out_scale, int fs, int depth, int waves,
+                                     int slab_policy, void* stream, int* return_code);
+
 /* "Balance" schedule for a handle: order_out int32[W] (device) lists the windows of every XCD range, inside chunks of
  * `chunk` (1..4096) consecutive windows, by descending TC-block count, so that co-resident waves sweep their sorted
  * columns at a similar pace and share gathered rows through L2.  Depends on blk_offsets only; results of the SpMM are

@@ -249,3 +249,58 @@ def test_native_piece_table_equals_the_torch_restatement(cuda_device, num_panels
         assert torch.equal(native.xcd_ptr.cpu(), ref.xcd_ptr)
         assert torch.equal(native.cuts.cpu(), ref.cuts)
         assert torch.equal(native.parts.cpu(), ref.parts)
+
+
+# ---- round 5: the stream kernel's tables (voltrix/stream_table.hpp behind voltrix_launch_stream_table_count / _fill) -----------
+@pytest.mark.parametrize("name,scale", [("yeast_like", 0.02), ("dd_like", 0.2), ("web_berkstan_like", 0.1), ("reddit_like", 0.02),
+                                        ("powerlaw_4m", 0.002)])
+@pytest.mark.parametrize("run_cost,cut", [(None, None), (6, 6), (48, 3), (2, 1), (128, 100000)])
+def test_stream_tables_of_the_library_match_their_restatement(cuda_device, name, scale, run_cost, cut):
+    """Element by element: units, runs, XCD ranges, cuts and the header figures of the device builder against
+    schedule.stream_tables_torch (graphs of one-stage windows, of hub windows, of long windows; forced and default bounds)."""
+    import synth_graphs
+    import voltrix
+    from voltrix.schedule import stream_tables, stream_tables_torch
+
+    indptr, indices, _ = synth_graphs.generate(name, device="cuda", scale=scale)
+    n = indptr.numel() - 1
+    handle = voltrix.csr_preprocess_device(indptr, indices, n)
+    got = stream_tables(*handle, n, run_cost=run_cost, cut_stages=cut)
+    want = stream_tables_torch(*handle, n, run_cost=run_cost, cut_stages=cut)
+    for field in ("run_cost", "cut_stages", "num_units", "num_runs", "num_cuts", "num_slots", "max_runs_per_xcd"):
+        assert getattr(got, field) == getattr(want, field), field
+    for field in ("units", "runs", "run_ptr", "cuts"):
+        assert torch.equal(getattr(got, field), getattr(want, field)), field
+    assert int(got.runs[:, 1].max()) <= 64
+
+
+def test_stream_kernel_through_the_c_abi(cuda_device):
+    """voltrix_launch_stream_table_count / _fill + voltrix_launch_spmm_stream_f16 / _bf16 + voltrix_launch_combine_partials, the
+    sequence a C host runs: exact on integer operands against the oracle, every ahead-of-time tile, default tile included."""
+    import synth_graphs
+    import voltrix
+    from oracle import torch_ref
+    from voltrix import capi
+    from voltrix.schedule import stream_tables
+
+    indptr, indices, _ = synth_graphs.generate("web_berkstan_like", scale=0.05)     # hub windows: cuts and partial tiles
+    n, e = indptr.numel() - 1, indices.numel()
+    handle = voltrix.csr_preprocess(indptr, indices, n)
+    table = stream_tables(*handle, n)
+    assert table.num_cuts > 0
+    for dtype in (torch.float16, torch.bfloat16):
+        for f, tiles in ((136, [(0, 0, 0), (128, 2, 1), (128, 3, 2), (128, 4, 1), (64, 2, 2)]), (32, [(0, 0, 0), (32, 4, 1)])):
+            feat = torch.randint(-3, 4, (n, f)).to(dtype)
+            ref = torch_ref.spmm(indptr.numpy(), indices.numpy(), feat.float(), n)
+            dev_feat = feat.cuda()
+            for tile in tiles:
+                out = torch.full((n, f), float("nan"), device="cuda")
+                partials = torch.empty(max(1, table.num_slots) * 16 * f, device="cuda")
+                assert capi.launch_spmm_stream(handle[1], handle[2], n, f, dev_feat, out, table, partials, tile=tile) == 0
+                rc = capi.launch_combine_partials(table, partials.data_ptr(), out.data_ptr(), n, f, False,
+                                                  torch.cuda.current_stream().cuda_stream)
+                assert rc == 0
+                assert torch.equal(out.cpu(), ref), (dtype, f, tile)
+    out = torch.empty((n, 128), device="cuda")
+    assert capi.launch_spmm_stream(handle[1], handle[2], n, 128, torch.zeros(n, 128, device="cuda").half(), out, table,
+                                   torch.empty(16, device="cuda"), tile=(128, 5, 1)) == 3          # not an ahead-of-time tile

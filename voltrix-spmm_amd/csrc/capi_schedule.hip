@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "voltrix/schedule_tables.hpp"
+#include "voltrix/stream_table.hpp"
 #include "voltrix/unit_table.hpp"
 #include "voltrix_capi.h"
 
@@ -65,6 +66,28 @@ void voltrix_launch_panel_parts_fill(void* panel_ptr, int num_panels, int cap, v
                                            static_cast<const int*>(panel_xcd_ptr), workspace, static_cast<int*>(parts),
                                            static_cast<int*>(part_xcd_ptr), static_cast<int*>(cuts),
                                            static_cast<hipStream_t>(stream));
+}
+
+int64_t voltrix_stream_table_workspace_bytes(int num_nodes) { return voltrix::stream_table_workspace_bytes(num_nodes); }
+
+int64_t voltrix_stream_table_fill_workspace_bytes(int64_t num_units) {
+  return voltrix::stream_table_fill_workspace_bytes(num_units);
+}
+
+void voltrix_launch_stream_table_count(void* blk_offsets, void* hspa_packed, void* hind, int num_nodes, int run_cost,
+                                       int cut_stages, void* workspace, void* header, void* stream, int* return_code) {
+  *return_code = voltrix::stream_table_count(static_cast<const int*>(blk_offsets), static_cast<const uint32_t*>(hspa_packed),
+                                             static_cast<const int*>(hind), num_nodes, run_cost, cut_stages, workspace,
+                                             static_cast<int*>(header), static_cast<hipStream_t>(stream));
+}
+
+void voltrix_launch_stream_table_fill(void* blk_offsets, int num_nodes, void* workspace, void* fill_workspace, int num_units,
+                                      int num_cuts, int run_bound, int run_cost, void* units, void* cuts, void* runs,
+                                      void* run_ptr, void* header2, void* stream, int* return_code) {
+  *return_code = voltrix::stream_table_fill(static_cast<const int*>(blk_offsets), num_nodes, workspace, fill_workspace,
+                                            num_units, num_cuts, run_bound, run_cost, static_cast<int*>(units),
+                                            static_cast<int*>(cuts), static_cast<int*>(runs), static_cast<int*>(run_ptr),
+                                            static_cast<int*>(header2), static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

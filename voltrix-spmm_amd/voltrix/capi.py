@@ -32,6 +32,12 @@ SYMBOLS = (
     "voltrix_launch_spmm_f16_sched",
     "voltrix_launch_spmm_bf16_sched",
     "voltrix_launch_combine_partials",
+    "voltrix_stream_table_workspace_bytes",
+    "voltrix_stream_table_fill_workspace_bytes",
+    "voltrix_launch_stream_table_count",
+    "voltrix_launch_stream_table_fill",
+    "voltrix_launch_spmm_stream_f16",
+    "voltrix_launch_spmm_stream_bf16",
     "voltrix_launch_spmm_panel_f16",
     "voltrix_launch_spmm_panel_bf16",
     "voltrix_launch_spmm_panel_parts_f16",
@@ -248,6 +254,59 @@ def build_unit_table(blk_offsets, num_nodes: int, max_stages: int = 0, stream=No
                                          _ptr(unit_ptr), _ptr(cuts), ctypes.c_void_p(stream), ctypes.byref(rc))
     check(rc.value, "voltrix_launch_unit_table_fill")
     return units, unit_ptr, cuts, head
+
+
+def build_stream_table(blk_offsets, hspa_packed, hind, num_nodes: int, run_cost: int = 0, cut_stages: int = 0, stream=None):
+    """The handle's stream tables through the library's two-phase builder (voltrix/stream_table.hpp): returns ``(units int32
+    [U, 8], runs int32 [R, 4], run_ptr int32 [9], cuts int32 [C, 4], header)`` with ``header`` = (num_units, num_cuts, num_slots,
+    num_runs, max_runs_per_xcd, run_cost, cut_stages).  Two host syncs (the sizes of the outputs, then the number of runs)."""
+    import torch
+
+    dev = blk_offsets.device
+    stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    L = lib()
+    workspace = torch.empty(max(16, int(L.voltrix_stream_table_workspace_bytes(ctypes.c_int(num_nodes)))), dtype=torch.uint8,
+                            device=dev)
+    header = torch.empty(8, dtype=torch.int32, device=dev)
+    rc = ctypes.c_int(-1)
+    L.voltrix_launch_stream_table_count(_ptr(blk_offsets), _ptr(hspa_packed), _ptr(hind), ctypes.c_int(num_nodes),
+                                        ctypes.c_int(int(run_cost)), ctypes.c_int(int(cut_stages)), _ptr(workspace),
+                                        _ptr(header), ctypes.c_void_p(stream), ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_stream_table_count")
+    num_units, num_cuts, num_slots, run_bound, rcost, cut = [int(v) for v in header.tolist()][:6]   # the sync
+    units = torch.empty((num_units, 8), dtype=torch.int32, device=dev)
+    cuts = torch.empty((num_cuts, 4), dtype=torch.int32, device=dev)
+    runs = torch.empty((max(1, run_bound), 4), dtype=torch.int32, device=dev)
+    run_ptr = torch.empty(9, dtype=torch.int32, device=dev)
+    header2 = torch.empty(4, dtype=torch.int32, device=dev)
+    fill_ws = torch.empty(max(16, int(L.voltrix_stream_table_fill_workspace_bytes(ctypes.c_int64(num_units)))),
+                          dtype=torch.uint8, device=dev)
+    L.voltrix_launch_stream_table_fill(_ptr(blk_offsets), ctypes.c_int(num_nodes), _ptr(workspace), _ptr(fill_ws),
+                                       ctypes.c_int(num_units), ctypes.c_int(num_cuts), ctypes.c_int(run_bound),
+                                       ctypes.c_int(max(2, rcost)), _ptr(units), _ptr(cuts), _ptr(runs), _ptr(run_ptr),
+                                       _ptr(header2), ctypes.c_void_p(stream), ctypes.byref(rc))
+    check(rc.value, "voltrix_launch_stream_table_fill")
+    num_runs, max_runs = [int(v) for v in header2.tolist()][:2]
+    return units, runs[:num_runs], run_ptr, cuts, (num_units, num_cuts, num_slots, num_runs, max_runs, rcost, cut)
+
+
+def launch_spmm_stream(hspa_packed, hind, num_nodes: int, embedding_dim: int, feat, output, table, partials, out_scale=None,
+                       tile=(0, 0, 0), stream=None, input_rows: int = 0, slab_policy: int = -1) -> int:
+    """``voltrix_launch_spmm_stream_f16 / _bf16`` on a ``voltrix.schedule.StreamTable`` (the stream kernel through the C-ABI)."""
+    import torch
+
+    stream = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    fn = lib().voltrix_launch_spmm_stream_bf16 if feat.dtype == torch.bfloat16 else lib().voltrix_launch_spmm_stream_f16
+    from .utils import timed_launch
+
+    rc = ctypes.c_int(-1)
+    with timed_launch("spmm_stream", stream):
+        fn(_ptr(hspa_packed), _ptr(hind), ctypes.c_int(num_nodes), ctypes.c_int(embedding_dim), _ptr(feat),
+           ctypes.c_int64(int(input_rows)), _ptr(output), _ptr(table.units), _ptr(table.runs), _ptr(table.run_ptr),
+           ctypes.c_int(table.max_runs_per_xcd), _ptr(partials), ctypes.c_void_p(out_scale.data_ptr() if out_scale is not None else 0),
+           ctypes.c_int(tile[0]), ctypes.c_int(tile[1]), ctypes.c_int(tile[2]), ctypes.c_int(int(slab_policy)),
+           ctypes.c_void_p(stream), ctypes.byref(rc))
+    return rc.value
 
 
 def xcd_ranges_of_work(work, align: int = 1, stream=None):

@@ -203,7 +203,21 @@ def last_block_columns(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hin
 
 def stream_tables(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tensor, num_nodes: int, run_cost: int = None,
                   cut_stages: int = None) -> StreamTable:
-    """The handle's stream table.  A unit = a whole window, or -- windows longer than ``cut_stages`` stages -- one of its
+    """The handle's stream table (layout and rules: :func:`stream_tables_torch`).  Built by the library's two-phase device
+    builder (``voltrix/stream_table.hpp`` through ``capi.build_stream_table`` -- the entry points a C host binds); CPU tensors go
+    through the torch-tensor restatement, which the tests also use to check the native tables element by element."""
+    if not blk_offsets.is_cuda or num_nodes == 0:
+        return stream_tables_torch(blk_offsets, hspa_packed, hind, num_nodes, run_cost, cut_stages)
+    from . import capi
+
+    units, runs, run_ptr, cuts, head = capi.build_stream_table(blk_offsets, hspa_packed, hind, num_nodes, run_cost or 0,
+                                                               cut_stages or 0)
+    return StreamTable(units, runs, run_ptr, cuts, head[4], head[3], head[0], head[1], head[2], head[5], head[6])
+
+
+def stream_tables_torch(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tensor, num_nodes: int,
+                        run_cost: int = None, cut_stages: int = None) -> StreamTable:
+    """The stream table as torch tensor ops (the definition the device builder is checked against).  A unit = a whole window, or -- windows longer than ``cut_stages`` stages -- one of its
     ``k = ceil(stages / cut_stages)`` interleaved pieces (unit j runs the stages j, j + k, ...; partial tiles summed in unit
     order by ``combine_partials``, exactly as in :func:`unit_table_torch`).  Units stay in WINDOW order (consecutive windows'
     metadata and rows of C are consecutive in memory; band graphs gather overlapping rows of B).  A unit costs its stages + 1
