@@ -58,6 +58,13 @@ class Runtime:
                 self._launch(*cargs, ctypes.byref(return_code))
         return return_code.value
 
+    def launcher(self):
+        """The loaded ``launch`` entry point (ctypes function) and the parsed ``kernel.args``: for callers that marshal a fixed
+        argument list once and patch only the pointers that change from call to call (jit_kernels/spmm.py::_LaunchPlan)."""
+        if self.lib is None:
+            self._load()
+        return self._launch, self.args
+
     @property
     def kernel_name(self) -> str:
         """``spmm_kernel`` for .../kernel.spmm_kernel.<hash>."""

@@ -56,6 +56,8 @@ class JITTuner:
         # signatures whose Runtime came from a persisted choice and has not run yet (no validation launch is made: the first
         # real launch is the validation -- ``forget`` + a sweep if it fails)
         self.unvalidated = set()
+        # bumped whenever a memoised choice is dropped: launch plans built on a choice (jit_kernels/spmm.py) check it
+        self.generation = 0
 
     # ---- persistent choices ------------------------------------------------------------------------------
     @staticmethod
@@ -103,6 +105,7 @@ class JITTuner:
     def forget(self, name: str, keys: Dict[str, Any]) -> None:
         """Drop the memoised choice for ``(name, keys)`` (its first launch failed): the next ``compile_and_tune`` sweeps."""
         sig = self._signature(name, keys)
+        self.generation += 1
         self.tuned.pop(sig, None)
         self.tuned_keys.pop(sig, None)
         self.unvalidated.discard(sig)
