@@ -515,18 +515,22 @@ def main():
     kernels_ms = {k: round(v[1], 4) for k, v in timer.summary().items()}
 
     # ---- what the operator ran (the tuner's choice), for the record -----------------------------------------------------
+    from voltrix.spmm.spmm import fp32_mode
+
+    fp32_as = fp32_mode(handle[1], local_rows)      # what fp32 features become on this handle: "fp16" (scaled cast) | "exact"
+
     def tuned(hspa_packed, beside_panel):
         from voltrix.jit_kernels.spmm import feature_hash
 
         keys = {"feature_hash": feature_hash(hspa_packed), "embedding_dim": num_feats,
                 "dtype": str(torch.float16 if is_f16 else torch.float32),
                 "device": torch.cuda.get_device_name(device), "two_level": bool(beside_panel), "weighted": False}
-        if not is_f16 and os.getenv("VOLTRIX_FP32_MODE", "fp16") != "exact":
+        if not is_f16 and fp32_as == "fp16":
             keys["dtype"] = str(torch.float16)   # fp32 features run as scaled fp16
         return jit_tuner.tuned_point("spmm_kernel", keys)
 
     padded_width = (num_feats + 7) // 8 * 8
-    operand_dtype = str(torch.float16) if (is_f16 or os.getenv("VOLTRIX_FP32_MODE", "fp16") != "exact") else str(torch.float32)
+    operand_dtype = str(torch.float16) if (is_f16 or fp32_as == "fp16") else str(torch.float32)
     hybrid_env = os.getenv("VOLTRIX_HYBRID", "auto")
     if two is None or hybrid_env in ("0", "off"):
         used_two = False

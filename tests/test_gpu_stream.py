@@ -32,18 +32,25 @@ def _stream_call(handle, n, nnz, feat, tag, monkeypatch):
     return out
 
 
-@pytest.mark.parametrize("dtype,mode", [(torch.float16, "fp16"), (torch.bfloat16, "exact"), (torch.float32, "fp16-scaled")])
+@pytest.mark.parametrize("dtype,mode", [(torch.float16, "fp16"), (torch.bfloat16, "exact"), (torch.float32, "fp16-scaled"),
+                                        (torch.float32, "exact")])
 def test_stream_kernel_on_fixtures(cuda_device, csr_fixture, dtype, mode, monkeypatch):
+    """fp32 features: the scaled-fp16 operand (VOLTRIX_FP32_MODE=fp16) and -- the default on these short-window handles -- the
+    fp32 rows as they are, exact products on v_mfma_f32_16x16x4_f32 (the stream kernel's EB = 4 tiles)."""
+    if dtype == torch.float32:
+        monkeypatch.setenv("VOLTRIX_FP32_MODE", "fp16" if mode == "fp16-scaled" else "auto")
     g = csr_fixture
     n = int(g["num_nodes"])
     handle = voltrix.csr_preprocess(torch.from_numpy(g["indptr"]), torch.from_numpy(g["indices"]), n)
     feat32 = torch.from_numpy(g["feat"]).float()
     if dtype != torch.float32:
         feat32 = feat32.to(dtype).float()
-    out = _stream_call(handle, n, len(g["indices"]), feat32.to(dtype).cuda(), f"stream_fixture_{n}_{dtype}", monkeypatch)
+    out = _stream_call(handle, n, len(g["indices"]), feat32.to(dtype).cuda(), f"stream_fixture_{n}_{dtype}_{mode}", monkeypatch)
     f = feat32.shape[1]
-    padded = (f + 7) // 8 * 8
-    assert _chosen(handle[1], padded, torch.float16 if dtype == torch.float32 else dtype).get("SCHED") == SCHED_STREAM
+    exact32 = dtype == torch.float32 and mode == "exact"
+    padded = (f + 3) // 4 * 4 if exact32 else (f + 7) // 8 * 8
+    point = _chosen(handle[1], padded, dtype if (exact32 or dtype != torch.float32) else torch.float16)
+    assert point.get("SCHED") == SCHED_STREAM and point.get("EB") == (4 if exact32 else 2)
     _assert_close(out, g["indptr"], g["indices"], feat32, n, mode)
 
 
@@ -141,3 +148,39 @@ def test_stream_kernel_64_bit_addressing(cuda_device, monkeypatch):
     for r in rows.tolist():
         cols = ix[ip[r]:ip[r + 1]].cuda()
         assert torch.equal(out[r], feat[cols].float().sum(0)), r
+
+
+@pytest.mark.parametrize("name,scale,f", [("yeast_like", 0.02, 128), ("dd_like", 0.1, 200), ("com_amazon_like", 0.1, 36),
+                                          ("yeasth_like", 0.01, 32), ("web_berkstan_like", 0.05, 64)])
+def test_exact_fp32_stream_kernel(cuda_device, name, scale, f, monkeypatch):
+    """fp32 features through the stream kernel's exact tiles (forced: VOLTRIX_FP32_MODE=exact): against the fp32 oracle the only
+    error left is the accumulation order, deg 2^-23 (A |B|); integer operands are exact; values far outside fp16's range pass
+    through untouched (no cast, no scale)."""
+    monkeypatch.setenv("VOLTRIX_FP32_MODE", "exact")
+    indptr, indices, _ = synth_graphs.generate(name, scale=scale)
+    n, nnz = indptr.numel() - 1, indices.numel()
+    handle = voltrix.csr_preprocess(indptr, indices, n)
+    torch.manual_seed(f)
+    feat = torch.randn(n, f) * torch.logspace(-30, 30, n)[:, None]      # 60 decades of row scales
+    out = _stream_call(handle, n, nnz, feat.cuda(), f"stream_exact/{name}/{f}", monkeypatch)
+    assert _chosen(handle[1], (f + 3) // 4 * 4, torch.float32).get("EB") == 4
+    _assert_close(out, indptr.numpy(), indices.numpy(), feat, n, "exact")
+    ints = torch.randint(-1000, 1001, (n, f)).float()
+    out = voltrix.spmm(*handle, num_nodes=n, num_edges=nnz, feat=ints.cuda())
+    assert torch.equal(out.cpu(), torch_ref.spmm(indptr.numpy(), indices.numpy(), ints, n))
+
+
+def test_fp32_mode_auto_follows_the_handle(cuda_device, monkeypatch):
+    """Short windows (at most six gathered rows of B per output row): the fp32 rows as they are; long windows: the scaled cast."""
+    from voltrix.spmm.spmm import fp32_mode
+
+    monkeypatch.delenv("VOLTRIX_FP32_MODE", raising=False)
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "default")
+    for name, scale, want in (("yeast_like", 0.02, "exact"), ("dd_like", 0.1, "exact"), ("amazon0505_like", 0.1, "fp16"),
+                              ("reddit_like", 0.02, "fp16")):
+        indptr, indices, _ = synth_graphs.generate(name, scale=scale)
+        n = indptr.numel() - 1
+        handle = voltrix.csr_preprocess(indptr, indices, n)
+        assert fp32_mode(handle[1], n) == want, name
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    assert fp32_mode(handle[1], n) == "fp16"

@@ -28,7 +28,7 @@ def test_spmm_kernel_asserts_like_reference():
 
 
 def test_tile_space_is_valid_and_bounded(monkeypatch):
-    for mode, lo, hi in (("default", 16, 74), ("full", 36, 226), ("none", 1, 1), ("stream", 1, 1)):
+    for mode, lo, hi in (("default", 16, 74), ("full", 36, 226), ("none", 1, 1), ("stream", 1, 1)):  # fp32: + 4 stream points
         monkeypatch.setenv("VOLTRIX_TUNE_SPACE", mode)
         for f in (16, 32, 64, 128, 512):
             for eb in (2, 4):
@@ -36,10 +36,11 @@ def test_tile_space_is_valid_and_bounded(monkeypatch):
                 assert lo <= len(space) <= hi, (mode, f, eb, len(space))
                 for p in space:
                     assert spmm_mod._lds_bytes(p["FS"], p["DEPTH"], p["WAVES"], p["EB"]) <= 160 * 1024
-                    assert p["EB"] == eb and p["FS"] in (32, 64, 128, 256) and p["SCHED"] in ((0, 1, 2, 3, 4, 5, 6) if eb == 2 else (0, 1, 2, 3))
+                    assert p["EB"] == eb and p["FS"] in (32, 64, 128, 256) and p["SCHED"] in ((0, 1, 2, 3, 4, 5, 6) if eb == 2 else (0, 1, 2, 3, 6))
                     assert p["SCHED"] != 5 or (p["WAVES"] == 4 and (p["FS"] >= 64 or f <= p["FS"]))   # paired units
                     if p["SCHED"] == 6:   # stream points: loads + stores behind a counted wait fit the 6-bit vmcnt
-                        ndma, slots = 32 * p["FS"] * 2 // 1024, p["FS"] // 16
+                        ndma, slots = 32 * p["FS"] * eb // 1024, p["FS"] // 16
+                        assert eb == 2 or p["FS"] <= 64
                         assert p["WAVES"] in (1, 2) and (1 + ndma) * (p["DEPTH"] - 1) + p["DEPTH"] * slots <= 63
                 # the stream kernel serves plain stores of a binary 16-bit operand only
                 for kw in (dict(weighted=True), dict(max_lds=spmm_mod.TWO_LEVEL_LDS_BUDGET), dict(stream_ok=False)):

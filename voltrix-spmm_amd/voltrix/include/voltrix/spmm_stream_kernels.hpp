@@ -28,7 +28,7 @@
 // runs int32 [R][4] = {first unit, units, stages, 0}, run_ptr int32 [9] = the runs of every XCD (contiguous windows, equal
 // work), cuts for combine_partials (windows longer than the cut length are split into interleaved units exactly like the
 // unit table of spmm_kernels.hpp; their partial tiles are summed in unit order by the same combine pass).
-// 16-bit operands (fp16 / bf16), binary A, plain stores.
+// Binary A, plain stores; B in fp16 / bf16 (v_mfma_f32_16x16x32) or, round 5, exact fp32 (v_mfma_f32_16x16x4_f32).
 #pragma once
 
 #include "voltrix/spmm_kernels.hpp"
@@ -91,17 +91,26 @@ __device__ __forceinline__ constexpr int stream_row(int c) { return (c % NDMA) *
 // slot swizzle of that image (logical 32-byte slot s of LDS row r at physical slot s ^ stream_swizzle(r)): conflict-free
 // transposed reads at FS = 128 (rows {4 q' + g}: 8 distinct slots per 32-lane half), 2-way at FS = 64 / 32 (two lane groups of
 // a half land on rows of one parity; 8 / 4 fragment reads per stage there, LDS is not their bound)
-template <int FS>
+template <int FS, int EB = 2>
 __device__ __forceinline__ constexpr int stream_swizzle(int r) {
+  if (EB == 4)   // fp32 rows (below): lane groups g and g + 1 of a 32-lane half read rows 4 (8) apart -- two slots apart
+    return FS >= 64 ? (((r >> 2) & 3) << 1) : (((r >> 3) & 1) << 1);
   return FS >= 128 ? (((r >> 2) & 3) | ((r & 1) << 2)) : (FS == 64 ? ((r >> 3) & 3) : ((r >> 4) & 1));
 }
+// EXACT fp32 operand (EB = 4; round 5): rows of B gathered as they are (no cast pass, no power-of-two scale -- on the
+// low-degree graphs the two passes of the cast moved more bytes than the product), multiplied on v_mfma_f32_16x16x4_f32
+// (exact products of {0, 1} x fp32, fp32 accumulation: the reference rounds B to TF32, spmm_kernels.cuh:1671).  K step m of a
+// stage covers the condensed columns 4 m + g (lane group g): LDS row stream_row(4 m + g), float column 16 s + R, one
+// ds_read_b32 per (m, slot); the adjacency bit of (row R, column 4 m + g) becomes 1.0f / 0.0f with a bit-field extract and a
+// convert.  The matrix pipe runs at 1/16 of the fp16 rate there -- 32 MFMAs of 32 cycles per stage -- which is still above what
+// the memory path feeds a CU on the graphs this kernel is for.
 
 // ADDR64 = false: B is smaller than 4 GiB and has fewer than 2^24 rows -- a gathered row's address is a scalar base plus ONE
 // full-rate v_mad_u32_u24 (row * row bytes + lane constant); true: 64-bit per-lane pointers (v_mad_u64_u32), any size.
 template <class T, bool ADDR64>
 static __global__ __launch_bounds__(T::THREADS) void spmm_stream_kernel(const StreamArgs<T> a) {
-  static_assert(T::EB == 2 && !T::WEIGHTED, "stream kernel: 16-bit binary operand");
-  constexpr int FS = T::FS, D = T::DEPTH, MS = T::META_SLOTS;
+  static_assert((T::EB == 2 || (T::EB == 4 && !T::BF16 && T::FS <= 64)) && !T::WEIGHTED, "stream kernel: binary A, fp16 / bf16 / fp32 B");
+  constexpr int FS = T::FS, D = T::DEPTH, MS = T::META_SLOTS, EB = T::EB;
   constexpr int ROW_BYTES = T::ROW_BYTES, STAGE_BYTES = T::STAGE_BYTES, NDMA = T::DMA_PER_STAGE;
   constexpr int RPD = T::ROWS_PER_DMA, LPR = T::LANES_PER_ROW, SLOTS = T::SLOTS;
   constexpr int OPS = 1 + NDMA;   // vector-memory loads per step: one metadata DMA + the row DMAs
@@ -168,15 +177,32 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_stream_kernel(const St
   const int q = lane / LPR;                  // lane group of the row DMAs: LDS row i * RPD + q, condensed column NDMA * q + i
   const unsigned a_shift = 4 * (R & 7);
   const int mj = (lane - 32) & 15;
-  unsigned tr_base;
-  int tr_delta[4];
+  unsigned tr_base = 0;
+  int tr_delta[4] = {0, 0, 0, 0};
   constexpr int TR_SECOND = (stream_row<NDMA, RPD>(4) - stream_row<NDMA, RPD>(0)) * ROW_BYTES;   // column c + 4 after column c
   static_assert(stream_row<NDMA, RPD>(13) - stream_row<NDMA, RPD>(9) == stream_row<NDMA, RPD>(4) - stream_row<NDMA, RPD>(0), "lane-invariant");
-  {
+  // fp32 operand: lane (g, R) reads float column 16 s + R of the LDS row of condensed column 4 m + g.  That row is
+  // F32_LANE_ROW * g + f32_row_const(m) in both geometries, its swizzle 2 gx (gx = g, or g & 1 at 128-byte rows), so the byte
+  // address is a per-slot lane base + an immediate of m
+  constexpr int F32_LANE_ROW = NDMA == 8 ? 4 : 8;
+  unsigned f32_base[SLOTS];
+  unsigned aword_base = 0, a_bit = 0;
+  if constexpr (EB == 4) {
+    static_assert(NDMA == 8 || NDMA == 4, "fp32 rows of 256 or 128 bytes");
+    const int gx = NDMA == 8 ? g : (g & 1);
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      f32_base[s] = lds0 + (unsigned)(F32_LANE_ROW * g) * ROW_BYTES + 64u * (unsigned)(s ^ gx) + 4u * (unsigned)R;
+      asm volatile("" : "+v"(f32_base[s]));
+    }
+    aword_base = 128 + 4 * (R >> 3);      // words (R >> 3) and 2 + (R >> 3) of every TC block of the stage
+    a_bit = 4 * (R & 7) + g;              // bit of (row R, column 4 (m & 1) + g of block m >> 1) in word (R >> 3) + 2 (m & 1)
+  }
+  if constexpr (EB == 2) {
     const int trow = stream_row<NDMA, RPD>(8 * g + ((lane >> 2) & 3));
-    const int tr_z = stream_swizzle<FS>(trow);
-    static_assert(stream_swizzle<FS>(stream_row<NDMA, RPD>(4)) == stream_swizzle<FS>(stream_row<NDMA, RPD>(0)) &&
-                  stream_swizzle<FS>(stream_row<NDMA, RPD>(15)) == stream_swizzle<FS>(stream_row<NDMA, RPD>(11)),
+    const int tr_z = stream_swizzle<FS, 2>(trow);
+    static_assert(EB != 2 || (stream_swizzle<FS, 2>(stream_row<NDMA, RPD>(4)) == stream_swizzle<FS, 2>(stream_row<NDMA, RPD>(0)) &&
+                              stream_swizzle<FS, 2>(stream_row<NDMA, RPD>(15)) == stream_swizzle<FS, 2>(stream_row<NDMA, RPD>(11))),
                   "the second fragment read shares the first one's swizzle");
     tr_base = lds0 + trow * ROW_BYTES + 8 * (lane & 3) + (tr_z << 5);
 #pragma unroll
@@ -211,19 +237,20 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_stream_kernel(const St
   // swizzle (LDS-DMA writes are lane-linear); the swizzle of row i * RPD + q repeats with period 4 in i, so four lane constants
   // serve all DMAs, and the four DMAs of a 4-KiB group share one M0 through the instruction's immediate offset (which is added
   // to the global address as well: the base is pre-decremented by it).
-  const unsigned row_bytes = (unsigned)F * 2u;
+  const unsigned row_bytes = (unsigned)F * (unsigned)EB;
   constexpr int NBASE = NDMA < 4 ? NDMA : 4;
-  static_assert(stream_swizzle<FS>(4 * RPD + 1) == stream_swizzle<FS>(1) || NDMA <= 4, "period of the row swizzle");
+  constexpr int CPS = 32 / EB;   // columns per 32-byte slot
+  static_assert(stream_swizzle<FS, EB>(4 * RPD + 1) == stream_swizzle<FS, EB>(1) || NDMA <= 4, "period of the row swizzle");
   unsigned lanecol[NBASE];      // byte offset of the lane's chunk inside the slab (ADDR64 = false)
   const char* cbase[NBASE];     // per-lane 64-bit bases (ADDR64 = true)
 #pragma unroll
   for (int i = 0; i < NBASE; ++i) {
     const int r = i * RPD + q;
     const int c = lane % LPR;
-    int col = fs0 + (((c >> 1) ^ stream_swizzle<FS>(r)) * 16) + (c & 1) * 8;
+    int col = fs0 + (((c >> 1) ^ stream_swizzle<FS, EB>(r)) * CPS) + (c & 1) * (CPS / 2);
     col = col < F ? col : fs0;
-    lanecol[i] = (unsigned)(col - fs0) * 2u;
-    unsigned long long cb = (unsigned long long)((const char*)a.input + ((long long)col * 2 - (i & 3) * 1024));
+    lanecol[i] = (unsigned)(col - fs0) * (unsigned)EB;
+    unsigned long long cb = (unsigned long long)((const char*)a.input + ((long long)col * EB - (i & 3) * 1024));
     if constexpr (ADDR64) {
       asm volatile("" : "+v"(cb));
     } else {
@@ -236,7 +263,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_stream_kernel(const St
   unsigned long long sbase[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    sbase[k] = (unsigned long long)((const char*)a.input + (long long)fs0 * 2 - k * 1024);
+    sbase[k] = (unsigned long long)((const char*)a.input + (long long)fs0 * EB - k * 1024);
     asm volatile("" : "+s"(sbase[k]));
   }
   auto issue_data = [&](int dslot, const int (&hr)[NDMA]) {
@@ -397,10 +424,57 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_stream_kernel(const St
 
     const unsigned mt = meta0 + mslot * T::META_BYTES;
     const unsigned md = meta0 + mslot_d * T::META_BYTES;
+    int hr[NDMA];
+    if constexpr (EB == 4) {
+      // ---- exact fp32: the stage's adjacency words (two per TC block), row ids of stage t + D, 8 x SLOTS floats of B ---------
+      unsigned aw[4][2];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        aw[b][0] = lds_read_b32(mt + aword_base + 16 * b);
+        aw[b][1] = lds_read_b32(mt + aword_base + 16 * b + 8);
+      }
+      read_rows(md, hr);
+      float bv[8][SLOTS];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const unsigned off = (unsigned)((NDMA == 8 ? 16 * (m & 1) + (m >> 1) : m) * ROW_BYTES) + (unsigned)dslot * STAGE_BYTES;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) bv[m][s] = lds_read_f32(f32_base[s] + off);
+      }
+      wait_lgkmcnt0();
+      stamp(2);
+      fix_rows(cr, hr);
+      float av[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        unsigned word = aw[m >> 1][m & 1];
+        if (cc.blk + (m >> 1) >= cc.end) word = 0u;   // TC blocks past the window's end contribute zero
+        av[m] = (float)((word >> a_bit) & 1u);
+      }
+      const bool any_edge = cc.ncl != 0;
+      issue_meta(cm, mslot_2d);
+      issue_data(dslot, hr);
+      stamp(3);
+      // operands swapped as in the 16-bit path: D'[column 4 g + j of the slot][row R]
+      if (fresh) {   // wave-uniform
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+          acc[s] = any_edge ? __builtin_amdgcn_mfma_f32_16x16x4f32(bv[0][s], av[0], float4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0)
+                            : float4_t{0.f, 0.f, 0.f, 0.f};
+      } else if (any_edge) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[0][s], av[0], acc[s], 0, 0, 0);
+      }
+      if (any_edge) {
+#pragma unroll
+        for (int m = 1; m < 8; ++m)
+#pragma unroll
+          for (int s = 0; s < SLOTS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[m][s], av[m], acc[s], 0, 0, 0);
+      }
+    } else {
     // A words of stage t (requested first), row ids of stage t + D, B fragments of stage t: one LDS round trip
     const unsigned wlo = lds_read_b32(mt + 128 + 4 * (4 * g + (R >> 3)));
     const unsigned whi = lds_read_b32(mt + 128 + 4 * (4 * g + 2 + (R >> 3)));
-    int hr[NDMA];
     read_rows(md, hr);
 
     unsigned taddr[SLOTS];
@@ -455,6 +529,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_stream_kernel(const St
 #pragma unroll
       for (int s = 0; s < SLOTS; ++s) acc[s] = mfma(s, acc[s]);
     }
+    }
     fresh = false;
     stamp(4);
     int stored = 0;
@@ -497,12 +572,12 @@ inline int launch_spmm_stream(const uint32_t* hspa_packed, const int* hind, int 
                               const int* runs /* int32[R][4] */, const int* run_ptr /* int32[9] */, int max_runs_per_xcd,
                               float* partials, const float* out_scale = nullptr, int slab_first = 0, int slab_count = 0,
                               long long input_rows = 0, int slab_policy = kSlabAuto) {
-  if constexpr (T::EB != 2 || T::WEIGHTED) {
-    return kErrBadConfig;   // 16-bit binary operand only (the tuner never asks for anything else)
+  if constexpr (T::WEIGHTED || T::FS > 128 || (T::EB == 4 && (T::FS > 64 || T::BF16))) {
+    return kErrBadConfig;   // binary A; fp16 / bf16 slabs up to 128 columns, fp32 slabs up to 64 (the tuner never asks for more)
   } else {
   if (num_nodes < 0 || embedding_dim < 0 || max_runs_per_xcd < 0) return kErrBadShape;
   if (num_nodes == 0 || embedding_dim == 0 || max_runs_per_xcd == 0) return kOk;
-  if (embedding_dim % 8 != 0) return kErrBadShape;
+  if (embedding_dim % (16 / T::EB) != 0) return kErrBadShape;
   if (((uintptr_t)input & 15) || ((uintptr_t)hspa_packed & 15) || ((uintptr_t)units & 15) || ((uintptr_t)runs & 15) ||
       ((uintptr_t)output & 15) || ((uintptr_t)partials & 15) || run_ptr == nullptr)
     return kErrBadShape;
@@ -540,7 +615,7 @@ inline int launch_spmm_stream(const uint32_t* hspa_packed, const int* hind, int 
   const long long grid = blocks_per_xcd * kNumXcd;
   if (grid > 0x7FFFFFFFll) return kErrBadShape;
   const long long b_rows = input_rows > 0 ? input_rows : (long long)num_nodes;
-  const bool small_b = b_rows < (1ll << 24) && b_rows * embedding_dim * 2 < (1ll << 32) - 8192 && embedding_dim * 2 < (1 << 24);
+  const bool small_b = b_rows < (1ll << 24) && b_rows * embedding_dim * T::EB < (1ll << 32) - 8192 && embedding_dim * T::EB < (1 << 24);
   if (small_b) {
     const int lds_rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&spmm_stream_kernel<T, false>), T::BLOCK_LDS);
     if (lds_rc != kOk) return lds_rc;

@@ -159,8 +159,7 @@ def tile_space(embedding_dim: int, elem_bytes: int, bf16: bool = False, max_lds:
 
 def _tile_space(embedding_dim: int, elem_bytes: int):
     mode = tune_space_mode()
-    if mode == "stream" and elem_bytes != 2:   # the stream kernel's own mode: operands it does not serve take the default tile
-        mode = "none"
+    fs4 = 32 if embedding_dim <= 32 else 64     # fp32 rows: slabs of 128 or 256 bytes
     fs_max = 128
     fs_fit = 32 if embedding_dim <= 32 else (64 if embedding_dim <= 64 else fs_max)
     if mode == "none":  # the ahead-of-time library's default tile (csrc/capi_common.hpp::default_tile) + unit table
@@ -168,7 +167,9 @@ def _tile_space(embedding_dim: int, elem_bytes: int):
         if elem_bytes == 4:
             return ({"FS": min(fs, 64), "DEPTH": 3, "WAVES": 1, "EB": 4, "SCHED": 2},)
         return ({"FS": fs, "DEPTH": 4 if fs == 32 else 3, "WAVES": 4, "EB": 2, "SCHED": SCHED_UNITS},)
-    if mode == "stream" and elem_bytes == 2:   # the stream kernel's default point alone (tests, experiments)
+    if mode == "stream":   # the stream kernel's default point alone (tests, experiments)
+        if elem_bytes == 4:
+            return ({"FS": fs4, "DEPTH": 3, "WAVES": 1, "EB": 4, "SCHED": SCHED_STREAM},)
         return ({"FS": fs_fit, "DEPTH": 3 if fs_fit >= 128 else 4, "WAVES": 1, "EB": 2, "SCHED": SCHED_STREAM},)
     if mode == "full":
         fs_list = sorted({fs_fit, max(32, fs_fit // 2), min(256, fs_fit * 2) if embedding_dim > 128 else fs_fit})
@@ -188,11 +189,12 @@ def _tile_space(embedding_dim: int, elem_bytes: int):
                         scheds += (SCHED_PAIRS,)   # two units per wave (several slabs: slab-major order, i.e. slabs >= 128 bytes)
                     for sched in scheds:
                         space.append({"FS": fs, "DEPTH": d, "WAVES": w, "EB": elem_bytes, "SCHED": sched})
-    if elem_bytes == 2:   # stream points: the full-width slab, one or two waves per workgroup (LDS decides the waves per CU)
-        for w in (1, 2):
-            for d in (2, 3, 4):
-                if (1 + 32 * fs_fit * 2 // 1024) * (d - 1) + d * (fs_fit // 16) <= 63:   # loads + stores behind a wait
-                    space.append({"FS": fs_fit, "DEPTH": d, "WAVES": w, "EB": 2, "SCHED": SCHED_STREAM})
+    # stream points: the full-width slab, one or two waves per workgroup (LDS decides the waves per CU); fp32 rows: exact products
+    fs_s = fs_fit if elem_bytes == 2 else fs4
+    for w in (1, 2):
+        for d in (2, 3, 4) if elem_bytes == 2 else (2, 3):
+            if (1 + 32 * fs_s * elem_bytes // 1024) * (d - 1) + d * (fs_s // 16) <= 63:   # loads + stores behind a wait
+                space.append({"FS": fs_s, "DEPTH": d, "WAVES": w, "EB": elem_bytes, "SCHED": SCHED_STREAM})
     return tuple(space)
 
 

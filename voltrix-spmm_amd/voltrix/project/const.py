@@ -19,7 +19,7 @@ PRINT_AUTOTUNE_FLAG = "VOLTRIX_PRINT_AUTO_TUNE"
 # gfx950 additions -- with the six above, the WHOLE switch surface of the package (INTEGRATION.md lists them with their
 # meaning; nothing else is read from the environment, and the native library reads nothing at all)
 HIPCC_COMPILER_FLAG = "VOLTRIX_HIPCC_COMPILER"        # path of hipcc (default /opt/rocm/bin/hipcc)
-FP32_MODE_FLAG = "VOLTRIX_FP32_MODE"                  # "fp16" (default: cast, fp16 MFMA) | "exact" (fp32 MFMA)
+FP32_MODE_FLAG = "VOLTRIX_FP32_MODE"                  # "auto" (default: by the handle) | "fp16" (scaled cast, fp16 MFMA) | "exact" (fp32 MFMA)
 PREPROCESS_FLAG = "VOLTRIX_PREPROCESS"                # "fused" (default, GPU) | "fused:sort|bitmap|mixed" | "reference" (CPU + 2 kernels)
 TUNE_SPACE_FLAG = "VOLTRIX_TUNE_SPACE"                # "default" | "full" | "none"
 TUNED_STORE_FLAG = "VOLTRIX_TUNED_STORE"              # file of persisted tile choices (default <cache dir>/tuned.json)

@@ -158,13 +158,41 @@ def csr_preprocess_hybrid(indptr: torch.Tensor, indices: torch.Tensor, num_nodes
     return two
 
 
-def _operand(feat: torch.Tensor):
-    """``feat`` -> (operand for the kernels, out_scale or None, padded width, exact-fp32 flag)."""
+# fp32 features, VOLTRIX_FP32_MODE=auto (the default since round 5): a handle of SHORT windows -- at most this many gathered rows
+# of B per output row -- multiplies the fp32 rows as they are (exact products on v_mfma_f32_16x16x4_f32: the stream kernel's
+# EB = 4 tiles); every other handle casts B to fp16 with one power-of-two scale per call.  The cast is two passes over B (an
+# absolute maximum, then the conversion: 10 bytes per element); on the low-degree graphs of the reference's evaluation set that
+# was more traffic than the product itself (YeastH-like F = 128: 0.80 ms of cast in front of a 0.52 ms product), while gathering
+# fp32 rows only doubles the gathered bytes.  Measured break-even: between 5.7 (com-amazon-like: exact wins) and 8.6
+# (amazon0601-like: the cast wins) gathered rows per output row.
+EXACT_FP32_MAX_GATHERED_ROWS_PER_ROW = 6.0
+
+
+def fp32_mode(hspa_packed: torch.Tensor = None, num_nodes: int = 0) -> str:
+    """``VOLTRIX_FP32_MODE``: ``fp16`` (scaled cast), ``exact`` (fp32 rows, exact products) or ``auto`` (default: by the handle,
+    above) -> "fp16" | "exact".  No host sync: the TC-block count is the size of ``hspa_packed``."""
+    mode = os.getenv(FP32_MODE_FLAG, "auto")
+    assert mode in ("fp16", "exact", "auto"), f"{FP32_MODE_FLAG}={mode}"
+    if mode != "auto":
+        return mode
+    from ..jit_kernels.spmm import tune_space_mode
+
+    if tune_space_mode() == "none":        # the untuned default tiles: the round-4 behaviour
+        return "fp16"
+    if hspa_packed is None or num_nodes <= 0 or sidecar.lookup(hspa_packed)[1] is not None:
+        return "fp16"
+    gathered_rows = 2.0 * hspa_packed.numel()           # 8 per TC block = 8 x numel / 4
+    return "exact" if gathered_rows <= EXACT_FP32_MAX_GATHERED_ROWS_PER_ROW * num_nodes else "fp16"
+
+
+def _operand(feat: torch.Tensor, mode: str = None):
+    """``feat`` -> (operand for the kernels, out_scale or None, padded width, exact-fp32 flag).  ``mode``: what fp32 features
+    become ("fp16" | "exact"; default: the environment's, ``auto`` counting as fp16 -- callers with a handle decide with it)."""
     assert feat.is_cuda and feat.dim() == 2
     feat = feat.contiguous()
     num_feats = feat.shape[1]
     assert feat.dtype in (torch.float32, torch.float16, torch.bfloat16), f"unsupported feature dtype {feat.dtype}"
-    exact = feat.dtype == torch.float32 and os.getenv(FP32_MODE_FLAG, "fp16") == "exact"
+    exact = feat.dtype == torch.float32 and (mode or fp32_mode()) == "exact"
     align = 4 if exact else 8
     padded = (num_feats + align - 1) // align * align
     if padded != num_feats:  # keep gathered rows 16-byte aligned
@@ -184,14 +212,15 @@ def spmm(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tenso
     """``csr(ones) @ feat`` -> new float32 ``[num_nodes, F]`` on ``feat.device``, on the current stream.
 
     ``feat``: CUDA, 2-D, contiguous; float32 (the reference's only dtype, jit_kernels/spmm.py:53), float16
-    (BASELINE.json's headline) or bfloat16.  float32 is rounded to fp16 for the MFMA -- the same 10-bit mantissa as the
-    reference's TF32 rounding (spmm_kernels.cuh:1671), after a per-call power-of-two rescale that keeps fp32's range --
-    unless ``VOLTRIX_FP32_MODE=exact``, which keeps exact fp32 products.  Every output row is written, including the
+    (BASELINE.json's headline) or bfloat16.  float32 (``VOLTRIX_FP32_MODE``, default ``auto``): handles of short windows
+    multiply the fp32 rows as they are -- exact products, no cast pass (``fp32_mode``) -- every other handle rounds B to fp16
+    for the MFMA -- the same 10-bit mantissa as the reference's TF32 rounding (spmm_kernels.cuh:1671), after a per-call
+    power-of-two rescale that keeps fp32's range; ``fp16`` / ``exact`` force either.  Every output row is written, including the
     ``num_nodes % 16`` tail the reference skips.  When ``csr_preprocess`` attached the two-level side-car to this very
     ``hspa_packed`` tensor, the 16-bit-operand product runs in that form (same result up to fp32 summation order).
     """
     num_feats = feat.shape[1]
-    operand, out_scale, padded, exact = _operand(feat)
+    operand, out_scale, padded, exact = _operand(feat, fp32_mode(hspa_packed, num_nodes) if feat.dtype == torch.float32 else None)
     output = torch.empty((num_nodes, padded), dtype=torch.float32, device=feat.device)
     known, two = sidecar.lookup(hspa_packed)
     mode = hybrid.hybrid_mode()
