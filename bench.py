@@ -80,6 +80,10 @@ def parse_args():
     ap.add_argument("--slabs", type=int, default=1,
                     help="N > 1: exchange and multiply B in this many feature slabs (gather of slab j+1 beside the SpMM of "
                          "slab j) instead of overlapping whole steps")
+    ap.add_argument("--weighted", action="store_true",
+                    help="N = 1: the WEIGHTED product (voltrix.csr_preprocess_weighted / spmm_weighted; SURVEY.md 8f rank 4, no "
+                         "reference counterpart) with the symmetric-normalised adjacency of a GCN layer as values, a_ij = "
+                         "1 / sqrt(out-degree(i) x in-degree(j)); algorithmic bytes then count 4 more bytes per edge (fp32 values)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (process group, sharded operator, all-gather, barriers) also at world "
                          "size 1: rehearses the RCCL calls of the scaling run on a one-GPU box")
@@ -316,6 +320,13 @@ def main():
     # ---- this rank's OWN device-resident shard (no full graph anywhere, no host round trip) -- the advertised class IS the
     # ---- measured one
     op = None
+    whandle = edge_values = None
+    if args.weighted:
+        assert not distributed, "--weighted is a single-GPU run"
+        d_out = (local_indptr[1:] - local_indptr[:-1]).float().clamp(min=1)
+        d_in = torch.bincount(local_indices.long(), minlength=num_cols).float().clamp(min=1)
+        edge_values = torch.repeat_interleave(d_out.rsqrt(), (local_indptr[1:] - local_indptr[:-1]).long()) * d_in.rsqrt()[local_indices.long()]
+        del d_out, d_in
     preprocess_ms = None
     for _ in range(2):   # first call pays library load / allocator warm-up; report the second (host wall clock, sync'd)
         torch.cuda.synchronize()
@@ -325,6 +336,9 @@ def main():
                                                  mode="collective" if args.gather == "auto" else args.gather,
                                                  slabs=args.slabs, exchange_at_world_1=args.force_dist)
             handle = op.handle
+        elif args.weighted:
+            whandle = voltrix.csr_preprocess_weighted(local_indptr, local_indices, edge_values, local_rows, num_cols=num_cols)
+            handle = (whandle.blk_offsets, whandle.hspa_packed, whandle.hind)
         else:
             handle = voltrix.csr_preprocess_device(local_indptr, local_indices, local_rows, num_cols=num_cols)
         torch.cuda.synchronize()
@@ -373,6 +387,8 @@ def main():
         """The operator call of a drop-in caller (allocates its output, like the reference's spmm.py:101)."""
         if op is not None:
             out_holder[0] = op.multiply(b)      # = voltrix.spmm(*op.handle, ...) on the gathered B
+        elif whandle is not None:
+            out_holder[0] = voltrix.spmm_weighted(whandle, b)
         else:
             out_holder[0] = voltrix.spmm(*handle, num_nodes=local_rows, num_edges=local_nnz, feat=b)
 
@@ -486,8 +502,9 @@ def main():
         e1 = min(local_nnz, e0 + row_of_edge_chunk)
         cols = check_indices[e0:e1].long()
         rows = torch.searchsorted(ip64, torch.arange(e0, e1, device=device), right=True) - 1
-        want.index_add_(0, rows, col_sums[cols])
-        scale.index_add_(0, rows, col_abs[cols])
+        w_e = edge_values[e0:e1] if edge_values is not None else 1.0
+        want.index_add_(0, rows, col_sums[cols] * w_e)
+        scale.index_add_(0, rows, col_abs[cols] * w_e)
         del cols, rows
     got = torch.zeros(local_rows, dtype=torch.float32, device=device)
     for q in range(0, local_rows, 1 << 22):
@@ -524,7 +541,7 @@ def main():
 
         keys = {"feature_hash": feature_hash(hspa_packed), "embedding_dim": num_feats,
                 "dtype": str(torch.float16 if is_f16 else torch.float32),
-                "device": torch.cuda.get_device_name(device), "two_level": bool(beside_panel), "weighted": False}
+                "device": torch.cuda.get_device_name(device), "two_level": bool(beside_panel), "weighted": bool(args.weighted)}
         if not is_f16 and fp32_as == "fp16":
             keys["dtype"] = str(torch.float16)   # fp32 features run as scaled fp16
         return jit_tuner.tuned_point("spmm_kernel", keys)
@@ -658,7 +675,8 @@ def main():
         flop = synth_graphs.flops(nnz, num_feats)
         # roofline of the step's kernels, per step on THIS rank's shard:
         # algorithmic bytes = int32 CSR once + B once + C once
-        alg_bytes = 4 * (local_nnz + local_rows + 1) + gathered.shape[0] * num_feats * in_bytes + local_rows * num_feats * 4
+        alg_bytes = ((8 if args.weighted else 4) * local_nnz + 4 * (local_rows + 1) + gathered.shape[0] * num_feats * in_bytes
+                     + local_rows * num_feats * 4)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         if used_two:   # rows actually gathered: 8 per residual TC block + 32 per k-step of the panel plan
             resid_blocks = int(two.blk_offsets[-1])
@@ -681,7 +699,9 @@ def main():
                        + (" ; combine_panel_partials_kernel" if two.plan.parts is not None and two.plan.parts.num_slots else ""))
         else:
             gather_bytes = 8 * total_blocks * num_feats * in_bytes  # rows gathered from L2 / Infinity Cache / HBM
-            fmt = {"format": "window (the reference's block format)"}
+            fmt = {"format": "window (the reference's block format)" + (
+                " + value plane [T, 16, 8] in the operand's 16-bit type (voltrix/weighted.py: 256 B per TC block, fetched by one "
+                "more LDS-DMA per stage; values = symmetric-normalised adjacency)" if args.weighted else "")}
             kernels = ("spmm_tc16_pair_kernel" if point.get("SCHED") == SCHED_PAIRS else
                        ("spmm_stream_kernel" if point.get("SCHED") == SCHED_STREAM else "spmm_tc16_kernel")) + (
                 " ; combine_partials_kernel" if point.get("SCHED") in (SCHED_UNITS, SCHED_PAIRS, SCHED_STREAM) else "")
@@ -689,7 +709,7 @@ def main():
                      "schedule": sched_name(point),
                      # wide operands: one launch per 256-byte group of column slabs (spmm_kernels.hpp::slab_launch_group)
                      "launches_per_step": slab_launches(num_feats, point.get("FS") or 128, in_bytes, num_nodes)}
-        counter_key = (f"{workload}|F{num_feats}|{args.dtype}|{'two-level' if used_two else 'window'}|"
+        counter_key = (f"{workload}{'+values' if args.weighted else ''}|F{num_feats}|{args.dtype}|{'two-level' if used_two else 'window'}|"
                        f"{point.get('FS')},{point.get('DEPTH')},{point.get('WAVES')}|sched{point.get('SCHED')}")
         from voltrix.jit.compiler import get_kernel_sources_version
 

@@ -332,3 +332,36 @@ def test_powerlaw_4m_f256_stated_tolerance(cuda_device):
 def test_papers_like_f128_stated_tolerance(cuda_device):
     """BASELINE config 5 on one GPU: B = 28 GB, C = 57 GB; the sampled rows reference rows of B all over it."""
     _stated_tolerance_window("papers_like", 128, 24, 111059956)
+
+
+def test_weighted_reddit_like_f128_stated_tolerance(cuda_device, monkeypatch):
+    """The weighted product (voltrix/weighted.py; no reference counterpart) at the headline size: values = the symmetric-
+    normalised adjacency, random fp16 B, sampled rows (degree up to 21 k) against torch.sparse.mm with fp32 values on the CPU.
+    A and B are both rounded to fp16: |out - ref| <= (2^-10 + deg 2^-23) (|A| |B|) + deg 2^-25 max|a|, norm-wise <= 1e-3."""
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    indptr, indices = _graph("reddit_like")
+    n, e, f = indptr.numel() - 1, indices.numel(), 128
+    deg = (indptr[1:] - indptr[:-1]).long()
+    d_out = deg.float().clamp(min=1)
+    d_in = torch.bincount(indices.long(), minlength=n).float().clamp(min=1)
+    values = torch.repeat_interleave(d_out.rsqrt(), deg) * d_in.rsqrt()[indices.long()]
+    handle = voltrix.csr_preprocess_weighted(indptr, indices, values, n)
+    feat = _random_fp16(n, f, 31)
+    out = voltrix.spmm_weighted(handle, feat, hash_tag="stated_tolerance_weighted_reddit")
+    rows = _sample_rows(indptr, n, 31)
+    sub_ptr, sub_idx, b_sub = _sub_problem(indptr, indices, rows, feat)
+    ip = indptr.long()
+    cnt = ip[rows + 1] - ip[rows]
+    pos = (torch.arange(int(cnt.sum()), device="cuda") - torch.repeat_interleave(torch.cumsum(cnt, 0) - cnt, cnt)
+           + torch.repeat_interleave(ip[rows], cnt))
+    v_sub = values[pos].cpu()
+    k = rows.numel()
+    a32 = torch.sparse_csr_tensor(sub_ptr, sub_idx, v_sub, size=(k, b_sub.shape[0]))
+    ref = (a32 @ b_sub).double().numpy()                                   # torch.sparse.mm with values: the oracle
+    aabs = (torch.sparse_csr_tensor(sub_ptr, sub_idx, v_sub.abs().double(), size=(k, b_sub.shape[0])) @ b_sub.abs().double()).numpy()
+    dg = np.diff(sub_ptr.numpy().astype(np.int64)).astype(np.float64)[:, None]
+    got = out[rows].double().cpu().numpy()
+    err = np.abs(got - ref)
+    assert not np.isnan(got).any() and int(dg.max()) > 15000
+    assert (err <= (2.0 ** -10 + dg * 2.0 ** -23) * aabs + dg * 2.0 ** -25 * float(v_sub.abs().max()) + 1e-30).all()
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-3
