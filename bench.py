@@ -295,7 +295,7 @@ def main():
     workload = args.workload or ("reddit_like" if world == 1 else "papers_like")
     config_index = {"cora_like": 0, "reddit_like": 1, "reddit_uniform": 1, "reddit_shuffled": 1, "reddit_sbm": 1,
                     "reddit_sbm_shuffled": 1, "products_like": 2,
-                    "products_shuffled": 2, "powerlaw_4m": 3, "papers_like": 4}[workload]
+                    "products_shuffled": 2, "powerlaw_4m": 3, "papers_like": 4}.get(workload)
     cfg = synth_graphs._resolve(workload)    # label-shuffled variants inherit their base config
     num_feats = args.feat or cfg["feat"]
     is_f16 = args.dtype == "f16"
@@ -730,8 +730,10 @@ def main():
             "dtype": "f16" if is_f16 else "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{workload}: N={num_nodes} nnz={nnz} (BASELINE.json configs[{config_index}] "
-                            f"stand-in, SURVEY.md 8d generator, seed {cfg['seed']}, exact degrees) x dense F={num_feats} "
+                "workload": f"{workload}: N={num_nodes} nnz={nnz} ("
+                            + (f"BASELINE.json configs[{config_index}] stand-in, SURVEY.md 8d generator" if config_index is not None
+                               else "stand-in for a graph of the reference's evaluation set, bench/plot.py:8; synth_graphs.py")
+                            + f", seed {cfg['seed']}, exact degrees) x dense F={num_feats} "
                             f"{'fp16' if is_f16 else 'fp32'} -> fp32",
                 "num_nodes": num_nodes, "nnz": nnz, "feat": num_feats, "tc_blocks_rank0": total_blocks,
                 "timed_call": "voltrix.spmm(*csr_preprocess handle, ...) -- the drop-in operator, output allocation included",

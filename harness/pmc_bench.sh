@@ -16,7 +16,7 @@ for CTRS in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_
 done
 python3 - <<PY
 import csv, glob, collections, json
-KEEP = ('spmm_tc16_kernel', 'spmm_tc16_pair_kernel', 'spmm_panel_kernel', 'spmm_fused_kernel', 'add_inplace_f32_kernel', 'combine_partials_kernel', 'FillFunctor<float>')
+KEEP = ('spmm_tc16_kernel', 'spmm_tc16_pair_kernel', 'spmm_stream_kernel', 'spmm_panel_kernel', 'spmm_fused_kernel', 'add_inplace_f32_kernel', 'combine_partials_kernel', 'FillFunctor<float>')
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob("$OUT/pass*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):

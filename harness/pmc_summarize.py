@@ -29,14 +29,16 @@ def main():
     fmt = cfg["sparse_format"]["format"]
     two_level = fmt.startswith("two-level")
     pair = "two units per wave" in (tile.get("schedule") or "")
+    stream = "stream of stages" in (tile.get("schedule") or "")
     tile_sig = f"SpmmTile<{tile['fs']}, {tile['depth']}, {tile['waves']},"
-    wanted = {("spmm_tc16_pair_kernel" if pair else "spmm_tc16_kernel<"): tile_sig, "combine_partials_kernel": "", "combine_panel_partials_kernel": "" if two_level else None,
+    wanted = {("spmm_tc16_pair_kernel" if pair else ("spmm_stream_kernel" if stream else "spmm_tc16_kernel<")): tile_sig, "combine_partials_kernel": "", "combine_panel_partials_kernel": "" if two_level else None,
               "spmm_panel_kernel": "" if two_level else None, "FillFunctor<float>": "" if two_level else None,
               "spmm_fused_kernel": ""}
 
     # wide operands: the window and panel kernels are launched once per group of column slabs (config.tile.launches_per_step)
     per_step = int(tile.get("launches_per_step", 1))
-    launches = {"spmm_tc16_pair_kernel": per_step, "spmm_tc16_kernel": per_step, "spmm_panel_kernel": per_step}
+    launches = {"spmm_tc16_pair_kernel": per_step, "spmm_tc16_kernel": per_step, "spmm_panel_kernel": per_step,
+                "spmm_stream_kernel": per_step}
 
     def role(name):
         for key, sig in wanted.items():
