@@ -336,7 +336,8 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_stream_kernel(const St
       dst = a.partials + ((long long)slot * kBlkH + R) * (long long)F;
       ok = true;
     } else {
-      const int row = win * kBlkH + R;
+      int row = win * kBlkH + R;
+      if (VOLTRIX_STREAM_DIAG & 32) row = (win & 255) * kBlkH + R;   // diagnostic: every store into the first 4096 rows of C
       ok = row < a.num_nodes;
       dst = a.output + (long long)row * F;
     }

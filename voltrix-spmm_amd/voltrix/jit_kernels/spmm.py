@@ -81,6 +81,7 @@ SCHED_PAIRS = 5
 # stores, and needs neither a prologue per window nor a 4-byte-per-lane epilogue -- the kernel for the short windows of the
 # reference's low-degree evaluation graphs.  16-bit binary operand, plain stores to C (no row map, no atomics).
 SCHED_STREAM = 6
+STREAM_MAX_BLOCKS_PER_WINDOW = 48   # 12 stages per window on average (the evaluation set's low-degree graphs: 3-30 TC blocks)
 PAIR_UNIT_FACTOR = 1.25   # x the median window length (measured: 1.0 .. 1.5 within 1 %, profiles/r02/experiment_pair_units.log)
 
 # How an operand wider than the tile's slab is launched (spmm_kernels.hpp::slab_launch_group): -1 = the library's rule (one
@@ -563,9 +564,14 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
     if values is not None:
         assert values.is_cuda and values.dtype == input.dtype and elem_bytes == 2 and values.is_contiguous()
         assert values.numel() * 4 == hspa_packed.numel() * 128, "value plane: 128 values per TC block"
+    # the stream kernel is a candidate for handles of SHORT windows only (at most STREAM_MAX_BLOCKS_PER_WINDOW TC blocks per
+    # window on average; the TC-block count is the size of hspa_packed: no host sync).  On the HBM-resident graphs of long windows
+    # the sweep's SAMPLE ranks it first and the full-size step loses 2-13 % to the half-width window tiles (products-like F = 128
+    # 3.74 vs 3.30 ms, F = 512 14.8 vs 13.5, papers-like 64.4 vs 62.2, power-law 117.8 vs 112.0: profiles/r05/retune_with_stream_points.log)
+    short_windows = hspa_packed.numel() // 4 <= STREAM_MAX_BLOCKS_PER_WINDOW * ((num_nodes + 15) // 16)
     space = tile_space(embedding_dim, elem_bytes, input.dtype == torch.bfloat16,
                        TWO_LEVEL_LDS_BUDGET if beside_panel else None, weighted=values is not None,
-                       stream_ok=not atomic_out and row_map is None)
+                       stream_ok=not atomic_out and row_map is None and (short_windows or tune_space_mode() == "stream"))
     keys = {
         "feature_hash": feature_hash(hspa_packed),
         "embedding_dim": embedding_dim,
