@@ -613,7 +613,7 @@ def main():
             extras["timed_step"] = ("dependent: all-gather(B), then the product that consumes it, on one stream; the next step "
                                     "starts when this one's product is done" if not overlap_timed else
                                     "independent products: the all-gather of step k + 1 beside the product of step k")
-        # what the step should take on a fully connected xGMI node, to read the measured one against
+        # what the step should take on a fully connected xGMI node (profiles/HISTORY.md section 6), to read the measured one against
         extras["predicted_ms"] = {k: round(v, 3) for k, v in vdist.predicted_step_ms(
             world, rows_padded * num_feats * gathered.element_size(), kernel_ms).items()}
         # the 1-GPU point of THIS workload's strong-scaling curve (the driver's own N = 1 run is the headline workload,
@@ -647,7 +647,7 @@ def main():
                                             f"threshold {vhybrid.min_shared_fraction()})")
             if (used_two and is_f16 and two.plan.waves == vhybrid.DEFAULT_WAVES
                     and two.plan.row_blocks == vhybrid.DEFAULT_ROW_BLOCKS):
-                # for the record: the same product as ONE launch (spmm_fused_kernel; not the default form)
+                # for the record: the same product as ONE launch (spmm_fused_kernel; not the default form, profiles/HISTORY.md 3.7)
                 if two.fused is None:
                     two.fused = vhybrid.build_fused_records(two.blk_offsets, two.hspa_packed, two.hind, two.num_nodes)
                 fused_out = torch.empty(local_rows, num_feats, dtype=torch.float32, device=device)
@@ -763,7 +763,7 @@ def main():
                 "kernel_ms": kernel_ms, "kernels_ms": kernels_ms, "algorithmic_bytes": alg_bytes,
                 "gather_bytes": gather_bytes, "gather_gbs": gather_bytes / (kernel_ms * 1e-3) / 1e9,
                 "note": "gather-bound: B rows are served by L2 / Infinity Cache (~8.6-19 TB/s row-gather ceilings), "
-                        "see DESIGN.md Roofline",
+                        "see DESIGN.md section 5",
                 "gather_model": gather_model(gather_bytes, counters.get("l2_hit_frac") if counters else None,
                                                  num_cols * num_feats * in_bytes, kernel_ms),
             },

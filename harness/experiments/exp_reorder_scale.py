@@ -1,4 +1,4 @@
-"""Locality reorder at BASELINE scale: the stand-in in its natural order, with its node labels
+"""Locality reorder at BASELINE scale (profiles/HISTORY.md section 3.4): the stand-in in its natural order, with its node labels
 shuffled (synth_graphs.*_shuffled), and the shuffled one after the row reorders of voltrix/reorder.py (bfs, spectral):
 TC blocks of the window format, share of edges the two-level plan takes, time of the operator call, reorder time.
 

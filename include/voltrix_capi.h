@@ -167,7 +167,7 @@ void voltrix_launch_combine_partials(void* cuts, int num_cuts, void* partials, v
 
 /* Unit table of a handle (the `units` / `unit_ptr` / `cuts` arguments above), built on the device from blk_offsets alone,
  * in two phases around the one host read that sizes the outputs (no reference counterpart -- its equal-work scheduler,
- * spmm_kernels.cuh:499-540, is dead code; layout and rules: voltrix/unit_table.hpp):
+ * spmm_kernels.cuh:499-540, is dead code; layout and rules: voltrix/unit_table.hpp, profiles/HISTORY.md section 3.2):
  *   phase 1  voltrix_launch_unit_table_count: header int32[8] (device) = {num_units U, num_cuts C, num_slots, max units per
  *            XCD, max_stages L, top (longest unit), 0, 0}.  max_stages <= 0: L = max(8, floor(1.5 x median stages per window)).
  *            workspace: voltrix_unit_table_workspace_bytes(num_nodes) bytes, device, 16-byte aligned.

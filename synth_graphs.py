@@ -31,7 +31,7 @@ CONFIGS = {
     "papers_like": dict(num_nodes=111059956, mean_deg=1615685872 / 111059956, sigma=1.0, max_deg=20000, band_frac=0.5,
                         band=32768, feat=128, seed=4),
     # the same graphs with their node LABELS randomly permuted (P A P^T, seed stated): what a dataset looks like before anybody
-    # reordered it -- the locality-reorder evidence of DESIGN.md section 3.4 (reference: bench/graph_gen.py:42-45 reads
+    # reordered it -- the locality-reorder evidence of profiles/HISTORY.md section 3.4 (reference: bench/graph_gen.py:42-45 reads
     # externally reordered <name>.reorder.npz files, bench_all.py:120-129 times both)
     "reddit_shuffled": dict(base="reddit_like", shuffle_seed=101),
     "products_shuffled": dict(base="products_like", shuffle_seed=102),

@@ -44,7 +44,7 @@ def test_tile_space_enumeration_and_defaults():
         for dim in (8, 32, 33, 64, 100, 128, 512, 1024):
             assert capi.default_tile(dim, f16_flag) in tiles
     assert capi.default_tile(32, True) == (32, 4, 4) and capi.default_tile(64, True) == (64, 3, 4)
-    assert capi.default_tile(128, True) == capi.default_tile(512, True) == (128, 3, 4)   # the measured best
+    assert capi.default_tile(128, True) == capi.default_tile(512, True) == (128, 3, 4)   # the measured best (profiles/HISTORY.md 5)
     assert capi.default_tile(128, False) == (64, 3, 1)
 
 

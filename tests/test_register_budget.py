@@ -1,6 +1,6 @@
 """CPU (hipcc cross-compiles): the two kernels of the default two-level step must fit one CU TOGETHER -- the matrix-core-bound
 panel kernel (8 waves, two per SIMD) beside a gather-bound window workgroup (one wave per SIMD), 512 registers per SIMD lane
-and 160 KiB of LDS per CU.  The fit is exact today (2 x 176 + 160 = 512): one more register in either
+and 160 KiB of LDS per CU (profiles/HISTORY.md section 3.3).  The fit is exact today (2 x 176 + 160 = 512): one more register in either
 kernel and the pair silently stops overlapping, so the compiler's own resource report is asserted here."""
 import os
 import re

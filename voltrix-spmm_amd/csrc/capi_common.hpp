@@ -85,7 +85,7 @@ inline int dispatch_spmm(int fs, int depth, int waves, const int* blk_offsets, c
   return voltrix::kErrBadConfig;
 }
 
-// Default tile (measured on MI355X; profiles/r02/experiment_units_reddit.log): the widest slab
+// Default tile (measured on MI355X, profiles/HISTORY.md section 5; profiles/r02/experiment_units_reddit.log): the widest slab
 // the feature width fills (up to 128 columns), a 3-deep ring, 4 waves per workgroup for the 16-bit operands -- (128, 3, 4)
 // is the fastest tile on every graph measured, alone (reddit-like F=128: 2.20 ms vs 2.40 ms for 64-column slabs) and
 // beside a panel-kernel workgroup (103 KB of LDS + 136 registers leave it room).  The exact-fp32 path is MFMA-heavier

@@ -1,5 +1,5 @@
 // libvoltrix_hip.so -- Cuthill-McKee row order on the device (include/voltrix_capi.h; voltrix/reorder_kernels.hpp,
-// DESIGN.md section 3.4).  No reference counterpart: the reference reads externally reordered graphs
+// profiles/HISTORY.md section 3.4).  No reference counterpart: the reference reads externally reordered graphs
 // (bench/graph_gen.py:42-45).
 #include <hip/hip_runtime.h>
 

@@ -1,6 +1,6 @@
 // libvoltrix_hip.so -- schedule builders (include/voltrix_capi.h): the window kernel's unit table, built on the device
-// from the handle's blk_offsets (no reference counterpart); round 4: the XCD ranges of equal work and
-// the panel kernel's piece table (schedule_tables.hpp).
+// from the handle's blk_offsets (no reference counterpart; profiles/HISTORY.md section 3.2); round 4: the XCD ranges of equal work and
+// the panel kernel's piece table (schedule_tables.hpp; profiles/HISTORY.md section 3.3).
 #include <hip/hip_runtime.h>
 
 #include "voltrix/schedule_tables.hpp"

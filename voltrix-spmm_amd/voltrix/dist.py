@@ -373,7 +373,7 @@ class RowShardedSpMM:
 def predicted_step_ms(world_size: int, shard_bytes: float, local_spmm_ms: float, link_gbs: float = 153.0,
                       ring_efficiency: float = 0.8) -> dict:
     """What one step (all-gather of B + local SpMM) should take on a fully connected xGMI node (MI355X guide: 7 links x
-    ~153 GB/s per GPU), for reading the first measured scaling curve against.  ``shard_bytes`` = bytes
+    ~153 GB/s per GPU), for reading the first measured scaling curve against (profiles/HISTORY.md section 6).  ``shard_bytes`` = bytes
     one rank contributes.  direct: every rank receives world - 1 shards over world - 1 links in parallel; ring: world - 1
     sequential hops of one shard over ONE link each.  ``overlapped`` = the exchange of step k + 1 hidden behind the product
     of step k (the step is whichever is longer)."""

@@ -499,7 +499,7 @@ def build_panel_plan_torch(indptr: torch.Tensor, indices: torch.Tensor, num_node
 # panel kernel tile per feature width: (fs, depth, ks); waves / row_blocks come from the plan.  Depth 3 at FS = 128 keeps
 # the workgroup at 36 KB of LDS and 176 registers, so that it fits on a CU NEXT TO a (128, 3, 4) pair window-kernel
 # workgroup (103 KB, 160 registers: 2 x 176 + 160 = 512, tests/test_register_budget.py) -- the two kernels overlap when they
-# run on two streams.
+# run on two streams (profiles/HISTORY.md section 3.3).
 def default_panel_tile(embedding_dim: int, waves: int, row_blocks: int = DEFAULT_ROW_BLOCKS):
     if embedding_dim <= 32:
         return (32, 6, 2)
@@ -637,7 +637,7 @@ def fused_enabled() -> bool:
     """``VOLTRIX_FUSED=1``: run the two-level product as ONE launch (spmm_fused_kernel: plain stores, no zero fill, no
     atomics, no second stream, one fixed summation order) instead of the panel kernel beside the window kernel with the
     atomic join.  Off by default: measured on the reddit-like graph the one-launch kernel takes 2.0-2.1 ms against 1.35 ms for
-    the pair (profiles/r03/experiment_fused_*.log) -- it stays as the form for hosts that want a
+    the pair (profiles/r03/experiment_fused_*.log, profiles/HISTORY.md section 3.7) -- it stays as the form for hosts that want a
     single stream-ordered launch and run-to-run identical bits."""
     return os.getenv("VOLTRIX_FUSED", "0") in ("1", "on")
 

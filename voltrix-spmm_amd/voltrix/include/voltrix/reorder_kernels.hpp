@@ -1,5 +1,5 @@
 // Voltrix-SpMM for MI355X (gfx950) -- Cuthill-McKee row order on the device (the "reorder"
-// half).
+// half; profiles/HISTORY.md section 3.4).
 //
 // Integer work on the CSR, once per graph; HBM-bound (every level reads the rows of its frontier in A and in A^T once),
 // no MFMA.  No reference counterpart: the reference reads externally reordered <name>.reorder.npz files

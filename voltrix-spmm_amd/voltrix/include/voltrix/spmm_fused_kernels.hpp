@@ -1,7 +1,7 @@
 // Voltrix-SpMM for MI355X (gfx950) -- the two-level format in ONE launch (round 3; rebuilt in round 4).
 //
 // spmm_panel_kernel + spmm_tc16_pair_kernel run side by side on two streams and meet in C through a zero fill and two
-// float-atomic epilogues.  Here one workgroup owns a 512-row panel for the whole product: every wave
+// float-atomic epilogues (profiles/HISTORY.md section 3.3).  Here one workgroup owns a 512-row panel for the whole product: every wave
 // keeps the accumulators of its 16-row blocks in registers and feeds them from BOTH halves of the format,
 //
 //   shared columns    the panel plan (panel_ptr / panel_cols / panel_bits, spmm_panel_kernels.hpp): 32 rows of B gathered
@@ -39,6 +39,8 @@
 // LDS (FS = 128, DP = 3): panel ring 24 KiB + panel metadata 4 x 5 x 768 B + residual rings 4 x 24 KiB + records 4 x 2 KiB
 // = 143 KiB: one workgroup per CU.
 #pragma once
+
+#include <mutex>
 
 #include <hip/hip_runtime.h>
 
@@ -207,7 +209,7 @@ struct FusedArgs {
   int* pace;                   // optional: zeroed int32 [8][kPaceGens][kPaceBlocks] arrival counters (launcher).  The workgroups
                                // that share an XCD label and a dispatch generation wait for each other -- bounded, advisory:
                                // correctness never depends on it -- at pace_blocks points of their column sweep, so that an
-                               // XCD's 16 k resident rows sweep the columns together (the L2-hit lever)
+                               // XCD's 16 k resident rows sweep the columns together (the L2-hit lever, profiles/HISTORY.md section 3.7)
   int pace_blocks;
 };
 constexpr int kPaceGens = 8, kPaceBlocks = 64;
@@ -618,9 +620,22 @@ inline int launch_spmm_fused(const int* panel_ptr, const int* panel_cols, const 
   a.pace_blocks = 0;
   pace_blocks = pace_blocks < 0 ? 0 : (pace_blocks > kPaceBlocks ? kPaceBlocks : pace_blocks);
   if (pace_blocks > 1 && slabs == 1) {
-    static int* counters = nullptr;
+    // one counter block per DEVICE (a process may drive several GPUs: a block allocated on the first one is foreign memory to the
+    // others), found under a lock; never freed.  Only one paced launch per device may be in flight at a time (the counters are
+    // cleared on the launch's own stream): pacing is an opt-in experiment (FUSED_PACE_BLOCKS = 0 by default), not a product path.
+    constexpr int kMaxDevices = 64;
+    static int* device_counters[kMaxDevices] = {};
+    static std::mutex pace_mutex;
     const size_t bytes = sizeof(int) * kNumXcd * kPaceGens * kPaceBlocks;
-    if (counters == nullptr && hipMalloc(reinterpret_cast<void**>(&counters), bytes) != hipSuccess) return kErrLaunch;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return kErrLaunch;
+    int* counters = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(pace_mutex);
+      if (device_counters[dev] == nullptr && hipMalloc(reinterpret_cast<void**>(&device_counters[dev]), bytes) != hipSuccess)
+        return kErrLaunch;
+      counters = device_counters[dev];
+    }
     if (hipMemsetAsync(counters, 0, bytes, stream) != hipSuccess) return kErrLaunch;
     a.pace = counters;
     a.pace_blocks = pace_blocks;

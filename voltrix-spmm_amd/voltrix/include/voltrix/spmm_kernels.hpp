@@ -27,7 +27,7 @@
 //   int32 offsets (:1568,:1688)                   64-bit row offsets
 //
 // Bound: the kernel is gather-bound (B rows from L2 / Infinity Cache / HBM); MFMA utilisation is a few percent
-// by construction (DESIGN.md "Roofline").
+// by construction.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -204,7 +204,7 @@ __device__ __forceinline__ void dma_b128_nt(const void* src, unsigned lds_byte_a
 
 // Slot swizzle: LDS row r keeps logical 32-byte slot s at physical slot s ^ slot_swizzle(r).  One transposed read
 // touches, per 32-lane half, rows {8g+q, 8g'+q : q<4} (+4 for the second read); this makes their 8 x 32 B land on
-// 8 distinct slots of the 256-B bank row for every FS (derivation in DESIGN.md "LDS image").
+// 8 distinct slots of the 256-B bank row for every FS (derivation in profiles/HISTORY.md section 3.1 "LDS image").
 template <int SLOTS>
 __device__ __forceinline__ constexpr int slot_swizzle(int r) {
   const int ident = (r & 3) | (((r >> 3) & 1) << 2);
@@ -330,7 +330,7 @@ __device__ __forceinline__ void spmm_tc16_body(const SpmmArgs<T>& a) {
   // XCD x = blockIdx.x % 8 owns the contiguous window range [x * windows_per_xcd, ...) (blocks b, b+8, ... share an
   // XCD: speed only, any placement is correct); its workgroups walk that range window by window (the slabs of a window
   // side by side, or slab by slab: slab_major_order below), so co-resident waves of one L2 gather overlapping row
-  // neighbourhoods.  (Measured alternative that lost: non-temporal loads for far rows -- DESIGN.md section 5.)
+  // neighbourhoods.  (Measured alternative that lost: non-temporal loads for far rows -- profiles/HISTORY.md section 5.)
   const int xcd = blockIdx.x % kNumXcd;
   int w_begin = xcd * a.windows_per_xcd;
   int w_count = (a.num_windows - w_begin) < a.windows_per_xcd ? (a.num_windows - w_begin) : a.windows_per_xcd;

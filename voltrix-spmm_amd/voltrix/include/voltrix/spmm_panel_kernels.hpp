@@ -3,7 +3,7 @@
 // The reference format (and spmm_tc16_kernel) condenses columns per 16-row window: a gathered row of B serves 16 rows
 // of A and, on graphs with a few hundred edges per row, about ONE of them (TC-block fill 6-7 %): every edge costs one
 // 2*F-byte row gather out of L2 / Infinity Cache, and that gather traffic -- not HBM, not the matrix cores -- is what
-// bounds the kernel.  Columns that are referenced by SEVERAL rows of a taller row panel (community /
+// bounds the kernel (profiles/HISTORY.md section 5).  Columns that are referenced by SEVERAL rows of a taller row panel (community /
 // band structure, hub columns) can do better: gathered once per panel into LDS, shared by all the panel's windows.
 //
 //   panel       PANEL_ROWS = WAVES * RB * 16 consecutive rows (256 or 512); one workgroup per (panel, feature slab)

@@ -1,7 +1,7 @@
 // Voltrix-SpMM for MI355X (gfx950) -- builder of the window kernel's unit table (SpmmArgs::units, spmm_kernels.hpp).
 //
 // Integer work on the handle's blk_offsets, once per handle.  No reference counterpart (the reference's equal-work
-// scheduler, spmm_kernels.cuh:499-540, is dead code); the table layout and its semantics are DESIGN.md section 3.2:
+// scheduler, spmm_kernels.cuh:499-540, is dead code); the table layout and its semantics are profiles/HISTORY.md section 3.2:
 //   * a window of nst stages (a stage = 4 TC blocks = one MFMA K step) longer than L stages is cut into
 //     k = ceil(nst / L) interleaved units, unit j = stages j, j + k, j + 2k, ...  (length ceil((nst - j) / k));
 //   * L = max(8, floor(1.5 x the lower median of nst)) unless the caller gives one;

@@ -64,7 +64,7 @@ if (__return_code == 0 && {SCHED} == 5 && combine_now != 0)
 
 # windows per length-sorted chunk of the "balance" schedule (spmm_kernels.hpp::launch_window_order) for SCHED 1/2/3.
 # Small chunks keep row neighbours together (banded graphs, wide features), wide chunks equalise more (uniform columns).
-# Measured optimum on MI355X: reddit-like F=128 -> 512, F=512 -> 128, uniform columns -> 2048.
+# Measured optimum on MI355X: reddit-like F=128 -> 512, F=512 -> 128, uniform columns -> 2048 (profiles/HISTORY.md section 5).
 ORDER_CHUNKS = {1: 128, 2: 512, 3: 2048}
 # SCHED 4: unit table (voltrix/schedule.py::unit_table) -- windows longer than 1.5 x the median cut into interleaved units,
 # units listed longest first per XCD range; the partial tiles of cut windows are summed in unit order by

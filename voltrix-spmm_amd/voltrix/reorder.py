@@ -438,7 +438,7 @@ AUTO_MS_PER_PANEL_KSTEP = 2.0e-3
 AUTO_MS_JOIN = 0.05
 AUTO_MIN_MEAN_DEGREE = 64      # below this mean degree no candidate is tried: 16 rows x 50 edges over millions of columns share no
                                # column whatever their order (products-like: 15.44 / 15.53 / 15.52 M TC blocks natural / shuffled /
-                               # reordered), and the two searches cost 0.47 s there
+                               # reordered, profiles/HISTORY.md section 3.4), and the two searches cost 0.47 s there
 
 
 def order_statistics(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None) -> dict:

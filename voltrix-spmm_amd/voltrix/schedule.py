@@ -1,4 +1,4 @@
-"""Unit tables: the schedule of ``spmm_tc16_kernel`` for skewed window lengths.
+"""Unit tables: the schedule of ``spmm_tc16_kernel`` for skewed window lengths (profiles/HISTORY.md section 3.2).
 
 Long windows are cut into interleaved units of bounded length, listed longest first per XCD range; the partial tiles of a cut
 window are summed in unit order by ``combine_partials_kernel``.  The table is built on the device by the library
@@ -46,7 +46,7 @@ def length_order(blk_offsets: torch.Tensor, num_nodes: int) -> torch.Tensor:
 
 def default_max_stages(blk_offsets: torch.Tensor, num_nodes: int) -> int:
     """1.5 x the median window length (in stages of 4 TC blocks): the measured optimum on the reddit-like graph, both for
-    the window format and for the residual of the two-level format."""
+    the window format and for the residual of the two-level format (profiles/HISTORY.md section 5)."""
     num_windows = (num_nodes + 15) // 16
     if num_windows == 0:
         return 1
