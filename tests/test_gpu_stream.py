@@ -184,3 +184,20 @@ def test_fp32_mode_auto_follows_the_handle(cuda_device, monkeypatch):
         assert fp32_mode(handle[1], n) == want, name
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
     assert fp32_mode(handle[1], n) == "fp16"
+
+
+@pytest.mark.parametrize("n,deg", [(1, 0), (1, 1), (15, 2), (16, 3), (17, 1), (33, 0), (100, 5), (1000, 0)])
+@pytest.mark.parametrize("f,dtype", [(8, torch.float16), (24, torch.bfloat16), (40, torch.float16), (72, torch.float32), (4, torch.float32)])
+def test_stream_kernel_edge_shapes(cuda_device, n, deg, f, dtype, monkeypatch):
+    """Tiny and degenerate inputs: fewer rows than a window, graphs without edges (every window owns one all-zero TC block),
+    widths that leave a partial 16-column slot, every operand type -- against the oracle, exact on integer operands."""
+    monkeypatch.setenv("VOLTRIX_FP32_MODE", "auto")
+    rng = np.random.default_rng(n * 131 + deg)
+    rows = [np.sort(rng.choice(n, size=min(deg, n), replace=False)) for _ in range(n)]
+    indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    indices = (np.concatenate(rows) if deg else np.zeros(0)).astype(np.int32)
+    handle = voltrix.csr_preprocess(torch.from_numpy(indptr), torch.from_numpy(indices), n)
+    feat = torch.randint(-4, 5, (n, f)).to(dtype)
+    out = _stream_call(handle, n, len(indices), feat.cuda(), f"stream_edge/{n}/{deg}/{f}/{dtype}", monkeypatch)
+    ref = torch_ref.spmm(indptr, indices, feat.float(), n)
+    assert out.shape == (n, f) and torch.equal(out.cpu(), ref)
