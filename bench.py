@@ -514,7 +514,10 @@ def main():
         t = torch.tensor([check_err], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         check_err = float(t)
-    assert check_err < 1e-4, f"row-sum check failed: {check_err}"
+    # edge values enter the MFMA as fp16: each term carries their rounding (2^-11 relative to |w b|), so the weighted
+    # bound is that unit roundoff on top of the unweighted bound
+    check_tol = 1e-4 + (0.0 if edge_values is None else 2.0 ** -11)
+    assert check_err < check_tol, f"row-sum check failed: {check_err} (tolerance {check_tol})"
 
     kernel_ms = sum(s.elapsed_time(e) for s, e in kernel_events) / len(kernel_events)
     if distributed:
