@@ -169,7 +169,8 @@ void voltrix_launch_combine_partials(void* cuts, int num_cuts, void* partials, v
  * in two phases around the one host read that sizes the outputs (no reference counterpart -- its equal-work scheduler,
  * spmm_kernels.cuh:499-540, is dead code; layout and rules: voltrix/unit_table.hpp, profiles/HISTORY.md section 3.2):
  *   phase 1  voltrix_launch_unit_table_count: header int32[8] (device) = {num_units U, num_cuts C, num_slots, max units per
- *            XCD, max_stages L, top (longest unit), 0, 0}.  max_stages <= 0: L = max(8, floor(1.5 x median stages per window)).
+ *            XCD, max_stages L, top (longest unit), 0, 0}.  max_stages <= 0: L = max(8, floor(1.5 x median stages per window)),
+ *            on handles of fewer than 1024 windows at most max(8, ceil(all stages / 1024)) (unit_table.hpp).
  *            workspace: voltrix_unit_table_workspace_bytes(num_nodes) bytes, device, 16-byte aligned.
  *   (caller reads the header; allocates units int32[U][4], unit_ptr int32[9], cuts int32[C][4], partials
  *    float[num_slots * 16 * embedding_dim] and voltrix_unit_table_fill_workspace_bytes(U) bytes of fill workspace)
@@ -198,7 +199,7 @@ void voltrix_launch_unit_table_fill(void* blk_offsets, int num_nodes, void* xcd_
  *   tables      built by the library from the handle's three tensors, two phases around the host reads that size the outputs:
  *     voltrix_launch_stream_table_count: header int32[8] (device) = {num_units U, cut windows C, partial-tile slots, bound on
  *       the number of runs, run_cost, cut_stages, 0, 0}.  run_cost <= 0: clamp((stages + windows) / 9216, 6, 48) (six runs per
- *       wave slot of the chip); cut_stages <= 0: max(run_cost, max(8, 1.5 x median stages per window)).  run_cost <= 128.
+ *       wave slot of the chip); cut_stages <= 0: max(run_cost, the unit table's default L).  run_cost <= 128.
  *       workspace: voltrix_stream_table_workspace_bytes(num_nodes) bytes, device, 16-byte aligned.
  *     (caller reads the header; allocates units int32[U][8], cuts int32[C][4], runs int32[bound][4], run_ptr int32[9],
  *      header2 int32[4], partials float[slots * 16 * embedding_dim], voltrix_stream_table_fill_workspace_bytes(U) bytes)

@@ -57,6 +57,24 @@ def test_native_unit_table_edge_cases(cuda_device):
             _same(unit_table(blk, n, max_stages), unit_table_torch(blk, n, max_stages))
 
 
+def test_few_long_windows_native_table_and_product(cuda_device):
+    """Fewer than 1024 windows of one length (ddi-like): the device builder applies the same cap as the restatement, every
+    window is cut, and the product through the cut table is exact on integers."""
+    dev = torch.device("cuda")
+    for counts in ([460] * 267, [7] * 1023, [300] * 1024, [40] * 900 + [16000] * 100, [280000] * 3):
+        blk = torch.tensor([0] + list(np.cumsum(counts)), dtype=torch.int32, device=dev)
+        n = 16 * len(counts)
+        _same(unit_table(blk, n), unit_table_torch(blk, n))
+    indptr, indices, _ = synth_graphs.generate("ddi_like", device="cuda")
+    n, nnz = indptr.numel() - 1, indices.numel()
+    handle = voltrix.csr_preprocess_device(indptr, indices, n)
+    table = unit_table(handle[0], n)
+    assert table.num_cuts == (n + 15) // 16 and 900 <= table.num_units <= 1400
+    feat = torch.randint(-3, 4, (n, 96), device="cuda").half()
+    ref = torch.sparse_csr_tensor(indptr, indices, torch.ones(nnz, device="cuda"), size=(n, n)) @ feat.float()
+    assert torch.equal(voltrix.spmm(*handle, num_nodes=n, num_edges=nnz, feat=feat), ref)
+
+
 def test_workspace_sizes_and_bad_arguments(cuda_device):
     lib = capi.lib()
     import ctypes

@@ -7,7 +7,7 @@ import torch
 
 from conftest import load_csr_fixture
 from oracle import oracle_c
-from voltrix.schedule import last_block_columns, stream_tables
+from voltrix.schedule import FEW_WINDOWS, default_max_stages, last_block_columns, stream_tables, unit_table_torch
 
 
 def _handle(g):
@@ -54,3 +54,22 @@ def test_last_block_columns_match_the_bitmaps(csr_fixture):
         cols = np.unique(indices[indptr[16 * w]:indptr[min(n, 16 * w + 16)]])
         want = 0 if len(cols) == 0 else (len(cols) - 1) % 8 + 1
         assert ncl[w] == want, w
+
+
+def test_few_long_windows_are_cut_to_about_one_unit_per_simd():
+    """Handles of fewer than FEW_WINDOWS windows: the default unit length is at most ceil(all stages / FEW_WINDOWS) (floor 8), so
+    a few hundred windows of one length become about FEW_WINDOWS units; handles with more windows, or whose windows are short,
+    keep 1.5 x the median."""
+    def offsets(stages_per_window):
+        return torch.tensor(np.concatenate([[0], np.cumsum(4 * np.asarray(stages_per_window))]), dtype=torch.int32)
+
+    few = offsets([115] * 267)                       # ddi-like: nothing is longer than 1.5 x the median
+    n = 16 * 267
+    assert default_max_stages(few, n) == -(-115 * 267 // FEW_WINDOWS) == 30
+    t = unit_table_torch(few, n)
+    assert t.max_stages == 30 and t.num_units == 267 * 4 and t.num_cuts == 267 and t.num_slots == t.num_units
+    assert default_max_stages(offsets([2] * 170), 16 * 170) == 8                     # short windows: the floor
+    assert default_max_stages(offsets([115] * FEW_WINDOWS), 16 * FEW_WINDOWS) == 172   # enough windows: 1.5 x the median
+    assert default_max_stages(offsets([40] * 900 + [4000] * 100), 16 * 1000) == 60     # the cap never raises the bound
+    long_bins = offsets([70000] * 3)                 # stages past the device histogram's last bin count as 65536
+    assert default_max_stages(long_bins, 48) == -(-3 * 65536 // FEW_WINDOWS)

@@ -517,7 +517,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_stream_kernel(const St
     };
     if (VOLTRIX_STREAM_DIAG & 1) {
 #pragma unroll
-      for (int s = 0; s < SLOTS; ++s) acc[s] = float4_t{(float)blo[s][0], (float)bhi[s][1], 0.f, 0.f};
+      for (int s = 0; s < SLOTS; ++s) acc[s] = float4_t{(float)blo[s][0], (float)bhi[s][1], (float)blo[s][1], (float)bhi[s][0]};
     } else if (fresh) {   // wave-uniform
       if (any_edge) {
 #pragma unroll
@@ -536,7 +536,13 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_stream_kernel(const St
     int stored = 0;
     if (cc.blk + cc.step >= cc.end) {   // the unit's last stage (wave-uniform): store it; the next unit starts from 0
       if (VOLTRIX_STREAM_DIAG & 2) {
-        if (acc[0][0] == 12345.678f) a.output[0] = acc[0][0];   // keeps the accumulators live
+        // keeps EVERY accumulator component live: with bit 0 they are copies of LDS-read outputs, and an asynchronous read
+        // whose output is dead may land in a register the compiler has handed out again (the inline-asm note of
+        // spmm_panel_kernels.hpp) -- bits 0 | 1 together gathered from garbage row ids that way
+        float live = 0.f;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) live += (acc[s][0] + acc[s][1]) + (acc[s][2] + acc[s][3]);
+        if (live == 12345.678f) a.output[0] = live;
       } else {
         store_unit(cc.u);
         stored = ns_live;

@@ -4,7 +4,11 @@
 // scheduler, spmm_kernels.cuh:499-540, is dead code); the table layout and its semantics are profiles/HISTORY.md section 3.2:
 //   * a window of nst stages (a stage = 4 TC blocks = one MFMA K step) longer than L stages is cut into
 //     k = ceil(nst / L) interleaved units, unit j = stages j, j + k, j + 2k, ...  (length ceil((nst - j) / k));
-//   * L = max(8, floor(1.5 x the lower median of nst)) unless the caller gives one;
+//   * L = max(8, floor(1.5 x the lower median of nst)) unless the caller gives one; handles of FEWER THAN 1024 WINDOWS
+//     (round 5): at most max(8, ceil(S / 1024)), S = all stages -- a window is one wave's serial stream, and a few hundred
+//     long windows of one length (ddi-like: 267 windows of ~115 stages, nothing above 1.5 x the median) leave three SIMDs of
+//     four without a wave; cut to about one unit per SIMD of the chip the product runs 1.7-2.0 x faster
+//     (profiles/r05/experiment_few_windows.log);
 //   * units int32[U][4] = {window, j, k, slot}: the units of XCD x's window range, back to back, LONGEST FIRST (ties: window,
 //     then j -- a stable order, so the table is a function of the handle).  The ranges: [x wpx, (x + 1) wpx), wpx =
 //     ceil(W / 8), or -- round 4 -- the caller's xcd_ptr int32[9] (first window of every range; xcd_ptr[8] = W): ranges of
@@ -33,6 +37,7 @@ namespace voltrix {
 
 constexpr int kUtHistBins = 65536;  // nst values above are counted in the last bin (a median up there: L = 1.5 x 65536)
 constexpr int kUtMinStages = 8;
+constexpr int kUtFewWindows = 1024;  // handles with fewer windows are cut into about this many units (one per SIMD)
 
 // header int32[8] (device; the caller reads it between the phases)
 enum UnitTableHeader {
@@ -137,21 +142,26 @@ static __global__ __launch_bounds__(256) void ut_hist_kernel(const int* __restri
 }
 
 // stats[0] = L: the caller's max_stages, or max(8, floor(1.5 x lower median of nst)) (torch.median = element (W-1)/2 of
-// the sorted values).  One workgroup walks the histogram.
+// the sorted values), capped at max(8, ceil(S / kUtFewWindows)) on handles of fewer than kUtFewWindows windows (S = sum of
+// min(nst, kUtHistBins)).  One workgroup walks the histogram.
 static __global__ __launch_bounds__(1024) void ut_median_kernel(const int* __restrict__ hist, const int num_windows,
                                                                 const int max_stages_arg, int* __restrict__ stats) {
   __shared__ int wsum[16];
   __shared__ int carry_s, median_s;
+  __shared__ unsigned long long stages_s;
   if (threadIdx.x == 0) {
     carry_s = 0;
     median_s = 0;
+    stages_s = 0ull;
   }
   __syncthreads();
   if (max_stages_arg <= 0) {
     const int target = (num_windows - 1) / 2;  // 0-based rank of the lower median
+    unsigned long long mine = 0ull;            // this thread's share of S (fewer than 2^10 windows of at most 2^16 stages)
     for (int base = 0; base <= kUtHistBins; base += 1024) {
       const int i = base + threadIdx.x;
       const int v = i <= kUtHistBins ? hist[i] : 0;
+      mine += (unsigned long long)v * (unsigned long long)i;
       const int inc = wave_inclusive_scan(v);
       if ((threadIdx.x & (kWave - 1)) == kWave - 1) wsum[threadIdx.x / kWave] = inc;
       __syncthreads();
@@ -167,6 +177,8 @@ static __global__ __launch_bounds__(1024) void ut_median_kernel(const int* __res
       if (threadIdx.x == 0) carry_s += tot;
       __syncthreads();
     }
+    if (num_windows < kUtFewWindows && mine) atomicAdd(&stages_s, mine);
+    __syncthreads();
   }
   if (threadIdx.x == 0) {
     int L = max_stages_arg;
@@ -174,6 +186,11 @@ static __global__ __launch_bounds__(1024) void ut_median_kernel(const int* __res
       const long long m = median_s;
       L = (int)((3 * m) / 2);
       if (L < kUtMinStages) L = kUtMinStages;
+      if (num_windows < kUtFewWindows) {
+        long long few = ((long long)stages_s + kUtFewWindows - 1) / kUtFewWindows;
+        if (few < kUtMinStages) few = kUtMinStages;
+        if (few < L) L = (int)few;
+      }
     }
     stats[0] = L;
   }

@@ -44,14 +44,25 @@ def length_order(blk_offsets: torch.Tensor, num_nodes: int) -> torch.Tensor:
     return torch.argsort((idx // wpx) * (top + 1) + (top - nblk), stable=True).to(torch.int32)
 
 
+FEW_WINDOWS = 1024        # handles with fewer windows are cut into about this many units: one per SIMD of the chip
+STAGE_HIST_BINS = 65536   # the device builder's histogram counts longer windows in its last bin (unit_table.hpp)
+
+
 def default_max_stages(blk_offsets: torch.Tensor, num_nodes: int) -> int:
     """1.5 x the median window length (in stages of 4 TC blocks): the measured optimum on the reddit-like graph, both for
-    the window format and for the residual of the two-level format (profiles/HISTORY.md section 5)."""
+    the window format and for the residual of the two-level format (profiles/HISTORY.md section 5).  Handles of fewer than
+    ``FEW_WINDOWS`` windows (round 5): at most ``ceil(all stages / FEW_WINDOWS)`` -- a window is one wave's serial stream, and a
+    few hundred long windows of one length (ddi-like) would leave most SIMDs without a wave
+    (profiles/r05/experiment_few_windows.log: 1.7-2.0 x)."""
     num_windows = (num_nodes + 15) // 16
     if num_windows == 0:
         return 1
     nst = ((blk_offsets[1:num_windows + 1] - blk_offsets[:num_windows]) + 3) // 4
-    return max(8, int(1.5 * float(nst.float().median())))
+    bound = max(8, int(1.5 * float(nst.float().median())))
+    if num_windows < FEW_WINDOWS:
+        stages = int(nst.clamp(max=STAGE_HIST_BINS).sum())
+        bound = min(bound, max(8, -(-stages // FEW_WINDOWS)))
+    return bound
 
 
 def balanced_xcd_windows(blk_offsets: torch.Tensor, num_nodes: int, align: int = 1) -> torch.Tensor:
