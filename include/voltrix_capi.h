@@ -248,7 +248,10 @@ void voltrix_launch_window_order(void* blk_offsets, int num_nodes, int chunk, vo
  * output [num_nodes, embedding_dim] float32: accumulate == 0 overwrites every row; 1 adds onto it (read-add-store: output
  * already holds the window kernel's result for the remaining edges); 2 adds with float atomics onto a pre-zeroed output that
  * the window kernel (atomic_out = 1) adds to as well, in any order.  input _Float16 (bfloat16 for _bf16) [*, embedding_dim], 16-byte
- * aligned, embedding_dim % 8 == 0.  Tile: fs in {32,64,128}, depth = ring slots, ksteps per ring slot in {1,2};
+ * aligned, embedding_dim % 8 == 0.  Tile: fs in {32,64,128}, depth = ring slots, ksteps per ring slot in {1,2}, or
+ * VOLTRIX_PANEL_KSTEPS_PIPELINED (17): one k-step per slot walked by the software-pipelined loop (fragment reads of one half of
+ * the column slots under the MFMAs of the other half; same bits as ksteps = 1; what the library uses for 8 x 2 workgroups =
+ * 256-row panels, the shape it picks when the panel kernel is the critical path -- voltrix/hybrid.py PANEL_DOMINATED_RATIO);
  * VOLTRIX_ERR_BAD_CONFIG if the combination is not instantiated; VOLTRIX_ERR_BAD_SHAPE for accumulate outside 0..2.
  * out_scale as for voltrix_launch_spmm_f16_tile.
  * input_rows = rows of `input` (0: num_nodes, a square adjacency); slab_policy: how an operand wider than the tile's fs is
@@ -263,6 +266,7 @@ void voltrix_launch_window_order(void* blk_offsets, int num_nodes, int chunk, vo
  * hardware's no-return global_atomic_add_f32, which is only defined on ordinary (coarse-grained) device memory -- hipMalloc,
  * torch's allocator.  On fine-grained or host-mapped output (hipHostMalloc, hipMallocManaged with fine-grained coherence) the
  * adds can be lost silently: give such outputs a device-memory staging buffer, or use accumulate 0 / 1. */
+#define VOLTRIX_PANEL_KSTEPS_PIPELINED 17
 void voltrix_launch_spmm_panel_f16(void* panel_ptr, void* panel_cols, void* panel_bits, void* panel_order, void* xcd_ptr,
                                    int max_panels_per_xcd, int num_nodes, int embedding_dim, void* input, int64_t input_rows, void* output,
                                    int accumulate, int fs, int depth, int waves, int row_blocks, int ksteps,

@@ -22,6 +22,9 @@ PANEL_CASES = [
     (8, 4, (128, 6, 1), 128), (8, 4, (128, 4, 1), 256), (8, 4, (128, 8, 1), 128), (4, 4, (128, 6, 1), 128),
     (8, 2, (128, 6, 1), 128), (4, 2, (128, 6, 1), 384), (4, 4, (64, 6, 1), 64), (8, 4, (64, 6, 2), 64),
     (4, 4, (64, 6, 2), 128), (4, 4, (32, 6, 2), 32), (8, 4, (32, 6, 2), 32), (8, 4, (128, 6, 1), 96),
+    # the software-pipelined loop (ksteps = hybrid.KSTEPS_PIPELINED; round 5)
+    (8, 4, (128, 3, 17), 128), (8, 4, (128, 4, 17), 200), (8, 2, (128, 4, 17), 128), (8, 2, (128, 6, 17), 384),
+    (8, 4, (64, 4, 17), 64), (8, 4, (64, 6, 17), 72),
 ]
 
 
@@ -404,7 +407,8 @@ def test_xcd_ranges_of_equal_work_give_the_same_bits(cuda_device, monkeypatch):
 
 
 @pytest.mark.parametrize("waves,rb,tile,feat_dim", [(8, 4, (128, 3, 1), 128), (8, 4, (128, 3, 1), 264), (4, 4, (64, 4, 1), 64),
-                                                    (8, 4, (64, 4, 2), 40), (8, 2, (128, 4, 1), 128)])
+                                                    (8, 4, (64, 4, 2), 40), (8, 2, (128, 4, 1), 128),
+                                                    (8, 2, (128, 4, 17), 128), (8, 4, (128, 3, 17), 264)])
 @pytest.mark.parametrize("cap", [1, 3, 1000])
 def test_panel_kernel_in_pieces(cuda_device, waves, rb, tile, feat_dim, cap):
     """Round 4: the panel kernel over PIECES of panels (PanelArgs::parts) -- cut panels leave partial tiles that
@@ -522,3 +526,52 @@ def test_slim_handle_runs_on_the_side_car_alone_and_refuses_the_window_paths(cud
     monkeypatch.setenv("VOLTRIX_HYBRID", "0")                         # a handle without a side-car is returned unchanged
     no_side_car = voltrix.csr_preprocess(indptr, indices, n)
     assert voltrix.slim_handle(no_side_car)[1] is no_side_car[1]
+
+
+def test_pipelined_loop_gives_the_classic_loop_bits(cuda_device):
+    """Round 5: PanelTile<..., PIPE> walks the k-steps in the same order per accumulator -- the same bits as the classic loop on
+    random data, for panels shorter than, equal to and longer than the ring (0 .. 40 k-steps), all three output modes."""
+    assert hybrid.KSTEPS_PIPELINED == 17
+    n = 2300
+    indptr, indices = _random_csr(n, 70, seed=5)
+    indptr[700:1300] = indptr[700]      # panels without k-steps
+    for waves, rb, classic, piped in ((8, 4, (128, 3, 1), (128, 3, 17)), (8, 4, (128, 4, 1), (128, 4, 17)),
+                                      (8, 2, (128, 4, 1), (128, 4, 17)), (8, 2, (128, 6, 1), (128, 6, 17)),
+                                      (8, 4, (64, 4, 2), (64, 4, 17))):
+        for tau in (1, 2, 9):
+            _, _, plan = hybrid.build_panel_plan(torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda(), n, None,
+                                                 waves, rb, tau)
+            feat_dim = 200 if classic[0] == 128 else 64
+            feat = torch.randn(n, feat_dim, device=cuda_device).half()
+            prior = torch.randn(n, feat_dim, device=cuda_device)
+            for acc in (0, 1, 2):
+                a, b = prior.clone(), prior.clone()
+                hybrid.launch_panel(plan, feat, a, accumulate=acc, tile=classic)
+                hybrid.launch_panel(plan, feat, b, accumulate=acc, tile=piped)
+                assert torch.equal(a, b), (waves, rb, tau, acc)
+
+
+def test_panel_dominated_graphs_get_256_row_panels(cuda_device, monkeypatch):
+    """Round 5: when the panel kernel of the default 8 x 4 plan would be the step's critical path (hybrid.panel_dominated),
+    ``csr_preprocess`` builds 8 x 2 = 256-row panels instead and the operator runs them with the pipelined tile; exact on
+    integers against hipSPARSE.  The one-launch form (VOLTRIX_FUSED) keeps its 8 x 4 panels."""
+    monkeypatch.setenv("VOLTRIX_HYBRID", "1")
+    monkeypatch.setenv("VOLTRIX_HYBRID_MIN_SHARE", "0")
+    indptr, indices, _ = synth_graphs.generate("protein_like", device="cuda", scale=0.1)
+    n, nnz = indptr.numel() - 1, indices.numel()
+    handle = voltrix.csr_preprocess_device(indptr, indices, n)
+    two = voltrix.two_level_of(handle[1])
+    assert two is not None and (two.plan.waves, two.plan.row_blocks, two.plan.panel_rows) == (8, 2, 256)
+    assert hybrid.default_panel_tile(128, 8, 2) == (128, 4, hybrid.KSTEPS_PIPELINED)
+    for f in (32, 128, 264):
+        feat = torch.randint(-3, 4, (n, f), device="cuda").half()
+        ref = torch.sparse_csr_tensor(indptr, indices, torch.ones(nnz, device="cuda"), size=(n, n)) @ feat.float()
+        assert torch.equal(voltrix.spmm(*handle, num_nodes=n, num_edges=nnz, feat=feat), ref), f
+    plan84 = hybrid.PanelPlan(panel_ptr=None, panel_cols=None, panel_bits=None, panel_order=None, num_nodes=n, waves=8,
+                              row_blocks=4, tau=3, num_ksteps=1000, num_shared_edges=0, num_resid_edges=32 * 6600)
+    assert not hybrid.panel_dominated(plan84)                  # 6.6 x 1000 against 2 x 6600 stages
+    plan84.num_resid_edges = 32 * 3300
+    assert hybrid.panel_dominated(plan84)
+    monkeypatch.setenv("VOLTRIX_FUSED", "1")
+    fused = voltrix.two_level_of(voltrix.csr_preprocess_device(indptr, indices, n)[1])
+    assert (fused.plan.waves, fused.plan.row_blocks) == (8, 4)

@@ -133,6 +133,11 @@ def test_every_default_panel_tile_is_instantiated():
     src = open(os.path.join(PKG_ROOT, "csrc", "capi_spmm_panel.hip")).read()
     inst = {tuple(map(int, m)) for m in re.findall(r"X\((\d+), (\d+), (\d+), (\d+), (\d+)\)", src)}
     assert len(inst) > 10
+    # tiles of the software-pipelined loop: X(FS, DEPTH, WAVES, RB) under ksteps = KSTEPS_PIPELINED
+    pipe_space = re.search(r"#define VOLTRIX_PANEL_PIPE_SPACE\(X\)(.*)", src).group(1)
+    piped = {tuple(map(int, m)) + (hybrid.KSTEPS_PIPELINED,) for m in re.findall(r"X\((\d+), (\d+), (\d+), (\d+)\)", pipe_space)}
+    assert len(piped) >= 4 and f"kPipelined = {hybrid.KSTEPS_PIPELINED};" in src
+    inst |= piped
     for feat in (8, 32, 48, 64, 96, 128, 200, 512):
         for waves in (4, 8):
             for rb in (2, 4):

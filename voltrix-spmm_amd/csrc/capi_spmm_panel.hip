@@ -16,6 +16,11 @@ namespace {
   X(32, 4, 4, 4, 2) X(32, 6, 4, 4, 2) X(32, 6, 8, 4, 2) X(64, 6, 4, 2, 2) X(64, 6, 8, 2, 2) X(32, 6, 4, 2, 2) X(32, 6, 8, 2, 2) \
   X(128, 3, 4, 4, 1) X(128, 4, 4, 2, 1)
 
+// the software-pipelined k-step loop (PanelTile<..., PIPE = true>; one k-step per ring slot): ksteps = 17
+constexpr int kPipelined = 17;
+static_assert(kPipelined == VOLTRIX_PANEL_KSTEPS_PIPELINED, "include/voltrix_capi.h");
+#define VOLTRIX_PANEL_PIPE_SPACE(X) X(128, 3, 8, 4) X(128, 4, 8, 4) X(128, 4, 8, 2) X(128, 6, 8, 2) X(64, 4, 8, 4) X(64, 6, 8, 4)
+
 template <bool BF16>
 int dispatch(int fs, int depth, int waves, int rb, int ks, const int* panel_ptr, const int* panel_cols,
              const uint32_t* panel_bits, const int* panel_order, int num_nodes, int embedding_dim, const void* input,
@@ -28,6 +33,13 @@ int dispatch(int fs, int depth, int waves, int rb, int ks, const int* panel_ptr,
         panel_ptr, panel_cols, panel_bits, panel_order, num_nodes, embedding_dim, input, output, accumulate, out_scale, \
         stream, 0, 0, input_rows, slab_policy, xcd_ptr, max_panels_per_xcd, parts, num_parts, partials);
   VOLTRIX_PANEL_SPACE(X)
+#undef X
+#define X(FS, D, W, RB)                                                                                              \
+  if (fs == FS && depth == D && waves == W && rb == RB && ks == kPipelined)                                           \
+    return voltrix::launch_spmm_panel<voltrix::PanelTile<FS, D, W, RB, 1, BF16, true>>(                               \
+        panel_ptr, panel_cols, panel_bits, panel_order, num_nodes, embedding_dim, input, output, accumulate, out_scale, \
+        stream, 0, 0, input_rows, slab_policy, xcd_ptr, max_panels_per_xcd, parts, num_parts, partials);
+  VOLTRIX_PANEL_PIPE_SPACE(X)
 #undef X
   return voltrix::kErrBadConfig;
 }

@@ -256,12 +256,13 @@ def balance_xcd_ranges(two: "TwoLevelHandle") -> None:
     plan = two.plan
     if plan.num_ksteps == 0 or plan.num_panels < 2 * 8:
         return
+    cost_x10 = max(1, KSTEP_COST_X10 * plan.panel_rows // 512)   # a k-step's MFMAs scale with the panel's rows
     if plan.panel_ptr.is_cuda:      # the library's builder (schedule_tables.hpp: the entry point a C host binds)
         xcd_ptr, two.window_xcd_ptr = capi.xcd_ranges_of_panels(plan.panel_ptr, two.blk_offsets, two.num_nodes, plan.panel_rows,
-                                                                KSTEP_COST_X10)
+                                                                cost_x10)
     else:
         xcd_ptr, two.window_xcd_ptr = xcd_ranges_of_panels_torch(plan.panel_ptr, two.blk_offsets, two.num_nodes,
-                                                                 plan.panel_rows, KSTEP_COST_X10)
+                                                                 plan.panel_rows, cost_x10)
     longest_range, longest_panel = torch.stack([(xcd_ptr[1:] - xcd_ptr[:-1]).max(),
                                                 (plan.panel_ptr[1:] - plan.panel_ptr[:-1]).max()]).tolist()   # the host read
     plan.xcd_ptr = xcd_ptr
@@ -500,14 +501,40 @@ def build_panel_plan_torch(indptr: torch.Tensor, indices: torch.Tensor, num_node
 # the workgroup at 36 KB of LDS and 176 registers, so that it fits on a CU NEXT TO a (128, 3, 4) pair window-kernel
 # workgroup (103 KB, 160 registers: 2 x 176 + 160 = 512, tests/test_register_budget.py) -- the two kernels overlap when they
 # run on two streams (profiles/HISTORY.md section 3.3).
+# ksteps value that selects the software-pipelined k-step loop (one k-step per ring slot; include/voltrix_capi.h
+# VOLTRIX_PANEL_KSTEPS_PIPELINED, spmm_panel_kernels.hpp PanelTile<..., PIPE = true>)
+KSTEPS_PIPELINED = 17
+
+
 def default_panel_tile(embedding_dim: int, waves: int, row_blocks: int = DEFAULT_ROW_BLOCKS):
     if embedding_dim <= 32:
         return (32, 6, 2)
     if embedding_dim <= 64:
         return (64, 6, 2)
     if waves == 8:
-        return (128, 3, 1) if row_blocks == 4 else (128, 4, 1)
+        # 8 x 2 (256-row panels of panel-dominated graphs, PANEL_DOMINATED_RATIO): 111 registers, two workgroups per CU, the
+        # pipelined loop (protein-like 0.860 -> 0.825 ms).  8 x 4 beside the window kernel: the classic loop -- squeezed
+        # into the pair's 176 registers the pipelined one gains nothing (profiles/r05/experiment_panel_pipe_176.log)
+        return (128, 3, 1) if row_blocks == 4 else (128, 4, KSTEPS_PIPELINED)
     return (128, 4, 1)
+
+
+# The default shape is 8 waves x 4 row blocks = 512-row panels: a gathered k-step serves 512 rows, and the workgroup fits on a
+# CU beside the window kernel's (both kernels are busy for about the same time on the graphs the format was built on).  When the
+# panel side is the critical path by this factor -- its k-steps, priced in window-kernel stages (KSTEP_COST_IN_STAGES), against the
+# residual's stages (~ residual edges / 32: a residual row gather serves about one edge) -- 8 x 2 = 256-row panels win: half the
+# registers, two workgroups per CU whose k-step barriers are independent (the matrix cores of one run under the barrier /
+# refill phase of the other), more and shorter panels over the 256 CUs.  Measured (profiles/r05/experiment_panel_shapes*.log,
+# F = 128): protein-like (ratio 4.2) 1.361 -> 0.825 ms; reddit-like (0.76) 1.37 -> 1.72-1.77, block model (0.94) 1.01 -> 1.34:
+# the balanced graphs keep 8 x 4.
+PANEL_DOMINATED_RATIO = 2.0
+PANEL_DOMINATED_ROW_BLOCKS = 2
+
+
+def panel_dominated(plan: "PanelPlan") -> bool:
+    """Is the panel kernel of this (8 x 4) plan the step's critical path by PANEL_DOMINATED_RATIO?  Host integers only."""
+    resid_stages = max(1.0, plan.num_resid_edges / 32.0)
+    return plan.num_ksteps * KSTEP_COST_IN_STAGES >= PANEL_DOMINATED_RATIO * resid_stages
 
 
 _SIDE_STREAMS = {}

@@ -55,10 +55,13 @@ namespace voltrix {
 //   WAVES  waves per workgroup (4 or 8)
 //   RB     16-row blocks per wave (2 or 4): PANEL_ROWS = WAVES * RB * 16
 //   KS     k-steps (of 32 columns) per ring slot / barrier
-template <int FS_, int DEPTH_, int WAVES_, int RB_, int KS_ = 1, bool BF16_ = false>
+//   PIPE   the software-pipelined k-step loop (round 5, below): fragment reads of one half of the slots under the MFMAs of the
+//          other half, the barrier and the refill between the halves
+template <int FS_, int DEPTH_, int WAVES_, int RB_, int KS_ = 1, bool BF16_ = false, bool PIPE_ = false>
 struct PanelTile {
   static constexpr int FS = FS_, DEPTH = DEPTH_, WAVES = WAVES_, RB = RB_, KS = KS_;
-  static constexpr bool BF16 = BF16_;
+  static constexpr bool BF16 = BF16_, PIPE = PIPE_;
+  static_assert(!PIPE || (KS == 1 && FS >= 32), "pipelined loop: one k-step per ring slot");
   static_assert(FS == 32 || FS == 64 || FS == 128, "feature slab");
   static_assert(RB >= 1 && RB <= 4, "a lane's adjacency word holds four row blocks");
   static_assert(KS == 1 || KS == 2, "one index DMA covers 64 columns");
@@ -85,7 +88,9 @@ struct PanelTile {
   // block model -3.5 % (the panel kernel is its critical path), 8 KiB less LDS.
   static constexpr int BITS_BYTES = KS * WAVES * 256;
   static constexpr int META_BYTES = BITS_BYTES + 256;
-  static constexpr int META_SLOTS = 2 * DEPTH - 1;
+  // classic loop: a group's metadata is issued 2 D - 2 steps ahead and dies with the group; pipelined loop: 2 D steps ahead
+  // (its column ids are read one barrier earlier, its rows issued one step later) and the words die one step earlier
+  static constexpr int META_SLOTS = PIPE ? 2 * DEPTH : 2 * DEPTH - 1;
   static constexpr int NBITS_DMA = BITS_BYTES / 1024;
   static_assert(BITS_BYTES % 1024 == 0 && NBITS_DMA + 1 <= WAVES, "metadata DMA roles");
   static constexpr int VM_PER_STEP = DPW + 1;                      // of waves 0 .. NBITS_DMA (one metadata DMA per step)
@@ -233,14 +238,16 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
     };
 
     // ---- prologue: metadata of groups 0 .. D-2, then the virtual steps -(D-1) .. -1 ------------------------------
+    // (pipelined loop: one group more of each -- its barrier comes AFTER a group's reads, so the ring holds D groups)
+    constexpr int PRO = T::PIPE ? D : D - 1;
 #pragma unroll
-    for (int s = 0; s < D - 1; ++s) issue_meta(s, s % MS);
+    for (int s = 0; s < PRO; ++s) issue_meta(s, s % MS);
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();           // the other waves' metadata DMAs have landed too
 #pragma unroll
-    for (int s = 0; s < D - 1; ++s) {
+    for (int s = 0; s < PRO; ++s) {
       issue_rows(s % MS, s % D);            // groups past the panel's end re-gather its last group (static DMA count)
-      issue_meta(s + D - 1, (s + D - 1) % MS);
+      issue_meta(s + PRO, (s + PRO) % MS);
     }
 
     // MFMA lane roles (as in spmm_tc16_kernel): A row R of block g's 8 columns; B column R, rows 8g+q (+4).  Physical
@@ -259,6 +266,147 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
     }
     asm volatile("" : "+v"(rd_off));
 
+    if constexpr (T::PIPE) {
+      // ---- the software-pipelined k-step loop (round 5) -------------------------------------------------------------------
+      // The classic loop below runs its phases one after the other in every wave -- barrier, LDS round trip for the row ids,
+      // refill, LDS round trip for 16 fragment reads, 32 MFMAs -- and the eight waves do so in step, so the matrix cores idle
+      // through everything that is not an MFMA (measured: the MFMA-free skeleton alone 0.22-0.33 ms of 0.81 on the headline
+      // graph, MFMA busy 30 %).  Here a k-step's slots are two halves: the fragments of half 1 are read under the MFMAs of
+      // half 0; then the barrier (every wave has read all of group t: its ring slot is refilled with group t + D) and the
+      // fragment reads of half 0 of group t + 1 -- under the MFMAs of half 1.  The row id for the refill and the next group's
+      // adjacency word ride along with fragment reads, so no LDS round trip stands alone.  Same accumulation order per
+      // element (k-steps in order): bit-identical to the classic loop.
+      constexpr int HS = SLOTS / 2 > 0 ? SLOTS / 2 : 1;     // slots per half
+      constexpr int NH = SLOTS / HS;                          // halves (1 at FS = 16-column slabs: not instantiated)
+      static_assert(NH == 2, "two halves");
+      uint2_t b0lo[HS], b0hi[HS], b1lo[HS], b1hi[HS];
+      // address of logical slot s: the ring is 256-byte aligned (checked below) and a row's slots are the address bits 5 .. 7,
+      // so the physical slot s ^ z is one XOR with a constant -- no per-lane delta registers as in the classic loop
+      if (data0 & 255u) __builtin_trap();   // wave-uniform; dynamic LDS starts at 0 in a kernel without static LDS
+      auto half_addr = [&](const unsigned dt, const int s) -> unsigned { return dt ^ ((unsigned)s << 5); };
+      auto read_half = [&](const int h, const unsigned dt, uint2_t (&lo)[HS], uint2_t (&hi)[HS]) {
+#pragma unroll
+        for (int s = 0; s < HS; ++s) {
+          const unsigned ad = half_addr(dt, h * HS + s);
+          if (VOLTRIX_PANEL_DIAG & 8) {
+            lo[s] = uint2_t{ad, 1u};
+            hi[s] = uint2_t{ad, 2u};
+            continue;
+          }
+          lo[s] = lds_read_tr16_b64<0>(ad);
+          hi[s] = lds_read_tr16_b64<4 * ROW_BYTES>(ad);
+        }
+      };
+      auto mfma_half = [&](const int h, unsigned aw, const uint2_t (&lo)[HS], const uint2_t (&hi)[HS]) {
+        // four row blocks: an opaque copy per half, so that the conversions are redone for the second half (8 VALU per row
+        // block) instead of sixteen fragment registers staying live across the barrier (the 176-register budget of the pair)
+        if constexpr (RB == 4) asm volatile("" : "+v"(aw));
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          const half8_t afrag = adjacency_to_half8_x2(aw, 4 * j);
+#pragma unroll
+          for (int s = 0; s < HS; ++s) {
+            const uint4_t bq = {lo[s][0], lo[s][1], hi[s][0], hi[s][1]};
+            if (VOLTRIX_PANEL_DIAG & 1) {
+              asm volatile("" ::"v"(afrag), "v"(bq));
+              continue;
+            }
+            if constexpr (T::BF16)
+              acc[j][h * HS + s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, afrag),
+                                                                             __builtin_bit_cast(bf16x8_t, bq), acc[j][h * HS + s], 0, 0, 0);
+            else
+              acc[j][h * HS + s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag, __builtin_bit_cast(half8_t, bq),
+                                                                            acc[j][h * HS + s], 0, 0, 0);
+          }
+        }
+      };
+      auto issue_rows_of = [&](const unsigned (&hrow)[DPW], const int ds) {
+        const unsigned dst = data0 + (unsigned)ds * STAGE_BYTES + (unsigned)dma0 * 1024u;
+#pragma unroll
+        for (int d = 0; d < DPW; ++d)
+          if (!(VOLTRIX_PANEL_DIAG & 2)) dma_b128(cbase[d] + (unsigned long long)hrow[d] * row_bytes, dst + d * 1024);
+      };
+      // steps issued so far: the prologue's D, then one per iteration (after its barrier) while t + D < ngroups.  Before the
+      // barrier of iteration t group t + 1 must have landed; younger: min(G - 2 - t, D - 2) steps, G = max(ngroups, D)
+      const int total_steps = ngroups > D ? ngroups : D;
+      auto wait_group = [&](const int young, auto per_step) {
+        constexpr int VM = decltype(per_step)::value;
+        if (young >= D - 2 && D >= 2) {
+          wait_vmcnt<VM * (D - 2)>();
+        } else {
+          switch (young) {
+            case 0: wait_vmcnt<0>(); break;
+            case 1: wait_vmcnt<VM * 1>(); break;
+            case 2: wait_vmcnt<VM * 2>(); break;
+            case 3: wait_vmcnt<VM * 3>(); break;
+            case 4: wait_vmcnt<VM * 4>(); break;
+            default: wait_vmcnt<VM * 5>(); break;
+          }
+        }
+      };
+      // group 0: the prologue issued D steps; D - 1 of them are younger than group 0
+      if (meta_wave) wait_vmcnt<T::VM_PER_STEP * (D - 1)>();
+      else wait_vmcnt<T::VM_PER_STEP_PLAIN * (D - 1)>();
+      if (!(VOLTRIX_PANEL_DIAG & 4)) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      unsigned aw_cur = lds_read_b32(meta0 + 256 * wave + 4 * lane);
+      read_half(0, data0 + rd_off, b0lo, b0hi);
+      wait_lgkmcnt0();
+      int ds_t = 0;                      // t % D
+      int ds_n = 1 % D;                  // (t + 1) % D
+      int ms_t = 0;                      // t % MS == (t + 2 D) % MS: the slot the metadata issued this step goes to
+      int ms_n = 1 % MS;                 // (t + 1) % MS
+      int ms_d = D % MS;                 // (t + D) % MS
+      for (int t = 0; t < ngroups; ++t) {
+        const unsigned dt = data0 + (unsigned)ds_t * STAGE_BYTES + rd_off;
+        const bool refill = t + D < ngroups;            // workgroup-uniform
+        // half 1 of group t and the row ids of group t + D (landed D steps ago; visible since the last barrier)
+        read_half(1, dt, b1lo, b1hi);
+        unsigned hrow[DPW];
+#pragma unroll
+        for (int d = 0; d < DPW; ++d) {
+          // the id's address is rebuilt from the lane id here (two VALU operations) instead of living in a register through
+          // the loop: the 8-wave tile sits exactly on the 176-register budget of the pair (tests/test_register_budget.py)
+          unsigned ad;
+          asm volatile("v_lshrrev_b32 %0, %2, %1\n\tv_lshl_add_u32 %0, %0, 2, %3"
+                       : "=&v"(ad)
+                       : "v"(lane), "n"(LPR == 16 ? 4 : (LPR == 8 ? 3 : 2)),
+                         "s"(meta0 + (unsigned)ms_d * T::META_BYTES + T::BITS_BYTES + 4u * (unsigned)((dma0 + d) * RPD)));
+          hrow[d] = lds_read_b32(ad);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(0, aw_cur, b0lo, b0hi);
+        __builtin_amdgcn_sched_barrier(0);   // the MFMAs stay ABOVE the wait: they are what covers the reads' latency
+        wait_lgkmcnt0();
+#pragma unroll
+        for (int d = 0; d < DPW; ++d) asm volatile("" ::"v"(hrow[d]));   // alive past the wait also when nothing is refilled
+        unsigned aw_next = aw_cur;
+        if (t + 1 < ngroups) {                          // workgroup-uniform
+          const int young = total_steps - 2 - t;
+          if (meta_wave) wait_group(young, std::integral_constant<int, T::VM_PER_STEP>{});
+          else wait_group(young, std::integral_constant<int, T::VM_PER_STEP_PLAIN>{});
+          if (!(VOLTRIX_PANEL_DIAG & 4))
+            __builtin_amdgcn_s_barrier();   // group t + 1 has landed in every wave's share; everyone is done reading group t
+          __builtin_amdgcn_sched_barrier(0);
+          if (refill) {
+            issue_rows_of(hrow, ds_t);      // group t + D into the slot group t has just left
+            if (!(VOLTRIX_PANEL_DIAG & 16)) issue_meta(t + 2 * D, ms_t);
+          }
+          aw_next = lds_read_b32(meta0 + (unsigned)ms_n * T::META_BYTES + 256 * wave + 4 * lane);
+          read_half(0, data0 + (unsigned)ds_n * STAGE_BYTES + rd_off, b0lo, b0hi);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        mfma_half(1, aw_cur, b1lo, b1hi);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_lgkmcnt0();
+        aw_cur = aw_next;
+        ds_t = ds_n;
+        ds_n = ds_n + 1 == D ? 0 : ds_n + 1;
+        ms_t = ms_n;
+        ms_n = ms_n + 1 == MS ? 0 : ms_n + 1;
+        ms_d = ms_d + 1 == MS ? 0 : ms_d + 1;
+      }
+    } else {
     int ds_t = 0, ms_t = 0;                              // group t
     int ds_r = (D - 1) % D, ms_r = (D - 1) % MS;         // group t + D - 1 (rows issued this step)
     int ms_m = (2 * D - 2) % MS;                         // group t + 2D - 2 (metadata issued this step)
@@ -341,6 +489,7 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_panel_kernel(const Pan
           }
         }
       }
+    }
     }
     wait_vmcnt<0>();  // nothing of this workgroup may still be writing LDS when it is released
   }

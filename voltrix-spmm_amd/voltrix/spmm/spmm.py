@@ -119,6 +119,12 @@ def _build_two_level(indptr_d, indices_d, num_nodes, num_cols, waves=hybrid.DEFA
                                                                 tau, min_share=min_share)
     if plan.num_ksteps == 0 or plan.num_shared_edges < min_share * max(1, indices_d.numel()):
         return None   # the builder stopped after its count phase: nothing of the two-level form was built
+    if (waves, row_blocks) == (hybrid.DEFAULT_WAVES, hybrid.DEFAULT_ROW_BLOCKS) and hybrid.panel_dominated(plan) \
+            and not hybrid.fused_enabled():
+        # the panel kernel would be the critical path: 256-row panels instead (hybrid.PANEL_DOMINATED_RATIO); one more plan build
+        del resid_indptr, resid_indices, plan
+        resid_indptr, resid_indices, plan = hybrid.build_panel_plan(indptr_d, indices_d, num_nodes, num_cols, waves,
+                                                                    hybrid.PANEL_DOMINATED_ROW_BLOCKS, tau, min_share=0.0)
     pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(resid_indptr, resid_indices, num_nodes, num_cols,
                                                                  path=preprocess_mode()[1])
     two = hybrid.TwoLevelHandle(pointer1, hspa_packed, hind, plan, num_nodes, int(indices_d.numel()))
