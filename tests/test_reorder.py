@@ -191,6 +191,72 @@ def test_spectral_order_recovers_the_shuffled_reddit_stand_in(cuda_device, monke
     assert float((out - ref).norm() / ref.norm()) < 1e-5
 
 
+# ---- round 5: the unfolding of a folded spectral order -----------------------------------------------------------------------
+def _band_graph(n, deg, band, seed):
+    """CSR of a band graph with a uniform background (half of the edges), natural order, plus an 8-dimensional embedding in which
+    the band is a smooth curve: the first eight harmonics, mixed by a random rotation (what nearly degenerate eigenvectors are)."""
+    g = torch.Generator().manual_seed(seed)
+    rows = torch.arange(n).repeat_interleave(deg)
+    local = (rows + torch.randint(-band, band + 1, (rows.numel(),), generator=g)).clamp(0, n - 1)
+    cols = torch.where(torch.rand(rows.numel(), generator=g) < 0.5, local, torch.randint(0, n, (rows.numel(),), generator=g))
+    keys = torch.sort(rows * n + cols).values
+    indptr = torch.zeros(n + 1, dtype=torch.int64)
+    indptr[1:] = torch.cumsum(torch.bincount(keys // n, minlength=n), 0)
+    theta = torch.linspace(0, 3.14159, n)
+    coords = torch.stack([torch.cos(j * theta) for j in range(1, 9)], 1) @ torch.linalg.qr(torch.randn(8, 8, generator=g))[0]
+    return indptr.int(), (keys % n).int(), coords + 0.01 * torch.randn(n, 8, generator=g)
+
+
+def test_unfolded_order_follows_the_curve_of_a_mixed_embedding():
+    """CPU.  No single coordinate of the mixed embedding is monotone along the band (sorting by any of them folds it); the
+    boxes' hop distances are: the order comes out along the band (either direction), boxes that caught two stretches are set
+    aside, and one round of neighbour votes puts every row within a quarter band of its place."""
+    n, band = 50000, 1000
+    indptr, indices, coords = _band_graph(n, 100, band, seed=0)
+    active = torch.ones(n, dtype=torch.bool)
+    k = torch.arange(n, dtype=torch.float64)
+    corr = lambda p: abs(float(torch.corrcoef(torch.stack([k, p.double()]))[0, 1]))   # noqa: E731
+    assert max(corr(torch.argsort(coords[:, j])) for j in range(8)) < 0.9              # every single coordinate folds
+    perm, info = reorder.unfolded_order(coords, indptr, indices, active, cells=512, return_info=True)
+    assert sorted(perm.tolist()) == list(range(n))
+    assert info["pure"] >= 480 and info["ordered"] >= 0.9 * info["pure"] and info["one_dimensional"] > 30, info
+    settled = info["settled"]
+    ordered_rows = perm[: int(settled.sum())].double()
+    assert abs(float(torch.corrcoef(torch.stack([torch.arange(ordered_rows.numel(), dtype=torch.float64), ordered_rows]))[0, 1])) > 0.999
+    a = torch.sparse_csr_tensor(indptr.long(), indices.long(), torch.ones(indices.numel()), size=(n, n))
+    voted = reorder.neighbour_votes(lambda b: a @ b.float(), perm, settled, active)
+    assert sorted(voted.tolist()) == list(range(n)) and corr(voted) > 0.9995
+    place = voted.double() if float(torch.corrcoef(torch.stack([k, voted.double()]))[0, 1]) > 0 else (n - 1) - voted.double()
+    assert float((place - k).abs().quantile(0.99)) < band
+    # rows without edges go last, in both steps
+    active[::7] = False
+    perm2 = reorder.unfolded_order(coords, indptr, indices, active, cells=256)
+    assert sorted(perm2.tolist()) == list(range(n)) and not active[perm2[-(n // 7):]].any()
+
+
+@pytest.mark.gpu
+def test_spectral_order_unfolds_the_full_size_shuffled_reddit_stand_in(cuda_device, monkeypatch):
+    """Full size (233 k rows, 114.6 M edges): the leading eigenvectors are nearly degenerate and the plain sort by the first one
+    is folded (correlation with the generating order 0.67); with the unfolding the order follows the band end to end and the
+    relabelled graph has the natural order's shared-column structure."""
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    dev = torch.device("cuda")
+    indptr, indices, _ = synth_graphs.generate("reddit_like", device=dev)
+    n = indptr.numel() - 1
+    s_indptr, s_indices, label = synth_graphs.shuffle_labels(indptr, indices, 101)
+    natural_of = torch.empty_like(label)
+    natural_of[label] = torch.arange(n, device=dev)
+    k = torch.arange(n, device=dev, dtype=torch.float64)
+    folded = reorder.spectral_permutation(s_indptr, s_indices, n, unfold=False)
+    perm, info = reorder.spectral_permutation(s_indptr, s_indices, n, return_info=True)
+    corr = lambda p: abs(float(torch.corrcoef(torch.stack([k, natural_of[p].double()]))[0, 1]))   # noqa: E731
+    assert info["unfolded"]["accepted"] and info["unfolded"]["one_dimensional"] > 30, info
+    assert corr(folded) < 0.9 and corr(perm) > 0.998, (corr(folded), corr(perm))
+    assert sorted(perm.tolist()) == list(range(n))
+    r_indptr, r_indices = reorder.relabel_csr(s_indptr, s_indices, n, perm)
+    assert reorder.local_fraction(r_indptr, r_indices, n) > 0.45          # natural order: 0.50, folded order: 0.22
+
+
 # ---- round 4: method="auto" -- never worse than no reorder ----------------------------------------------------------------
 def _median_ms(fn, reps=7, batch=5):
     for _ in range(3):
