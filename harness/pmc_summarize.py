@@ -33,7 +33,9 @@ def main():
     tile_sig = f"SpmmTile<{tile['fs']}, {tile['depth']}, {tile['waves']},"
     wanted = {("spmm_tc16_pair_kernel" if pair else ("spmm_stream_kernel" if stream else "spmm_tc16_kernel<")): tile_sig, "combine_partials_kernel": "", "combine_panel_partials_kernel": "" if two_level else None,
               "spmm_panel_kernel": "" if two_level else None, "FillFunctor<float>": "" if two_level else None,
-              "spmm_fused_kernel": ""}
+              # the one-launch form only when IT is the timed form (bench.py also times it once "for the record" beside the pair:
+              # those launches are not steps)
+              "spmm_fused_kernel": "" if ("one launch" in fmt or "one-launch" in fmt or "fused" in fmt) and not two_level else None}
 
     # wide operands: the window and panel kernels are launched once per group of column slabs (config.tile.launches_per_step)
     per_step = int(tile.get("launches_per_step", 1))
