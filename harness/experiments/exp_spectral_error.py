@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--refine", default="0,4")
     ap.add_argument("--vectors", type=int, default=32)
     ap.add_argument("--iterations", type=int, default=16)
+    ap.add_argument("--vote_rounds", default="2")
+    ap.add_argument("--min_one_dimensional", type=float, default=None)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     indptr, indices, _ = synth_graphs.generate(args.graph, device=dev)
@@ -32,9 +34,11 @@ def main():
     s_indptr, s_indices, label = synth_graphs.shuffle_labels(indptr, indices, args.seed)     # label[old] = new
     orig_of_new = torch.empty(n, dtype=torch.int64, device=dev)
     orig_of_new[label] = torch.arange(n, device=dev)
-    for refine in [int(x) for x in args.refine.split(",")]:
+    if args.min_one_dimensional is not None:
+        reorder.UNFOLD_MIN_ONE_DIMENSIONAL = args.min_one_dimensional
+    for refine, rounds in [(int(x), int(v)) for x in args.refine.split(",") for v in args.vote_rounds.split(",")]:
         perm, info = reorder.spectral_permutation(s_indptr, s_indices, n, refine=refine, vectors=args.vectors,
-                                                  iterations=args.iterations, return_info=True)
+                                                  iterations=args.iterations, return_info=True, vote_rounds=rounds)
         true_pos = orig_of_new[perm].double()            # original index of the row at recovered position k
         k = torch.arange(n, device=dev, dtype=torch.float64)
         corr = float(torch.corrcoef(torch.stack([k, true_pos]))[0, 1])
@@ -46,7 +50,7 @@ def main():
         fit = pad.unfold(0, w, 1).median(dim=1).values
         err = (true_pos - fit).abs()
         adj = (true_pos[1:] - true_pos[:-1]).abs()
-        line = {"graph": args.graph, "refine": refine, "eigenvalues": [round(v, 5) for v in info["eigenvalues"]],
+        line = {"graph": args.graph, "refine": refine, "vote_rounds": rounds, "eigenvalues": [round(v, 5) for v in info["eigenvalues"]],
                 "corr": round(abs(corr), 5), "phase_ms": info.get("phase_ms"), "unfolded": info.get("unfolded"), "extra_rounds": info.get("extra_rounds"), "fit_monotone_frac": round(float((fit[1:] >= fit[:-1]).double().mean()), 4),
                 "fit_range": [round(float(fit.min())), round(float(fit.max()))]}
         deciles = []

@@ -341,7 +341,9 @@ def unfolded_order(coords: torch.Tensor, indptr: torch.Tensor, indices: torch.Te
     w[:, ~pure] = 0.0
     # a box's links: its strongest ones (at most 16), as long as they stand clear of the background's noise (five standard
     # deviations of its count) and are not dwarfed by the box's best link -- a band narrower than 16 boxes must not pick up
-    # chance links, one shortcut would shorten every distance across it -- and only when BOTH boxes name each other.
+    # chance links, one shortcut would shorten every distance across it -- and only when BOTH boxes name each other (with
+    # either-names-the-other, or with a further purity test by the neighbours' mutual links, both stand-ins came out worse:
+    # reddit-like correlation 0.39, products-like hop count 9).
     links = min(16, g - 1)
     top = torch.topk(w, links, dim=1)
     strong = (top.values >= 5.0 * (background.gather(1, top.indices) + 1.0).sqrt()) & (top.values >= 0.15 * top.values[:, :1])
@@ -419,7 +421,7 @@ def neighbour_votes(apply_a, perm: torch.Tensor, settled: torch.Tensor, active: 
 
 def spectral_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
                          vectors: int = 32, iterations: int = 16, seed: int = 0, return_info: bool = False,
-                         refine: int = 4, refine_width: int = 8192, unfold: bool = None):
+                         refine: int = 4, refine_width: int = 8192, unfold: bool = None, vote_rounds: int = 2):
     """Spectral row order on the device, computed WITH the SpMM kernels (round 3): int64 [N], position k holds row ``perm[k]``.
 
     Rows that reference the same columns should share a 16-row window (and a 512-row panel).  Their similarity is the
@@ -545,7 +547,8 @@ def spectral_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes:
 
             if unfold_info["accepted"]:
                 perm = neighbour_votes(apply_a, perm, settled, deg_r > 0)
-                perm = neighbour_votes(apply_a, perm, deg_r > 0, deg_r > 0, buckets=512, reach=5)   # everybody settled: finer stretches
+                for _ in range(max(0, vote_rounds - 1)):                                                # everybody settled: finer stretches
+                    perm = neighbour_votes(apply_a, perm, deg_r > 0, deg_r > 0, buckets=512, reach=5)
             else:
                 perm = plain
             stamp("unfolding")
