@@ -944,8 +944,23 @@ static __global__ __launch_bounds__(256) void combine_partials_kernel(const int4
     if (row_map) row = row_map[row];
     if (row < 0 || row >= num_nodes) continue;  // tail window / padding rows
     float4 sum = src[i];
-    for (int u = 1; u < c.z; ++u) {
-      const float4 p = src[u * tile4 + i];
+    int u = 1;
+    // eight tiles' loads in flight per round trip, added in unit order (the same bits as one load per addition; a hub window
+    // of the web-BerkStan-like stand-in has ~85 units: the serial chain was 62 us, 18 % of that graph's step)
+    for (; u + 8 <= c.z; u += 8) {
+      float4 p[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) p[k] = src[(long long)(u + k) * tile4 + i];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        sum.x += p[k].x;
+        sum.y += p[k].y;
+        sum.z += p[k].z;
+        sum.w += p[k].w;
+      }
+    }
+    for (; u < c.z; ++u) {
+      const float4 p = src[(long long)u * tile4 + i];
       sum.x += p.x;
       sum.y += p.y;
       sum.z += p.z;
