@@ -240,6 +240,7 @@ def bfs_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int,
 UNFOLD_CELLS = 2048
 UNFOLD_VECTORS = 8
 UNFOLD_MIN_ROWS = 1 << 16
+UNFOLD_MAX_ROWS = 1 << 22      # the neighbour votes hold a [rows, 512] fp32 matrix (8.6 GB here); larger graphs keep the plain sort
 UNFOLD_MIN_ONE_DIMENSIONAL = 30.0   # leading / second eigenvalue of the boxes' distance scaling below which the unfolding is dropped
 SUBSPACE_SPREAD = 0.8          # more subspace-iteration rounds while the smallest Ritz value is above this x the largest ...
 SUBSPACE_EXTRA_ROUNDS = 5      # ... at most this many rounds of `iterations` steps
@@ -524,7 +525,7 @@ def spectral_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes:
         key = torch.where(deg_r > 0, fiedler[:, 0], torch.full_like(deg_r, float("inf")))
         perm = torch.argsort(key, stable=True)
         if unfold is None:
-            unfold = m == n and n >= UNFOLD_MIN_ROWS and nnz < (1 << 31) and vectors >= UNFOLD_VECTORS
+            unfold = m == n and UNFOLD_MIN_ROWS <= n <= UNFOLD_MAX_ROWS and nnz < (1 << 31) and vectors >= UNFOLD_VECTORS
         if unfold:   # nearly degenerate leading vectors: order along the CURVE of the leading subspace (unfolded_order)
             lead = (x @ torch.from_numpy(evecs_np[:, -UNFOLD_VECTORS:].astype(np.float32)).to(dev)) * ir
             plain = perm
