@@ -542,13 +542,14 @@ def test_pipelined_loop_gives_the_classic_loop_bits(cuda_device):
             _, _, plan = hybrid.build_panel_plan(torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda(), n, None,
                                                  waves, rb, tau)
             feat_dim = 200 if classic[0] == 128 else 64
-            feat = torch.randn(n, feat_dim, device=cuda_device).half()
             prior = torch.randn(n, feat_dim, device=cuda_device)
-            for acc in (0, 1, 2):
-                a, b = prior.clone(), prior.clone()
-                hybrid.launch_panel(plan, feat, a, accumulate=acc, tile=classic)
-                hybrid.launch_panel(plan, feat, b, accumulate=acc, tile=piped)
-                assert torch.equal(a, b), (waves, rb, tau, acc)
+            for dtype in (torch.float16, torch.bfloat16):
+                feat = torch.randn(n, feat_dim, device=cuda_device).to(dtype)
+                for acc in (0, 1, 2):
+                    a, b = prior.clone(), prior.clone()
+                    hybrid.launch_panel(plan, feat, a, accumulate=acc, tile=classic)
+                    hybrid.launch_panel(plan, feat, b, accumulate=acc, tile=piped)
+                    assert torch.equal(a, b), (waves, rb, tau, acc, dtype)
 
 
 def test_panel_dominated_graphs_get_256_row_panels(cuda_device, monkeypatch):
