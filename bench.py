@@ -537,7 +537,7 @@ def main():
     # ---- what the operator ran (the tuner's choice), for the record -----------------------------------------------------
     from voltrix.spmm.spmm import fp32_mode
 
-    fp32_as = fp32_mode(handle[1], local_rows)      # what fp32 features become on this handle: "fp16" (scaled cast) | "exact"
+    fp32_as = fp32_mode(handle[1], local_rows, num_feats)   # what fp32 features become on this handle: "fp16" (scaled cast) | "exact"
 
     def tuned(hspa_packed, beside_panel):
         from voltrix.jit_kernels.spmm import feature_hash

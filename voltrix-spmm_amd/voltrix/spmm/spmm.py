@@ -172,11 +172,17 @@ def csr_preprocess_hybrid(indptr: torch.Tensor, indices: torch.Tensor, num_nodes
 # fp32 rows only doubles the gathered bytes.  Measured break-even: between 5.7 (com-amazon-like: exact wins) and 8.6
 # (amazon0601-like: the cast wins) gathered rows per output row.
 EXACT_FP32_MAX_GATHERED_ROWS_PER_ROW = 6.0
+# ... and up to this many when the operand is at most 32 columns wide: an fp32 row of 32 columns is ONE 128-byte line, exactly what
+# the half-line fp16 row costs the CU's request path, so the exact tiles gather "for free" while the cast keeps its launches
+# (profiles/r05/experiment_fp32_modes.log, F = 32: ppi-like 0.036 -> 0.025 ms, amazon0601-like 0.108 -> 0.074, DD-like 0.078 -> 0.046;
+# FraudYelp-like at 112 gathered rows per row: 0.054 -> 0.155, stays with the cast)
+EXACT_FP32_MAX_GATHERED_ROWS_PER_ROW_NARROW = 16.0
+EXACT_FP32_NARROW_COLUMNS = 32
 
 
-def fp32_mode(hspa_packed: torch.Tensor = None, num_nodes: int = 0) -> str:
-    """``VOLTRIX_FP32_MODE``: ``fp16`` (scaled cast), ``exact`` (fp32 rows, exact products) or ``auto`` (default: by the handle,
-    above) -> "fp16" | "exact".  No host sync: the TC-block count is the size of ``hspa_packed``."""
+def fp32_mode(hspa_packed: torch.Tensor = None, num_nodes: int = 0, num_feats: int = None) -> str:
+    """``VOLTRIX_FP32_MODE``: ``fp16`` (scaled cast), ``exact`` (fp32 rows, exact products) or ``auto`` (default: by the handle
+    and the operand's width, above) -> "fp16" | "exact".  No host sync: the TC-block count is the size of ``hspa_packed``."""
     mode = os.getenv(FP32_MODE_FLAG, "auto")
     assert mode in ("fp16", "exact", "auto"), f"{FP32_MODE_FLAG}={mode}"
     if mode != "auto":
@@ -188,7 +194,9 @@ def fp32_mode(hspa_packed: torch.Tensor = None, num_nodes: int = 0) -> str:
     if hspa_packed is None or num_nodes <= 0 or sidecar.lookup(hspa_packed)[1] is not None:
         return "fp16"
     gathered_rows = 2.0 * hspa_packed.numel()           # 8 per TC block = 8 x numel / 4
-    return "exact" if gathered_rows <= EXACT_FP32_MAX_GATHERED_ROWS_PER_ROW * num_nodes else "fp16"
+    narrow = num_feats is not None and num_feats <= EXACT_FP32_NARROW_COLUMNS
+    limit = EXACT_FP32_MAX_GATHERED_ROWS_PER_ROW_NARROW if narrow else EXACT_FP32_MAX_GATHERED_ROWS_PER_ROW
+    return "exact" if gathered_rows <= limit * num_nodes else "fp16"
 
 
 def _operand(feat: torch.Tensor, mode: str = None):
@@ -226,7 +234,8 @@ def spmm(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tenso
     ``hspa_packed`` tensor, the 16-bit-operand product runs in that form (same result up to fp32 summation order).
     """
     num_feats = feat.shape[1]
-    operand, out_scale, padded, exact = _operand(feat, fp32_mode(hspa_packed, num_nodes) if feat.dtype == torch.float32 else None)
+    operand, out_scale, padded, exact = _operand(feat, fp32_mode(hspa_packed, num_nodes, feat.shape[1])
+                                                 if feat.dtype == torch.float32 else None)
     output = torch.empty((num_nodes, padded), dtype=torch.float32, device=feat.device)
     known, two = sidecar.lookup(hspa_packed)
     mode = hybrid.hybrid_mode()
