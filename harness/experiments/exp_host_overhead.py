@@ -32,7 +32,7 @@ for dtype in (torch.float16, torch.float32):
     torch.cuda.synchronize()
     t_total = (time.perf_counter() - t0) / 2000 * 1e6
     print(f"{name} F={f} {dtype}: host issue {t_issue:.1f} us/call, with the device {t_total:.1f} us/call")
-    if dtype == torch.float16:
+    if True:
         pr = cProfile.Profile()
         pr.enable()
         for _ in range(2000):

@@ -1079,11 +1079,13 @@ inline int cast_f32_to_f16(const float* src, _Float16* dst, long long n, hipStre
 // epilogue through SpmmArgs::out_scale) moves the operand's largest magnitude to [2^14, 2^15) and keeps the 10-bit
 // mantissa (= TF32's) for everything within 2^-28 of it.  All on the stream, no host sync.  Inf / NaN operands:
 // scale 1 (they propagate as in fp32).  scale[1] is scratch (max |src| bits).
-// One atomic per WORKGROUP, and only when it can raise the maximum: round 4 measured the per-wave atomicMax of the first
-// version (16 k atomics onto one address, serialised in L2) at 0.18 ms of a 0.23 ms cast at F = 128
-// (profiles/r04/experiment_cast.log) -- the whole fixed cost of the fp32-input path.
+// NO atomics (round 5): every workgroup leaves its maximum in a scratch word and a one-workgroup kernel reduces the words.  The
+// scratch is the head of `dst` itself -- the convert pass overwrites it afterwards, in stream order.  History: one atomicMax
+// per wave, 16 k atomics onto one address, was 0.18 ms of a 0.23 ms cast (round 4, profiles/r04/experiment_cast.log); one per
+// workgroup "only when it can raise the maximum" still serialised the first thousands that finish together while the maximum
+// is 0: 47 us of the 58 us cast of a 29 MB operand (ppi-like, rocprofv3 kernel stats, round 5).
 static __global__ __launch_bounds__(256) void amax_abs_f32_kernel(const float* __restrict__ src, const long long n4,
-                                                           unsigned* __restrict__ amax_bits) {
+                                                           unsigned* __restrict__ block_max) {
   __shared__ unsigned wave_max[256 / kWave];
   const long long stride = (long long)gridDim.x * blockDim.x;
   unsigned m = 0u;  // |x| as bits: non-negative floats order like unsigned integers (NaN > Inf > finite)
@@ -1113,8 +1115,27 @@ static __global__ __launch_bounds__(256) void amax_abs_f32_kernel(const float* _
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int w = 1; w < 256 / kWave; ++w) m = m > wave_max[w] ? m : wave_max[w];
-    // a stale (smaller) read only costs an atomic that changes nothing
-    if (m > __hip_atomic_load(amax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_bits, m);
+    block_max[blockIdx.x] = m;
+  }
+}
+
+// scale[1] <- max of the `blocks` workgroup maxima (bits of a non-negative float); one workgroup.  blocks == 0: 0.
+static __global__ __launch_bounds__(256) void amax_finish_kernel(const unsigned* __restrict__ block_max, const int blocks,
+                                                                 float* __restrict__ scale) {
+  __shared__ unsigned wave_max[256 / kWave];
+  unsigned m = 0u;
+  for (int i = threadIdx.x; i < blocks; i += 256) m = m > block_max[i] ? m : block_max[i];
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    const unsigned o = (unsigned)__shfl_xor((int)m, off, kWave);
+    m = m > o ? m : o;
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0) wave_max[threadIdx.x / kWave] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < 256 / kWave; ++w) m = m > wave_max[w] ? m : wave_max[w];
+    reinterpret_cast<unsigned*>(scale)[1] = m;
   }
 }
 
@@ -1141,24 +1162,18 @@ static __global__ __launch_bounds__(256) void cast_f32_to_f16_scaled_kernel(cons
   }
 }
 
-// scale[0 .. 1] <- 0 as a KERNEL: inside a captured HIP graph a memset node in front of the amax kernel did not order
-// reliably against that kernel's atomics (graph replays rounded a few tiny elements on a different fp16 grid than the
-// eager call: the maximum had lost contributions) -- kernel nodes of one stream are strictly ordered.
-static __global__ void zero_scale_kernel(float* __restrict__ scale) {
-  if (threadIdx.x < 2) scale[threadIdx.x] = 0.f;
-}
-
 // scale: device float[2], 8-byte aligned.  scale[0] <- 2^e (pass it to launch_spmm_tc16 as out_scale).
 inline int cast_f32_to_f16_scaled(const float* src, _Float16* dst, long long n, float* scale, hipStream_t stream) {
   if (n < 0 || (n % 8) != 0 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15) || scale == nullptr ||
       ((uintptr_t)scale & 7))
     return kErrBadShape;
-  hipLaunchKernelGGL(zero_scale_kernel, dim3(1), dim3(64), 0, stream, scale);
   const long long n8 = n / 8;
   const int blocks = (int)(n8 / 256 + 1 < 256 * 16 ? n8 / 256 + 1 : 256 * 16);
-  if (n > 0)
-    hipLaunchKernelGGL(amax_abs_f32_kernel, dim3(blocks), dim3(256), 0, stream, src, n / 4,
-                       reinterpret_cast<unsigned*>(scale) + 1);
+  // three kernels of one stream (kernel nodes are strictly ordered, also inside a captured graph): workgroup maxima into the
+  // head of dst (blocks x 4 bytes <= 2 n: at most one word per 2048 elements), their maximum, the conversion
+  unsigned* const block_max = reinterpret_cast<unsigned*>(dst);
+  if (n > 0) hipLaunchKernelGGL(amax_abs_f32_kernel, dim3(blocks), dim3(256), 0, stream, src, n / 4, block_max);
+  hipLaunchKernelGGL(amax_finish_kernel, dim3(1), dim3(256), 0, stream, block_max, n > 0 ? blocks : 0, scale);
   hipLaunchKernelGGL(cast_f32_to_f16_scaled_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, n8, scale);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }

@@ -217,7 +217,9 @@ def _operand(feat: torch.Tensor, mode: str = None):
     # the reference's TF32 multiply has and a plain fp16 cast has not; on the stream, no host sync.
     operand = torch.empty(feat.shape, dtype=torch.float16, device=feat.device)
     out_scale = torch.empty(2, dtype=torch.float32, device=feat.device)
-    capi.launch_cast_f32_f16_scaled(feat, operand, out_scale, torch.cuda.current_stream().cuda_stream)
+    from ..jit_kernels.spmm import _raw_stream     # the stream's handle without a torch.cuda.Stream object (8 us)
+
+    capi.launch_cast_f32_f16_scaled(feat, operand, out_scale, _raw_stream(feat.device))
     return operand, out_scale, padded, exact
 
 
