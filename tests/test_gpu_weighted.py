@@ -92,3 +92,30 @@ def test_weighted_with_unit_values_is_the_binary_product_and_duplicates_add(cuda
         hd = voltrix.csr_preprocess_weighted(dup_indptr, dup_indices, vals, 900)
         out = voltrix.spmm_weighted(hd, torch.ones(900, 8).half().cuda(), hash_tag="weighted_dup")
         assert float(out[0, 0]) == float(indptr[1]) + 3.0
+
+
+def test_value_plane_in_chunks_and_without_an_fp32_master(cuda_device, monkeypatch):
+    """Round 5: the plane is built window chunk by window chunk (bounded temporaries) -- the same bits as in one piece -- and a
+    handle too large for an fp32 master keeps only the 16-bit plane it was built with."""
+    from voltrix import weighted
+
+    indptr_np, indices_np = _random_csr(2500, 40, seed=11)
+    indptr, indices = torch.from_numpy(indptr_np), torch.from_numpy(indices_np)
+    n = 2500
+    torch.manual_seed(5)
+    values = torch.randn(len(indices_np))
+    whole = voltrix.csr_preprocess_weighted(indptr, indices, values, n)
+    for chunk in (1, 1000, 7777):
+        monkeypatch.setattr(weighted, "CHUNK_EDGES", chunk)
+        again = voltrix.csr_preprocess_weighted(indptr, indices, values, n)
+        assert torch.equal(again.values32, whole.values32), chunk
+    monkeypatch.setattr(weighted, "MASTER_PLANE_MAX_BYTES", 0)
+    lean = voltrix.csr_preprocess_weighted(indptr, indices, values, n)
+    assert lean.values32 is None and list(lean.planes) == [torch.float16]
+    assert torch.equal(lean.planes[torch.float16], whole.values32.half())
+    feat = torch.randn(n, 64, device=cuda_device).half()
+    assert torch.equal(voltrix.spmm_weighted(lean, feat, hash_tag="lean"), voltrix.spmm_weighted(whole, feat, hash_tag="lean"))
+    with pytest.raises(AssertionError, match="without an fp32 master"):
+        voltrix.spmm_weighted(lean, feat.bfloat16())
+    lean_bf = voltrix.csr_preprocess_weighted(indptr, indices, values, n, plane_dtype=torch.bfloat16)
+    assert list(lean_bf.planes) == [torch.bfloat16] and torch.equal(lean_bf.planes[torch.bfloat16], whole.values32.bfloat16())
