@@ -487,8 +487,13 @@ def main():
         b_used = op.gather_into(bufs[0], feat_local)
     else:
         b_used = bufs[(step_no[0] - 1) % len(bufs)] if overlap_timed else bufs[0]
-    col_sums = b_used.float().sum(dim=1)
-    col_abs = b_used.float().abs().sum(dim=1)
+    col_sums = torch.empty(b_used.shape[0], dtype=torch.float32, device=device)
+    col_abs = torch.empty(b_used.shape[0], dtype=torch.float32, device=device)
+    for q in range(0, b_used.shape[0], 1 << 22):      # by row chunks: a float copy of B is 53 GB at the papers-like size
+        x = b_used[q:q + (1 << 22)].float()
+        col_sums[q:q + (1 << 22)] = x.sum(dim=1)
+        col_abs[q:q + (1 << 22)] = x.abs().sum(dim=1)
+        del x
     want = torch.zeros(local_rows, dtype=torch.float32, device=device)
     scale = torch.zeros(local_rows, dtype=torch.float32, device=device)
     row_of_edge_chunk = 1 << 27
