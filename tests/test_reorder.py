@@ -228,6 +228,17 @@ def test_unfolded_order_follows_the_curve_of_a_mixed_embedding():
     assert sorted(voted.tolist()) == list(range(n)) and corr(voted) > 0.9995
     place = voted.double() if float(torch.corrcoef(torch.stack([k, voted.double()]))[0, 1]) > 0 else (n - 1) - voted.double()
     assert float((place - k).abs().quantile(0.99)) < band
+    # stretches the unfolding left out come back from their ends inwards (grow_settled), rows without a confident window stay out
+    gap = settled.clone()
+    x = torch.arange(n)
+    gap[(x > 8000) & (x < 20000)] = False
+    gap[(x > 30000) & (x < 38000)] = False
+    start = torch.argsort(torch.where(gap, voted.argsort().double(), torch.full((n,), float("inf"), dtype=torch.float64)), stable=True)
+    degree = (indptr[1:] - indptr[:-1]).float()
+    grown, grown_mask = reorder.grow_settled(lambda b: a @ b.float(), start, gap, active, degree)
+    m = int(grown_mask.sum())
+    assert m > 0.99 * n and sorted(grown.tolist()) == list(range(n))
+    assert abs(float(torch.corrcoef(torch.stack([torch.arange(m, dtype=torch.float64), grown[:m].double()]))[0, 1])) > 0.99
     # rows without edges go last, in both steps
     active[::7] = False
     perm2 = reorder.unfolded_order(coords, indptr, indices, active, cells=256)

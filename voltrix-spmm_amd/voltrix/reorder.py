@@ -240,6 +240,8 @@ def bfs_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int,
 UNFOLD_CELLS = 2048
 UNFOLD_VECTORS = 8
 UNFOLD_MIN_ROWS = 1 << 16
+UNFOLD_ALL_PAIRS_CELLS = 4096  # up to this many boxes: hop distances between all of them; above: to 256 landmark boxes
+UNFOLD_ROWS_PER_CELL = 160     # graphs of more than 2048 x this many rows get more boxes (up to 16384) and 16 leading vectors
 UNFOLD_MAX_ROWS = 1 << 22      # the neighbour votes hold a [rows, 512] fp32 matrix (8.6 GB here); larger graphs keep the plain sort
 UNFOLD_MIN_ONE_DIMENSIONAL = 30.0   # leading / second eigenvalue of the boxes' distance scaling below which the unfolding is dropped
 SUBSPACE_SPREAD = 0.8          # more subspace-iteration rounds while the smallest Ritz value is above this x the largest ...
@@ -351,27 +353,64 @@ def unfolded_order(coords: torch.Tensor, indptr: torch.Tensor, indices: torch.Te
     adj = torch.zeros(g, g, dtype=torch.bool, device=dev)
     adj[torch.arange(g, device=dev)[:, None].expand(-1, links)[strong], top.indices[strong]] = True
     adj = adj & adj.T                                        # both boxes name each other
-    # hop distances over the links: frontier expansion for all boxes at once
-    reach = torch.eye(g, dtype=torch.bool, device=dev)
-    dist = torch.full((g, g), float("inf"), dtype=torch.float32, device=dev)
-    dist[reach] = 0.0
-    adj_f = adj.float()
+    # hop distances over the links
     hops = 0
-    while hops < g:
-        hops += 1
-        nxt = ((reach.float() @ adj_f) > 0) & ~reach
-        if not bool(nxt.any()):
-            break
-        dist[nxt] = float(hops)
-        reach |= nxt
-    mark("hop distances")
-    # the largest connected set of pure boxes carries the order; the others are placed by the refinement
-    comp = reach[int(reach.sum(1).argmax())] & pure
-    idx = torch.nonzero(comp).flatten()
-    dd = dist[idx][:, idx].double() ** 2
-    j = dd - dd.mean(0, keepdim=True) - dd.mean(1, keepdim=True) + dd.mean()
-    evals, evecs = torch.linalg.eigh(-0.5 * j)
-    coord = evecs[:, -1]
+    if g <= UNFOLD_ALL_PAIRS_CELLS:
+        # all boxes at once: frontier expansion by dense boolean products
+        reach = torch.eye(g, dtype=torch.bool, device=dev)
+        dist = torch.full((g, g), float("inf"), dtype=torch.float32, device=dev)
+        dist[reach] = 0.0
+        adj_f = adj.float()
+        while hops < g:
+            hops += 1
+            nxt = ((reach.float() @ adj_f) > 0) & ~reach
+            if not bool(nxt.any()):
+                break
+            dist[nxt] = float(hops)
+            reach |= nxt
+        mark("hop distances")
+        # the largest connected set of pure boxes carries the order; the others are placed by the neighbour votes
+        comp = reach[int(reach.sum(1).argmax())] & pure
+        idx = torch.nonzero(comp).flatten()
+        dd = dist[idx][:, idx].double() ** 2
+        j = dd - dd.mean(0, keepdim=True) - dd.mean(1, keepdim=True) + dd.mean()
+        evals, evecs = torch.linalg.eigh(-0.5 * j)
+        coord = evecs[:, -1]
+    else:
+        # many boxes (long thin graphs): distances to LANDMARK boxes only, and landmark scaling (de Silva & Tenenbaum): the
+        # leading eigenpair of the landmarks' own double-centred squared distances, every other box by triangulation
+        num_landmarks = 256
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0)
+        cand = torch.nonzero(pure & (adj.sum(1) > 0)).flatten()
+        lm = cand[torch.randperm(cand.numel(), generator=gen, device=dev)[:num_landmarks]]
+        num_landmarks = lm.numel()
+        reach = torch.zeros(g, num_landmarks, dtype=torch.bool, device=dev)
+        reach[lm, torch.arange(num_landmarks, device=dev)] = True
+        dist = torch.full((g, num_landmarks), float("inf"), dtype=torch.float32, device=dev)
+        dist[reach] = 0.0
+        adj_h = adj.half()
+        while hops < g:
+            hops += 1
+            nxt = ((adj_h @ reach.half()) > 0) & ~reach      # at most 16 links per box: the sums are exact in fp16
+            if not bool(nxt.any()):
+                break
+            dist[nxt] = float(hops)
+            reach |= nxt
+        mark("hop distances")
+        # landmarks of the largest connected set, and the boxes that set reaches
+        ll = reach[lm]                                        # [L, L]: landmark i reached from landmark j
+        main = ll[:, int(ll.sum(0).argmax())]
+        keep = torch.nonzero(main).flatten()
+        comp = reach[:, keep].all(1) & pure
+        idx = torch.nonzero(comp).flatten()
+        dl = dist[lm[keep]][:, keep].double() ** 2            # landmark-landmark squared distances
+        mean_col = dl.mean(0)
+        j = dl - dl.mean(0, keepdim=True) - dl.mean(1, keepdim=True) + dl.mean()
+        evals, evecs = torch.linalg.eigh(-0.5 * j)
+        v1, l1 = evecs[:, -1], evals[-1].clamp(min=1e-30)
+        dx = dist[idx][:, keep].double() ** 2
+        coord = -0.5 * ((dx - mean_col[None, :]) @ v1) / l1.sqrt()
     mark("scaling")
     cell_pos = torch.full((g,), float("nan"), dtype=torch.float64, device=dev)
     cell_pos[idx] = torch.argsort(torch.argsort(coord)).double()
@@ -388,7 +427,7 @@ def unfolded_order(coords: torch.Tensor, indptr: torch.Tensor, indices: torch.Te
 
 
 def neighbour_votes(apply_a, perm: torch.Tensor, settled: torch.Tensor, active: torch.Tensor, buckets: int = 256,
-                    reach: int = 3) -> torch.Tensor:
+                    reach: int = 3, degree: torch.Tensor = None, confidence: float = 0.1) -> torch.Tensor:
     """One round of neighbour votes (round 5): every row moves to where most of its neighbours are.  ``perm`` orders the
     ``settled`` rows (they come first); their positions are cut into ``buckets`` equal stretches, ``apply_a(B)`` = ``A @ B`` of the
     one-hot bucket matrix counts every row's neighbours per stretch (one SpMM, ``buckets`` columns), and the row goes to the
@@ -415,9 +454,60 @@ def neighbour_votes(apply_a, perm: torch.Tensor, settled: torch.Tensor, active: 
     idx = best[:, None] + offs[None, :]
     wts = votes.gather(1, idx)
     centre = (wts * (idx.float() + 0.5)).sum(1) / wts.sum(1).clamp(min=1e-30)
-    new_pos = torch.where(total > 0, centre * (ns / buckets), pos.float())
+    sure = total > 0
+    if degree is not None:   # a window that holds only chance votes moves nobody (argmax of noise: the first stretch)
+        sure = (total >= 2.0) & (total >= confidence * degree)
+    new_pos = torch.where(sure, centre * (ns / buckets), pos.float())
     key = torch.where(active, new_pos, torch.full_like(new_pos, float("inf")))
     return torch.argsort(key, stable=True)
+
+
+def grow_settled(apply_a, perm: torch.Tensor, settled: torch.Tensor, active: torch.Tensor, degree: torch.Tensor,
+                 buckets: int = 256, reach: int = 3, max_rounds: int = 256, confidence: float = 0.15):
+    """Rows the unfolding could not order (boxes off the main chain: whole stretches of a long thin band) join it from its ends
+    inwards (round 5): per round one SpMM counts every row's SETTLED neighbours per stretch of the settled order; an unsettled
+    row whose densest window holds at least ``confidence`` of its edges (the uniform background puts ``(2 reach + 1) / buckets``
+    of them into any window) is placed at that window's centroid and settles; its own neighbours find it there in the next
+    round.  Settled rows keep their relative order.  Returns ``(perm, settled)``: settled rows first, in order."""
+    dev = perm.device
+    n = perm.numel()
+    settled = settled.clone()
+    pos = torch.full((n,), float("inf"), dtype=torch.float64, device=dev)
+    ns = int(settled.sum())
+    pos[perm[:ns]] = torch.arange(ns, device=dev, dtype=torch.float64)
+    width = 2 * reach + 1
+    offs = torch.arange(width, device=dev)
+    for _ in range(max_rounds):
+        todo = active & ~settled
+        if not bool(todo.any()) or ns == 0:
+            break
+        rank = torch.empty(n, dtype=torch.int64, device=dev)
+        order = torch.argsort(pos, stable=True)
+        rank[order] = torch.arange(n, device=dev)
+        b = (rank * buckets // ns).clamp(max=buckets - 1)
+        onehot = torch.zeros(n, buckets, dtype=torch.float16, device=dev)
+        rows = torch.nonzero(settled).flatten()
+        onehot[rows, b[rows]] = 1.0
+        votes = apply_a(onehot).float()
+        del onehot
+        cs = torch.nn.functional.pad(votes.cumsum(1), (1, 0))
+        window = cs[:, width:] - cs[:, :-width]
+        best = window.argmax(1)
+        total = window.gather(1, best[:, None])[:, 0]
+        idx = best[:, None] + offs[None, :]
+        wts = votes.gather(1, idx)
+        centre = (wts * (idx.float() + 0.5)).sum(1) / wts.sum(1).clamp(min=1e-30)
+        sure = todo & (total >= 2.0) & (total >= confidence * degree)   # two votes in one window: 3 % by chance at 7 of 256 stretches
+        if not bool(sure.any()):
+            break
+        # a stretch's centre in the positions of the settled order: (centre / buckets) ns, between the ranks of its neighbours
+        pos[sure] = centre[sure].double() * (ns / buckets) - 0.5
+        settled |= sure
+        ns = int(settled.sum())
+        order = torch.argsort(pos, stable=True)
+        pos[order[:ns]] = torch.arange(ns, device=dev, dtype=torch.float64)    # ranks again: the next round's stretches
+    key = torch.where(settled, pos, torch.full_like(pos, float("inf")))
+    return torch.argsort(key, stable=True), settled
 
 
 def spectral_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
@@ -527,9 +617,13 @@ def spectral_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes:
         if unfold is None:
             unfold = m == n and UNFOLD_MIN_ROWS <= n <= UNFOLD_MAX_ROWS and nnz < (1 << 31) and vectors >= UNFOLD_VECTORS
         if unfold:   # nearly degenerate leading vectors: order along the CURVE of the leading subspace (unfolded_order)
-            lead = (x @ torch.from_numpy(evecs_np[:, -UNFOLD_VECTORS:].astype(np.float32)).to(dev)) * ir
+            cells = UNFOLD_CELLS
+            while cells < 16384 and n > cells * UNFOLD_ROWS_PER_CELL * 4:
+                cells *= 2
+            lead_vectors = UNFOLD_VECTORS if cells == UNFOLD_CELLS else min(2 * UNFOLD_VECTORS, x.shape[1] // 2)
+            lead = (x @ torch.from_numpy(evecs_np[:, -lead_vectors:].astype(np.float32)).to(dev)) * ir
             plain = perm
-            perm, unfold_info = unfolded_order(lead, indptr, indices, deg_r > 0, return_info=True)
+            perm, unfold_info = unfolded_order(lead, indptr, indices, deg_r > 0, cells=cells, return_info=True)
             settled = unfold_info.pop("settled")
             # trust the unfolded order only when the boxes hang together and their distance matrix IS one-dimensional (leading
             # eigenvalue of the scaling far above the second: 100-126 x on the reddit-like stand-in; 2-16 x on the products-like
@@ -547,9 +641,12 @@ def spectral_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes:
                     return spmm(*handle, num_nodes=n, num_edges=nnz, feat=b)
 
             if unfold_info["accepted"]:
-                perm = neighbour_votes(apply_a, perm, settled, deg_r > 0)
+                unfold_info["settled_rows_before_growth"] = int(settled.sum())
+                perm, settled = grow_settled(apply_a, perm, settled, deg_r > 0, deg_r)
+                unfold_info["settled_rows"] = int(settled.sum())
+                perm = neighbour_votes(apply_a, perm, settled, deg_r > 0, degree=deg_r)
                 for _ in range(max(0, vote_rounds - 1)):                                                # everybody settled: finer stretches
-                    perm = neighbour_votes(apply_a, perm, deg_r > 0, deg_r > 0, buckets=512, reach=5)
+                    perm = neighbour_votes(apply_a, perm, deg_r > 0, deg_r > 0, buckets=512, reach=5, degree=deg_r)
             else:
                 perm = plain
             stamp("unfolding")
