@@ -149,6 +149,46 @@ def vendor_baseline(indptr, indices, num_nodes, num_feats, device):
         return {"name": "torch.sparse.mm on the GPU (hipSPARSE CSR SpMM)", "error": str(exc)[:200]}
 
 
+def rocsparse_baseline(indptr, indices, num_nodes, feat, ms_per_step):
+    """Round 6: rocSPARSE's generic SpMM, every CSR algorithm it offers (buffer-size and preprocess stages outside the timed
+    loop, as the reference keeps cuSPARSE's: bench/bm_sparse.py:20-45), on fp32 operands (what the reference's speed-ups are
+    quoted on) and on the timed path's own fp16-in / fp32-compute, plus a plain CSR row-gather kernel ("no format").
+    harness/bm_rocsparse.cpp: plain HIP + rocSPARSE; warm, back to back, like the timed steps."""
+    try:
+        from harness import bm_rocsparse
+
+        out = {}
+        for label, operand in (("fp32", feat.float()), ("fp16", feat.half())):
+            cells = bm_rocsparse.baselines(indptr, indices, num_nodes, operand.contiguous(), iters=5, warmup=2)
+            name, ms = bm_rocsparse.best(cells)
+            gname, gms = bm_rocsparse.best(cells, prefix="csr_row_gather")
+            out[label] = {"ms": {k: (None if v is None else round(v, 4)) for k, v in cells.items()},
+                          "rocsparse_best": name, "rocsparse_best_ms": ms,
+                          "speedup_of_this_work": None if ms is None else ms / ms_per_step,
+                          "csr_row_gather_ms": gms, "speedup_over_csr_row_gather": None if gms is None else gms / ms_per_step}
+            del operand
+        return out
+    except Exception as exc:  # noqa: BLE001  (library missing / out of memory: report, do not fail the bench)
+        return {"error": repr(exc)[:200]}
+
+
+def gather_ceiling(gather_bytes, operand_bytes, kernel_ms):
+    """An INDEPENDENT ceiling for the format's gathered bytes: the time the step's gathered rows of B would
+    take at the per-CU rates MI355X_MICROARCH.md measures for rows gathered into LDS ('Indexed rows: gather into LDS') -- the
+    guide's constants, not this kernel's own rate: 73 GB/s per CU when every row is an L2 hit (the upper end of its 66-73), and
+    the rate of where B actually lives when none is (33.5 Infinity Cache up to 128 MB, 30 up to 256 MB, 23.5 HBM).  frac =
+    ceiling time / measured kernel time: the share of the step the gathers would need at that rate."""
+    if not gather_bytes:
+        return None
+    beyond = 33.5 if operand_bytes <= (128 << 20) else (30.0 if operand_bytes <= (256 << 20) else 23.5)
+    per_cu = gather_bytes / 256
+    l2_ms, far_ms = per_cu / 73.0e9 * 1e3, per_cu / (beyond * 1e9) * 1e3
+    return {"bytes": gather_bytes, "all_l2": {"gb_s_per_cu": 73.0, "ms": l2_ms, "frac": l2_ms / kernel_ms},
+            "none_l2": {"gb_s_per_cu": beyond, "ms": far_ms, "frac": far_ms / kernel_ms},
+            "what": "gathered bytes / 256 CUs / the guide's per-CU LDS-gather rate (MI355X_MICROARCH.md 'Indexed rows'); frac = "
+                    "ceiling time / measured kernel time (1.0 = the step runs at the guide's gather rate)"}
+
+
 def gather_model(gather_bytes, l2_hit_frac, operand_bytes, kernel_ms):
     """A MODEL beside the HBM roofline, for the reader: what the CU's row-gather path delivers for this step's hit mix, from the
     per-CU rates MI355X_MICROARCH.md measures for rows gathered into LDS (section 'Indexed rows') -- 66-73 GB/s per CU when the
@@ -544,6 +584,23 @@ def main():
             step()
     kernels_ms = {k: round(v[1], 4) for k, v in timer.summary().items()}
 
+    # ---- the like-for-like step for the fp32 baselines: the same operator call on fp32 features, outside
+    # ---- the timed region (the reference feeds fp32; here they become scaled fp16 or exact fp32 tiles: `config.fp32_in_runs_as`)
+    fp32_in_ms = None
+    if world == 1 and is_f16 and whandle is None and not args.no_cpu_baseline and gathered.numel() * 4 < (8 << 30):
+        feat32 = gathered.float()
+        call32 = lambda: voltrix.spmm(*handle, num_nodes=local_rows, num_edges=local_nnz, feat=feat32)  # noqa: E731
+        for _ in range(3):
+            call32()
+        ev32 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev32[0].record()
+        for _ in range(10):
+            call32()
+        ev32[1].record()
+        ev32[1].synchronize()
+        fp32_in_ms = ev32[0].elapsed_time(ev32[1]) / 10
+        del feat32
+
     # ---- what the operator ran (the tuner's choice), for the record -----------------------------------------------------
     from voltrix.spmm.spmm import fp32_mode
 
@@ -759,6 +816,7 @@ def main():
                        + (f", {args.slabs} feature slabs pipelined" if slab_pipeline else ""))
                     if distributed else ""),
                 "preprocess_ms": preprocess_ms,
+                "fp32_in_ms_per_step": fp32_in_ms, "fp32_in_runs_as": fp32_as,
                 "rowsum_check_max_rel_err": check_err,
                 "cache_state": "warm (steps back to back; B stays in the Infinity Cache when it fits)",
                 "hbm_gbs_algorithmic": synth_graphs.algorithmic_bytes(num_nodes, nnz, num_feats, in_bytes)
@@ -777,6 +835,7 @@ def main():
                 "gather_bytes": gather_bytes, "gather_gbs": gather_bytes / (kernel_ms * 1e-3) / 1e9,
                 "note": "gather-bound: B rows are served by L2 / Infinity Cache (~8.6-19 TB/s row-gather ceilings), "
                         "see DESIGN.md section 5",
+                "gather_ceiling": gather_ceiling(gather_bytes, num_cols * num_feats * in_bytes, kernel_ms),
                 "gather_model": gather_model(gather_bytes, counters.get("l2_hit_frac") if counters else None,
                                                  num_cols * num_feats * in_bytes, kernel_ms),
             },
@@ -786,6 +845,7 @@ def main():
             vb = vendor_baseline(local_indptr, local_indices, num_nodes, num_feats, device)
             if "ms" in vb:
                 vb["speedup_of_this_work"] = vb["ms"] / ms_per_step
+            vb["rocsparse"] = rocsparse_baseline(local_indptr, local_indices, num_nodes, gathered, ms_per_step)
             line["vendor_gpu_baseline"] = vb
             line["cpu_baseline"] = cpu_baseline(local_indptr, local_indices, num_nodes, num_nodes, num_feats)
         print(json.dumps(line), flush=True)

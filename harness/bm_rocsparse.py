@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""rocSPARSE's generic CSR SpMM with every algorithm it offers + a plain CSR row-gather kernel, on device CSR arrays (round 6,
+VERDICT r5 item 4: a vendor baseline worth beating; the role of the reference's bench/bm_sparse.py:6-52, cuSPARSE there).
+
+    from harness import bm_rocsparse
+    cells = bm_rocsparse.baselines(indptr, indices, num_nodes, feat, flush=False)   # {name: ms or None}
+    best_name, best_ms = bm_rocsparse.best(cells, prefix="rocsparse")
+
+``harness/bm_rocsparse.cpp`` (plain HIP + rocSPARSE, no torch) does the work; torch only owns the device buffers.  Buffer sizing
+and the preprocess stage are OUTSIDE the timed loop, as the reference keeps cuSPARSE's (bm_sparse.py:20-45).  fp16 operands use
+rocSPARSE's mixed precision (fp16 A / B, fp32 C and compute).  Command line: the files graph_gen.py writes, like bm_sparse.py.
+Bench infrastructure, not part of the product."""
+import argparse
+import ctypes
+import os
+import subprocess
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+ALGORITHMS = {"rocsparse_csr": 1, "rocsparse_csr_row_split": 4, "rocsparse_csr_nnz_split": 5, "rocsparse_csr_merge_path": 9}
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(HERE, "libbm_rocsparse.so")
+        if not os.path.exists(path):     # normally built by __graft_entry__.build() / `make -C harness`
+            subprocess.check_call(["make", "-s", "-C", HERE, "libbm_rocsparse.so"])
+        _lib = ctypes.CDLL(path)
+        _lib.bm_rocsparse_spmm.restype = ctypes.c_int
+        _lib.bm_rocsparse_spmm.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64] * 3 + [ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float),
+                                           ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_float)]
+        _lib.bm_csr_row_gather.restype = ctypes.c_int
+        _lib.bm_csr_row_gather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+    return _lib
+
+
+FLUSH_BYTES = 512 << 20      # the amount voltrix.utils._flush_cache writes (L2 + Infinity Cache)
+
+
+def baselines(indptr, indices, num_nodes, feat, flush=False, iters=10, warmup=3, algorithms=None, row_gather=True,
+              out=None, details=None, reference=None):
+    """{name: mean ms of one product, or None when the library refuses the combination}.  ``feat`` fp16 or fp32 [N, F] on the
+    device; C fp32.  ``out``: receives the last computed C (for checks).  ``details``: dict that receives buffer sizes /
+    preprocess times / return codes (and, with ``reference`` = the expected fp32 C, every cell's ``calc_diff`` against it)."""
+    assert indptr.is_cuda and indices.is_cuda and feat.is_cuda and feat.is_contiguous()
+    assert indptr.dtype == torch.int32 and indices.dtype == torch.int32
+    dtype = {torch.float16: 1, torch.float32: 0}[feat.dtype]
+    nnz, num_feats = int(indices.numel()), int(feat.shape[1])
+    values = torch.ones(nnz, dtype=feat.dtype, device=feat.device)
+    c = out if out is not None else torch.empty(num_nodes, num_feats, dtype=torch.float32, device=feat.device)
+    scratch = torch.empty(FLUSH_BYTES, dtype=torch.uint8, device=feat.device) if flush else None
+    stream = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    cells = {}
+    for name, alg in (algorithms or ALGORITHMS).items():
+        ms, bytes_, pre = ctypes.c_float(0), ctypes.c_size_t(0), ctypes.c_float(0)
+        rc = lib().bm_rocsparse_spmm(indptr.data_ptr(), indices.data_ptr(), values.data_ptr(), num_nodes, int(feat.shape[0]), nnz,
+                                     num_feats, feat.data_ptr(), c.data_ptr(), dtype, alg, warmup, iters,
+                                     scratch.data_ptr() if flush else None, FLUSH_BYTES if flush else 0, stream,
+                                     ctypes.byref(ms), ctypes.byref(bytes_), ctypes.byref(pre))
+        cells[name] = ms.value if rc == 0 else None
+        if details is not None:
+            details[name] = {"rc": rc, "buffer_bytes": bytes_.value, "preprocess_ms": pre.value}
+            if reference is not None and rc == 0:
+                details[name]["calc_diff"] = _calc_diff(c, reference)
+    if row_gather:
+        vec = 8 if dtype == 1 else 4
+        if num_feats % vec == 0 and 256 % (num_feats // vec) == 0:
+            for unroll in (4, 8):
+                ms = ctypes.c_float(0)
+                rc = lib().bm_csr_row_gather(indptr.data_ptr(), indices.data_ptr(), num_nodes, num_feats, feat.data_ptr(),
+                                             c.data_ptr(), dtype, unroll, warmup, iters, scratch.data_ptr() if flush else None,
+                                             FLUSH_BYTES if flush else 0, stream, ctypes.byref(ms))
+                cells[f"csr_row_gather_u{unroll}"] = ms.value if rc == 0 else None
+                if details is not None and reference is not None and rc == 0:
+                    details[f"csr_row_gather_u{unroll}"] = {"rc": rc, "calc_diff": _calc_diff(c, reference)}
+    torch.cuda.synchronize()
+    return cells
+
+
+def _calc_diff(x, y):
+    x, y = x.double(), y.double()
+    return float(1 - 2 * (x * y).sum() / (x * x + y * y).sum())
+
+
+def best(cells, prefix="rocsparse"):
+    got = {k: v for k, v in cells.items() if k.startswith(prefix) and v is not None}
+    if not got:
+        return None, None
+    name = min(got, key=got.get)
+    return name, got[name]
+
+
+def main(argv=None):
+    import numpy as np
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dir", default=".")
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--npz", default=None)
+    ap.add_argument("--num_feats", type=int, default=128)
+    ap.add_argument("--seed", type=int, default=20)
+    ap.add_argument("--half", action="store_true", help="fp16 values / features (rocSPARSE mixed precision), fp32 result")
+    args = ap.parse_args(argv)
+    f = lambda name: os.path.join(args.dir, name)  # noqa: E731
+    if args.npz:
+        sys.path.insert(0, REPO)
+        from harness.graph_gen import load_graph
+
+        ip, ix = load_graph(args.npz)
+        offsets, indices = torch.from_numpy(ip).cuda(), torch.from_numpy(ix).cuda()
+        n = offsets.numel() - 1
+        torch.manual_seed(args.seed)
+        weight = torch.randn(n, args.num_feats, dtype=torch.float32).cuda()
+        base = None
+    else:
+        indices = torch.tensor(np.loadtxt(f("indices.csv"), delimiter=",", dtype=np.int32), dtype=torch.int32).cuda()
+        offsets = torch.tensor(np.loadtxt(f("indptr.csv"), delimiter=",", dtype=np.int32), dtype=torch.int32).cuda()
+        n = offsets.numel() - 1
+        weight = torch.tensor(np.fromfile(f("feat.csv"), dtype=np.float32)).cuda().view(n, -1)
+        base = np.fromfile(f("output_base.csv"), dtype=np.float32).reshape(n, -1)
+    feat = weight.half() if args.half else weight
+    out = torch.empty(n, weight.shape[1], dtype=torch.float32, device="cuda")
+    cells = baselines(offsets, indices, n, feat.contiguous(), iters=args.iters, warmup=10, out=out)
+    if base is not None:
+        print(bool(np.allclose(out.cpu().numpy(), base, atol=1e-1)))
+    for name, ms in cells.items():
+        print(f"[{name}] " + (f"Elapsed time: {ms:.4f} ms" if ms is not None else "not implemented"))
+    name, ms = best(cells)
+    print(f"[rocSPARSE-best] Elapsed time: {ms:.4f} ms ({name})")
+
+
+if __name__ == "__main__":
+    main()

@@ -73,7 +73,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--datasets", default=",".join(synth_graphs.EVALUATION_SET))
     ap.add_argument("--feature_dims", default="32,128,256,512,1024")
-    ap.add_argument("--methods", default="hipSPARSE,Voltrix,Voltrix-fp16")
+    ap.add_argument("--methods", default="hipSPARSE,rocSPARSE-best,rocSPARSE-best-fp16,Voltrix,Voltrix-fp16")
     ap.add_argument("--output_file", default="results.csv")
     ap.add_argument("--jsonl", default="eval_set.jsonl")
     ap.add_argument("--scale", type=float, default=1.0)
@@ -132,6 +132,31 @@ def main(argv=None):
                 if "hipSPARSE" in methods:
                     ms = GPU_bench(run, iters=args.iters, warmup=3, kernel_name="spmm")
                     record("hipSPARSE", name, dim, "N", ms, dict(num_nodes=n, nnz=nnz, steady_ms=steady_ms(run, iters=3, batch=3)))
+            # round 6: rocSPARSE's generic SpMM, the best of its four CSR algorithms per cell (buffer size + preprocess stages
+            # outside the timed loop), fp32 and fp16-in / fp32-compute, and a plain CSR row-gather kernel beside them
+            for method in [m for m in methods if m.startswith("rocSPARSE-best")]:
+                from harness import bm_rocsparse
+
+                operand = feat32.half() if method.endswith("fp16") else feat32
+                suffix = "-fp16" if method.endswith("fp16") else ""
+                got = torch.empty(n, dim, device=dev)
+                detail = {}
+                flushed = bm_rocsparse.baselines(indptr, indices, n, operand, flush=True, iters=args.iters, out=got, details=detail,
+                                                  reference=base if args.check else None)
+                steady = bm_rocsparse.baselines(indptr, indices, n, operand, flush=False, iters=args.iters)
+                name_f, ms_f = bm_rocsparse.best(flushed)
+                name_s, ms_s = bm_rocsparse.best(steady)
+                extra = dict(num_nodes=n, nnz=nnz, steady_ms=ms_s, best_algorithm=name_s, best_algorithm_flushed=name_f,
+                             flushed=flushed, steady=steady, preprocess={k: v for k, v in detail.items()})
+                if args.check and base is not None:
+                    extra["calc_diff_vs_hipsparse"] = max((v.get("calc_diff", 0.0) for v in detail.values()), default=None)
+                if ms_f is not None:
+                    record(method, name, dim, "N", ms_f, extra)
+                name_g, ms_g = bm_rocsparse.best(flushed, prefix="csr_row_gather")
+                if ms_g is not None:
+                    record("CSR-gather" + suffix, name, dim, "N", ms_g,
+                           dict(num_nodes=n, nnz=nnz, steady_ms=bm_rocsparse.best(steady, prefix="csr_row_gather")[1]))
+                del got, operand
             for method in [m for m in methods if m.startswith("Voltrix")]:
                 feat = feat32.half() if method == "Voltrix-fp16" else feat32
                 for mark, h, reorder_ms in variants:

@@ -198,3 +198,26 @@ def test_cache_version_follows_the_include_graph_of_the_jit_kernels():
     assert {"voltrix/spmm_kernels.hpp", "voltrix/bmat_kernels.hpp", "voltrix/traits.hpp"} <= set(closure)
     assert "voltrix/reorder_kernels.hpp" not in closure and "voltrix/unit_table.hpp" not in closure
     assert len(compiler.get_repo_version()) == 12
+
+
+def test_compiler_version_is_read_without_starting_a_program(monkeypatch):
+    """Round 6: loading a cached kernel must not spawn anything -- `hipcc --version` (which runs hipconfig)
+    was started from inside the first spmm call, i.e. after the GPU was initialised under `rocprofv3 --pmc`.  The version comes
+    from hip_version.h beside the compiler and equals what `hipcc --version` prints (the cache keys do not move)."""
+    import subprocess
+
+    path, version = vcompiler.get_hipcc_compiler()
+    printed = re.search(r"HIP version:\s*([\d.]+)", subprocess.run([path, "--version"], capture_output=True, text=True).stdout).group(1)
+    assert version == printed
+
+    def no_spawn(*a, **k):
+        raise AssertionError(f"spawned {a}")
+
+    monkeypatch.setattr(subprocess, "run", no_spawn)
+    monkeypatch.setattr(subprocess, "Popen", no_spawn)
+    vcompiler.get_hipcc_compiler.cache_clear()
+    try:
+        assert vcompiler.get_hipcc_compiler() == (path, version)
+        assert vcompiler.kernel_dir("probe", "int x;")
+    finally:
+        vcompiler.get_hipcc_compiler.cache_clear()

@@ -113,11 +113,30 @@ def get_hipcc_compiler() -> Tuple[str, str]:
     pattern = re.compile(r"HIP version:\s*([\d.]+)")
     for path in candidates:
         if path and os.path.exists(path):
-            out = subprocess.run([path, "--version"], capture_output=True, text=True).stdout
-            match = pattern.search(out)
-            assert match, f"Cannot get the version of HIP compiler {path}"
-            return path, match.group(1)
+            # the version WITHOUT starting a program (round 6): a cached kernel must load without any spawn -- `hipcc --version`
+            # runs hipconfig, and a process whose GPU is already initialised (every program under `rocprofv3 --pmc`) must not
+            # exec anything on this pool.  <rocm>/include/hip/hip_version.h holds the same "major.minor.patch" hipcc prints.
+            version = _hip_version_from_header(path)
+            if version is None:
+                out = subprocess.run([path, "--version"], capture_output=True, text=True).stdout
+                match = pattern.search(out)
+                assert match, f"Cannot get the version of HIP compiler {path}"
+                version = match.group(1)
+            return path, version
     raise RuntimeError("Cannot find any available hipcc compiler")
+
+
+def _hip_version_from_header(hipcc_path: str):
+    """"7.2.26015" from the hip_version.h that ships beside ``hipcc`` (None when it is not there)."""
+    root = os.path.dirname(os.path.dirname(os.path.realpath(hipcc_path)))
+    header = os.path.join(root, "include", "hip", "hip_version.h")
+    try:
+        with open(header) as f:
+            text = f.read()
+    except OSError:
+        return None
+    parts = [re.search(rf"#define\s+HIP_VERSION_{k}\s+(\d+)", text) for k in ("MAJOR", "MINOR", "PATCH")]
+    return ".".join(m.group(1) for m in parts) if all(parts) else None
 
 
 get_nvcc_compiler = get_hipcc_compiler  # drop-in alias (reference name)
