@@ -15,8 +15,9 @@ Two timings per cell:
   * the jsonl line adds the steady-state time (median of batches of back-to-back calls: bench.py's protocol), the HBM-roofline
     fraction of the algorithmic bytes 4 (nnz + N + 1) + N F (s_in + 4), launches per call, the first call's
     wall time, the handle's TC blocks / stages (= gathered bytes) and the tile the tuner picked.
-``--reorder`` adds Reorder=Y rows: the library's symmetric relabelling (csr_preprocess_reordered(..., relabel=True)), features
-permuted outside the timed call, as bench_all.py:120-129 runs Voltrix on ``<name>.reorder.npz``.
+``--reorder`` adds Reorder=S and Reorder=Y rows (round 6): S = the graph with its labels SHUFFLED (seeded random P A P^T), Y = the
+library's symmetric relabelling of THAT (csr_preprocess_reordered(shuffled, method="auto", relabel=True)), features permuted
+outside the timed call, as bench_all.py:120-129 runs Voltrix on ``<name>.reorder.npz``; N = the stand-in as generated.
 Bench infrastructure, not part of the product.
 """
 import argparse
@@ -114,11 +115,23 @@ def main(argv=None):
         two = voltrix.two_level_of(handle[1])
         variants = [("N", handle, None)]
         if args.reorder:
+            # round 6: the Reorder rows start from SHUFFLED labels -- P A P^T for a seeded random P, what a
+            # dataset looks like before anybody reordered it.  "S" = that graph as it is, "Y" = the library's own symmetric
+            # reorder of it (bench_all.py:120-149 times Voltrix on <name>.reorder.npz of every dataset); "N" = the stand-in in its
+            # generating order (what a well-reordered file looks like).
+            s_indptr, s_indices, _ = synth_graphs.shuffle_labels(indptr, indices, 4242)
+            sh = voltrix.csr_preprocess_device(s_indptr, s_indices, n)
+            sh[1].hash_tag = f"eval/{standin}/{args.scale}/shuffled"
+            variants.append(("S", sh, None))
+            reorder_info = {}
+            torch.cuda.synchronize()
             t0 = time.perf_counter()
-            rh = voltrix.csr_preprocess_reordered(indptr.cpu(), indices.cpu(), n, method="auto", relabel=True)
+            rh = voltrix.csr_preprocess_reordered(s_indptr, s_indices, n, method="auto", relabel=True, info=reorder_info)
             torch.cuda.synchronize()
             reorder_ms = (time.perf_counter() - t0) * 1e3
+            rh.hspa_packed.hash_tag = f"eval/{standin}/{args.scale}/reordered"
             variants.append(("Y", rh, reorder_ms))
+            del s_indptr, s_indices
         csr = None
         if "hipSPARSE" in methods or args.check:
             csr = torch.sparse_csr_tensor(indptr, indices, torch.ones(nnz, device=dev), size=(n, n))
@@ -163,6 +176,8 @@ def main(argv=None):
                     if mark == "Y":
                         fin = voltrix.permute_features(h, feat)
                         call = lambda: voltrix.spmm_reordered(h, fin)  # noqa: E731  (B and C in the new order)
+                    elif mark == "S":
+                        call = lambda: voltrix.spmm(*h, num_nodes=n, num_edges=nnz, feat=feat)  # noqa: E731
                     else:
                         call = lambda: voltrix.spmm(*h, num_nodes=n, num_edges=nnz, feat=feat)  # noqa: E731
                     torch.cuda.synchronize()
@@ -174,16 +189,23 @@ def main(argv=None):
                     st = steady_ms(call)
                     s_in = feat.element_size()
                     alg = synth_graphs.algorithmic_bytes(n, nnz, dim, s_in)
+                    if mark != "N":      # the variant's own handle: TC blocks / stages of the shuffled or reordered graph
+                        offs = h.blk_offsets if mark == "Y" else h[0]
+                        v_blocks, v_stages = int(offs[-1]), int((((offs[1:] - offs[:-1]) + 3) // 4).sum())
+                    else:
+                        v_blocks, v_stages = blocks, stages
                     extra = dict(num_nodes=n, nnz=nnz, steady_ms=st, first_call_ms=first_ms, preprocess_ms=prep_ms,
                                  algorithmic_bytes=alg, hbm_roofline_frac=alg / (st * 1e-3) / HBM_PEAK,
                                  hbm_roofline_frac_flushed=alg / (ms * 1e-3) / HBM_PEAK, gflops=2.0 * nnz * dim / st / 1e6,
-                                 tc_blocks=blocks, stages=stages, gathered_bytes=stages * 32 * dim * 2,
+                                 tc_blocks=v_blocks, stages=v_stages, gathered_bytes=v_stages * 32 * dim * 2,
                                  two_level=two is not None and mark == "N", launches=launches_per_call(call),
                                  tile=tuned_point(two.hspa_packed if (two is not None and mark == "N") else h[1],
                                                   (dim + 7) // 8 * 8, two is not None and mark == "N", dev) if mark == "N" else None,
                                  tuner=dict(jit_tuner.stats))
                     if reorder_ms is not None:
                         extra["reorder_ms"] = reorder_ms
+                        extra["reorder_picked"] = h.method
+                        extra["reorder_estimates"] = {k: round(v.get("estimated_ms", 0.0), 4) for k, v in (reorder_info.get("report") or {}).items()}
                     if args.check and base is not None and mark == "N":
                         extra["calc_diff_vs_hipsparse"] = float(calc_diff(out, base))
                     record(method, name, dim, mark, ms, extra)
