@@ -84,6 +84,12 @@ def parse_args():
                     help="N = 1: the WEIGHTED product (voltrix.csr_preprocess_weighted / spmm_weighted; SURVEY.md 8f rank 4, no "
                          "reference counterpart) with the symmetric-normalised adjacency of a GCN layer as values, a_ij = "
                          "1 / sqrt(out-degree(i) x in-degree(j)); algorithmic bytes then count 4 more bytes per edge (fp32 values)")
+    ap.add_argument("--weighted-plane", action="store_true",
+                    help="with --weighted: force the general value plane (separable=False) instead of letting csr_preprocess_weighted "
+                         "detect that these values factor as r_i c_j (round 6: then the binary operator runs between two row scalings)")
+    ap.add_argument("--backward", action="store_true",
+                    help="N = 1: the step is the BACKWARD product dB = A^T dC through the transposed handle (voltrix/autograd.py; "
+                         "with --weighted the transposed values): same machinery, same roofline accounting, on A^T")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N > 1 code path (process group, sharded operator, all-gather, barriers) also at world "
                          "size 1: rehearses the RCCL calls of the scaling run on a one-GPU box")
@@ -367,6 +373,16 @@ def main():
         d_in = torch.bincount(local_indices.long(), minlength=num_cols).float().clamp(min=1)
         edge_values = torch.repeat_interleave(d_out.rsqrt(), (local_indptr[1:] - local_indptr[:-1]).long()) * d_in.rsqrt()[local_indices.long()]
         del d_out, d_in
+    if args.backward:   # the transposed operator: what autograd.SpMM builds for the gradient with respect to B
+        assert not distributed, "--backward is a single-GPU run"
+        from voltrix import capi as _capi
+        from voltrix.weighted import transpose_weighted
+
+        if edge_values is not None:
+            local_indptr, local_indices, edge_values = transpose_weighted(local_indptr, local_indices, edge_values, local_rows, num_cols)
+        else:
+            local_indptr, local_indices = _capi.csr_transpose(local_indptr.contiguous(), local_indices.contiguous(), local_rows, num_cols)
+        torch.cuda.empty_cache()
     preprocess_ms = None
     for _ in range(2):   # first call pays library load / allocator warm-up; report the second (host wall clock, sync'd)
         if args.weighted:   # the first handle (62 GB with its value plane at the papers-like size) must not outlive its purpose
@@ -380,7 +396,8 @@ def main():
                                                  slabs=args.slabs, exchange_at_world_1=args.force_dist)
             handle = op.handle
         elif args.weighted:
-            whandle = voltrix.csr_preprocess_weighted(local_indptr, local_indices, edge_values, local_rows, num_cols=num_cols)
+            whandle = voltrix.csr_preprocess_weighted(local_indptr, local_indices, edge_values, local_rows, num_cols=num_cols,
+                                                      separable=False if args.weighted_plane else "auto")
             handle = (whandle.blk_offsets, whandle.hspa_packed, whandle.hind)
         else:
             handle = voltrix.csr_preprocess_device(local_indptr, local_indices, local_rows, num_cols=num_cols)
@@ -388,7 +405,8 @@ def main():
         preprocess_ms = (time.perf_counter() - t0) * 1e3
     if args.weighted:
         torch.cuda.empty_cache()   # the plane builder's chunk temporaries
-    handle[1].hash_tag = f"bench/{workload}/s{args.scale}/r{rank}of{world}"
+    handle[1].hash_tag = f"bench/{workload}/s{args.scale}/r{rank}of{world}" + ("/transposed" if args.backward else "")
+    weighted_plane = args.weighted and not whandle.separable    # the kernels read a value plane (else: binary kernels + row scalings)
     two = voltrix.two_level_of(handle[1])
     total_blocks = int(handle[0][-1])
     from voltrix import hybrid as vhybrid
@@ -611,7 +629,7 @@ def main():
 
         keys = {"feature_hash": feature_hash(hspa_packed), "embedding_dim": num_feats,
                 "dtype": str(torch.float16 if is_f16 else torch.float32),
-                "device": torch.cuda.get_device_name(device), "two_level": bool(beside_panel), "weighted": bool(args.weighted)}
+                "device": torch.cuda.get_device_name(device), "two_level": bool(beside_panel), "weighted": bool(weighted_plane)}
         if not is_f16 and fp32_as == "fp16":
             keys["dtype"] = str(torch.float16)   # fp32 features run as scaled fp16
         return jit_tuner.tuned_point("spmm_kernel", keys)
@@ -771,7 +789,10 @@ def main():
             gather_bytes = 8 * total_blocks * num_feats * in_bytes  # rows gathered from L2 / Infinity Cache / HBM
             fmt = {"format": "window (the reference's block format)" + (
                 " + value plane [T, 16, 8] in the operand's 16-bit type (voltrix/weighted.py: 256 B per TC block, fetched by one "
-                "more LDS-DMA per stage; values = symmetric-normalised adjacency)" if args.weighted else "")}
+                "more LDS-DMA per stage; values = symmetric-normalised adjacency)" if weighted_plane else "")}
+        if args.weighted and not weighted_plane:
+            fmt["values"] = ("separable: v_ij = r_i c_j detected by csr_preprocess_weighted (exact edge-by-edge check); the step is "
+                             "scale_rows(B, c) ; the binary operator ; scale_rows(C, r) -- no value plane (voltrix/weighted.py)")
             kernels = ("spmm_tc16_pair_kernel" if point.get("SCHED") == SCHED_PAIRS else
                        ("spmm_stream_kernel" if point.get("SCHED") == SCHED_STREAM else "spmm_tc16_kernel")) + (
                 " ; combine_partials_kernel" if point.get("SCHED") in (SCHED_UNITS, SCHED_PAIRS, SCHED_STREAM) else "")
@@ -779,7 +800,7 @@ def main():
                      "schedule": sched_name(point),
                      # wide operands: one launch per 256-byte group of column slabs (spmm_kernels.hpp::slab_launch_group)
                      "launches_per_step": slab_launches(num_feats, point.get("FS") or 128, in_bytes, num_nodes)}
-        counter_key = (f"{workload}{'+values' if args.weighted else ''}|F{num_feats}|{args.dtype}|{'two-level' if used_two else 'window'}|"
+        counter_key = (f"{workload}{'+values' if weighted_plane else ('+scales' if args.weighted else '')}{'^T' if args.backward else ''}|F{num_feats}|{args.dtype}|{'two-level' if used_two else 'window'}|"
                        f"{point.get('FS')},{point.get('DEPTH')},{point.get('WAVES')}|sched{point.get('SCHED')}")
         from voltrix.jit.compiler import get_kernel_sources_version
 
@@ -806,7 +827,9 @@ def main():
                             + f", seed {cfg['seed']}, exact degrees) x dense F={num_feats} "
                             f"{'fp16' if is_f16 else 'fp32'} -> fp32",
                 "num_nodes": num_nodes, "nnz": nnz, "feat": num_feats, "tc_blocks_rank0": total_blocks,
-                "timed_call": "voltrix.spmm(*csr_preprocess handle, ...) -- the drop-in operator, output allocation included",
+                "timed_call": ("voltrix.spmm_weighted(csr_preprocess_weighted handle, ...)" if args.weighted else
+                               "voltrix.spmm(*csr_preprocess handle, ...) -- the drop-in operator") + ", output allocation included"
+                              + (" -- on the TRANSPOSED matrix (the backward product dB = A^T dC)" if args.backward else ""),
                 "tile": tile_desc,
                 "sparse_format": fmt,
                 "parallelism": f"row-window shards x{world}" + (

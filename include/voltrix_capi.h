@@ -203,8 +203,10 @@ void voltrix_launch_unit_table_fill(void* blk_offsets, int num_nodes, void* xcd_
  *       workspace: voltrix_stream_table_workspace_bytes(num_nodes) bytes, device, 16-byte aligned.
  *     (caller reads the header; allocates units int32[U][8], cuts int32[C][4], runs int32[bound][4], run_ptr int32[9],
  *      header2 int32[4], partials float[slots * 16 * embedding_dim], voltrix_stream_table_fill_workspace_bytes(U) bytes)
- *     voltrix_launch_stream_table_fill: writes them all; header2 = {runs R, max runs per XCD, 0, 0} (the launch's
- *       max_runs_per_xcd); same workspace, untouched since phase 1; run_cost as read from the header.
+ *     voltrix_launch_stream_table_fill: writes them all; header2 = {runs R, max runs per XCD, oversized, 0} (the launch's
+ *       max_runs_per_xcd); same workspace, untouched since phase 1; run_cost as read from the header: 2 .. 128, anything else is
+ *       refused (kErrBadShape) -- a larger value would make runs of more than 64 units, which the kernel (one lane per unit of a
+ *       run) cannot walk; `oversized` != 0 reports such a run should one ever be built: do not launch with that table.
  *     units[u] = {first TC block, end TC block of the window, 4 x stride, window, partial-tile slot or -1, stages, columns of the
  *     window's last TC block that carry an edge (0: a window without edges), 0}; runs[r] = {first unit, units (<= 64), stages,
  *     0}; run_ptr[x] .. run_ptr[x + 1] = the runs of XCD x (contiguous windows, equal cost).  The tables depend on the handle
@@ -414,6 +416,14 @@ void voltrix_launch_cast_f32_f16(void* src, void* dst, int64_t count, void* stre
  * element in the epilogue; exact).  No host sync.  Inf / NaN in src: scale 1, they propagate as in fp32. */
 void voltrix_launch_cast_f32_f16_scaled(void* src, void* dst, int64_t count, void* scale, void* stream,
                                         int* return_code);
+
+/* Rows of a dense row-major matrix times a per-row factor: dst[i, :] = T(float(src[i, :]) * scale[i]); dst may be src.
+ * dtype 0 fp32 / 1 fp16 / 2 bfloat16; a row (num_feats elements) must be a multiple of 16 bytes; scale: device float[rows].
+ * What edge values of the form v_ij = r_i * c_j cost on top of the binary product (voltrix/weighted.py: B's rows times c before,
+ * C's rows times r after -- the normalised adjacencies of GCN / mean aggregation); the reference has no edge values at all
+ * (spmm_kernels.cuh:1632-1644: bits -> 1.0). */
+void voltrix_launch_scale_rows(void* src, void* scale, void* dst, int64_t rows, int num_feats, int dtype, void* stream,
+                               int* return_code);
 
 /* Fused GPU preprocess: CSR on the DEVICE -> (pointer1, hspa_packed, hind) without the reference's host
  * preprocess, the O(TCb*E) rescan or the 512-byte/TC-block fp32 `hspa` intermediate.  Two phases because the

@@ -334,8 +334,11 @@ def test_papers_like_f128_stated_tolerance(cuda_device):
     _stated_tolerance_window("papers_like", 128, 24, 111059956)
 
 
-def test_weighted_reddit_like_f128_stated_tolerance(cuda_device, monkeypatch):
-    """The weighted product (voltrix/weighted.py; no reference counterpart) at the headline size: values = the symmetric-
+@pytest.mark.parametrize("path", ["separable", "value_plane"])
+def test_weighted_reddit_like_f128_stated_tolerance(cuda_device, path, monkeypatch):
+    """Round 6: the same values through BOTH weighted paths -- detected as r_i c_j (the binary operator with its two-level side-car
+    between two row scalings; the default) and forced through the general value plane.
+    The weighted product (voltrix/weighted.py; no reference counterpart) at the headline size: values = the symmetric-
     normalised adjacency, random fp16 B, sampled rows (degree up to 21 k) against torch.sparse.mm with fp32 values on the CPU.
     A and B are both rounded to fp16: |out - ref| <= (2^-10 + deg 2^-23) (|A| |B|) + deg 2^-25 max|a|, norm-wise <= 1e-3."""
     monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
@@ -345,9 +348,12 @@ def test_weighted_reddit_like_f128_stated_tolerance(cuda_device, monkeypatch):
     d_out = deg.float().clamp(min=1)
     d_in = torch.bincount(indices.long(), minlength=n).float().clamp(min=1)
     values = torch.repeat_interleave(d_out.rsqrt(), deg) * d_in.rsqrt()[indices.long()]
-    handle = voltrix.csr_preprocess_weighted(indptr, indices, values, n)
+    handle = voltrix.csr_preprocess_weighted(indptr, indices, values, n, separable="auto" if path == "separable" else False)
+    assert handle.separable == (path == "separable")
+    if path == "separable":
+        assert voltrix.two_level_of(handle.hspa_packed) is not None, "the binary operator of this graph carries the two-level side-car"
     feat = _random_fp16(n, f, 31)
-    out = voltrix.spmm_weighted(handle, feat, hash_tag="stated_tolerance_weighted_reddit")
+    out = voltrix.spmm_weighted(handle, feat, hash_tag=f"stated_tolerance_weighted_reddit_{path}")
     rows = _sample_rows(indptr, n, 31)
     sub_ptr, sub_idx, b_sub = _sub_problem(indptr, indices, rows, feat)
     ip = indptr.long()
@@ -365,3 +371,38 @@ def test_weighted_reddit_like_f128_stated_tolerance(cuda_device, monkeypatch):
     assert not np.isnan(got).any() and int(dg.max()) > 15000
     assert (err <= (2.0 ** -10 + dg * 2.0 ** -23) * aabs + dg * 2.0 ** -25 * float(v_sub.abs().max()) + 1e-30).all()
     assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-3
+
+
+def test_backward_product_reddit_like_f128_stated_tolerance(cuda_device, monkeypatch):
+    """Round 6: the BACKWARD product dB = A^T dC at the headline size through the transposed handle that
+    voltrix.autograd.SpMM builds (two-level side-car included), sampled rows of A^T (in-degree up to thousands) against
+    torch.sparse.mm on the CPU with the window kernel's stated bound; and its step next to the forward's."""
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    from voltrix.autograd import SpMM
+
+    indptr, indices = _graph("reddit_like")
+    n, f = indptr.numel() - 1, 128
+    op = SpMM(indptr, indices, n, hash_tag="stated_tolerance_backward_reddit")
+    assert voltrix.two_level_of(op.handle_t[1]) is not None, "A^T of this graph takes the two-level format as well"
+    grad_out = _random_fp16(n, f, 47)
+    out = voltrix.spmm(*op.handle_t, num_nodes=n, num_edges=indices.numel(), feat=grad_out)
+    from voltrix.autograd import csr_transpose_device
+
+    t_indptr, t_indices = csr_transpose_device(indptr, indices, n, n)
+    rows = _sample_rows(t_indptr, n, 47)
+    _assert_stated_tolerance(out[rows], _sub_problem(t_indptr, t_indices, rows, grad_out), "reddit_like backward (A^T, two-level)")
+    import time
+
+    def step_ms(handle):
+        for _ in range(3):
+            voltrix.spmm(*handle, num_nodes=n, num_edges=indices.numel(), feat=grad_out)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            voltrix.spmm(*handle, num_nodes=n, num_edges=indices.numel(), feat=grad_out)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 100
+
+    fwd, bwd = step_ms(op.handle), step_ms(op.handle_t)
+    print(f"reddit-like F=128 fp16: forward {fwd:.3f} ms, backward (A^T) {bwd:.3f} ms")
+    assert bwd <= 1.3 * fwd + 0.05, (fwd, bwd)

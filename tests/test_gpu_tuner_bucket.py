@@ -71,3 +71,25 @@ def test_bucket_miss_first_call_is_bounded(tmp_path, workload, feat):
     assert st["first_call_s"] <= max(3.0, 25 * st["step_s"]), st
     print(f"{workload} F={feat}: first call {st['first_call_s']:.2f} s ({st['tuner']['timed_candidates']} candidates, sweep "
           f"{st['tuner']['sweep_seconds']:.2f} s), step {st['step_s'] * 1e3:.2f} ms, chosen {st['points']}")
+
+
+@pytest.mark.parametrize("graph", ["copurchase_half", "union_double", "zipf_mid_degree", "reddit_half"])
+def test_shipped_buckets_on_held_out_graphs(tmp_path, graph):
+    """Round 6: tuned_defaults.json was collected on the same stand-ins, seeds and sizes the benches run on --
+    in-sample.  Four graphs it has never seen (other seeds, half / twice the nodes, a degree law of their own): the step with
+    the SHIPPED buckets (whatever they answer: a bucket hit, or a bounded sweep on a miss) against the step after a FULL sweep of
+    the tile x schedule space on an empty store, each in a fresh process.  F = 128 fp16.  <= 1.10 x."""
+    got = {}
+    for mode in ("shipped", "swept"):
+        out = tmp_path / f"{graph}_{mode}.json"
+        run = subprocess.run([sys.executable, os.path.join(REPO, "tests", "tuner_heldout_worker.py"), mode, graph, "128",
+                              str(tmp_path / f"tuned_{mode}.json"), str(out)], capture_output=True, text=True, timeout=900)
+        assert run.returncode == 0, run.stderr[-3000:]
+        got[mode] = json.load(open(out))
+    shipped, swept = got["shipped"], got["swept"]
+    print(f"held-out {graph} (N={shipped['num_nodes']} nnz={shipped['nnz']}): shipped {shipped['step_ms']:.4f} ms "
+          f"(first call {shipped['first_call_s'] * 1e3:.1f} ms, bucket hits {shipped['tuner']['bucket_hits']}, sweeps "
+          f"{shipped['tuner']['sweeps']}) vs full sweep {swept['step_ms']:.4f} ms ({swept['tuner']['timed_candidates']} candidates); "
+          f"shipped {shipped['points']} swept {swept['points']}")
+    assert swept["tuner"]["sweeps"] >= 1 and swept["tuner"]["bucket_hits"] == 0
+    assert shipped["step_ms"] <= 1.10 * swept["step_ms"] + 0.003, (shipped, swept)

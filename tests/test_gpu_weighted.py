@@ -119,3 +119,120 @@ def test_value_plane_in_chunks_and_without_an_fp32_master(cuda_device, monkeypat
         voltrix.spmm_weighted(lean, feat.bfloat16())
     lean_bf = voltrix.csr_preprocess_weighted(indptr, indices, values, n, plane_dtype=torch.bfloat16)
     assert list(lean_bf.planes) == [torch.bfloat16] and torch.equal(lean_bf.planes[torch.bfloat16], whole.values32.bfloat16())
+
+
+# ---- round 6: values that factor as r_i c_j run on the BINARY operator between two row scalings (no value plane) ----------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_scale_rows_kernel_matches_torch(cuda_device, dtype):
+    from voltrix import capi
+
+    torch.manual_seed(0)
+    x = torch.randn(1003, 136, device=cuda_device).to(dtype)
+    f = (torch.rand(1003, device=cuda_device) * 4 - 2).float()
+    out = torch.empty_like(x)
+    capi.launch_scale_rows(x, f, out, torch.cuda.current_stream().cuda_stream)
+    want = (x.float() * f[:, None]).to(dtype)
+    assert torch.equal(out.view(torch.int16 if dtype != torch.float32 else torch.int32),
+                       want.view(torch.int16 if dtype != torch.float32 else torch.int32))
+    capi.launch_scale_rows(x, f, x, torch.cuda.current_stream().cuda_stream)          # in place
+    assert torch.equal(x.view(torch.int16 if dtype != torch.float32 else torch.int32),
+                       want.view(torch.int16 if dtype != torch.float32 else torch.int32))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("kind", ["symmetric", "row_mean", "random_factors", "stated"])
+def test_separable_values_run_on_the_binary_operator_and_match_the_oracle(cuda_device, dtype, kind, monkeypatch):
+    """v_ij = r_i c_j (GCN's D^-1/2 A D^-1/2, the mean aggregator's D^-1 A, arbitrary positive factors): detected exactly, no value
+    plane is built, and the product obeys a TIGHTER bound than the value-plane path (one 16-bit rounding, of c_j b_jk, instead of
+    two): |out - ref| <= (u + (deg + 2) 2^-23) (|A| |B|)."""
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    g = load_csr_fixture("skewed_1005")
+    n = int(g["num_nodes"])
+    indptr, indices = torch.from_numpy(g["indptr"]), torch.from_numpy(g["indices"])
+    deg = torch.from_numpy(np.diff(g["indptr"]).astype(np.int64))
+    rows = torch.repeat_interleave(torch.arange(n), deg)
+    indeg = torch.bincount(indices.long(), minlength=n).double().clamp(min=1)
+    torch.manual_seed(8)
+    if kind == "symmetric":
+        r, c = deg.double().clamp(min=1).rsqrt(), indeg.rsqrt()
+    elif kind == "row_mean":
+        r, c = 1.0 / deg.double().clamp(min=1), torch.ones(n, dtype=torch.float64)
+    else:
+        r, c = torch.rand(n, dtype=torch.float64) * 3 + 0.05, torch.rand(n, dtype=torch.float64) * 2 + 0.1
+    values = (r[rows] * c[indices.long()]).float()
+    if kind == "stated":
+        h = voltrix.csr_preprocess_weighted(indptr, indices, None, n, row_scale=r.float(), col_scale=c.float())
+    else:
+        h = voltrix.csr_preprocess_weighted(indptr, indices, values, n)
+    assert h.separable and h.values32 is None and not h.planes
+    feat32 = torch.randn(n, 72)
+    feat = feat32.to(dtype)
+    out = voltrix.spmm_weighted(h, feat.cuda(), hash_tag=f"separable_{kind}")
+    assert out.shape == (n, 72) and out.dtype == torch.float32
+    ref = _oracle(g["indptr"], g["indices"], values, feat if dtype != torch.float32 else feat32, n, n)
+    absref = _oracle(g["indptr"], g["indices"], values.abs(), feat32.abs(), n, n)
+    u = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11        # ONE rounding of the scaled operand (fp32 features: to fp16)
+    if kind != "stated":
+        u += 2.0 ** -13                                             # the detection's tolerance on r_i c_j itself
+    bound = (u + (deg.double()[:, None] + 2) * 2.0 ** -23) * absref + 1e-6
+    assert ((out.cpu().double() - ref).abs() <= bound).all()
+    # the general value plane computes the same product (two roundings): the two paths agree within the sum of their bounds
+    plane = voltrix.csr_preprocess_weighted(indptr, indices, values, n, separable=False)
+    assert not plane.separable and plane.values32 is not None
+    out_plane = voltrix.spmm_weighted(plane, feat.cuda(), hash_tag=f"separable_{kind}_plane")
+    u2 = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    assert ((out.cpu().double() - out_plane.cpu().double()).abs() <= (u + u2 + (2 * deg.double()[:, None] + 4) * 2.0 ** -23) * absref + 2e-6).all()
+
+
+def test_non_separable_and_duplicate_values_keep_the_value_plane(cuda_device, monkeypatch):
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    g = load_csr_fixture("skewed_1005")
+    n = int(g["num_nodes"])
+    indptr, indices = torch.from_numpy(g["indptr"]), torch.from_numpy(g["indices"])
+    torch.manual_seed(1)
+    assert not voltrix.csr_preprocess_weighted(indptr, indices, torch.rand(len(indices)) + 0.5, n).separable     # random positive
+    assert not voltrix.csr_preprocess_weighted(indptr, indices, torch.randn(len(indices)), n).separable         # signs
+    with pytest.raises(AssertionError, match="do not factor"):
+        voltrix.csr_preprocess_weighted(indptr, indices, torch.rand(len(indices)) + 0.5, n, separable=True)
+    # duplicate (row, col) entries ADD in the weighted product and count once in the binary format: never separable
+    ip, ix = _random_csr(300, 20, seed=2)
+    ip, ix = torch.from_numpy(ip), torch.from_numpy(ix)
+    if int(ip[1]) >= 2:
+        dup_ix = torch.cat([ix[:2], ix])
+        dup_ip = ip.clone()
+        dup_ip[1:] += 2
+        assert not voltrix.csr_preprocess_weighted(dup_ip, dup_ix, torch.ones(len(dup_ix)), 300).separable
+
+
+@pytest.mark.parametrize("kind", ["symmetric", "general"])
+def test_weighted_autograd_gradient_is_the_transposed_weighted_product(cuda_device, kind, monkeypatch):
+    """d/dB of sum(w * (A_values B)) = A_values^T w, separable values (both directions on the binary operator, factors swapped) and
+    general ones (value planes of A and A^T) against torch.sparse on the CPU."""
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    from voltrix.autograd import SpMM
+
+    ip_np, ix_np = _random_csr(700, 30, seed=6)
+    ip, ix = torch.from_numpy(ip_np), torch.from_numpy(ix_np)
+    n = 700
+    deg = torch.from_numpy(np.diff(ip_np).astype(np.int64))
+    rows = torch.repeat_interleave(torch.arange(n), deg)
+    torch.manual_seed(4)
+    if kind == "symmetric":
+        indeg = torch.bincount(ix.long(), minlength=n).double().clamp(min=1)
+        values = (deg.double().clamp(min=1).rsqrt()[rows] * indeg.rsqrt()[ix.long()]).float()
+    else:
+        values = torch.randn(len(ix_np))
+    op = SpMM(ip, ix, n, values=values, hash_tag=f"autograd_weighted_{kind}")
+    assert op.weighted.separable == (kind == "symmetric") == op.weighted_t.separable
+    feat = torch.randn(n, 40, device=cuda_device).half().requires_grad_(True)
+    w = torch.randn(n, 40, device=cuda_device)
+    out = op(feat)
+    (out * w).sum().backward()
+    a = torch.sparse_csr_tensor(ip, ix, values.double(), size=(n, n))
+    ref_out = a @ feat.detach().cpu().double()
+    ref_grad = a.to_dense().T @ w.cpu().double()
+    scale_o = (torch.sparse_csr_tensor(ip, ix, values.abs().double(), size=(n, n)) @ feat.detach().cpu().abs().double())
+    scale_g = (torch.sparse_csr_tensor(ip, ix, values.abs().double(), size=(n, n)).to_dense().T @ w.cpu().abs().double())
+    assert ((out.detach().cpu().double() - ref_out).abs() <= 2.0 ** -9 * scale_o + 1e-5).all()
+    # the gradient passes through fp16 twice more: the incoming gradient is rounded like any operand, the result is cast to feat's dtype
+    assert ((feat.grad.cpu().double() - ref_grad).abs() <= 2.0 ** -8 * scale_g + 2.0 ** -10 * ref_grad.abs() + 1e-4).all()

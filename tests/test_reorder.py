@@ -294,7 +294,7 @@ def test_auto_reorder_is_never_worse_than_no_reorder(cuda_device, graph, scale, 
     reddit-like graph takes the spectral order (1.78 -> 1.47 ms; the breadth-first order, whose longest panel holds 5,547
     k-steps against the identity's 1,091, is rejected as a hub pile-up: it would run 5.7 ms), the natural-order graph and the
     products-like graph keep the identity.  Here, at a quarter of the size, whatever is picked: the product is right and the
-    step is at most 1.07x the un-reordered one; the products-like graph (degree 50: below the degree at which a row order
+    step is at most 1.05x the un-reordered one (A B A B, the better median of each); the products-like graph (degree 50: below the degree at which a row order
     changes the TC-block count) must keep the identity without trying anything."""
     import voltrix
     from oracle import torch_ref
@@ -333,7 +333,7 @@ def test_auto_reorder_is_never_worse_than_no_reorder(cuda_device, graph, scale, 
     print(graph, scale, "picked", info["picked"], "step", t_auto, "vs", t_plain,
           {k: (round(v["estimated_ms"], 3), v["tc_blocks"], round(v["shared_fraction"], 3), v["longest_panel_ksteps"])
            for k, v in info["report"].items()})
-    assert t_auto <= 1.07 * t_plain + 0.01, (t_auto, t_plain, info["picked"],
+    assert t_auto <= 1.05 * t_plain + 0.01, (t_auto, t_plain, info["picked"],
                                              {k: (v["estimated_ms"], v["longest_panel_ksteps"]) for k, v in info["report"].items()})
 
 

@@ -92,6 +92,12 @@ void voltrix_launch_cast_f32_f16_scaled(void* src, void* dst, int64_t count, voi
                                                  static_cast<float*>(scale), static_cast<hipStream_t>(stream));
 }
 
+void voltrix_launch_scale_rows(void* src, void* scale, void* dst, int64_t rows, int num_feats, int dtype, void* stream,
+                               int* return_code) {
+  *return_code = voltrix::scale_rows(src, static_cast<const float*>(scale), dst, rows, num_feats, dtype,
+                                     static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"
 
 namespace voltrix_capi {

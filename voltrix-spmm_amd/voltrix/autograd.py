@@ -36,26 +36,58 @@ class _SpMMFunction(torch.autograd.Function):
     def forward(ctx, feat, op):
         ctx.op = op
         ctx.in_dtype = feat.dtype
+        if op.weighted is not None:
+            from .weighted import spmm_weighted
+
+            return spmm_weighted(op.weighted, feat)
         return spmm(*op.handle, num_nodes=op.num_rows, num_edges=op.num_edges, feat=feat)
 
     @staticmethod
     def backward(ctx, grad_out):
         op = ctx.op
+        if op.weighted is not None:
+            from .weighted import spmm_weighted
+
+            return spmm_weighted(op.weighted_t, grad_out.contiguous()).to(ctx.in_dtype), None
         grad = spmm(*op.handle_t, num_nodes=op.num_cols, num_edges=op.num_edges, feat=grad_out.contiguous())
         return grad.to(ctx.in_dtype), None
 
 
 class SpMM:
     """``C = A @ B`` with a gradient for ``B``.  ``A``: binary CSR [num_rows, num_cols] (``num_cols`` defaults to
-    ``num_rows``).  Builds two reference-format handles on the current device (A and A^T); both go through
+    ``num_rows``), or, with ``values`` (round 6), the weighted matrix ``csr(values)``.  Builds two reference-format handles on the current device (A and A^T); both go through
     ``voltrix.spmm`` -- tuner, schedules and the two-level side-car included."""
 
-    def __init__(self, indptr: torch.Tensor, indices: torch.Tensor, num_rows: int, num_cols: int = None, hash_tag: str = None):
+    def __init__(self, indptr: torch.Tensor, indices: torch.Tensor, num_rows: int, num_cols: int = None, hash_tag: str = None,
+                 values: torch.Tensor = None):
         assert indptr.dtype == torch.int32 and indices.dtype == torch.int32 and indptr.numel() == num_rows + 1
         self.num_rows = num_rows
         self.num_cols = num_rows if num_cols is None else int(num_cols)
         self.num_edges = int(indices.numel())
         indptr_d, indices_d = indptr.contiguous().cuda(), indices.contiguous().cuda()
+        self.weighted = self.weighted_t = None
+        if values is not None:
+            # round 6: edge values.  Separable ones (v_ij = r_i c_j: normalised adjacencies) run both directions on the binary
+            # operator between two row scalings -- A^T has the factors swapped --; general ones through value planes of A and A^T
+            from .weighted import WeightedHandle, csr_preprocess_weighted, transpose_weighted
+
+            values_d = values.contiguous().cuda()
+            self.weighted = csr_preprocess_weighted(indptr_d, indices_d, values_d, num_rows, num_cols=self.num_cols)
+            if self.weighted.separable:
+                t_indptr, t_indices = csr_transpose_device(indptr_d, indices_d, num_rows, self.num_cols)
+                t_handle = csr_preprocess_device(t_indptr, t_indices, self.num_cols, num_cols=num_rows)
+                self.weighted_t = WeightedHandle(*t_handle, None, self.num_cols, self.num_edges,
+                                                 row_scale=self.weighted.col_scale, col_scale=self.weighted.row_scale)
+            else:
+                t_indptr, t_indices, t_values = transpose_weighted(indptr_d, indices_d, values_d, num_rows, self.num_cols)
+                self.weighted_t = csr_preprocess_weighted(t_indptr, t_indices, t_values, self.num_cols, num_cols=num_rows,
+                                                          separable=False)
+            self.handle = (self.weighted.blk_offsets, self.weighted.hspa_packed, self.weighted.hind)
+            self.handle_t = (self.weighted_t.blk_offsets, self.weighted_t.hspa_packed, self.weighted_t.hind)
+            if hash_tag is not None:
+                self.handle[1].hash_tag = hash_tag
+                self.handle_t[1].hash_tag = hash_tag + "/transposed"
+            return
         self.handle = csr_preprocess_device(indptr_d, indices_d, num_rows, num_cols=self.num_cols)
         t_indptr, t_indices = csr_transpose_device(indptr_d, indices_d, num_rows, self.num_cols)
         self.handle_t = csr_preprocess_device(t_indptr, t_indices, self.num_cols, num_cols=num_rows)

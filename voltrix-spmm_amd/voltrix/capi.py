@@ -67,6 +67,7 @@ SYMBOLS = (
     "voltrix_launch_spmm_bf16_tile",
     "voltrix_launch_cast_f32_f16",
     "voltrix_launch_cast_f32_f16_scaled",
+    "voltrix_launch_scale_rows",
     "voltrix_csr_preprocess_workspace_bytes",
     "voltrix_launch_csr_window_count",
     "voltrix_launch_csr_fill",
@@ -286,7 +287,8 @@ def build_stream_table(blk_offsets, hspa_packed, hind, num_nodes: int, run_cost:
                                        ctypes.c_int(max(2, rcost)), _ptr(units), _ptr(cuts), _ptr(runs), _ptr(run_ptr),
                                        _ptr(header2), ctypes.c_void_p(stream), ctypes.byref(rc))
     check(rc.value, "voltrix_launch_stream_table_fill")
-    num_runs, max_runs = [int(v) for v in header2.tolist()][:2]
+    num_runs, max_runs, oversized = [int(v) for v in header2.tolist()][:3]
+    assert oversized == 0, "stream table with a run of more than 64 units (run_cost > 128?): the kernel cannot walk it"
     return units, runs[:num_runs], run_ptr, cuts, (num_units, num_cuts, num_slots, num_runs, max_runs, rcost, cut)
 
 
@@ -552,6 +554,28 @@ def launch_cast_f32_f16_scaled(src, dst, scale, stream) -> None:
         check(rc.value, "voltrix_launch_cast_f32_f16_scaled")
 
 
+_scale_rows = None
+
+
+def launch_scale_rows(src, scale, dst, stream) -> None:
+    """dst[i, :] = src[i, :] * scale[i] (``scale`` float32 [rows]; fp32 / fp16 / bf16 rows of a 16-byte multiple; in place
+    allowed); see include/voltrix_capi.h."""
+    import torch
+
+    global _scale_rows
+    if _scale_rows is None:
+        fn = lib().voltrix_launch_scale_rows
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                       ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        _scale_rows = fn
+    assert src.dim() == 2 and src.is_contiguous() and dst.is_contiguous() and dst.shape == src.shape and dst.dtype == src.dtype
+    assert scale.dtype == torch.float32 and scale.numel() == src.shape[0] and scale.is_contiguous()
+    dtype = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[src.dtype]
+    rc = ctypes.c_int(-1)
+    _scale_rows(src.data_ptr(), scale.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1], dtype, stream, rc)
+    check(rc.value, "voltrix_launch_scale_rows")
+
+
 # ---- kernel-isolated timing hook (utils.KernelTimer / bench_kineto): every launch wrapper above that takes a stream is
 # ---- bracketed by an event pair on that stream while a timer is active; free otherwise.
 def _timed(fn, name, stream_index=None, stream_kw="stream"):
@@ -579,6 +603,7 @@ launch_spmm_fused = _timed(launch_spmm_fused, "spmm_fused", 8)
 launch_combine_partials = _timed(launch_combine_partials, "combine_partials", 6)
 launch_cast_f32_f16_scaled = _timed(launch_cast_f32_f16_scaled, "cast_f32_f16_scaled", 3)
 launch_cast_f32_f16 = _timed(launch_cast_f32_f16, "cast_f32_f16", 2)
+launch_scale_rows = _timed(launch_scale_rows, "scale_rows", 3)
 launch_spmm_f32_as_f16 = _timed(launch_spmm_f32_as_f16, "spmm_f32_as_f16", 9)
 launch_window_order = _timed(launch_window_order, "window_order", 3)
 launch_csr_window_count = _timed(launch_csr_window_count, "csr_window_count", 8)

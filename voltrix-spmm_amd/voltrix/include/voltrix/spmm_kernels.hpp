@@ -1073,6 +1073,61 @@ inline int cast_f32_to_f16(const float* src, _Float16* dst, long long n, hipStre
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
+// ---- rows of a dense matrix times a per-row factor (round 6: edge values that factor as r_i c_j, voltrix/weighted.py) ----------
+// dst[i, :] = T(float(src[i, :]) * scale[i]); in place allowed (dst == src).  16 bytes per lane; rows are 16-byte multiples.
+// HBM-bound, one pass: B of the headline graph (60 MB fp16) in ~25 us, C (119 MB fp32) in ~45 us.
+template <typename T, int V>   // V elements of T = 16 bytes
+static __global__ __launch_bounds__(256) void scale_rows_kernel(const T* __restrict__ src, const float* __restrict__ scale,
+                                                                T* __restrict__ dst, const long long chunks, const int chunks_per_row) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += stride) {
+    const float f = scale[i / chunks_per_row];
+    uint4_t raw = reinterpret_cast<const uint4_t*>(src)[i];
+    if constexpr (std::is_same<T, float>::value) {
+      float4_t v = __builtin_bit_cast(float4_t, raw);
+      v *= f;
+      raw = __builtin_bit_cast(uint4_t, v);
+    } else if constexpr (std::is_same<T, _Float16>::value) {
+      half8_t v = __builtin_bit_cast(half8_t, raw);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = (_Float16)((float)v[k] * f);
+      raw = __builtin_bit_cast(uint4_t, v);
+    } else {   // bfloat16 as bits: widen, multiply, round to nearest even
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned w = raw[k];
+        float lo = __builtin_bit_cast(float, w << 16) * f, hi = __builtin_bit_cast(float, w & 0xffff0000u) * f;
+        unsigned bl = __builtin_bit_cast(unsigned, lo), bh = __builtin_bit_cast(unsigned, hi);
+        bl = (bl + 0x7fffu + ((bl >> 16) & 1u)) >> 16;
+        bh = (bh + 0x7fffu + ((bh >> 16) & 1u)) & 0xffff0000u;
+        raw[k] = bh | bl;
+      }
+    }
+    reinterpret_cast<uint4_t*>(dst)[i] = raw;
+  }
+}
+
+// dtype: 0 fp32, 1 fp16, 2 bfloat16.  num_feats elements per row; a row must be a multiple of 16 bytes.
+inline int scale_rows(const void* src, const float* scale, void* dst, long long rows, int num_feats, int dtype, hipStream_t stream) {
+  const int per_chunk = dtype == 0 ? 4 : 8;
+  if (rows < 0 || num_feats < 0 || dtype < 0 || dtype > 2 || num_feats % per_chunk) return kErrBadShape;
+  if (rows == 0 || num_feats == 0) return kOk;
+  if (src == nullptr || dst == nullptr || scale == nullptr || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return kErrBadShape;
+  const int cpr = num_feats / per_chunk;
+  const long long chunks = rows * cpr;
+  const int blocks = (int)(chunks / 256 + 1 < 256 * 16 ? chunks / 256 + 1 : 256 * 16);
+  if (dtype == 0)
+    hipLaunchKernelGGL((scale_rows_kernel<float, 4>), dim3(blocks), dim3(256), 0, stream, static_cast<const float*>(src), scale,
+                       static_cast<float*>(dst), chunks, cpr);
+  else if (dtype == 1)
+    hipLaunchKernelGGL((scale_rows_kernel<_Float16, 8>), dim3(blocks), dim3(256), 0, stream, static_cast<const _Float16*>(src),
+                       scale, static_cast<_Float16*>(dst), chunks, cpr);
+  else
+    hipLaunchKernelGGL((scale_rows_kernel<bfloat16_bits, 8>), dim3(blocks), dim3(256), 0, stream,
+                       static_cast<const bfloat16_bits*>(src), scale, static_cast<bfloat16_bits*>(dst), chunks, cpr);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
 // ---- range-safe fp32 -> fp16 operand: dst = fp16(src * 2^-e), scale[0] = 2^e with e = exponent(max |src|) - 14 --------
 // The reference multiplies in TF32 (8-bit exponent); a plain fp16 cast would overflow above 65504 and flush below
 // 6e-8.  A binary A makes the product linear in B, so one power-of-two scale per launch (exact, undone in the SpMM

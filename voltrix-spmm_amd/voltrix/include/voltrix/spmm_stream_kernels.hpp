@@ -107,6 +107,11 @@ __device__ __forceinline__ constexpr int stream_swizzle(int r) {
 
 // ADDR64 = false: B is smaller than 4 GiB and has fewer than 2^24 rows -- a gathered row's address is a scalar base plus ONE
 // full-rate v_mad_u32_u24 (row * row bytes + lane constant); true: 64-bit per-lane pointers (v_mad_u64_u32), any size.
+// One global_store_dwordx4 exactly where it is written (see store_unit).  byte_offset: an immediate (0 .. 4095).
+__device__ __forceinline__ void store_f32x4(float* base, const float4_t v, const int byte_offset) {
+  asm volatile("global_store_dwordx4 %0, %1, off offset:%2" ::"v"(base), "v"(v), "n"(byte_offset) : "memory");
+}
+
 template <class T, bool ADDR64>
 static __global__ __launch_bounds__(T::THREADS) void spmm_stream_kernel(const StreamArgs<T> a) {
   static_assert((T::EB == 2 || (T::EB == 4 && !T::BF16 && T::FS <= 64)) && !T::WEIGHTED, "stream kernel: binary A, fp16 / bf16 / fp32 B");
@@ -354,16 +359,21 @@ static __global__ __launch_bounds__(T::THREADS) void spmm_stream_kernel(const St
         }
         return v;
       };
+      // The stores are INLINE ASM (round 6): the run-time vmcnt budget of the ring counts exactly ns_live store instructions per
+      // finished unit, issued after the step's LDS-DMA loads.  A compiler-generated store may be merged, split or hoisted above
+      // issue_data; a volatile asm with a memory clobber is one instruction where it stands (tests/test_stream_isa.py reads
+      // the disassembly).  A predicate that is false in every lane would skip the instruction (s_cbranch_execz); neither
+      // predicate can be: row 0 of a window exists, and column 4 g = 0 of a live slot is below F.
       if (full_slab) {   // wave-uniform: SLOTS store instructions under one row predicate
         if (ok) {
 #pragma unroll
-          for (int s = 0; s < SLOTS; ++s) *reinterpret_cast<float4_t*>(dst + 16 * s) = value(s);
+          for (int s = 0; s < SLOTS; ++s) store_f32x4(dst, value(s), 64 * s);
         }
       } else {
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
           if (s < ns_live) {   // wave-uniform: exactly ns_live store instructions per unit (the wait counts them)
-            if (ok && fs0 + 16 * s + 4 * g < F) *reinterpret_cast<float4_t*>(dst + 16 * s) = value(s);
+            if (ok && fs0 + 16 * s + 4 * g < F) store_f32x4(dst, value(s), 64 * s);
           }
         }
       }

@@ -317,6 +317,7 @@ static __global__ __launch_bounds__(256) void st_run_fill_kernel(const int* __re
     const int a = runs[4ll * r];
     const int b = r + 1 < R ? runs[4ll * (r + 1)] : num_units;   // the next run's first unit was written by st_run_first_kernel
     runs[4ll * r + 1] = b - a;
+    if (b - a > 64) atomicOr(header2 + 2, 1);   // never with run_cost <= 128 (a unit costs >= 2): the launcher refuses such a table
     runs[4ll * r + 2] = unit_stage_before[b] - unit_stage_before[a];
     runs[4ll * r + 3] = 0;
   }
@@ -329,20 +330,19 @@ static __global__ __launch_bounds__(256) void st_run_fill_kernel(const int* __re
       prev = p;
     }
     header2[0] = R;
-    header2[1] = mx;
-    header2[2] = 0;
-    header2[3] = 0;
+    header2[1] = mx;    // header2[2]: bit 0 set by a run of more than 64 units (zeroed by the launcher's memset); [3] = 0
   }
 }
 
 // Phase 2.  units int32 [U][8], cuts int32 [C][4], runs int32 [run_bound][4] (the first R are the runs), run_ptr int32 [9],
-// header2 int32 [4] = {R, max runs per XCD, 0, 0}.
+// header2 int32 [4] = {R, max runs per XCD, 1 if a run holds more than 64 units (invalid for the kernel), 0}.
 inline int stream_table_fill(const int* blk_offsets, int num_nodes, void* workspace, void* fill_workspace, int num_units,
                              int num_cuts, int run_bound, int run_cost, int* units, int* cuts, int* runs, int* run_ptr,
                              int* header2, hipStream_t stream) {
   if (int rc = unit_table_check(num_nodes)) return rc;
   if (((uintptr_t)workspace & 15) || ((uintptr_t)fill_workspace & 15) || ((uintptr_t)units & 15) || ((uintptr_t)runs & 15) ||
-      ((uintptr_t)cuts & 15) || run_ptr == nullptr || header2 == nullptr || num_units < 0 || run_bound < 0 || run_cost < 2)
+      ((uintptr_t)cuts & 15) || run_ptr == nullptr || header2 == nullptr || num_units < 0 || run_bound < 0 || run_cost < 2 ||
+      run_cost > 128)   // > 128: runs of more than 64 units -- the kernel keeps a run's unit table one unit per lane (as the count phase)
     return kErrBadShape;
   const int W = (num_nodes + kBlkH - 1) / kBlkH;
   if (hipMemsetAsync(run_ptr, 0, 9 * sizeof(int), stream) != hipSuccess) return kErrLaunch;

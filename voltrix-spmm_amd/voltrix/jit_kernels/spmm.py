@@ -490,7 +490,8 @@ class _LaunchPlan:
     so that a repeated call patches five pointers and launches (round 5: the wrapper cost 57 us of host time per call, more than
     the kernel on the small graphs of the reference's evaluation set: ppi, ddi, FraudYelp).  Kept on the ``hspa_packed`` tensor
     OBJECT (it dies with it; a copy of the tensor starts without plans)."""
-    __slots__ = ("fn", "cargs", "generation", "partials_index", "partials_floats", "combine_table", "combine_args", "device")
+    __slots__ = ("fn", "cargs", "generation", "partials_index", "partials_floats", "combine_table", "combine_args", "device",
+                 "keepalive")
 
     def launch(self, input, output, out_scale, values, defer_combine):
         import ctypes
@@ -715,6 +716,13 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
         plan = _LaunchPlan()
         plan.fn, plan.generation, plan.device = fn, jit_tuner.generation, input.device
         plan.cargs = [map_ctype(a) for a in args]
+        # every tensor whose ADDRESS the list holds stays alive with the plan (round 6): the schedule-table caches on
+        # hspa_packed keep one entry each, so a call with another xcd_ptr / blk_offsets replaces a table this plan still points at
+        # -- the handle's own tensors, window orders, the three schedules' tables, row map, XCD ranges; NOT the per-call operands
+        # (input, output, out_scale, values, partial tiles: patched at every launch) and not hspa_packed (the plan lives on it)
+        plan.keepalive = tuple(args[i] for i in (0, 2, 8, 9, 10, 13, 14, 16, 19, 20, 22, 26, 31, 32, 33, 35)
+                               if isinstance(args[i], torch.Tensor)) + tuple(
+            t for t in (table, table_p, table_s, xcd_ptr) if t is not None)
         plan.partials_index, plan.partials_floats, plan.combine_table, plan.combine_args = None, 0, None, None
         chosen_table = {SCHED_UNITS: (table, 18), SCHED_PAIRS: (table_p, 24), SCHED_STREAM: (table_s, 37)}.get(sched)
         if chosen_table is not None and chosen_table[0] is not None and chosen_table[0].num_slots > 0:

@@ -1047,7 +1047,12 @@ def spmm_reordered(handle: ReorderedHandle, feat: torch.Tensor, hash_tag: str = 
         permuted = spmm(handle.blk_offsets, handle.hspa_packed, handle.hind, num_nodes=handle.num_nodes,
                         num_edges=handle.num_edges, feat=feat)
         return torch.empty_like(permuted).index_copy_(0, handle.perm, permuted)
-    operand, out_scale, padded, _ = _operand(feat)
+    # fp32 features: the same decision voltrix.spmm makes for this handle (exact fp32 tiles on handles of short windows, else
+    # the scaled fp16 cast) -- one handle, one numerics, whichever entry point (round 6)
+    from .spmm.spmm import fp32_mode
+
+    operand, out_scale, padded, _ = _operand(feat, fp32_mode(handle.hspa_packed, handle.num_nodes, num_feats)
+                                             if feat.dtype == torch.float32 else None)
     output = torch.empty((handle.num_nodes, padded), dtype=torch.float32, device=feat.device)
     spmm_kernel(handle.blk_offsets, handle.hspa_packed, handle.hind, num_nodes=handle.num_nodes,
                 num_edges=handle.num_edges, embedding_dim=padded, input=operand, output=output, out_scale=out_scale,

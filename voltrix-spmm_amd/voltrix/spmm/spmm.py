@@ -124,7 +124,11 @@ def _build_two_level(indptr_d, indices_d, num_nodes, num_cols, waves=hybrid.DEFA
         # the panel kernel would be the critical path: 256-row panels instead (hybrid.PANEL_DOMINATED_RATIO); one more plan build
         del resid_indptr, resid_indices, plan
         resid_indptr, resid_indices, plan = hybrid.build_panel_plan(indptr_d, indices_d, num_nodes, num_cols, waves,
-                                                                    hybrid.PANEL_DOMINATED_ROW_BLOCKS, tau, min_share=0.0)
+                                                                    hybrid.PANEL_DOMINATED_ROW_BLOCKS, tau, min_share=min_share)
+        # columns shared only at 512-row granularity can leave the 256-row plan (nearly) empty: the same test as for the first
+        # plan (round 6) -- the window format of the whole matrix is the better form then
+        if plan.num_ksteps == 0 or plan.num_shared_edges < min_share * max(1, indices_d.numel()):
+            return None
     pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(resid_indptr, resid_indices, num_nodes, num_cols,
                                                                  path=preprocess_mode()[1])
     two = hybrid.TwoLevelHandle(pointer1, hspa_packed, hind, plan, num_nodes, int(indices_d.numel()))
@@ -231,7 +235,12 @@ def spmm(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tenso
     (BASELINE.json's headline) or bfloat16.  float32 (``VOLTRIX_FP32_MODE``, default ``auto``): handles of short windows
     multiply the fp32 rows as they are -- exact products, no cast pass (``fp32_mode``) -- every other handle rounds B to fp16
     for the MFMA -- the same 10-bit mantissa as the reference's TF32 rounding (spmm_kernels.cuh:1671), after a per-call
-    power-of-two rescale that keeps fp32's range; ``fp16`` / ``exact`` force either.  Every output row is written, including the
+    power-of-two rescale that keeps fp32's range; ``fp16`` / ``exact`` force either.  NOTE the decision depends on the handle AND
+    on the operand's width (<= 32 columns: up to 16 gathered rows per output row run exact, wider: up to 6) and on
+    ``VOLTRIX_TUNE_SPACE`` (``none`` = always the cast): a forward and a backward product of different widths on one graph may
+    round differently (exact vs 2^-11 relative per element of B); pin ``VOLTRIX_FP32_MODE`` when that matters.  ``spmm_reordered``
+    makes the same decision for its handle; ``spmm_weighted``, ``spmm_two_level`` and the sharded operator always take the 16-bit
+    operand (their kernels have no fp32 tiles).  Every output row is written, including the
     ``num_nodes % 16`` tail the reference skips.  When ``csr_preprocess`` attached the two-level side-car to this very
     ``hspa_packed`` tensor, the 16-bit-operand product runs in that form (same result up to fp32 summation order).
     """

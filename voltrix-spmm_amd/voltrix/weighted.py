@@ -40,6 +40,14 @@ class WeightedHandle:
     num_nodes: int
     num_edges: int
     planes: dict = dataclasses.field(default_factory=dict)   # dtype -> value plane in that 16-bit type
+    # round 6 -- values of the form v_ij = r_i * c_j (the normalised adjacencies of GCN / mean aggregation): no value plane at
+    # all; C = diag(r) (A_binary (diag(c) B)) on the BINARY operator, two-level side-car included
+    row_scale: torch.Tensor = None     # float32 [num_nodes]
+    col_scale: torch.Tensor = None     # float32 [num_cols]
+
+    @property
+    def separable(self) -> bool:
+        return self.row_scale is not None
 
 
 def _chunk_plane(indptr, indices, values, blk_offsets, w0, w1, num_nodes, num_cols):
@@ -91,16 +99,91 @@ def value_plane(indptr: torch.Tensor, indices: torch.Tensor, values: torch.Tenso
     return out.view(total, 16, 8)
 
 
+SEPARABLE_TOLERANCE = 2.0 ** -13     # |v_ij / (r_i c_j) - 1| below this counts as separable: a quarter of the fp16 rounding the
+                                      # value plane applies to every value anyway (2^-11)
+SEPARABLE_SWEEPS = 64
+
+
+def separable_scales(indptr: torch.Tensor, indices: torch.Tensor, values: torch.Tensor, num_nodes: int, num_cols: int,
+                     tolerance: float = SEPARABLE_TOLERANCE, sweeps: int = SEPARABLE_SWEEPS):
+    """``(row_scale float32 [N], col_scale float32 [M])`` with ``values[e] == row_scale[row(e)] * col_scale[col(e)]`` within
+    ``tolerance`` (relative) for every edge, or None.  Positive values only; duplicate (row, col) entries: None (they ADD in the
+    weighted product but count once in the binary format).  log v_ij = a_i + b_j solved by alternating row / column means
+    (exact after one sweep for the common normalisations -- 1 / sqrt(d_i d_j), 1 / d_i, 1 / d_j --, a few dozen sweeps for general
+    separable values on a well-connected graph); the answer is CHECKED edge by edge, so a slow or failed convergence only means
+    "not separable" and the general value plane.  Torch tensor ops on the CSR's device; a handful of host reads."""
+    dev = indptr.device
+    e = int(indices.numel())
+    if e == 0:
+        return torch.ones(num_nodes, device=dev), torch.ones(num_cols, device=dev)
+    v = values.double()
+    if not bool((v > 0).all()) or not bool(torch.isfinite(v).all()):
+        return None
+    deg = (indptr[1:] - indptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(num_nodes, device=dev, dtype=torch.int64), deg)
+    cols = indices.long()
+    if int(cols.max()) >= num_cols:
+        return None
+    key = rows * num_cols + cols
+    if int(torch.unique(key).numel()) != e:
+        return None
+    del key
+    logv = torch.log(v)
+    cdeg = torch.bincount(cols, minlength=num_cols).double().clamp(min=1.0)
+    rdeg = deg.double().clamp(min=1.0)
+    a = torch.zeros(num_nodes, dtype=torch.float64, device=dev)
+    b = torch.zeros(num_cols, dtype=torch.float64, device=dev)
+    log_tol = float(torch.log1p(torch.tensor(tolerance, dtype=torch.float64)))
+    for sweep in range(sweeps):
+        a = torch.zeros_like(a).index_add_(0, rows, logv - b[cols]) / rdeg
+        b = torch.zeros_like(b).index_add_(0, cols, logv - a[rows]) / cdeg
+        if sweep in (0, 1, 3, 7, 15, 31, sweeps - 1):
+            if float((logv - a[rows] - b[cols]).abs().max()) <= 0.5 * log_tol:
+                break
+    else:
+        return None
+    if float((logv - a[rows] - b[cols]).abs().max()) > 0.5 * log_tol:
+        return None
+    # balance the two factors (their product is what is defined): both near 1 keeps the scaled B inside fp16's range
+    shift = 0.5 * (float(a.mean()) - float(b.mean()))
+    return torch.exp(a - shift).float(), torch.exp(b + shift).float()
+
+
 def csr_preprocess_weighted(indptr: torch.Tensor, indices: torch.Tensor, values: torch.Tensor, num_nodes: int,
-                            num_cols: int = None, plane_dtype: torch.dtype = None) -> WeightedHandle:
+                            num_cols: int = None, plane_dtype: torch.dtype = None, separable="auto",
+                            row_scale: torch.Tensor = None, col_scale: torch.Tensor = None) -> WeightedHandle:
     """CSR with values (CPU or CUDA; int32 ``indptr`` / ``indices``, floating ``values``) -> ``WeightedHandle``.
     ``plane_dtype`` (float16 / bfloat16): build that 16-bit plane now; handles whose fp32 master would exceed
-    ``MASTER_PLANE_MAX_BYTES`` keep only it (default float16) -- ``spmm_weighted`` with an operand of the other type then raises."""
+    ``MASTER_PLANE_MAX_BYTES`` keep only it (default float16) -- ``spmm_weighted`` with an operand of the other type then raises.
+
+    Round 6 -- SEPARABLE values ``v_ij = r_i c_j`` (symmetric / row / column normalised adjacencies: what a GCN or a mean
+    aggregator multiplies by) need no value plane: ``C = diag(r) A (diag(c) B)`` runs on the binary operator, with its two-level
+    side-car and every schedule of it, at the cost of one pass over B before and one over C after (``scale_rows``).
+    ``separable="auto"`` (default) detects it (``separable_scales``: exact check, edge by edge); ``row_scale`` / ``col_scale``
+    (float [N] / [M]) state it (``values`` may then be None); ``separable=False`` forces the general value plane."""
     assert indptr.dtype == torch.int32 and indices.dtype == torch.int32 and indptr.numel() == num_nodes + 1
-    assert values.numel() == indices.numel() and values.is_floating_point()
     assert plane_dtype in (None, torch.float16, torch.bfloat16)
-    indptr_d, indices_d, values_d = indptr.contiguous().cuda(), indices.contiguous().cuda(), values.contiguous().cuda()
     num_cols = num_nodes if num_cols is None else int(num_cols)
+    indptr_d, indices_d = indptr.contiguous().cuda(), indices.contiguous().cuda()
+    scales = None
+    if row_scale is not None or col_scale is not None:
+        dev = indptr_d.device
+        scales = (torch.ones(num_nodes, device=dev) if row_scale is None else row_scale.to(dev, torch.float32).contiguous(),
+                  torch.ones(num_cols, device=dev) if col_scale is None else col_scale.to(dev, torch.float32).contiguous())
+        assert scales[0].numel() == num_nodes and scales[1].numel() == num_cols
+    else:
+        assert values is not None and values.numel() == indices.numel() and values.is_floating_point()
+        if separable in ("auto", True):
+            scales = separable_scales(indptr_d, indices_d, values.contiguous().cuda(), num_nodes, num_cols)
+            assert scales is not None or separable == "auto", "separable=True but the values do not factor as r_i * c_j"
+    if scales is not None:
+        from .spmm.spmm import csr_preprocess_device
+
+        pointer1, hspa_packed, hind = csr_preprocess_device(indptr_d, indices_d, num_nodes, num_cols)   # side-car policy included
+        return WeightedHandle(pointer1, hspa_packed, hind, None, num_nodes, int(indices.numel()), row_scale=scales[0],
+                              col_scale=scales[1])
+    assert values.numel() == indices.numel() and values.is_floating_point()
+    values_d = values.contiguous().cuda()
     pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(indptr_d, indices_d, num_nodes, num_cols)
     universe = max(num_cols, int(indices_d.max()) + 1) if indices_d.numel() else num_cols
     total = int(pointer1[-1])
@@ -125,6 +208,8 @@ def spmm_weighted(handle: WeightedHandle, feat: torch.Tensor, hash_tag: str = No
     if hash_tag is not None and getattr(handle.hspa_packed, "hash_tag", None) is None:
         handle.hspa_packed.hash_tag = hash_tag
     num_feats = feat.shape[1]
+    if handle.separable:
+        return _spmm_separable(handle, feat)
     operand, out_scale, padded, exact = _operand(feat)
     assert not exact, "the weighted kernel takes a 16-bit operand (unset VOLTRIX_FP32_MODE=exact)"
     if operand.dtype not in handle.planes:
@@ -136,3 +221,38 @@ def spmm_weighted(handle: WeightedHandle, feat: torch.Tensor, hash_tag: str = No
                 num_edges=handle.num_edges, embedding_dim=padded, input=operand, output=output, out_scale=out_scale,
                 values=handle.planes[operand.dtype])
     return output if padded == num_feats else output[:, :num_feats].contiguous()
+
+
+def _spmm_separable(handle: WeightedHandle, feat: torch.Tensor) -> torch.Tensor:
+    """``diag(r) (A (diag(c) feat))``: rows of B times c (one HIP pass, in B's own dtype -- fp32 features are scaled in fp32 and
+    then take ``voltrix.spmm``'s own fp32 path), the BINARY operator on the handle (two-level side-car, tuned tiles, launch
+    plans), rows of C times r in place (one HIP pass)."""
+    from . import capi
+    from .jit_kernels.spmm import _raw_stream
+    from .spmm.spmm import spmm
+
+    assert feat.is_cuda and feat.dim() == 2 and feat.shape[0] == handle.col_scale.numel()
+    feat = feat.contiguous()
+    num_feats = feat.shape[1]
+    align = 4 if feat.dtype == torch.float32 else 8
+    padded = (num_feats + align - 1) // align * align
+    if padded != num_feats:
+        feat = torch.nn.functional.pad(feat, (0, padded - num_feats))
+    stream = _raw_stream(feat.device)
+    scaled = torch.empty_like(feat)
+    capi.launch_scale_rows(feat, handle.col_scale, scaled, stream)
+    out = spmm(handle.blk_offsets, handle.hspa_packed, handle.hind, num_nodes=handle.num_nodes, num_edges=handle.num_edges,
+               feat=scaled)
+    capi.launch_scale_rows(out, handle.row_scale, out, stream)
+    return out if padded == num_feats else out[:, :num_feats].contiguous()
+
+
+def transpose_weighted(indptr: torch.Tensor, indices: torch.Tensor, values: torch.Tensor, num_rows: int, num_cols: int):
+    """Device CSR with values of ``A`` -> ``(t_indptr, t_indices, t_values)`` of ``A^T`` (rows sorted; one stable sort by column)."""
+    dev = indptr.device
+    deg = (indptr[1:] - indptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(num_rows, device=dev, dtype=torch.int64), deg)
+    order = torch.argsort(indices.long() * num_rows + rows)
+    t_indptr = torch.zeros(num_cols + 1, dtype=torch.int64, device=dev)
+    t_indptr[1:] = torch.cumsum(torch.bincount(indices.long(), minlength=num_cols), 0)
+    return t_indptr.to(torch.int32), rows[order].to(torch.int32), values[order].contiguous()
