@@ -790,12 +790,13 @@ def main():
             fmt = {"format": "window (the reference's block format)" + (
                 " + value plane [T, 16, 8] in the operand's 16-bit type (voltrix/weighted.py: 256 B per TC block, fetched by one "
                 "more LDS-DMA per stage; values = symmetric-normalised adjacency)" if weighted_plane else "")}
-        if args.weighted and not weighted_plane:
-            fmt["values"] = ("separable: v_ij = r_i c_j detected by csr_preprocess_weighted (exact edge-by-edge check); the step is "
-                             "scale_rows(B, c) ; the binary operator ; scale_rows(C, r) -- no value plane (voltrix/weighted.py)")
             kernels = ("spmm_tc16_pair_kernel" if point.get("SCHED") == SCHED_PAIRS else
                        ("spmm_stream_kernel" if point.get("SCHED") == SCHED_STREAM else "spmm_tc16_kernel")) + (
                 " ; combine_partials_kernel" if point.get("SCHED") in (SCHED_UNITS, SCHED_PAIRS, SCHED_STREAM) else "")
+        if args.weighted and not weighted_plane:
+            fmt["values"] = ("separable: v_ij = r_i c_j detected by csr_preprocess_weighted (exact edge-by-edge check); the step is "
+                             "scale_rows(B, c) ; the binary operator ; scale_rows(C, r) -- no value plane (voltrix/weighted.py)")
+            kernels = "scale_rows_kernel(B) ; " + kernels + " ; scale_rows_kernel(C)"
         tile_desc = {"fs": point.get("FS"), "depth": point.get("DEPTH"), "waves": point.get("WAVES"),
                      "schedule": sched_name(point),
                      # wide operands: one launch per 256-byte group of column slabs (spmm_kernels.hpp::slab_launch_group)

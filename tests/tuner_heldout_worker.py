@@ -36,7 +36,10 @@ HELD_OUT = {
     "reddit_half": dict(C["reddit_like"], num_nodes=C["reddit_like"]["num_nodes"] // 2, seed=914),
 }
 
-indptr, indices = synth_graphs.generate_csr(device="cuda", **HELD_OUT[graph])
+if graph in HELD_OUT:
+    indptr, indices = synth_graphs.generate_csr(device="cuda", **HELD_OUT[graph])
+else:       # a named stand-in (experiments: what does the full sweep find on the graphs the shipped buckets were collected on?)
+    indptr, indices, _ = synth_graphs.generate(graph, device="cuda")
 n, e = indptr.numel() - 1, indices.numel()
 handle = voltrix.csr_preprocess_device(indptr, indices, n)
 handle[1].hash_tag = f"heldout/{graph}/{mode}"

@@ -108,8 +108,12 @@ __device__ __forceinline__ constexpr int stream_swizzle(int r) {
 // ADDR64 = false: B is smaller than 4 GiB and has fewer than 2^24 rows -- a gathered row's address is a scalar base plus ONE
 // full-rate v_mad_u32_u24 (row * row bytes + lane constant); true: 64-bit per-lane pointers (v_mad_u64_u32), any size.
 // One global_store_dwordx4 exactly where it is written (see store_unit).  byte_offset: an immediate (0 .. 4095).
+// The s_nop is the hazard the compiler handles for its OWN stores and cannot see inside an asm: a VMEM store of more than 64 bits
+// reads its data registers after issue, and a VALU write of them within two wait states (gfx940 family; LLVM
+// GCNHazardRecognizer "VmemStoreHazard") corrupts the stored value -- the scaled path reuses one temporary for every slot
+// (measured: tests/test_gpu_stream.py fp16-scaled failed without it).
 __device__ __forceinline__ void store_f32x4(float* base, const float4_t v, const int byte_offset) {
-  asm volatile("global_store_dwordx4 %0, %1, off offset:%2" ::"v"(base), "v"(v), "n"(byte_offset) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off offset:%2\n\ts_nop 1" ::"v"(base), "v"(v), "n"(byte_offset) : "memory");
 }
 
 template <class T, bool ADDR64>

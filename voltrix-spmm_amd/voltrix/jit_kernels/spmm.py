@@ -127,11 +127,16 @@ TWO_LEVEL_LDS_BUDGET = 160 * 1024 - 47 * 1024   # panel workgroup: 24 KiB ring +
 
 
 def tile_space(embedding_dim: int, elem_bytes: int, bf16: bool = False, max_lds: int = None, weighted: bool = False,
-               stream_ok: bool = True):
+               stream_ok: bool = True, shallow_ok: bool = True):
     """Points of the tile space worth trying for this feature width (``bf16``: the 2-byte operand is bfloat16;
     ``max_lds``: keep only tiles whose workgroup fits that many bytes of LDS; ``weighted``: the A operand is a value
     plane, 1 KiB more per metadata slot)."""
     points = tuple(dict(point, BF16=int(bf16), WEIGHTED=int(weighted)) for point in _tile_space(embedding_dim, elem_bytes))
+    if not shallow_ok and tune_space_mode() == "default":
+        # two-slot rings of the window kernel (round 6) are candidates for handles of SHORT windows only: on long windows the sweep's
+        # sample ranks them first and the full-size step loses (fresh sweeps with them everywhere: protein-like 0.84 -> 1.11 ms,
+        # products-like F = 128 3.3 -> 4.1 ms, profiles/r06/experiment_depth2_default_space.log)
+        points = tuple(p for p in points if p["DEPTH"] != 2 or p["SCHED"] == SCHED_STREAM)
     if weighted or max_lds is not None or not stream_ok:   # the stream kernel: binary operand, plain stores, alone on the CU
         points = tuple(p for p in points if p["SCHED"] != SCHED_STREAM)
         if not points:   # VOLTRIX_TUNE_SPACE=stream on a launch the stream kernel does not serve: the default tile
@@ -177,7 +182,13 @@ def _tile_space(embedding_dim: int, elem_bytes: int):
         depths, waves = (2, 3, 4), (1, 2, 4)
     else:
         fs_list = sorted({fs_fit, max(32, fs_fit // 2)})
-        depths, waves = (3, 4), (1, 4)
+        # round 6: ring depth 2 joins the default space.  A FULL sweep on the low-degree stand-ins found half-width, two-slot
+        # window tiles 7-17 % ahead of what the default space could offer (profiles/r06/experiment_sweep_compare.log: amazon0505-like
+        # 0.160 -> 0.132 ms, amazon0601-like 0.133 -> 0.114, DD-like 0.080 -> 0.069, ppi-like 0.027 -> 0.023, all FS 64 / DEPTH 2):
+        # with one or two stages per window a third ring slot only costs LDS, i.e. waves per CU.  The staged sweep starts every
+        # shape at its shallowest ring, so this adds no first-stage candidate (6 + <= 4 + 2 = 12 timed at most).  Short-window
+        # handles only (tile_space: shallow_ok).
+        depths, waves = (2, 3, 4), (1, 4)
     space = []
     for fs in fs_list:
         for d in depths:
@@ -572,7 +583,8 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
     short_windows = hspa_packed.numel() // 4 <= STREAM_MAX_BLOCKS_PER_WINDOW * ((num_nodes + 15) // 16)
     space = tile_space(embedding_dim, elem_bytes, input.dtype == torch.bfloat16,
                        TWO_LEVEL_LDS_BUDGET if beside_panel else None, weighted=values is not None,
-                       stream_ok=not atomic_out and row_map is None and (short_windows or tune_space_mode() == "stream"))
+                       stream_ok=not atomic_out and row_map is None and (short_windows or tune_space_mode() == "stream"),
+                       shallow_ok=short_windows)
     keys = {
         "feature_hash": feature_hash(hspa_packed),
         "embedding_dim": embedding_dim,
