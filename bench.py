@@ -798,7 +798,7 @@ def main():
                              "scale_rows(B, c) ; the binary operator ; scale_rows(C, r) -- no value plane (voltrix/weighted.py)")
             kernels = "scale_rows_kernel(B) ; " + kernels + " ; scale_rows_kernel(C)"
         tile_desc = {"fs": point.get("FS"), "depth": point.get("DEPTH"), "waves": point.get("WAVES"),
-                     "schedule": sched_name(point),
+                     "schedule": sched_name(point), "sched": point.get("SCHED"),
                      # wide operands: one launch per 256-byte group of column slabs (spmm_kernels.hpp::slab_launch_group)
                      "launches_per_step": slab_launches(num_feats, point.get("FS") or 128, in_bytes, num_nodes)}
         counter_key = (f"{workload}{'+values' if weighted_plane else ('+scales' if args.weighted else '')}{'^T' if args.backward else ''}|F{num_feats}|{args.dtype}|{'two-level' if used_two else 'window'}|"

@@ -27,7 +27,7 @@ SO = os.path.join(HERE, "build", "tail_stamps_f16.so")
 def build():
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                           "-DVOLTRIX_DIAG=8", f"-I{PKG}/voltrix/include", f"-I{REPO}/include", f"-I{PKG}/csrc",
+                           "-DVOLTRIX_DIAG=8", "-DVOLTRIX_EXPERIMENTAL", f"-I{PKG}/voltrix/include", f"-I{REPO}/include", f"-I{PKG}/csrc",
                            os.path.join(PKG, "csrc", "capi_spmm_f16.hip"), "-o", SO])
 
 

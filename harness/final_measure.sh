@@ -21,7 +21,11 @@ headline)
   ;;
 pmc)
   for W in "$@"; do
-    if [ "$W" = headline ]; then ARGS="--no-cpu-baseline --no-reference-formats"; else ARGS="--workload $W --feat 128 --no-cpu-baseline --no-reference-formats"; fi
+    # <workload> (F = 128), <workload>:<F>, or <workload>:<F>:<steps> (the big configurations: fewer timed steps per pass)
+    WL=${W%%:*}; REST=${W#*:}; F=128; STEPS=""
+    if [ "$REST" != "$W" ]; then F=${REST%%:*}; if [ "${REST#*:}" != "$REST" ]; then STEPS="--steps ${REST#*:} --warmup 2"; fi; fi
+    if [ "$W" = headline ]; then ARGS="--no-cpu-baseline --no-reference-formats"; else ARGS="--workload $WL --feat $F $STEPS --no-cpu-baseline --no-reference-formats"; fi
+    if [ "$W" != headline ]; then W=${WL}_f$F; fi
     python bench.py $ARGS > /dev/null 2>&1      # persists the tile choice: the five passes run the same kernels
     harness/pmc_bench.sh ${O#gpurun_out/}/pmc_$W $ARGS > $O/pmc_$W.txt 2>&1 && python harness/pmc_summarize.py $O/pmc_$W > $O/pmc_${W}_step.txt 2>&1
     rm -rf $O/pmc_$W/pass*/

@@ -6,6 +6,7 @@ sources of the same round -- a stale sources_hash with a source under profiles/<
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -23,7 +24,7 @@ def main():
     for d in sorted(glob.glob(os.path.join(out, "pmc_*", ""))):
         name = os.path.basename(os.path.dirname(d))[4:]
         (key, entry), = json.load(open(os.path.join(d, "traffic_entry.json"))).items()
-        target = NAMES.get(name, f"pmc_{name}_f128.txt")
+        target = NAMES.get(name) or (f"pmc_{name}.txt" if re.search(r"_f\d+$", name) else f"pmc_{name}_f128.txt")
         entry["source"] = f"profiles/{rnd}/{target}"
         runs[key] = entry
         fresh = entry["sources_hash"]

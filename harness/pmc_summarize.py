@@ -95,8 +95,11 @@ def main():
              "source": args.source or args.dir,
              # the kernel sources the counters were measured on (bench.py replays the entry only while they match the tree)
              "sources_hash": bench["roofline"].get("kernel_sources_hash")}
+    sched = tile.get("sched")     # the schedule's number (bench lines since round 6); older lines: from its description
+    if sched is None:
+        sched = 5 if pair else (6 if 'stream' in tile['schedule'] else ('4' if 'unit table' in tile['schedule'] else ('0' if 'natural' in tile['schedule'] else '?')))
     key = (f"{cfg['workload'].split(':')[0]}|F{cfg['feat']}|{bench['dtype']}|{'two-level' if two_level else 'window'}|"
-           f"{tile['fs']},{tile['depth']},{tile['waves']}|sched{5 if pair else (6 if 'stream' in tile['schedule'] else ('4' if 'unit table' in tile['schedule'] else ('0' if 'natural' in tile['schedule'] else '?')))}")
+           f"{tile['fs']},{tile['depth']},{tile['waves']}|sched{sched}")
     out.append(f"per step [{key}]: " + json.dumps(entry))
     open(os.path.join(args.dir, "summary_step.txt"), "w").write("\n".join(out) + "\n")
     json.dump({key: entry}, open(os.path.join(args.dir, "traffic_entry.json"), "w"), indent=1)
