@@ -314,6 +314,14 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     distributed = world > 1 or args.force_dist
+    # Only the JSON line may reach stdout.  The communication libraries print banners there (RCCL: version / HIP / hostname, five
+    # lines per rank; gloo: "Rank r is connected to ..."): in a distributed run everything written to fd 1 goes to stderr and the
+    # line is written to the saved descriptor at the end.
+    result_fd = None
+    if distributed:
+        sys.stdout.flush()
+        result_fd = os.dup(1)
+        os.dup2(2, 1)
     if distributed:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -872,7 +880,11 @@ def main():
             vb["rocsparse"] = rocsparse_baseline(local_indptr, local_indices, num_nodes, gathered, ms_per_step)
             line["vendor_gpu_baseline"] = vb
             line["cpu_baseline"] = cpu_baseline(local_indptr, local_indices, num_nodes, num_nodes, num_feats)
-        print(json.dumps(line), flush=True)
+        if result_fd is not None:
+            sys.stdout.flush()
+            os.write(result_fd, (json.dumps(line) + "\n").encode())
+        else:
+            print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

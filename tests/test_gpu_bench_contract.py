@@ -54,6 +54,7 @@ def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
     assert run.returncode == 0, run.stderr[-3000:]
     lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
+    assert run.stdout.strip() == lines[0], "only the JSON line on stdout (round 6: gloo / RCCL banners go to stderr)"
     line = json.loads(lines[0])
     cfg = line["config"]
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "strong"

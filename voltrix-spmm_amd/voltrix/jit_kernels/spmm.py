@@ -258,8 +258,14 @@ def sweep_stages(space, best=None, stage_no=0):
     def shape(p):
         return (p["FS"], p["WAVES"], p["EB"], p["SCHED"] == SCHED_STREAM)
 
+    # short-window handles (their space carries two-slot window tiles: tile_space(shallow_ok)): the first-stage schedule of a window
+    # shape is the NATURAL order -- nothing is cut there, and the unit table's longest-first order gives up what consecutive windows
+    # share in L2 (held-out co-purchase graph: the staged sweep kept the stream kernel at 0.0856 ms, a full sweep found (64, 2, 1,
+    # natural) at 0.0706; profiles/r06/experiment_sweep_compare.log)
+    short = any(p["DEPTH"] == 2 and p["SCHED"] != SCHED_STREAM for p in space)
+
     def robust(points):
-        for pref in (SCHED_STREAM, SCHED_UNITS, 2, 0):
+        for pref in ((SCHED_STREAM, 0, SCHED_UNITS, 2) if short else (SCHED_STREAM, SCHED_UNITS, 2, 0)):
             for p in points:
                 if p["SCHED"] == pref:
                     return p
