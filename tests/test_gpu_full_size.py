@@ -391,17 +391,23 @@ def test_backward_product_reddit_like_f128_stated_tolerance(cuda_device, monkeyp
     t_indptr, t_indices = csr_transpose_device(indptr, indices, n, n)
     rows = _sample_rows(t_indptr, n, 47)
     _assert_stated_tolerance(out[rows], _sub_problem(t_indptr, t_indices, rows, grad_out), "reddit_like backward (A^T, two-level)")
-    import time
 
     def step_ms(handle):
+        """Median of five event-timed batches of five calls (a wall clock around ten calls read 7.8 ms once for a 1.27 ms step:
+        one allocator stall inside the loop)."""
+        call = lambda: voltrix.spmm(*handle, num_nodes=n, num_edges=indices.numel(), feat=grad_out)  # noqa: E731
         for _ in range(3):
-            voltrix.spmm(*handle, num_nodes=n, num_edges=indices.numel(), feat=grad_out)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            voltrix.spmm(*handle, num_nodes=n, num_edges=indices.numel(), feat=grad_out)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) * 100
+            call()
+        times = []
+        for _ in range(5):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(5):
+                call()
+            e.record()
+            e.synchronize()
+            times.append(s.elapsed_time(e) / 5)
+        return sorted(times)[2]
 
     fwd, bwd = step_ms(op.handle), step_ms(op.handle_t)
     print(f"reddit-like F=128 fp16: forward {fwd:.3f} ms, backward (A^T) {bwd:.3f} ms")
