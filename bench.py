@@ -805,11 +805,21 @@ def main():
             fmt["values"] = ("separable: v_ij = r_i c_j detected by csr_preprocess_weighted (exact edge-by-edge check); the step is "
                              "scale_rows(B, c) ; the binary operator ; scale_rows(C, r) -- no value plane (voltrix/weighted.py)")
             kernels = "scale_rows_kernel(B) ; " + kernels + " ; scale_rows_kernel(C)"
+        # round 6: handles of short windows may run the CSR row-gather kernel instead (voltrix.spmm measured both on its first call)
+        from voltrix import sidecar as vsidecar
+
+        csr_sc = vsidecar.lookup_csr(handle[1]) if not args.weighted else None
+        used_csr = csr_sc is not None and csr_sc.choice.get((int(gathered.shape[1]), str(gathered.dtype))) == "csr"
+        if used_csr:
+            gather_bytes = local_nnz * num_feats * in_bytes
+            fmt = {"format": "CSR row-gather kernel (spmm_csr_kernels.hpp: no block format, no matrix cores; chosen by measurement "
+                             "against the block-format path on the first call)"}
+            kernels = "spmm_csr_rows_kernel"
         tile_desc = {"fs": point.get("FS"), "depth": point.get("DEPTH"), "waves": point.get("WAVES"),
                      "schedule": sched_name(point), "sched": point.get("SCHED"),
                      # wide operands: one launch per 256-byte group of column slabs (spmm_kernels.hpp::slab_launch_group)
                      "launches_per_step": slab_launches(num_feats, point.get("FS") or 128, in_bytes, num_nodes)}
-        counter_key = (f"{workload}{'+values' if weighted_plane else ('+scales' if args.weighted else '')}{'^T' if args.backward else ''}|F{num_feats}|{args.dtype}|{'two-level' if used_two else 'window'}|"
+        counter_key = (f"{workload}{'+values' if weighted_plane else ('+scales' if args.weighted else '')}{'^T' if args.backward else ''}|F{num_feats}|{args.dtype}|{'csr' if used_csr else ('two-level' if used_two else 'window')}|"
                        f"{point.get('FS')},{point.get('DEPTH')},{point.get('WAVES')}|sched{point.get('SCHED')}")
         from voltrix.jit.compiler import get_kernel_sources_version
 

@@ -202,6 +202,10 @@ def main(argv=None):
                                  tile=tuned_point(two.hspa_packed if (two is not None and mark == "N") else h[1],
                                                   (dim + 7) // 8 * 8, two is not None and mark == "N", dev) if mark == "N" else None,
                                  tuner=dict(jit_tuner.stats))
+                    from voltrix import sidecar as _sidecar
+
+                    csr_sc = _sidecar.lookup_csr(h.hspa_packed if mark == "Y" else h[1])
+                    extra["path"] = None if csr_sc is None else csr_sc.choice.get((int(feat.shape[1]), str(feat.dtype)))   # "csr" | "block"
                     if reorder_ms is not None:
                         extra["reorder_ms"] = reorder_ms
                         extra["reorder_picked"] = h.method

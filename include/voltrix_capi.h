@@ -417,6 +417,17 @@ void voltrix_launch_cast_f32_f16(void* src, void* dst, int64_t count, void* stre
 void voltrix_launch_cast_f32_f16_scaled(void* src, void* dst, int64_t count, void* scale, void* stream,
                                         int* return_code);
 
+/* CSR row-gather kernel (round 6; spmm_csr_kernels.hpp): output[i, :] = sum over the entries of row i of input[indices[e], :],
+ * straight from a DEVICE CSR (int32 indptr[num_rows + 1], indices[nnz]; binary A: entries count as 1, a duplicate (row, col) entry
+ * counts TWICE here -- callers with duplicates keep to the block format, which counts it once like the reference's bitmaps,
+ * bmat_kernels.cuh:100-103).  dtype 0 fp32 / 1 fp16 / 2 bfloat16 rows of `input` (embedding_dim a multiple of 16 bytes), fp32
+ * `output` [num_rows, embedding_dim], every row written; exact products, fp32 sum in entry order.  No workspace, no tables.
+ * xcd_ranges: 0 = consecutive row groups go round the XCDs (default), 1 = every XCD owns a contiguous eighth of the rows.  The
+ * operator takes it for handles of short windows where it measured faster than the block-format kernels (fp32 features; wide
+ * operands): voltrix/spmm/spmm.py.  No reference counterpart (the reference has the block format only). */
+void voltrix_launch_spmm_csr_rows(void* indptr, void* indices, int num_rows, int embedding_dim, void* input, int dtype, void* output,
+                                  int xcd_ranges, void* stream, int* return_code);
+
 /* Rows of a dense row-major matrix times a per-row factor: dst[i, :] = T(float(src[i, :]) * scale[i]); dst may be src.
  * dtype 0 fp32 / 1 fp16 / 2 bfloat16; a row (num_feats elements) must be a multiple of 16 bytes; scale: device float[rows].
  * What edge values of the form v_ij = r_i * c_j cost on top of the binary product (voltrix/weighted.py: B's rows times c before,

@@ -68,6 +68,7 @@ SYMBOLS = (
     "voltrix_launch_cast_f32_f16",
     "voltrix_launch_cast_f32_f16_scaled",
     "voltrix_launch_scale_rows",
+    "voltrix_launch_spmm_csr_rows",
     "voltrix_csr_preprocess_workspace_bytes",
     "voltrix_launch_csr_window_count",
     "voltrix_launch_csr_fill",
@@ -554,6 +555,30 @@ def launch_cast_f32_f16_scaled(src, dst, scale, stream) -> None:
         check(rc.value, "voltrix_launch_cast_f32_f16_scaled")
 
 
+_spmm_csr_rows = None
+
+
+def launch_spmm_csr_rows(indptr, indices, num_rows: int, feat, output, stream, xcd_ranges: int = 0) -> None:
+    """``output = csr(ones) @ feat`` with the CSR row-gather kernel (device int32 CSR; fp32 / fp16 / bf16 ``feat`` whose rows are a
+    multiple of 16 bytes; fp32 ``output`` [num_rows, F]); see include/voltrix_capi.h."""
+    import torch
+
+    global _spmm_csr_rows
+    if _spmm_csr_rows is None:
+        fn = lib().voltrix_launch_spmm_csr_rows
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                       ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        _spmm_csr_rows = fn
+    assert indptr.dtype == torch.int32 and indices.dtype == torch.int32 and indptr.numel() == num_rows + 1
+    assert feat.dim() == 2 and feat.is_contiguous() and output.is_contiguous() and output.dtype == torch.float32
+    assert output.shape == (num_rows, feat.shape[1])
+    dtype = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[feat.dtype]
+    rc = ctypes.c_int(-1)
+    _spmm_csr_rows(indptr.data_ptr(), indices.data_ptr(), num_rows, feat.shape[1], feat.data_ptr(), dtype, output.data_ptr(),
+                   int(xcd_ranges), stream, rc)
+    check(rc.value, "voltrix_launch_spmm_csr_rows")
+
+
 _scale_rows = None
 
 
@@ -604,6 +629,7 @@ launch_combine_partials = _timed(launch_combine_partials, "combine_partials", 6)
 launch_cast_f32_f16_scaled = _timed(launch_cast_f32_f16_scaled, "cast_f32_f16_scaled", 3)
 launch_cast_f32_f16 = _timed(launch_cast_f32_f16, "cast_f32_f16", 2)
 launch_scale_rows = _timed(launch_scale_rows, "scale_rows", 3)
+launch_spmm_csr_rows = _timed(launch_spmm_csr_rows, "spmm_csr_rows", 5)
 launch_spmm_f32_as_f16 = _timed(launch_spmm_f32_as_f16, "spmm_f32_as_f16", 9)
 launch_window_order = _timed(launch_window_order, "window_order", 3)
 launch_csr_window_count = _timed(launch_csr_window_count, "csr_window_count", 8)

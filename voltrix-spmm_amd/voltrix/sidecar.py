@@ -52,6 +52,36 @@ def _drop(key) -> None:
     with _LOCK:
         _ENTRIES.pop(key, None)
         _SLIM.discard(key)
+        _CSR.pop(key, None)
+
+
+# ---- CSR side-car (round 6): handles of short windows keep the device CSR they were built from, for the CSR row-gather kernel
+# ---- (spmm_csr_kernels.hpp); voltrix.spmm times it once per (width, dtype) against the block-format path and keeps the faster
+_CSR = {}
+
+
+class CsrSideCar:
+    """Device CSR of a handle (int32 ``indptr`` [N + 1], ``indices`` [nnz], duplicate-free) + what ``voltrix.spmm`` decided per
+    (padded width, dtype): "csr" | "block"."""
+    __slots__ = ("indptr", "indices", "num_rows", "num_cols", "choice")
+
+    def __init__(self, indptr, indices, num_rows, num_cols):
+        self.indptr, self.indices, self.num_rows, self.num_cols, self.choice = indptr, indices, num_rows, num_cols, {}
+
+
+def register_csr(hspa_packed: torch.Tensor, csr: "CsrSideCar") -> None:
+    key, storage = _key(hspa_packed)
+    with _LOCK:
+        fresh = key not in _ENTRIES and key not in _CSR
+        _CSR[key] = csr
+    if fresh:
+        weakref.finalize(storage, _drop, key)
+
+
+def lookup_csr(hspa_packed: torch.Tensor):
+    key, _ = _key(hspa_packed)
+    with _LOCK:
+        return _CSR.get(key)
 
 
 def lookup(hspa_packed: torch.Tensor):

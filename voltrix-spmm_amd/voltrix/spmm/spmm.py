@@ -101,7 +101,41 @@ def csr_preprocess_device(indptr: torch.Tensor, indices: torch.Tensor, num_nodes
     # the decision -- a side-car or "window format" -- is recorded for the MEMORY of hspa_packed (voltrix/sidecar.py): views
     # and re-packed tuples of the handle keep it, it dies with the storage
     sidecar.register(hspa_packed, two)
+    if two is None:
+        _attach_csr_side_car(hspa_packed, indptr, indices, num_nodes, num_cols)
     return pointer1, hspa_packed, hind
+
+
+# The CSR row-gather kernel (round 6; spmm_csr_kernels.hpp) is a candidate for handles of SHORT windows (the same bound as the stream
+# kernel's: at most this many TC blocks per window on average -- 16 rows that share no column), of at most this many edges (the
+# duplicate check below sorts them), without duplicate (row, col) entries (the CSR kernel would count them twice, the bitmaps once).
+CSR_MAX_BLOCKS_PER_WINDOW = 48
+CSR_MAX_EDGES = 1 << 26
+
+
+def csr_path_mode() -> str:
+    """``VOLTRIX_CSR_PATH``: ``auto`` (default: handles of short windows keep their CSR; the first ``voltrix.spmm`` per (width, dtype)
+    times the CSR row-gather kernel against the block-format path -- three calls each, one host sync -- and keeps the faster) |
+    ``1`` (always the CSR kernel where a CSR side-car exists: tests) | ``0`` (never)."""
+    v = os.getenv("VOLTRIX_CSR_PATH", "auto")
+    return "off" if v in ("0", "off") else ("on" if v in ("1", "on") else "auto")
+
+
+def _attach_csr_side_car(hspa_packed, indptr, indices, num_nodes, num_cols) -> None:
+    if csr_path_mode() == "off" or num_nodes == 0 or indices.numel() == 0 or indices.numel() > CSR_MAX_EDGES:
+        return
+    windows = (num_nodes + 15) // 16
+    if hspa_packed.numel() // 4 > CSR_MAX_BLOCKS_PER_WINDOW * windows:
+        return
+    cols = num_nodes if num_cols is None else int(num_cols)
+    deg = (indptr[1:] - indptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(num_nodes, device=indptr.device, dtype=torch.int64), deg)
+    key = rows * max(cols, 1) + indices.long()
+    lo, hi = torch.aminmax(indices)
+    distinct = torch.unique(key).numel()
+    if int(lo) < 0 or int(hi) >= cols or distinct != indices.numel():      # ids outside the universe / duplicates: block format only
+        return
+    sidecar.register_csr(hspa_packed, sidecar.CsrSideCar(indptr, indices, num_nodes, cols))
 
 
 def two_level_of(hspa_packed: torch.Tensor):
@@ -245,6 +279,10 @@ def spmm(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tenso
     ``hspa_packed`` tensor, the 16-bit-operand product runs in that form (same result up to fp32 summation order).
     """
     num_feats = feat.shape[1]
+    csr = sidecar.lookup_csr(hspa_packed) if _CSR_DEPTH[0] == 0 else None
+    if csr is not None and csr.num_rows == num_nodes and feat.is_cuda and feat.dim() == 2:
+        if _csr_choice(csr, blk_offsets, hspa_packed, hind, num_nodes, num_edges, feat) == "csr":
+            return _spmm_csr(csr, feat)
     operand, out_scale, padded, exact = _operand(feat, fp32_mode(hspa_packed, num_nodes, feat.shape[1])
                                                  if feat.dtype == torch.float32 else None)
     output = torch.empty((num_nodes, padded), dtype=torch.float32, device=feat.device)
@@ -276,6 +314,76 @@ def spmm(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tenso
             two.format_choice[key] = _choose_format(hspa_packed, key, window, two_level)
         (two_level if two.format_choice[key] == "two-level" else window)()
     return output if padded == num_feats else output[:, :num_feats].contiguous()
+
+
+_CSR_DEPTH = [0]      # > 0 while _csr_choice times the block-format path through voltrix.spmm itself
+CSR_MIN_GAIN = 0.03   # the CSR kernel must beat the block-format path by this much to be taken
+
+
+def _spmm_csr(csr, feat: torch.Tensor) -> torch.Tensor:
+    """``csr(ones) @ feat`` with the CSR row-gather kernel: fp32 / fp16 / bf16 rows as they are (no cast pass), fp32 result."""
+    from ..jit_kernels.spmm import _raw_stream
+
+    feat = feat.contiguous()
+    num_feats = feat.shape[1]
+    align = 4 if feat.dtype == torch.float32 else 8
+    padded = (num_feats + align - 1) // align * align
+    if padded != num_feats:
+        feat = torch.nn.functional.pad(feat, (0, padded - num_feats))
+    output = torch.empty((csr.num_rows, padded), dtype=torch.float32, device=feat.device)
+    capi.launch_spmm_csr_rows(csr.indptr, csr.indices, csr.num_rows, feat, output, _raw_stream(feat.device), 1)
+    return output if padded == num_feats else output[:, :num_feats].contiguous()
+
+
+def _csr_choice(csr, blk_offsets, hspa_packed, hind, num_nodes, num_edges, feat) -> str:
+    """"csr" | "block" for this (handle, width, dtype): decided once.  ``VOLTRIX_CSR_PATH=1`` forces "csr".  Otherwise the first call
+    times both paths (one warm-up -- the block path's own first-call tuning included -- then three calls each; one host sync; not
+    inside a stream capture, where the block path is taken) and the choice is remembered on the side-car and, for tagged handles,
+    persisted next to the tile choices."""
+    mode = csr_path_mode()
+    if mode == "off" or feat.dtype not in (torch.float32, torch.float16, torch.bfloat16) or feat.shape[0] < csr.num_cols:
+        return "block"
+    if mode == "on":
+        return "csr"
+    key = (int(feat.shape[1]), str(feat.dtype))
+    if key in csr.choice:
+        return csr.choice[key]
+    if torch.cuda.is_current_stream_capturing():
+        return "block"
+    from ..jit_kernels import jit_tuner
+    from ..jit_kernels.spmm import feature_hash
+
+    tagged = isinstance(getattr(hspa_packed, "hash_tag", None), str)
+    signature = ("spmm_csr_path", f"{{'device': '{torch.cuda.get_device_name(hspa_packed.device)}', 'dtype': '{key[1]}', "
+                                  f"'embedding_dim': {key[0]}, 'feature_hash': '{feature_hash(hspa_packed) if tagged else ''}'}}")
+    if tagged:
+        stored = jit_tuner._load_store().get(f"{signature[0]}|{signature[1]}")
+        if stored in ("csr", "block"):
+            csr.choice[key] = stored
+            return stored
+    times = {}
+    _CSR_DEPTH[0] += 1
+    try:
+        for name, fn in (("block", lambda: spmm(blk_offsets, hspa_packed, hind, num_nodes, num_edges, feat)),
+                         ("csr", lambda: _spmm_csr(csr, feat))):
+            fn()
+            fn()
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
+            for _ in range(3):
+                fn()
+            end.record()
+            end.synchronize()
+            times[name] = start.elapsed_time(end) / 3
+    finally:
+        _CSR_DEPTH[0] -= 1
+    best = "csr" if times["csr"] < (1.0 - CSR_MIN_GAIN) * times["block"] else "block"
+    if os.getenv("VOLTRIX_PRINT_AUTO_TUNE") or os.getenv("VOLTRIX_JIT_DEBUG"):
+        print(f"voltrix.spmm path for width {key[0]} {key[1]}: {times} -> {best}")
+    csr.choice[key] = best
+    if tagged:
+        jit_tuner._save_choice(signature, best)
+    return best
 
 
 def _choose_format(hspa_packed, key, window, two_level) -> str:
