@@ -116,11 +116,7 @@ def _contract(u, v, w, label, sizes):
 
 
 def default_caps():
-    """``VOLTRIX_CLUSTER_CAPS=32,512,8192`` overrides the three cluster sizes (experiments)."""
-    import os
-
-    text = os.environ.get("VOLTRIX_CLUSTER_CAPS")
-    return tuple(int(c) for c in text.split(",")) if text else CLUSTER_CAPS
+    return CLUSTER_CAPS
 
 
 def cluster_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, caps=None, seed: int = 0,

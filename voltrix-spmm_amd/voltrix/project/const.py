@@ -27,6 +27,7 @@ TUNED_DEFAULTS_FLAG = "VOLTRIX_TUNED_DEFAULTS"        # 0: ignore the shipped bu
 HYBRID_FLAG = "VOLTRIX_HYBRID"                        # auto (default) | 1 | 0 | tune : the two-level side-car (hybrid.py)
 HYBRID_MIN_SHARE_FLAG = "VOLTRIX_HYBRID_MIN_SHARE"    # fraction of the edges in shared columns the side-car needs
 FUSED_FLAG = "VOLTRIX_FUSED"                          # 1: the two-level product as one launch (spmm_fused_kernels.hpp)
+CSR_PATH_FLAG = "VOLTRIX_CSR_PATH"                    # auto (default) | 1 | 0 : the CSR row-gather kernel for short-window handles (round 6)
 SUPPORTED_FLAGS = (DEBUG_FLAG, NVCC_COMPILER_FLAG, CACHE_DIR_FLAG, PTXAS_VERBOSE_FLAG, JIT_PRINT_NVCC_COMMAND_FLAG,
                    PRINT_AUTOTUNE_FLAG, HIPCC_COMPILER_FLAG, FP32_MODE_FLAG, PREPROCESS_FLAG, TUNE_SPACE_FLAG,
-                   TUNED_STORE_FLAG, TUNED_DEFAULTS_FLAG, HYBRID_FLAG, HYBRID_MIN_SHARE_FLAG, FUSED_FLAG)
+                   TUNED_STORE_FLAG, TUNED_DEFAULTS_FLAG, HYBRID_FLAG, HYBRID_MIN_SHARE_FLAG, FUSED_FLAG, CSR_PATH_FLAG)

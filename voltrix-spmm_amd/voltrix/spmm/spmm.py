@@ -16,7 +16,7 @@ from ..jit_kernels import (
     spmm_kernel,
 )
 from .. import capi, hybrid, sidecar
-from ..project import FP32_MODE_FLAG, PREPROCESS_FLAG
+from ..project import CSR_PATH_FLAG, FP32_MODE_FLAG, PREPROCESS_FLAG
 
 BLK_H = 16
 BLK_W = 8
@@ -117,7 +117,7 @@ def csr_path_mode() -> str:
     """``VOLTRIX_CSR_PATH``: ``auto`` (default: handles of short windows keep their CSR; the first ``voltrix.spmm`` per (width, dtype)
     times the CSR row-gather kernel against the block-format path -- three calls each, one host sync -- and keeps the faster) |
     ``1`` (always the CSR kernel where a CSR side-car exists: tests) | ``0`` (never)."""
-    v = os.getenv("VOLTRIX_CSR_PATH", "auto")
+    v = os.getenv(CSR_PATH_FLAG, "auto")
     return "off" if v in ("0", "off") else ("on" if v in ("1", "on") else "auto")
 
 
