@@ -40,7 +40,8 @@ def test_csr_kernel_matches_the_oracle(cuda_device, csr_fixture, dtype, width):
 def test_operator_keeps_the_csr_for_short_window_handles_and_both_paths_agree(cuda_device, graph, scale, dtype, monkeypatch):
     """csr_preprocess attaches the device CSR to handles of short windows; VOLTRIX_CSR_PATH=1 / 0 force either path, auto times
     them once per (width, dtype) and remembers; all three give the oracle's product (integers: bit for bit)."""
-    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "default")         # "none" / "stream" pin the block-format kernel: no measured choice then
+    monkeypatch.delenv("VOLTRIX_FP32_MODE", raising=False)
     indptr, indices, _ = synth_graphs.generate(graph, scale=scale)
     n, e = indptr.numel() - 1, indices.numel()
     handle = voltrix.csr_preprocess(indptr, indices, n)
@@ -58,6 +59,12 @@ def test_operator_keeps_the_csr_for_short_window_handles_and_both_paths_agree(cu
     before = dict(csr.choice)
     voltrix.spmm(*handle, num_nodes=n, num_edges=e, feat=feat)
     assert csr.choice == before
+    # pinned kernels / numerics stay pinned: no measured choice, the block-format path
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    other = torch.randint(-3, 4, (n, 40)).to(dtype).cuda()
+    assert torch.equal(voltrix.spmm(*handle, num_nodes=n, num_edges=e, feat=other).cpu(),
+                       torch_ref.spmm(indptr.numpy(), indices.numpy(), other.float().cpu(), n))
+    assert (40, str(dtype)) not in csr.choice
 
 
 def test_no_csr_side_car_for_duplicates_long_windows_or_when_switched_off(cuda_device, monkeypatch):

@@ -345,6 +345,12 @@ def _csr_choice(csr, blk_offsets, hspa_packed, hind, num_nodes, num_edges, feat)
         return "block"
     if mode == "on":
         return "csr"
+    # pinned numerics / pinned kernels stay pinned: VOLTRIX_FP32_MODE=fp16 asks for the scaled 16-bit operand (this kernel would
+    # compute the exact fp32 product), VOLTRIX_TUNE_SPACE=none / stream name the block-format kernel to run (tests, experiments)
+    from ..jit_kernels.spmm import tune_space_mode
+
+    if (feat.dtype == torch.float32 and os.getenv(FP32_MODE_FLAG, "auto") == "fp16") or tune_space_mode() in ("none", "stream"):
+        return "block"
     key = (int(feat.shape[1]), str(feat.dtype))
     if key in csr.choice:
         return csr.choice[key]
