@@ -98,3 +98,14 @@ def test_relabelled_operator_on_shuffled_family_graphs_equals_the_oracle(cuda_de
         new = torch.empty(n, dtype=torch.int64)
         new[perm] = torch.arange(n)
         assert reorder.local_fraction(s_indptr, s_indices, n, new) >= local_before     # never less local than it came
+
+
+def test_cluster_order_edge_cases():
+    """No edges, isolated nodes, self loops, the empty graph: always a permutation; nodes without edges keep their relative order."""
+    ip, ix = torch.zeros(11, dtype=torch.int32), torch.zeros(0, dtype=torch.int32)
+    assert cluster_order.cluster_permutation(ip, ix, 10).tolist() == list(range(10))
+    ip, ix = torch.tensor([0, 2, 3, 3, 4, 4], dtype=torch.int32), torch.tensor([1, 0, 0, 3], dtype=torch.int32)   # 3 -> 3: a self loop
+    info = {}
+    perm = cluster_order.cluster_permutation(ip, ix, 5, info=info)
+    assert sorted(perm.tolist()) == list(range(5)) and info["components"] == 4
+    assert cluster_order.cluster_permutation(torch.zeros(1, dtype=torch.int32), ix[:0], 0).numel() == 0
