@@ -380,6 +380,9 @@ def main():
         d_out = (local_indptr[1:] - local_indptr[:-1]).float().clamp(min=1)
         d_in = torch.bincount(local_indices.long(), minlength=num_cols).float().clamp(min=1)
         edge_values = torch.repeat_interleave(d_out.rsqrt(), (local_indptr[1:] - local_indptr[:-1]).long()) * d_in.rsqrt()[local_indices.long()]
+        # graphs too large for the automatic detection of v_ij = r_i c_j (weighted.SEPARABLE_MAX_EDGES): the caller states the factors,
+        # as a GCN layer that builds the normalisation itself would
+        stated_scales = (d_out.rsqrt(), d_in.rsqrt()) if local_nnz > (1 << 29) and not args.weighted_plane else None
         del d_out, d_in
     if args.backward:   # the transposed operator: what autograd.SpMM builds for the gradient with respect to B
         assert not distributed, "--backward is a single-GPU run"
@@ -404,8 +407,12 @@ def main():
                                                  slabs=args.slabs, exchange_at_world_1=args.force_dist)
             handle = op.handle
         elif args.weighted:
-            whandle = voltrix.csr_preprocess_weighted(local_indptr, local_indices, edge_values, local_rows, num_cols=num_cols,
-                                                      separable=False if args.weighted_plane else "auto")
+            if stated_scales is not None and not args.backward:
+                whandle = voltrix.csr_preprocess_weighted(local_indptr, local_indices, None, local_rows, num_cols=num_cols,
+                                                          row_scale=stated_scales[0], col_scale=stated_scales[1])
+            else:
+                whandle = voltrix.csr_preprocess_weighted(local_indptr, local_indices, edge_values, local_rows, num_cols=num_cols,
+                                                          separable=False if args.weighted_plane else "auto")
             handle = (whandle.blk_offsets, whandle.hspa_packed, whandle.hind)
         else:
             handle = voltrix.csr_preprocess_device(local_indptr, local_indices, local_rows, num_cols=num_cols)
@@ -802,7 +809,9 @@ def main():
                        ("spmm_stream_kernel" if point.get("SCHED") == SCHED_STREAM else "spmm_tc16_kernel")) + (
                 " ; combine_partials_kernel" if point.get("SCHED") in (SCHED_UNITS, SCHED_PAIRS, SCHED_STREAM) else "")
         if args.weighted and not weighted_plane:
-            fmt["values"] = ("separable: v_ij = r_i c_j detected by csr_preprocess_weighted (exact edge-by-edge check); the step is "
+            fmt["values"] = ("separable: v_ij = r_i c_j " + ("stated by the caller (row_scale / col_scale: above weighted.SEPARABLE_MAX_EDGES "
+                                                              "the detection is not tried)" if stated_scales is not None and not args.backward
+                                                              else "detected by csr_preprocess_weighted (exact edge-by-edge check)") + "; the step is "
                              "scale_rows(B, c) ; the binary operator ; scale_rows(C, r) -- no value plane (voltrix/weighted.py)")
             kernels = "scale_rows_kernel(B) ; " + kernels + " ; scale_rows_kernel(C)"
         # round 6: handles of short windows may run the CSR row-gather kernel instead (voltrix.spmm measured both on its first call)

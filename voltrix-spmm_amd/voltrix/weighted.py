@@ -102,6 +102,8 @@ def value_plane(indptr: torch.Tensor, indices: torch.Tensor, values: torch.Tenso
 SEPARABLE_TOLERANCE = 2.0 ** -13     # |v_ij / (r_i c_j) - 1| below this counts as separable: a quarter of the fp16 rounding the
                                       # value plane applies to every value anyway (2^-11)
 SEPARABLE_SWEEPS = 64
+SEPARABLE_MAX_EDGES = 1 << 29        # the detection holds five edge-sized 64-bit arrays and sorts one of them: above this many edges it is
+                                      # not tried (papers-like: 1.6 G edges beside a 28 GB B and a 57 GB C) -- state the factors instead
 
 
 def separable_scales(indptr: torch.Tensor, indices: torch.Tensor, values: torch.Tensor, num_nodes: int, num_cols: int,
@@ -173,7 +175,7 @@ def csr_preprocess_weighted(indptr: torch.Tensor, indices: torch.Tensor, values:
         assert scales[0].numel() == num_nodes and scales[1].numel() == num_cols
     else:
         assert values is not None and values.numel() == indices.numel() and values.is_floating_point()
-        if separable in ("auto", True):
+        if separable is True or (separable == "auto" and indices.numel() <= SEPARABLE_MAX_EDGES):
             scales = separable_scales(indptr_d, indices_d, values.contiguous().cuda(), num_nodes, num_cols)
             assert scales is not None or separable == "auto", "separable=True but the values do not factor as r_i * c_j"
     if scales is not None:
