@@ -421,7 +421,10 @@ def main():
     if args.weighted:
         torch.cuda.empty_cache()   # the plane builder's chunk temporaries
     handle[1].hash_tag = f"bench/{workload}/s{args.scale}/r{rank}of{world}" + ("/transposed" if args.backward else "")
-    weighted_plane = args.weighted and not whandle.separable    # the kernels read a value plane (else: binary kernels + row scalings)
+    # the kernels read a value plane (else: binary kernels between two row scalings; a separable handle still takes the plane where the
+    # scalings would move more bytes than it: weighted.separable_pays)
+    from voltrix.weighted import separable_pays
+    weighted_plane = args.weighted and not (whandle.separable and separable_pays(whandle, num_feats, in_bytes))
     two = voltrix.two_level_of(handle[1])
     total_blocks = int(handle[0][-1])
     from voltrix import hybrid as vhybrid

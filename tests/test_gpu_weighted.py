@@ -236,3 +236,28 @@ def test_weighted_autograd_gradient_is_the_transposed_weighted_product(cuda_devi
     assert ((out.detach().cpu().double() - ref_out).abs() <= 2.0 ** -9 * scale_o + 1e-5).all()
     # the gradient passes through fp16 twice more: the incoming gradient is rounded like any operand, the result is cast to feat's dtype
     assert ((feat.grad.cpu().double() - ref_grad).abs() <= 2.0 ** -8 * scale_g + 2.0 ** -10 * ref_grad.abs() + 1e-4).all()
+
+
+def test_separable_handle_takes_the_value_plane_where_the_row_scalings_would_cost_more(cuda_device, monkeypatch):
+    """2 N F (s + 4) bytes of row scalings against 256 bytes per TC block: a handle of short windows multiplied by a WIDE operand is
+    better off with the plane (papers-like x 128: 94 ms separable, 80.5 with the plane), built lazily from the kept CSR -- same product."""
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    from voltrix import weighted
+
+    g = load_csr_fixture("cora_like")
+    n = int(g["num_nodes"])
+    indptr, indices = torch.from_numpy(g["indptr"]), torch.from_numpy(g["indices"])
+    deg = torch.from_numpy(np.diff(g["indptr"]).astype(np.int64))
+    rows = torch.repeat_interleave(torch.arange(n), deg)
+    values = (1.0 / deg.double().clamp(min=1))[rows].float()
+    h = voltrix.csr_preprocess_weighted(indptr, indices, values, n)
+    assert h.separable and not h.planes
+    assert weighted.separable_pays(h, 8, 2) and not weighted.separable_pays(h, 512, 2)      # narrow: scalings; wide: the plane
+    feat = torch.randn(n, 512).half()
+    out = voltrix.spmm_weighted(h, feat.cuda(), hash_tag="separable_lazy_plane")
+    assert torch.float16 in h.planes                                                          # built on demand, once
+    ref = _oracle(g["indptr"], g["indices"], values, feat, n, n)
+    absref = _oracle(g["indptr"], g["indices"], values.abs(), feat.float().abs(), n, n)
+    assert ((out.cpu().double() - ref).abs() <= (2.0 ** -10 + (deg.double()[:, None] + 1) * 2.0 ** -23) * absref + 1e-6).all()
+    narrow = voltrix.spmm_weighted(h, feat[:, :8].contiguous().cuda())                       # the separable path on the same handle
+    assert ((narrow.cpu().double() - ref[:, :8]).abs() <= (2.0 ** -10 + (deg.double()[:, None] + 2) * 2.0 ** -23) * absref[:, :8] + 1e-6).all()

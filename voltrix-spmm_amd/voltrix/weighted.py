@@ -45,6 +45,9 @@ class WeightedHandle:
     row_scale: torch.Tensor = None     # float32 [num_nodes]
     col_scale: torch.Tensor = None     # float32 [num_cols]
 
+    csr: tuple = None                  # separable handles: (indptr, indices, values or None, num_cols) on the device -- what a value plane
+                                       # is built from should a call be better off with one (``separable_pays``)
+
     @property
     def separable(self) -> bool:
         return self.row_scale is not None
@@ -183,7 +186,8 @@ def csr_preprocess_weighted(indptr: torch.Tensor, indices: torch.Tensor, values:
 
         pointer1, hspa_packed, hind = csr_preprocess_device(indptr_d, indices_d, num_nodes, num_cols)   # side-car policy included
         return WeightedHandle(pointer1, hspa_packed, hind, None, num_nodes, int(indices.numel()), row_scale=scales[0],
-                              col_scale=scales[1])
+                              col_scale=scales[1],
+                              csr=(indptr_d, indices_d, values.contiguous().cuda() if values is not None else None, num_cols))
     assert values.numel() == indices.numel() and values.is_floating_point()
     values_d = values.contiguous().cuda()
     pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(indptr_d, indices_d, num_nodes, num_cols)
@@ -211,9 +215,12 @@ def spmm_weighted(handle: WeightedHandle, feat: torch.Tensor, hash_tag: str = No
         handle.hspa_packed.hash_tag = hash_tag
     num_feats = feat.shape[1]
     if handle.separable:
-        return _spmm_separable(handle, feat)
+        if separable_pays(handle, num_feats, feat.element_size()):
+            return _spmm_separable(handle, feat)
     operand, out_scale, padded, exact = _operand(feat)
     assert not exact, "the weighted kernel takes a 16-bit operand (unset VOLTRIX_FP32_MODE=exact)"
+    if handle.separable:
+        _materialise_plane(handle, operand.dtype)
     if operand.dtype not in handle.planes:
         assert handle.values32 is not None, (f"this handle was built without an fp32 master (too large) and holds only the "
                                              f"{list(handle.planes)} plane(s): pass plane_dtype={operand.dtype} to csr_preprocess_weighted")
@@ -223,6 +230,33 @@ def spmm_weighted(handle: WeightedHandle, feat: torch.Tensor, hash_tag: str = No
                 num_edges=handle.num_edges, embedding_dim=padded, input=operand, output=output, out_scale=out_scale,
                 values=handle.planes[operand.dtype])
     return output if padded == num_feats else output[:, :num_feats].contiguous()
+
+
+def separable_pays(handle: WeightedHandle, num_feats: int, elem_bytes: int) -> bool:
+    """The two row scalings of the separable path move B twice and C twice -- 2 N F (s_in + 4) bytes --, the value plane 256 bytes per TC
+    block whatever the width.  On graphs whose B and C are far beyond the caches and whose windows are short the passes cost more than
+    the plane (papers-like x 128: 94 ms separable against 80.5 with the plane; the binary product is 62): the separable path is taken
+    when the handle carries the two-level side-car (the panel kernel has no value plane: reddit-like 1.43 against 2.47 ms) or when its
+    extra bytes are fewer.  Host integers only."""
+    from . import sidecar
+
+    if handle.csr is None or sidecar.lookup(handle.hspa_packed)[1] is not None:
+        return True
+    rows = max(handle.num_nodes, handle.col_scale.numel())
+    return 2 * rows * num_feats * (elem_bytes + 4) <= 64 * handle.hspa_packed.numel()      # 256 bytes per TC block = 64 x 4 words
+
+
+def _materialise_plane(handle: WeightedHandle, dtype: torch.dtype) -> None:
+    """A separable handle that is better off with a value plane for this call's width builds it now, once per 16-bit type (chunk by
+    chunk, no fp32 master; values restated from the factors when the caller gave those)."""
+    if dtype in handle.planes:
+        return
+    indptr, indices, values, num_cols = handle.csr
+    if values is None:
+        deg = (indptr[1:] - indptr[:-1]).long()
+        values = torch.repeat_interleave(handle.row_scale, deg) * handle.col_scale[indices.long()]
+    universe = max(num_cols, int(indices.max()) + 1) if indices.numel() else num_cols
+    handle.planes[dtype] = value_plane(indptr, indices, values, handle.blk_offsets, handle.num_nodes, universe, dtype=dtype)
 
 
 def _spmm_separable(handle: WeightedHandle, feat: torch.Tensor) -> torch.Tensor:
