@@ -210,3 +210,20 @@ def test_experiment_scripts_only_call_entry_points_that_exist():
                 if not hasattr(mod, node.attr):
                     missing.append(f"{os.path.relpath(path, root)}: {node.value.id}.{node.attr}")
     assert not missing, missing
+
+
+def test_rocsparse_baseline_library_builds_and_exports_its_entry_points():
+    """harness/bm_rocsparse.cpp (round 6: rocSPARSE's four CSR SpMM algorithms + the plain CSR row-gather kernel; plain HIP + rocSPARSE, no
+    torch) is compiled ahead of time by build() / `make -C harness`; no GPU call here."""
+    import ctypes
+    import subprocess as sp
+
+    sp.check_call(["make", "-s", "-C", os.path.join(REPO, "harness"), "libbm_rocsparse.so"])
+    lib = ctypes.CDLL(os.path.join(REPO, "harness", "libbm_rocsparse.so"))
+    assert hasattr(lib, "bm_rocsparse_spmm") and hasattr(lib, "bm_csr_row_gather")
+    sys.path.insert(0, REPO)
+    from harness import bm_rocsparse
+
+    assert set(bm_rocsparse.ALGORITHMS.values()) == {1, 4, 5, 9}          # csr, csr_row_split, csr_nnz_split (= merge), csr_merge_path
+    assert bm_rocsparse.best({"rocsparse_csr": 2.0, "rocsparse_csr_row_split": None, "csr_row_gather_u4": 1.0}) == ("rocsparse_csr", 2.0)
+    assert bm_rocsparse.best({"rocsparse_csr": None}) == (None, None)
