@@ -4,7 +4,7 @@ bench/bench_all.py:62-172: for every ``<name>.npz`` of a folder (files with "reo
 bench_all.py:64-66) and every feature width, dump the graph with graph_gen.py, time every method in its own process,
 scrape the method's time line (bench_all.py:21-29) and append ``Method,Dataset,FeatDim,Reorder,Time (ms)`` rows
 (bench_all.py:75; Reorder is ``N`` / ``Y`` as in bench_all.py:131,158).  Methods that do not reorder run on ``<name>.npz``
-(hipSPARSE here; the reference's TC-GNN / GE-SPMM / RoDe / Sputnik / DTC runners are competitor kernels, out of scope),
+(hipSPARSE = torch.sparse.mm and, round 6, rocSPARSE-best here; the reference's TC-GNN / GE-SPMM / RoDe / Sputnik / DTC runners are competitor kernels, out of scope),
 Voltrix runs on ``<name>.reorder.npz`` -- written by ``graph_gen.py --write_reorder METHOD`` when it is not there yet, where
 the reference expects an externally reordered file -- and, beyond the reference, also on the un-reordered file, so the CSV
 shows what the reorder buys.  ``--synthetic reddit_like:0.05,...`` sweeps the stand-in generators instead of a folder.
@@ -22,7 +22,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 
-TIME_PATTERN = {"Voltrix": "[Voltrix] time: ", "Voltrix-fp16": "[Voltrix] time: ", "hipSPARSE": "[hipSPARSE] Elapsed time: "}
+TIME_PATTERN = {"Voltrix": "[Voltrix] time: ", "Voltrix-fp16": "[Voltrix] time: ", "hipSPARSE": "[hipSPARSE] Elapsed time: ",
+                # round 6: rocSPARSE's generic SpMM, the best of its four CSR algorithms (harness/bm_rocsparse.py; -fp16: its fp16-in path)
+                "rocSPARSE-best": "[rocSPARSE-best] Elapsed time: ", "rocSPARSE-best-fp16": "[rocSPARSE-best] Elapsed time: "}
 FEATURE_DIMS = [256, 512, 1024]        # bench_all.py:18
 
 
@@ -106,6 +108,10 @@ def main(argv=None):
                 r = run([os.path.join(HERE, "bm_sparse.py"), "--npz", path, "--num_feats", str(dim), "--iters",
                          str(max(args.iters, 10))], env)
                 record("hipSPARSE", name, dim, "N", scrape("hipSPARSE", r.stdout))
+            for method in [m for m in methods if m.startswith("rocSPARSE-best")]:
+                r = run([os.path.join(HERE, "bm_rocsparse.py"), "--npz", path, "--num_feats", str(dim), "--iters",
+                         str(max(args.iters, 10)), *(["--half"] if method.endswith("fp16") else [])], env)
+                record(method, name, dim, "N", scrape(method, r.stdout))
             for method in [m for m in methods if m.startswith("Voltrix")]:
                 fp16 = ["--fp16"] if method == "Voltrix-fp16" else []
                 for mark, flag in (("N", []), ("Y", ["--reorder"])) if want_reorder else (("N", []),):
@@ -123,6 +129,9 @@ def main(argv=None):
             if "hipSPARSE" in methods:
                 r = run([os.path.join(HERE, "bm_sparse.py"), "--dir", dump], env)
                 record("hipSPARSE", name, dim, "N", scrape("hipSPARSE", r.stdout))
+            if "rocSPARSE-best" in methods:
+                r = run([os.path.join(HERE, "bm_rocsparse.py"), "--dir", dump, "--iters", str(max(args.iters, 10))], env)
+                record("rocSPARSE-best", name, dim, "N", scrape("rocSPARSE-best", r.stdout))
             if "Voltrix" in methods:
                 r = run([os.path.join(HERE, "bm_voltrix.py"), "--dir", dump, "--dataset", name, "--iters", str(args.iters)], env)
                 record("Voltrix", name, dim, "N", scrape("Voltrix", r.stdout))

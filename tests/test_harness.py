@@ -92,14 +92,14 @@ def test_bench_all_sweeps_methods_and_writes_the_reference_csv(tmp_path, cuda_de
     <name>.reorder.npz is produced by the breadth-first order on the device."""
     env = dict(os.environ, VOLTRIX_TUNE_SPACE="none")
     out = subprocess.run([sys.executable, os.path.join(REPO, "harness", "bench_all.py"), "--synthetic", "reddit_like:0.02",
-                          "--feature_dims", "64", "--reorder_method", "bfs", "--iters", "3",
+                          "--feature_dims", "64", "--reorder_method", "bfs", "--iters", "3", "--methods", "hipSPARSE,rocSPARSE-best,Voltrix",
                           "--output_file", str(tmp_path / "results.csv")],
                          capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     rows = [r.split(",") for r in open(tmp_path / "results.csv").read().strip().split("\n")]
     assert rows[0] == ["Method", "Dataset", "FeatDim", "Reorder", "Time (ms)"]
-    assert [r[:4] for r in rows[1:]] == [["hipSPARSE", "reddit_like", "64", "N"], ["Voltrix", "reddit_like", "64", "N"],
-                                         ["Voltrix", "reddit_like", "64", "Y"]]
+    assert [r[:4] for r in rows[1:]] == [["hipSPARSE", "reddit_like", "64", "N"], ["rocSPARSE-best", "reddit_like", "64", "N"],
+                                         ["Voltrix", "reddit_like", "64", "N"], ["Voltrix", "reddit_like", "64", "Y"]]
     assert all(0 < float(r[4]) < 100 for r in rows[1:]), rows
 
 
