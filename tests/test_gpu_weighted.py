@@ -264,3 +264,26 @@ def test_separable_handle_takes_the_value_plane_where_the_row_scalings_would_cos
     assert ((out.cpu().double() - ref).abs() <= (2.0 ** -10 + (deg.double()[:, None] + 1) * 2.0 ** -23) * absref + 1e-6).all()
     narrow = voltrix.spmm_weighted(h, feat[:, :8].contiguous().cuda())                       # the separable path on the same handle
     assert ((narrow.cpu().double() - ref[:, :8]).abs() <= (2.0 ** -10 + (deg.double()[:, None] + 2) * 2.0 ** -23) * absref[:, :8] + 1e-6).all()
+
+
+def test_prescaled_and_unscaled_forms_of_the_separable_product(cuda_device, monkeypatch):
+    """Callers that fold the factors into their own kernels: prescaled=True skips the pass over B, postscale=False the pass over C;
+    composing them by hand gives the same bits as the full call."""
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    from voltrix import weighted
+
+    monkeypatch.setattr(weighted, "separable_pays", lambda *a: True)
+    g = load_csr_fixture("skewed_1005")
+    n = int(g["num_nodes"])
+    indptr, indices = torch.from_numpy(g["indptr"]), torch.from_numpy(g["indices"])
+    torch.manual_seed(3)
+    r, c = torch.rand(n) + 0.5, torch.rand(n) + 0.5
+    h = voltrix.csr_preprocess_weighted(indptr, indices, None, n, row_scale=r, col_scale=c)
+    feat = torch.randn(n, 64, device=cuda_device).half()
+    full = voltrix.spmm_weighted(h, feat, hash_tag="separable_forms")
+    pre = (feat.float() * h.col_scale[:, None]).half()
+    by_hand = voltrix.spmm_weighted(h, pre, prescaled=True, postscale=False) * h.row_scale[:, None]
+    assert torch.equal(full, by_hand)
+    plane = voltrix.csr_preprocess_weighted(indptr, indices, torch.ones(len(indices)), n, separable=False)
+    with pytest.raises(AssertionError, match="separable values only"):
+        voltrix.spmm_weighted(plane, feat, prescaled=True)

@@ -205,18 +205,25 @@ def csr_preprocess_weighted(indptr: torch.Tensor, indices: torch.Tensor, values:
     return handle
 
 
-def spmm_weighted(handle: WeightedHandle, feat: torch.Tensor, hash_tag: str = None) -> torch.Tensor:
+def spmm_weighted(handle: WeightedHandle, feat: torch.Tensor, hash_tag: str = None, prescaled: bool = False,
+                  postscale: bool = True) -> torch.Tensor:
     """``csr(values) @ feat`` -> float32 [num_nodes, F] on the current stream.  ``feat``: CUDA, 2-D; float16 / bfloat16, or
-    float32 (rounded to fp16 after one power-of-two rescale, as in ``voltrix.spmm``)."""
+    float32 (rounded to fp16 after one power-of-two rescale, as in ``voltrix.spmm``).
+
+    Separable handles only (round 6): ``prescaled=True`` -- the caller has already multiplied row j of ``feat`` by
+    ``handle.col_scale[j]`` (e.g. in the epilogue of the GEMM that produced it): no pass over B here; ``postscale=False`` -- return
+    ``A (diag(c) feat)`` WITHOUT the row factors, for callers that fold ``handle.row_scale`` into what consumes C (bias, activation):
+    no pass over C here.  With both the weighted product costs exactly the binary one."""
     from .spmm.spmm import _operand
 
     assert isinstance(handle, WeightedHandle)
     if hash_tag is not None and getattr(handle.hspa_packed, "hash_tag", None) is None:
         handle.hspa_packed.hash_tag = hash_tag
     num_feats = feat.shape[1]
+    assert handle.separable or (not prescaled and postscale), "prescaled / postscale=False: handles of separable values only"
     if handle.separable:
-        if separable_pays(handle, num_feats, feat.element_size()):
-            return _spmm_separable(handle, feat)
+        if prescaled or not postscale or separable_pays(handle, num_feats, feat.element_size()):
+            return _spmm_separable(handle, feat, prescaled, postscale)
     operand, out_scale, padded, exact = _operand(feat)
     assert not exact, "the weighted kernel takes a 16-bit operand (unset VOLTRIX_FP32_MODE=exact)"
     if handle.separable:
@@ -259,7 +266,7 @@ def _materialise_plane(handle: WeightedHandle, dtype: torch.dtype) -> None:
     handle.planes[dtype] = value_plane(indptr, indices, values, handle.blk_offsets, handle.num_nodes, universe, dtype=dtype)
 
 
-def _spmm_separable(handle: WeightedHandle, feat: torch.Tensor) -> torch.Tensor:
+def _spmm_separable(handle: WeightedHandle, feat: torch.Tensor, prescaled: bool = False, postscale: bool = True) -> torch.Tensor:
     """``diag(r) (A (diag(c) feat))``: rows of B times c (one HIP pass, in B's own dtype -- fp32 features are scaled in fp32 and
     then take ``voltrix.spmm``'s own fp32 path), the BINARY operator on the handle (two-level side-car, tuned tiles, launch
     plans), rows of C times r in place (one HIP pass)."""
@@ -275,11 +282,14 @@ def _spmm_separable(handle: WeightedHandle, feat: torch.Tensor) -> torch.Tensor:
     if padded != num_feats:
         feat = torch.nn.functional.pad(feat, (0, padded - num_feats))
     stream = _raw_stream(feat.device)
-    scaled = torch.empty_like(feat)
-    capi.launch_scale_rows(feat, handle.col_scale, scaled, stream)
+    scaled = feat
+    if not prescaled:
+        scaled = torch.empty_like(feat)
+        capi.launch_scale_rows(feat, handle.col_scale, scaled, stream)
     out = spmm(handle.blk_offsets, handle.hspa_packed, handle.hind, num_nodes=handle.num_nodes, num_edges=handle.num_edges,
                feat=scaled)
-    capi.launch_scale_rows(out, handle.row_scale, out, stream)
+    if postscale:
+        capi.launch_scale_rows(out, handle.row_scale, out, stream)
     return out if padded == num_feats else out[:, :num_feats].contiguous()
 
 
