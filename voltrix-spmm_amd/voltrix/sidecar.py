@@ -78,6 +78,15 @@ def register_csr(hspa_packed: torch.Tensor, csr: "CsrSideCar") -> None:
         weakref.finalize(storage, _drop, key)
 
 
+def lookup_both(hspa_packed: torch.Tensor):
+    """``(known, two, csr)`` with ONE key computation (``voltrix.spmm`` asks for both on every call: the key costs a storage lookup)."""
+    key, _ = _key(hspa_packed)
+    with _LOCK:
+        if key in _ENTRIES:
+            return True, _ENTRIES[key], _CSR.get(key)
+        return False, None, _CSR.get(key)
+
+
 def lookup_csr(hspa_packed: torch.Tensor):
     key, _ = _key(hspa_packed)
     with _LOCK:

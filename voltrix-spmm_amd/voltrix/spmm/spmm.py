@@ -279,14 +279,15 @@ def spmm(blk_offsets: torch.Tensor, hspa_packed: torch.Tensor, hind: torch.Tenso
     ``hspa_packed`` tensor, the 16-bit-operand product runs in that form (same result up to fp32 summation order).
     """
     num_feats = feat.shape[1]
-    csr = sidecar.lookup_csr(hspa_packed) if _CSR_DEPTH[0] == 0 else None
+    known, two, csr = sidecar.lookup_both(hspa_packed)
+    if _CSR_DEPTH[0]:
+        csr = None
     if csr is not None and csr.num_rows == num_nodes and feat.is_cuda and feat.dim() == 2:
         if _csr_choice(csr, blk_offsets, hspa_packed, hind, num_nodes, num_edges, feat) == "csr":
             return _spmm_csr(csr, feat)
     operand, out_scale, padded, exact = _operand(feat, fp32_mode(hspa_packed, num_nodes, feat.shape[1])
                                                  if feat.dtype == torch.float32 else None)
     output = torch.empty((num_nodes, padded), dtype=torch.float32, device=feat.device)
-    known, two = sidecar.lookup(hspa_packed)
     mode = hybrid.hybrid_mode()
     if not known and mode == "auto" and not exact:
         sidecar.warn_if_unknown(hspa_packed, num_nodes, num_edges, hybrid.AUTO_MIN_EDGES, hybrid.AUTO_MIN_ROWS,
