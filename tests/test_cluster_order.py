@@ -62,6 +62,15 @@ def test_band_graph_with_random_edges_most_edges_end_up_inside_their_cluster():
     assert info["edges_inside_cluster"] > 4 * 4096 / n
     again = cluster_order.cluster_permutation(s_indptr, s_indices, n, caps=(32, 512, 4096))
     assert torch.equal(again, perm)                                    # deterministic for a seed
+    # the clusters are laid out along the chain they form (Fiedler order of the cluster graph): the generating order comes back
+    # up to its direction, which no single eigenvector of the fine graph manages at this degree
+    true_pos = torch.empty(n, dtype=torch.int64)
+    true_pos[label] = torch.arange(n)
+    corr = float(torch.corrcoef(torch.stack([true_pos[perm].double(), torch.arange(n).double()]))[0, 1])
+    assert abs(corr) > 0.6, corr            # ten clusters here: one cluster of two stretches already costs 0.2
+    unchained = cluster_order.cluster_permutation(s_indptr, s_indices, n, caps=(32, 512, 4096), chain=False)
+    corr0 = float(torch.corrcoef(torch.stack([true_pos[unchained].double(), torch.arange(n).double()]))[0, 1])
+    assert abs(corr0) < abs(corr)
 
 
 @pytest.mark.gpu
