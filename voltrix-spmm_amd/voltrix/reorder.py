@@ -687,48 +687,7 @@ def spectral_permutation(indptr: torch.Tensor, indices: torch.Tensor, num_nodes:
     return (perm, info) if return_info else perm
 
 
-LOCAL_VOTE_WIDTHS = (1024, 256)     # rows per stretch of the local vote rounds (neighbour_votes_local)
-
-
-def neighbour_votes_local(apply_a, perm: torch.Tensor, active: torch.Tensor, degree: torch.Tensor, width: int, buckets: int = 256,
-                          reach: int = 3, confidence: float = 0.1) -> torch.Tensor:
-    """Neighbour votes at FINE resolution on an order that is already right to within a few thousand rows (round 6).  ``neighbour_votes``
-    cuts the whole order into ``buckets`` stretches: on a graph of millions of rows a stretch is wider than the band (products-like: 2.4 M
-    rows / 512 = 4.7 k rows against a band of +- 8 k -- the order came back with the generating order's local share and still ran 27 %
-    slower: the XCD's L2 holds exactly that band, every thousand rows of jitter spill it).  Here a stretch is ``width`` rows and its column
-    is its index MODULO ``buckets``: far neighbours alias onto all residues alike (a flat background), the row's near neighbours --
-    within +- buckets / 2 stretches of where it stands -- land around its own residue.  Votes are read in a frame centred on the row's own
-    stretch, the densest window of ``2 reach + 1`` stretches gives the offset.  One SpMM of ``buckets`` columns, whatever the graph's size."""
-    dev = perm.device
-    n = perm.numel()
-    pos = torch.empty(n, dtype=torch.int64, device=dev)
-    pos[perm] = torch.arange(n, device=dev)
-    stretch = pos // width
-    onehot = torch.zeros(n, buckets, dtype=torch.float16, device=dev)
-    rows = torch.nonzero(active).flatten()
-    onehot[rows, (stretch % buckets)[rows]] = 1.0
-    votes = apply_a(onehot).float()
-    del onehot
-    half = buckets // 2 - 1
-    offs = torch.arange(-half, half + 1, device=dev)
-    frame = votes.gather(1, (stretch[:, None] + offs[None, :]) % buckets)          # column half = the row's own stretch
-    del votes
-    w = 2 * reach + 1
-    cs = torch.nn.functional.pad(frame.cumsum(1), (1, 0))
-    window = cs[:, w:] - cs[:, :-w]
-    best = window.argmax(1)
-    total = window.gather(1, best[:, None])[:, 0]
-    idx = best[:, None] + torch.arange(w, device=dev)[None, :]
-    wts = frame.gather(1, idx)
-    centre = (wts * (idx.float() + 0.5)).sum(1) / wts.sum(1).clamp(min=1e-30) - half   # in stretches, relative to the row's own one
-    sure = (total >= 2.0) & (total >= confidence * degree)
-    new_pos = torch.where(sure, (stretch.float() + centre) * width, pos.float())
-    key = torch.where(active, new_pos, torch.full_like(new_pos, float("inf")))
-    return torch.argsort(key, stable=True)
-
-
-def refine_by_votes(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, perm: torch.Tensor, rounds=((256, 3), (512, 5)),
-                    local_widths=None):
+def refine_by_votes(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, perm: torch.Tensor, rounds=((256, 3), (512, 5))):
     """Neighbour votes on an order that is right at the scale of thousands of rows (the chained cluster order, round 6): per round one
     SpMM of the one-hot stretch matrix (the product's own kernel, default tile, no side-car) counts every row's neighbours per stretch
     of the current order and the row moves to the centroid of its densest window (``neighbour_votes``).  ``rounds``: (stretches, reach)."""
@@ -753,12 +712,6 @@ def refine_by_votes(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int,
 
         for buckets, reach in rounds:
             perm = neighbour_votes(apply_a, perm, active, active, buckets=buckets, reach=reach, degree=deg)
-        # graphs whose 512 stretches are still wider than a band can be: local rounds at fixed resolution (LOCAL_VOTE_WIDTHS rows per
-        # stretch), as long as a stretch of the global rounds was coarser than that
-        if local_widths is None:
-            local_widths = tuple(wd for wd in LOCAL_VOTE_WIDTHS if n // rounds[-1][0] > wd) if rounds else LOCAL_VOTE_WIDTHS
-        for width in local_widths:
-            perm = neighbour_votes_local(apply_a, perm, active, deg, width)
     return perm
 
 
