@@ -51,7 +51,7 @@ def test_untagged_graph_of_a_known_bucket_starts_without_a_sweep(tmp_path):
 def test_bucket_miss_first_call_is_bounded(tmp_path, workload, feat):
     """a graph of a bucket the store does not know (shipped defaults off, empty store) pays ONE bounded
     sweep on its first call -- <= 12 candidates per kernel (tile shapes, then the winner's schedules), timed on a 1/16 sample of
-    the handle, capped at max(2 s, 20 steps) -- instead of 44 candidates x 11 full-size launches (round 3: 60 s on the power-law
+    the handle, capped at max(2 s, 20 steps), then two or three finalists at FULL size (round 6: <= 12 more launches) -- instead of 44 candidates x 11 full-size launches (round 3: 60 s on the power-law
     graph, 39 s on the papers-like one).  BASELINE configs 3-5 at their stated sizes.  No compile time is in the figure
     (asserted): the JIT kernels come from the in-tree cache; on a tree without it the first run only fills the cache and a
     second run, with a fresh store, is the one measured."""
@@ -68,7 +68,7 @@ def test_bucket_miss_first_call_is_bounded(tmp_path, workload, feat):
     assert st["tuner"]["sweeps"] >= 1 and st["tuner"]["bucket_hits"] == 0 and st["tuner"]["stored_hits"] == 0, st
     assert st["tuner"]["timed_candidates"] <= 12 * st["tuner"]["sweeps"], st
     assert st["jit"]["compiled"] == 0, st
-    assert st["first_call_s"] <= max(3.0, 25 * st["step_s"]), st
+    assert st["first_call_s"] <= max(3.5, 32 * st["step_s"]), st
     print(f"{workload} F={feat}: first call {st['first_call_s']:.2f} s ({st['tuner']['timed_candidates']} candidates, sweep "
           f"{st['tuner']['sweep_seconds']:.2f} s), step {st['step_s'] * 1e3:.2f} ms, chosen {st['points']}")
 

@@ -221,3 +221,18 @@ def test_compiler_version_is_read_without_starting_a_program(monkeypatch):
         assert vcompiler.kernel_dir("probe", "int x;")
     finally:
         vcompiler.get_hipcc_compiler.cache_clear()
+
+
+def test_finalists_of_a_sampled_sweep_cover_other_schedules():
+    """Round 6: a sweep timed on a sample lets its best candidate and the best of every other SCHEDULE run the whole handle before
+    the choice is made (the sample ranks shapes and depths reliably, schedules not: products-like relabelled, 3.33 vs 4.14 ms)."""
+    from voltrix.jit_kernels.tuner import pick_finalists
+
+    timed = [(1.00, {"FS": 64, "DEPTH": 4, "SCHED": 4}), (1.01, {"FS": 64, "DEPTH": 3, "SCHED": 4}),
+             (1.05, {"FS": 64, "DEPTH": 3, "SCHED": 2}), (1.20, {"FS": 64, "DEPTH": 3, "SCHED": 3}),
+             (0.99, {"FS": 128, "DEPTH": 3, "SCHED": 4})]
+    got = pick_finalists(timed, 3)
+    assert got[0] == {"FS": 128, "DEPTH": 3, "SCHED": 4}
+    assert [g["SCHED"] for g in got] == [4, 2, 3]
+    assert pick_finalists(timed[:2], 3) == [timed[0][1], timed[1][1]]          # one schedule only: the runner-up
+    assert pick_finalists([(1.0, {"A": 1})], 3) == [{"A": 1}]
