@@ -6,6 +6,7 @@
 #   big        PMC passes for power-law 4 M x 256 and papers-like x 128, the per-CU finish-time histogram of the power-law configuration
 #   lines      bench lines of the other configurations / widths / weighted / backward (after `python harness/merge_traffic.py
 #              gpurun_out/r06/final3 r06`, so that they replay the counters), the N > 1 code path on one GPU
+#   widths     the remaining widths of the sweep on configurations 3-4 (products-like x 32, power-law x 32 / 128 / 512)
 #   suite      smoke() and the whole `pytest -m gpu` suite
 #   refresh    cell-by-cell A/B refresh of the shipped tuner buckets for the short-window stand-ins (harness/collect_cells.py)
 set -u
@@ -29,6 +30,14 @@ lines)
   done
   timeout -k 10 300 python bench.py --gpus 2 --backend gloo --one-device --workload reddit_like --feat 128 --scale 0.25 --steps 10 --warmup 3 --no-cpu-baseline --no-reference-formats > $O/bench_gpus2_one_device_dependent_step.json 2> $O/bench_gpus2.err
   timeout -k 10 300 python bench.py --gpus 1 --force-dist --workload reddit_like --feat 128 --steps 10 --warmup 3 --no-cpu-baseline --no-reference-formats > $O/bench_force_dist_1rank_rccl.json 2> $O/bench_force_dist.err
+  ;;
+widths)
+  # SURVEY 8(d) "feat_dim sweep F in {32, 128, 512} on configs 2-4": the widths the `lines` part does not carry
+  for WF in products_like:32 powerlaw_4m:32 powerlaw_4m:128 powerlaw_4m:512; do
+    W=${WF%%:*}; F=${WF##*:}
+    timeout -k 10 500 python bench.py --workload $W --feat $F --steps 5 --warmup 2 --no-cpu-baseline --no-reference-formats > $O/bench_${W}_f${F}_final.json 2> $O/bench_${W}_f$F.err || tail -3 $O/bench_${W}_f$F.err
+    python -c "import json; d=json.loads(open('$O/bench_${W}_f${F}_final.json').read().strip().splitlines()[-1]); print('$W', $F, round(d['ms_per_step'], 3), round(d['roofline']['frac'], 4), d['config'].get('tile'))"
+  done
   ;;
 suite)
   python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"
