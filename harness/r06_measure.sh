@@ -3,6 +3,7 @@
 # fresh one-GPU box; everything lands under gpurun_out/r06/final3/ and is copied / merged into profiles/ afterwards):
 #   final      default bench line + `rocprofv3 --kernel-trace --stats` of the same command, PMC passes for the headline, the reddit widths and
 #              products-like x 512 (harness/final_measure.sh), the 12-graph evaluation set with the Reorder rows (harness/eval_set.py)
+#   headline_eval  bench line + kernel stats + evaluation set only (the round's last tree)
 #   big        PMC passes for power-law 4 M x 256 and papers-like x 128, the per-CU finish-time histogram of the power-law configuration
 #   lines      bench lines of the other configurations / widths / weighted / backward (after `python harness/merge_traffic.py
 #              gpurun_out/r06/final3 r06`, so that they replay the counters), the N > 1 code path on one GPU
@@ -16,6 +17,11 @@ case $PART in
 final)
   bash harness/final_measure.sh headline r06/final3
   bash harness/final_measure.sh pmc r06/final3 headline reddit_like:32 reddit_like:512 products_like:512:5
+  timeout -k 10 1000 python harness/eval_set.py --reorder --check --output_file $O/results.csv --jsonl $O/eval_set.jsonl > $O/eval_set.log 2>&1; echo "eval rc=$?"
+  ;;
+headline_eval)
+  # the last tree of the round (kernel sources unchanged since the counter passes: same sources hash): bench line + kernel stats + evaluation set
+  bash harness/final_measure.sh headline r06/final3
   timeout -k 10 1000 python harness/eval_set.py --reorder --check --output_file $O/results.csv --jsonl $O/eval_set.jsonl > $O/eval_set.log 2>&1; echo "eval rc=$?"
   ;;
 big)
