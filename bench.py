@@ -761,6 +761,23 @@ def main():
                 extras["one_launch_form_max_abs_diff"] = float((fused_out - out).abs().max())
                 two.fused = None
                 del fused_out
+        # the reference's boundary hands csr_preprocess HOST buffers (CPU int32 indptr / indices, reference spmm/spmm.py:21-22): the same
+        # handle built from them, H2D copy over PCIe included (pageable memory, as a caller's numpy / torch CPU arrays are) -- never part of
+        # `value`, whose operands are resident in HBM
+        if not args.weighted and not args.backward and local_nnz <= (1 << 28):
+            h_indptr, h_indices = local_indptr.cpu(), local_indices.cpu()
+            host_ms = []
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                from_host = voltrix.csr_preprocess(h_indptr, h_indices, local_rows)
+                torch.cuda.synchronize()
+                host_ms.append((time.perf_counter() - t0) * 1e3)
+            same = all(torch.equal(a, b) for a, b in zip(from_host, handle)) if num_cols == local_rows else None
+            extras["preprocess_from_host"] = {"ms": host_ms[-1], "h2d_bytes": 4 * (local_nnz + local_rows + 1), "same_handle": same,
+                                              "what": "voltrix.csr_preprocess(indptr.cpu(), indices.cpu(), N): the reference's call with "
+                                                      "host buffers, H2D copy included; second of two calls"}
+            del h_indptr, h_indices, from_host
         # cold caches: 512 MB written between steps (more than L2 + the 256 MB Infinity Cache), as the reference's
         # bench_kineto does with 256 MB for a 50 MB L2 (utils.py:277-281); the headline number is the warm-cache one
         flush = torch.empty(512 << 20, dtype=torch.uint8, device=device)
