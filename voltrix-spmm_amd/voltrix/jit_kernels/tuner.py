@@ -52,7 +52,7 @@ class JITTuner:
         # what this process has done so far (tests / bench.py): sweeps run, candidate kernels timed, choices taken from the
         # persisted exact key / from the persisted graph-statistics bucket
         self.stats: Dict[str, Any] = {"sweeps": 0, "timed_candidates": 0, "stored_hits": 0, "bucket_hits": 0,
-                                      "sweep_seconds": 0.0, "sweeps_cut_by_budget": 0}
+                                      "sweep_seconds": 0.0, "sweeps_cut_by_budget": 0, "full_size_checks": 0}
         # signatures whose Runtime came from a persisted choice and has not run yet (no validation launch is made: the first
         # real launch is the validation -- ``forget`` + a sweep if it fails)
         self.unvalidated = set()
@@ -271,7 +271,7 @@ class JITTuner:
                     b.synchronize()
                     runs.append(a.elapsed_time(b))
                 full_ms[str(tk)] = (sorted(runs)[1], tk, rt)
-                self.stats["full_size_checks"] = self.stats.get("full_size_checks", 0) + 1
+                self.stats["full_size_checks"] += 1
             if len(full_ms) >= 2:
                 best_time, best_keys, best_runtime = min(full_ms.values(), key=lambda v: v[0])
                 if _debug() or os.getenv(PRINT_AUTOTUNE_FLAG, None):
