@@ -221,3 +221,22 @@ def test_bucket_ranking_mid_size_windows_and_clustered_columns(cuda_device, path
     ip, ix = torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda()
     p1, packed, hind, _ = voltrix.csr_fused_preprocess_kernel(ip, ix, n, num_cols=ncols, path=path)
     _check((p1, packed, hind), indptr, indices, n)
+
+
+FAMILY_SCALES = {"cora_like": 1.0, "reddit_like": 0.015, "products_like": 0.012, "protein_like": 0.05, "amazon0505_like": 0.3,
+                 "amazon0601_like": 0.4, "com_amazon_like": 0.6, "dd_like": 0.8, "yeast_like": 0.4, "yeasth_like": 0.2,
+                 "web_berkstan_like": 0.2, "ppi_like": 1.0, "ddi_like": 0.6, "fraud_yelp_rsr_like": 0.25}
+
+
+@pytest.mark.parametrize("shuffled", [False, True])
+@pytest.mark.parametrize("family", sorted(FAMILY_SCALES))
+def test_every_graph_family_bit_exact(cuda_device, family, shuffled):
+    """Round 6: one mid-size graph (0.01-2 M edges) of every stand-in family -- band, community, union of small graphs, Zipf rows with
+    hub windows, dense blocks -- in its generating order and with shuffled labels (the windows of a shuffled graph share nothing:
+    the other extreme of TC-block fill), through the operator's default device route: the oracle's bytes."""
+    indptr, indices, _ = synth_graphs.generate(family, device="cuda", scale=FAMILY_SCALES[family])
+    n = indptr.numel() - 1
+    if shuffled:
+        indptr, indices, _ = synth_graphs.shuffle_labels(indptr, indices, 31)
+    handle = voltrix.csr_preprocess_device(indptr, indices, n)
+    _check(handle, indptr.cpu().numpy(), indices.cpu().numpy(), n)
