@@ -551,7 +551,10 @@ def spmm_kernel(blk_offsets, hspa_packed, hind, num_nodes, num_edges, embedding_
     ``defer_combine``  with a unit-table schedule, do not sum the cut windows' partial tiles now: return a
                        ``PendingCombine`` (or None when nothing is pending) for the caller to ``run()`` later.
     ``row_map``        int32 [16 W] device tensor: row i of the handle is row ``row_map[i]`` of ``output`` (-1 = padding);
-                       handles of a row-permuted CSR (voltrix/reorder.py) write the product through it.
+                       handles of a row-permuted CSR (voltrix/reorder.py) write the product through it.  INJECTIVE apart from
+                       the -1 entries: the combine pass of the unit-table schedules adds a cut window's tiles to its rows of C
+                       by read-add-store, which two windows mapped onto the same rows would race on
+                       (profiles/r06/experiment_column_sliced_residual.log ran into exactly that with a many-to-one map).
     ``values``         weighted SpMM (voltrix/weighted.py): the value plane [T, 16, 8] of ``input``'s 16-bit dtype that
                        replaces the bitmaps as the A operand.
     ``xcd_ptr``        int32 [9] device tensor: first window of every XCD's range for the unit-table schedules (the two-level
