@@ -287,3 +287,96 @@ def test_prescaled_and_unscaled_forms_of_the_separable_product(cuda_device, monk
     plane = voltrix.csr_preprocess_weighted(indptr, indices, torch.ones(len(indices)), n, separable=False)
     with pytest.raises(AssertionError, match="separable values only"):
         voltrix.spmm_weighted(plane, feat, prescaled=True)
+
+
+# ---- round 6: new values on the same pattern (attention coefficients, trained edge weights): one scatter, no rebuild ------------------
+@pytest.mark.parametrize("duplicates", [False, True])
+def test_update_values_equals_a_rebuilt_handle_bit_for_bit(cuda_device, duplicates, monkeypatch):
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    from voltrix import weighted
+
+    ip_np, ix_np = _random_csr(900, 35, seed=21)
+    if duplicates:      # the first entry of every non-empty row once more: the two values ADD in the weighted product
+        rows = [ix_np[ip_np[r]:ip_np[r + 1]] for r in range(900)]
+        rows = [np.concatenate([r[:1], r]) for r in rows]
+        ip_np = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+        ix_np = np.concatenate(rows).astype(np.int32)
+    ip, ix = torch.from_numpy(ip_np), torch.from_numpy(ix_np)
+    n = 900
+    torch.manual_seed(8)
+    v1, v2, v3 = torch.randn(len(ix_np)), torch.randn(len(ix_np)), torch.rand(len(ix_np)) + 0.1
+    h = voltrix.csr_preprocess_weighted(ip, ix, v1, n, plane_dtype=torch.float16, separable=False)
+    only_master = voltrix.csr_preprocess_weighted(ip, ix, v1, n, separable=False)
+    feat = torch.randn(n, 72, device=cuda_device).half()
+    for v in (v2, v3):
+        assert voltrix.update_edge_values(h, v) is h
+        fresh = voltrix.csr_preprocess_weighted(ip, ix, v, n, separable=False)
+        assert h.slot_duplicates == duplicates
+        # duplicates add in the fp32 master (kept); without them the 16-bit planes are written directly and the master is dropped:
+        # a plane of another 16-bit type is then made from the latest values through the same edge -> plane map
+        assert (h.values32 is not None) == duplicates
+        assert torch.equal(h.planes[torch.float16], fresh.values32.half())
+        voltrix.spmm_weighted(h, feat.bfloat16(), hash_tag=f"upd{duplicates}")
+        assert torch.equal(h.planes[torch.bfloat16], fresh.values32.bfloat16())
+        voltrix.update_edge_values(only_master, v)          # no 16-bit plane yet: the master itself is rewritten
+        assert not only_master.planes and torch.equal(only_master.values32, fresh.values32)
+        out = voltrix.spmm_weighted(h, feat)
+        assert torch.equal(out, voltrix.spmm_weighted(fresh, feat, hash_tag=f"upd{duplicates}"))
+        ref = _oracle(ip_np, ix_np, v, feat.cpu(), n, n)
+        scale = _oracle(ip_np, ix_np, v.abs(), feat.cpu().abs(), n, n)
+        assert ((out.cpu().double() - ref).abs() <= 2.0 ** -9 * scale + 1e-5).all()
+    # a handle without an fp32 master: the 16-bit plane is written directly (duplicate-free), refused with duplicates
+    monkeypatch.setattr(weighted, "MASTER_PLANE_MAX_BYTES", 0)
+    lean = voltrix.csr_preprocess_weighted(ip, ix, v1, n, separable=False)
+    if duplicates:
+        with pytest.raises(AssertionError, match="fp32 master"):
+            voltrix.update_edge_values(lean, v2)
+    else:
+        voltrix.update_edge_values(lean, v2)
+        assert torch.equal(lean.planes[torch.float16], voltrix.csr_preprocess_weighted(ip, ix, v2, n, separable=False).planes[torch.float16])
+
+
+def test_update_values_on_separable_handles_and_through_autograd(cuda_device, monkeypatch):
+    """Separable -> separable replaces the factors; separable -> general turns the handle into a value-plane one; autograd.SpMM updates
+    both directions (the transposed plane through the transposed edge order)."""
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    from voltrix.autograd import SpMM
+
+    ip_np, ix_np = _random_csr(600, 25, seed=23)
+    ip, ix = torch.from_numpy(ip_np), torch.from_numpy(ix_np)
+    n = 600
+    deg = torch.from_numpy(np.diff(ip_np).astype(np.int64))
+    rows = torch.repeat_interleave(torch.arange(n), deg)
+    indeg = torch.bincount(ix.long(), minlength=n).double().clamp(min=1)
+    sym = (deg.double().clamp(min=1).rsqrt()[rows] * indeg.rsqrt()[ix.long()]).float()
+    mean = (1.0 / deg.double().clamp(min=1))[rows].float()
+    torch.manual_seed(9)
+    general = torch.rand(len(ix_np)) + 0.2
+    feat = torch.randn(n, 48, device=cuda_device).half()
+
+    def close(out, values):
+        ref = _oracle(ip_np, ix_np, values, feat.cpu(), n, n)
+        scale = _oracle(ip_np, ix_np, values.abs(), feat.cpu().abs(), n, n)
+        return bool(((out.cpu().double() - ref).abs() <= 2.0 ** -9 * scale + 1e-5).all())
+
+    h = voltrix.csr_preprocess_weighted(ip, ix, sym, n)
+    assert h.separable and close(voltrix.spmm_weighted(h, feat, hash_tag="upd_sep"), sym)
+    voltrix.update_edge_values(h, mean)
+    assert h.separable and close(voltrix.spmm_weighted(h, feat), mean)
+    voltrix.update_edge_values(h, general)
+    assert not h.separable and h.values32 is not None and close(voltrix.spmm_weighted(h, feat), general)
+    voltrix.update_edge_values(h, sym)          # a general handle stays general: the values go through the plane
+    assert not h.separable and close(voltrix.spmm_weighted(h, feat), sym)
+
+    for first, second in ((general, general * 0.5 + 0.1), (sym, mean), (sym, general)):
+        op = SpMM(ip, ix, n, values=first, hash_tag="upd_autograd")
+        op.update_values(second)
+        b = feat.clone().requires_grad_(True)
+        w = torch.randn(n, 48, device=cuda_device)
+        out = op(b)
+        (out * w).sum().backward()
+        assert close(out.detach(), second)
+        a = torch.sparse_csr_tensor(ip, ix, second.double(), size=(n, n)).to_dense()
+        ref_grad = a.T @ w.cpu().double()
+        scale_g = a.abs().T @ w.cpu().abs().double()
+        assert ((b.grad.cpu().double() - ref_grad).abs() <= 2.0 ** -8 * scale_g + 2.0 ** -10 * ref_grad.abs() + 1e-4).all()

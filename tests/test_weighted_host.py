@@ -52,3 +52,31 @@ def test_what_does_not_factor_is_refused():
     w = (1 / deg.clamp(min=1)[rows]).float()
     w[11] *= 1.01
     assert weighted.separable_scales(indptr, indices, w, n, n) is None
+
+
+def test_edge_slots_are_where_value_plane_puts_every_edge():
+    """Round 6 (update_values): the edge -> plane map, chunk by chunk, against the plane builder itself -- reading the plane at the
+    slots gives the values back (duplicate-free rows), slots are distinct, and everything else in the plane is zero."""
+    import numpy as np
+
+    from oracle import oracle_c
+
+    indptr, indices, n, _, _ = _graph()
+    p1 = torch.from_numpy(oracle_c.csr_preprocess(indptr.numpy().astype(np.int32), indices.numpy().astype(np.int32), n)[0])
+    values = torch.arange(1, indices.numel() + 1, dtype=torch.float32)
+    plane = weighted.value_plane(indptr, indices, values, p1, n, n)
+    for chunk in (weighted.CHUNK_EDGES, 997):
+        old = weighted.CHUNK_EDGES
+        weighted.CHUNK_EDGES = chunk
+        try:
+            slot = weighted.edge_slots(indptr, indices, p1, n, n)
+        finally:
+            weighted.CHUNK_EDGES = old
+        assert slot.dtype == torch.int64 and slot.numel() == indices.numel()
+        assert torch.unique(slot).numel() == slot.numel()
+        assert torch.equal(plane.view(-1)[slot], values)
+        assert int((plane != 0).sum()) == indices.numel()
+    # transpose_order: entry k of A^T's CSR is entry order[k] of A's
+    order = weighted.transpose_order(indptr, indices, n)
+    t_indptr, t_indices, t_values = weighted.transpose_weighted(indptr, indices, values, n, n)
+    assert torch.equal(t_values, values[order])

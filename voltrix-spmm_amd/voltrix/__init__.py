@@ -14,6 +14,7 @@ from .hybrid import TwoLevelHandle
 from .sidecar import copy_side_car, load_handle, save_handle, slim_handle
 from .reorder import ReorderedHandle, csr_preprocess_reordered, permute_features, spmm_reordered, unpermute_output
 from .weighted import WeightedHandle, csr_preprocess_weighted, spmm_weighted
+from .weighted import update_values as update_edge_values
 from .graphed import GraphedSpMM
 from . import autograd, hybrid, jit, sidecar, utils
 

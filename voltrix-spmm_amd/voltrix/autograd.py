@@ -95,6 +95,32 @@ class SpMM:
             self.handle[1].hash_tag = hash_tag
             self.handle_t[1].hash_tag = hash_tag + "/transposed"
 
+    def update_values(self, values: torch.Tensor) -> None:
+        """New edge values on the same pattern (CSR order of the constructor's ``indices``): both directions, in place
+        (``weighted.update_values``: one scatter per plane, no rebuild).  No gradient flows to ``values`` -- that is a sampled
+        dense-dense product, not on this path."""
+        from .weighted import csr_preprocess_weighted, transpose_order, transpose_weighted, update_values
+
+        assert self.weighted is not None, "this operator was built without values"
+        values_d = values.contiguous().cuda()
+        was_separable = self.weighted.separable
+        update_values(self.weighted, values_d)
+        indptr_d, indices_d = self.weighted.csr[0], self.weighted.csr[1]
+        if self.weighted.separable:                    # A^T has the factors swapped
+            self.weighted_t.row_scale, self.weighted_t.col_scale = self.weighted.col_scale, self.weighted.row_scale
+        elif was_separable:                            # the new values do not factor: A^T needs a value plane of its own now
+            t_indptr, t_indices, t_values = transpose_weighted(indptr_d, indices_d, values_d, self.num_rows, self.num_cols)
+            tag = getattr(self.handle_t[1], "hash_tag", None)
+            self.weighted_t = csr_preprocess_weighted(t_indptr, t_indices, t_values, self.num_cols, num_cols=self.num_rows,
+                                                      separable=False)
+            self.handle_t = (self.weighted_t.blk_offsets, self.weighted_t.hspa_packed, self.weighted_t.hind)
+            if tag is not None:
+                self.handle_t[1].hash_tag = tag
+        else:
+            if getattr(self, "_t_order", None) is None:
+                self._t_order = transpose_order(indptr_d, indices_d, self.num_rows)
+            update_values(self.weighted_t, values_d[self._t_order])
+
     def __call__(self, feat: torch.Tensor) -> torch.Tensor:
         assert feat.shape[0] == self.num_cols
         return _SpMMFunction.apply(feat, self)

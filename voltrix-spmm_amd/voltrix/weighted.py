@@ -45,16 +45,20 @@ class WeightedHandle:
     row_scale: torch.Tensor = None     # float32 [num_nodes]
     col_scale: torch.Tensor = None     # float32 [num_cols]
 
-    csr: tuple = None                  # separable handles: (indptr, indices, values or None, num_cols) on the device -- what a value plane
-                                       # is built from should a call be better off with one (``separable_pays``)
+    csr: tuple = None                  # (indptr, indices, values or None, num_cols) on the device -- what a separable handle builds a value
+                                       # plane from should a call be better off with one (``separable_pays``), and what ``update_values``
+                                       # derives the edge -> plane map of a general handle from (kept up to KEEP_CSR_MAX_EDGES edges)
+    edge_slot: torch.Tensor = None     # int64 [nnz]: ``edge_slots`` of this handle, built by the first ``update_values``
+    slot_duplicates: bool = None       # some (row, col) pair occurs more than once: updates ADD per slot instead of storing
 
     @property
     def separable(self) -> bool:
         return self.row_scale is not None
 
 
-def _chunk_plane(indptr, indices, values, blk_offsets, w0, w1, num_nodes, num_cols):
-    """float32 [blocks of windows w0 .. w1) * 128]: the value plane of a range of windows (definition: ``value_plane``)."""
+def _chunk_slots(indptr, indices, blk_offsets, w0, w1, num_nodes, num_cols):
+    """int64 [edges of windows w0 .. w1)]: where every edge of a range of windows sits in the range's part of the value plane
+    (definition: ``value_plane``; offsets relative to the first TC block of window w0)."""
     dev = indptr.device
     r0, r1 = 16 * w0, min(16 * w1, num_nodes)
     e0, e1 = int(indptr[r0]), int(indptr[r1])
@@ -68,11 +72,42 @@ def _chunk_plane(indptr, indices, values, blk_offsets, w0, w1, num_nodes, num_co
     del key, uniq
     b0 = int(blk_offsets[w0])
     block = blk_offsets.long()[win + w0] - b0 + q // 8
-    flat = (block * 16 + rows % 16) * 8 + q % 8
-    del block, rows, win
-    plane = torch.zeros((int(blk_offsets[w1]) - b0) * 128, dtype=torch.float32, device=dev)
+    return (block * 16 + rows % 16) * 8 + q % 8, e0, e1
+
+
+def _chunk_plane(indptr, indices, values, blk_offsets, w0, w1, num_nodes, num_cols):
+    """float32 [blocks of windows w0 .. w1) * 128]: the value plane of a range of windows (definition: ``value_plane``)."""
+    flat, e0, e1 = _chunk_slots(indptr, indices, blk_offsets, w0, w1, num_nodes, num_cols)
+    plane = torch.zeros((int(blk_offsets[w1]) - int(blk_offsets[w0])) * 128, dtype=torch.float32, device=indptr.device)
     plane.index_add_(0, flat, values[e0:e1].float())
     return plane
+
+
+def _window_chunks(indptr, num_nodes):
+    """Window boundaries of chunks of about ``CHUNK_EDGES`` edges (bounded temporaries in the builders)."""
+    dev = indptr.device
+    num_windows = (num_nodes + 15) // 16
+    win_edges = indptr[(torch.arange(0, num_windows + 1, device=dev) * 16).clamp(max=num_nodes)].long()
+    targets = torch.arange(CHUNK_EDGES, int(win_edges[-1]) + CHUNK_EDGES, CHUNK_EDGES, device=dev)
+    return torch.unique(torch.cat([torch.zeros(1, dtype=torch.int64, device=dev),
+                                   torch.searchsorted(win_edges, targets).clamp(max=num_windows),
+                                   torch.full((1,), num_windows, dtype=torch.int64, device=dev)])).tolist()
+
+
+def edge_slots(indptr: torch.Tensor, indices: torch.Tensor, blk_offsets: torch.Tensor, num_nodes: int, num_cols: int) -> torch.Tensor:
+    """int64 [nnz]: the element of the flat value plane [T * 128] every CSR entry lands on (``value_plane``'s definition), in CSR
+    order.  What ``update_values`` scatters new values through: the pattern's part of building a plane (sorts, ranks) is done
+    once, a change of values is one pass."""
+    out = torch.empty(indices.numel(), dtype=torch.int64, device=indptr.device)
+    if (num_nodes + 15) // 16 == 0:
+        return out
+    cuts = _window_chunks(indptr, num_nodes)
+    for w0, w1 in zip(cuts[:-1], cuts[1:]):
+        if w1 <= w0:
+            continue
+        flat, e0, e1 = _chunk_slots(indptr, indices, blk_offsets, w0, w1, num_nodes, num_cols)
+        out[e0:e1] = flat + int(blk_offsets[w0]) * 128
+    return out
 
 
 def value_plane(indptr: torch.Tensor, indices: torch.Tensor, values: torch.Tensor, blk_offsets: torch.Tensor,
@@ -87,12 +122,7 @@ def value_plane(indptr: torch.Tensor, indices: torch.Tensor, values: torch.Tenso
     out = torch.empty(total * 128, dtype=dtype, device=dev)
     if num_windows == 0:
         return out.view(total, 16, 8)
-    # window boundaries of the chunks: prefix of edges per window, cut every CHUNK_EDGES
-    win_edges = indptr[(torch.arange(0, num_windows + 1, device=dev) * 16).clamp(max=num_nodes)].long()
-    targets = torch.arange(CHUNK_EDGES, int(win_edges[-1]) + CHUNK_EDGES, CHUNK_EDGES, device=dev)
-    cuts = torch.unique(torch.cat([torch.zeros(1, dtype=torch.int64, device=dev),
-                                   torch.searchsorted(win_edges, targets).clamp(max=num_windows),
-                                   torch.full((1,), num_windows, dtype=torch.int64, device=dev)])).tolist()
+    cuts = _window_chunks(indptr, num_nodes)       # prefix of edges per window, cut every CHUNK_EDGES
     for w0, w1 in zip(cuts[:-1], cuts[1:]):
         if w1 <= w0:
             continue
@@ -105,6 +135,7 @@ def value_plane(indptr: torch.Tensor, indices: torch.Tensor, values: torch.Tenso
 SEPARABLE_TOLERANCE = 2.0 ** -13     # |v_ij / (r_i c_j) - 1| below this counts as separable: a quarter of the fp16 rounding the
                                       # value plane applies to every value anyway (2^-11)
 SEPARABLE_SWEEPS = 64
+KEEP_CSR_MAX_EDGES = 1 << 30         # general handles keep their device CSR (4 bytes per edge) up to this size: update_values
 SEPARABLE_MAX_EDGES = 1 << 29        # the detection holds five edge-sized 64-bit arrays and sorts one of them: above this many edges it is
                                       # not tried (papers-like: 1.6 G edges beside a 28 GB B and a 57 GB C) -- state the factors instead
 
@@ -193,16 +224,92 @@ def csr_preprocess_weighted(indptr: torch.Tensor, indices: torch.Tensor, values:
     pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(indptr_d, indices_d, num_nodes, num_cols)
     universe = max(num_cols, int(indices_d.max()) + 1) if indices_d.numel() else num_cols
     total = int(pointer1[-1])
+    csr = (indptr_d, indices_d, None, universe) if indices_d.numel() <= KEEP_CSR_MAX_EDGES else None   # for update_values
     if total * 512 > MASTER_PLANE_MAX_BYTES:
         dt = plane_dtype or torch.float16
-        handle = WeightedHandle(pointer1, hspa_packed, hind, None, num_nodes, int(indices.numel()))
+        handle = WeightedHandle(pointer1, hspa_packed, hind, None, num_nodes, int(indices.numel()), csr=csr)
         handle.planes[dt] = value_plane(indptr_d, indices_d, values_d, pointer1, num_nodes, universe, dtype=dt)
         return handle
     plane = value_plane(indptr_d, indices_d, values_d, pointer1, num_nodes, universe)
-    handle = WeightedHandle(pointer1, hspa_packed, hind, plane, num_nodes, int(indices.numel()))
+    handle = WeightedHandle(pointer1, hspa_packed, hind, plane, num_nodes, int(indices.numel()), csr=csr)
     if plane_dtype is not None:
         handle.planes[plane_dtype] = plane.to(plane_dtype).contiguous()
     return handle
+
+
+def update_values(handle: WeightedHandle, values: torch.Tensor) -> WeightedHandle:
+    """New edge values on the SAME sparsity pattern, in the CSR order the handle was built from (attention coefficients, edge
+    weights that are trained: they change every step, the pattern never does).  The pattern's share of building a value plane --
+    ranking every column inside its window: sorts and searches over all edges -- is done once (``edge_slots``, cached on the
+    handle: 8 bytes per edge) and a change of values is one scatter per plane the handle holds; the handle (tile choices,
+    launch plans, unit tables) is otherwise untouched.  Returns ``handle``.
+
+    Separable handles: the new values are checked like the first ones (``separable_scales``); if they factor the two scale
+    vectors are replaced, otherwise the handle becomes a general one (value plane built now) -- build with ``separable=False``
+    when the values are known to be general and this check is not wanted."""
+    assert isinstance(handle, WeightedHandle) and values.is_floating_point() and values.numel() == handle.num_edges
+    assert handle.csr is not None, (f"this handle did not keep its CSR (more than {KEEP_CSR_MAX_EDGES} edges): values cannot be "
+                                    f"replaced in place -- rebuild it with csr_preprocess_weighted")
+    indptr, indices, _, num_cols = handle.csr
+    values = values.contiguous().to(indptr.device)
+    if handle.separable:
+        scales = separable_scales(indptr, indices, values, handle.num_nodes, num_cols) if values.numel() <= SEPARABLE_MAX_EDGES else None
+        if scales is not None:
+            handle.row_scale, handle.col_scale = scales
+            handle.csr = (indptr, indices, values, num_cols)
+            handle.planes.clear()                     # lazily built planes of the old values (separable_pays)
+            return handle
+        handle.row_scale = handle.col_scale = None    # a general handle from here on: the plane path of spmm_weighted
+        handle.planes.clear()
+        handle.csr = (indptr, indices, None, num_cols)
+        total = int(handle.blk_offsets[-1])
+        if total * 512 > MASTER_PLANE_MAX_BYTES:
+            handle.planes[torch.float16] = value_plane(indptr, indices, values, handle.blk_offsets, handle.num_nodes, num_cols,
+                                                       dtype=torch.float16)
+        else:
+            handle.values32 = value_plane(indptr, indices, values, handle.blk_offsets, handle.num_nodes, num_cols)
+        return handle
+    if handle.edge_slot is None:
+        handle.edge_slot = edge_slots(indptr, indices, handle.blk_offsets, handle.num_nodes, num_cols)
+        handle.slot_duplicates = bool(values.numel()) and int(torch.unique(handle.edge_slot).numel()) != int(values.numel())
+    slot = handle.edge_slot
+    if handle.slot_duplicates:      # duplicate (row, col) entries ADD (fp32, rounded once): through the master, like the first build
+        assert handle.values32 is not None, "duplicate entries need the fp32 master plane to add in: rebuild the handle"
+        flat = handle.values32.view(-1)
+        flat.zero_()
+        flat.index_add_(0, slot, values.float())
+        for dt in list(handle.planes):
+            handle.planes[dt].copy_(handle.values32)
+        return handle
+    # no duplicates: every edge owns its element and every other element of the plane is a structural zero that stays one.  One scatter
+    # per 16-bit plane the handle holds (reddit-like: 2.5 ms each for 114.6 M edges -- torch's scatter; a rebuild is 107 ms); the fp32
+    # master is only written when it is the ONLY plane -- otherwise it is dropped, and a plane of another 16-bit type is later made
+    # from the latest values through the same map (``_plane_for``)
+    handle.csr = (indptr, indices, values, num_cols)
+    if handle.planes:
+        handle.values32 = None
+        for dt in list(handle.planes):
+            handle.planes[dt].view(-1)[slot] = values.to(dt)
+    else:
+        handle.values32.view(-1)[slot] = values.float()
+    return handle
+
+
+def _plane_for(handle: WeightedHandle, dtype: torch.dtype) -> torch.Tensor:
+    """The handle's value plane in ``dtype``, made on first use: from the fp32 master, or -- after ``update_values`` dropped it --
+    from the latest values through the edge -> plane map."""
+    if dtype not in handle.planes:
+        if handle.values32 is not None:
+            handle.planes[dtype] = handle.values32.to(dtype).contiguous()
+        else:
+            latest = handle.csr[2] if handle.csr is not None else None
+            assert latest is not None and handle.edge_slot is not None and not handle.slot_duplicates, (
+                f"this handle was built without an fp32 master (too large) and holds only the {list(handle.planes)} plane(s): pass "
+                f"plane_dtype={dtype} to csr_preprocess_weighted")
+            plane = torch.zeros(int(handle.blk_offsets[-1]) * 128, dtype=dtype, device=latest.device)
+            plane[handle.edge_slot] = latest.to(dtype)
+            handle.planes[dtype] = plane.view(-1, 16, 8)
+    return handle.planes[dtype]
 
 
 def spmm_weighted(handle: WeightedHandle, feat: torch.Tensor, hash_tag: str = None, prescaled: bool = False,
@@ -228,14 +335,10 @@ def spmm_weighted(handle: WeightedHandle, feat: torch.Tensor, hash_tag: str = No
     assert not exact, "the weighted kernel takes a 16-bit operand (unset VOLTRIX_FP32_MODE=exact)"
     if handle.separable:
         _materialise_plane(handle, operand.dtype)
-    if operand.dtype not in handle.planes:
-        assert handle.values32 is not None, (f"this handle was built without an fp32 master (too large) and holds only the "
-                                             f"{list(handle.planes)} plane(s): pass plane_dtype={operand.dtype} to csr_preprocess_weighted")
-        handle.planes[operand.dtype] = handle.values32.to(operand.dtype).contiguous()
     output = torch.empty((handle.num_nodes, padded), dtype=torch.float32, device=feat.device)
     spmm_kernel(handle.blk_offsets, handle.hspa_packed, handle.hind, num_nodes=handle.num_nodes,
                 num_edges=handle.num_edges, embedding_dim=padded, input=operand, output=output, out_scale=out_scale,
-                values=handle.planes[operand.dtype])
+                values=_plane_for(handle, operand.dtype))
     return output if padded == num_feats else output[:, :num_feats].contiguous()
 
 
@@ -291,6 +394,13 @@ def _spmm_separable(handle: WeightedHandle, feat: torch.Tensor, prescaled: bool 
     if postscale:
         capi.launch_scale_rows(out, handle.row_scale, out, stream)
     return out if padded == num_feats else out[:, :num_feats].contiguous()
+
+
+def transpose_order(indptr: torch.Tensor, indices: torch.Tensor, num_rows: int) -> torch.Tensor:
+    """int64 [nnz]: entry k of the CSR of ``A^T`` (``transpose_weighted``) is entry ``order[k]`` of the CSR of ``A``."""
+    deg = (indptr[1:] - indptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(num_rows, device=indptr.device, dtype=torch.int64), deg)
+    return torch.argsort(indices.long() * num_rows + rows)
 
 
 def transpose_weighted(indptr: torch.Tensor, indices: torch.Tensor, values: torch.Tensor, num_rows: int, num_cols: int):
