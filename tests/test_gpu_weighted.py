@@ -380,3 +380,35 @@ def test_update_values_on_separable_handles_and_through_autograd(cuda_device, mo
         ref_grad = a.T @ w.cpu().double()
         scale_g = a.abs().T @ w.cpu().abs().double()
         assert ((b.grad.cpu().double() - ref_grad).abs() <= 2.0 ** -8 * scale_g + 2.0 ** -10 * ref_grad.abs() + 1e-4).all()
+
+
+@pytest.mark.parametrize("relabel,method", [(True, "clusters"), (False, "bfs"), (True, "identity")])
+def test_normalised_adjacency_on_a_reordered_handle(cuda_device, relabel, method, monkeypatch):
+    """Round 6: reorder + separable edge values in one handle -- csr_preprocess_reordered(row_scale=, col_scale=) permutes the factors
+    with the rows, spmm_reordered runs diag(r) A (diag(c) B) on the binary operator; against torch.sparse with the values, in the new
+    order, un-permuted, and for a row-only handle (B and C in the caller's order)."""
+    import synth_graphs
+
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    indptr, indices, _ = synth_graphs.generate("com_amazon_like", scale=0.05)
+    n = indptr.numel() - 1
+    indptr, indices, _ = synth_graphs.shuffle_labels(indptr, indices, 3)
+    deg = (indptr[1:] - indptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(n), deg)
+    indeg = torch.bincount(indices.long(), minlength=n)
+    r = deg.double().clamp(min=1).rsqrt().float()
+    c = indeg.double().clamp(min=1).rsqrt().float()
+    values = r[rows] * c[indices.long()]
+    h = voltrix.csr_preprocess_reordered(indptr, indices, n, method=method, relabel=relabel, row_scale=r, col_scale=c)
+    assert h.relabelled == (relabel and method != "identity")
+    for width in (64, 100):
+        feat = torch.randn(n, width, device=cuda_device).half()
+        ref = _oracle(indptr.numpy(), indices.numpy(), values, feat.cpu(), n, n)
+        scale = _oracle(indptr.numpy(), indices.numpy(), values.abs(), feat.cpu().abs(), n, n)
+        fin = voltrix.permute_features(h, feat)
+        out_new = voltrix.spmm_reordered(h, fin, hash_tag=f"reordered_weighted_{relabel}_{method}")
+        out = voltrix.unpermute_output(h, out_new)
+        assert out.shape == (n, width) and ((out.cpu().double() - ref).abs() <= 2.0 ** -10 * scale + 1e-6).all()
+        again = voltrix.spmm_reordered(h, fin, unpermute=True)
+        assert torch.equal(again, out)
+        assert torch.equal(fin, voltrix.permute_features(h, feat))        # the operand was not scaled in place

@@ -982,10 +982,16 @@ class ReorderedHandle:
     num_edges: int
     method: str
     relabelled: bool = False     # True: the handle is that of P A P^T (columns relabelled too): B and C live in the NEW order
+    # round 6 -- separable edge values v_ij = r_i c_j (normalised adjacencies) on a reordered handle: the binary product between two row
+    # scalings, as in voltrix/weighted.py.  Stored in the orders spmm_reordered works in: col_scale in the order of the B it takes,
+    # row_scale in the order of the C it returns without ``unpermute`` (both the NEW order on relabelled handles, the caller's otherwise)
+    row_scale: torch.Tensor = None
+    col_scale: torch.Tensor = None
 
 
 def csr_preprocess_reordered(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None,
-                             method="auto", info: dict = None, relabel: bool = False) -> ReorderedHandle:
+                             method="auto", info: dict = None, relabel: bool = False, row_scale: torch.Tensor = None,
+                             col_scale: torch.Tensor = None) -> ReorderedHandle:
     """CSR (CPU or CUDA int32) -> handle of the row-reordered matrix for ``spmm_reordered``.  ``method``: "auto" (default,
     round 4: the breadth-first and the spectral order are tried and judged by the format's own statistics; the caller's order
     is KEPT unless one of them clearly pays -- never worse than no reorder, ``auto_permutation``), "bfs" (Cuthill-McKee
@@ -1000,7 +1006,12 @@ def csr_preprocess_reordered(indptr: torch.Tensor, indices: torch.Tensor, num_no
     bench_all.py:120-129).  The handle then describes the relabelled matrix: ``spmm_reordered`` takes B in the NEW order
     (``permute_features(handle, feat)``, once per feature matrix) and returns C in the new order (``unpermute=True`` puts the
     rows back).  Only this form restores the address locality of B (a row-only order cannot: products-like 4.4 ms natural, 4.9
-    shuffled, 5.7 row-reordered); ``auto`` judges the candidates with that term and tries them at any mean degree."""
+    shuffled, 5.7 row-reordered); ``auto`` judges the candidates with that term and tries them at any mean degree.
+
+    ``row_scale`` / ``col_scale`` (round 6; float [N] / [num_cols], in the CALLER's node order): edge values ``v_ij = r_i c_j`` -- the
+    normalised adjacency a GCN layer multiplies by -- on the reordered handle: ``spmm_reordered`` computes
+    ``diag(r) A (diag(c) B)`` on the binary operator between two ``scale_rows`` passes (voltrix/weighted.py).  The vectors are
+    permuted with the handle; factors of general values: ``weighted.separable_scales``."""
     assert indptr.dtype == torch.int32 and indices.dtype == torch.int32 and indptr.numel() == num_nodes + 1
     assert not relabel or num_cols in (None, num_nodes), "relabel=True relabels rows and columns alike: a square adjacency"
     indptr_d, indices_d = indptr.contiguous().cuda(), indices.contiguous().cuda()
@@ -1046,8 +1057,17 @@ def csr_preprocess_reordered(indptr: torch.Tensor, indices: torch.Tensor, num_no
     if not name.endswith("identity") and not relabel:   # the identity order and relabelled handles need no map: C is written in place
         row_map = torch.full((padded,), -1, dtype=torch.int32, device=indptr_d.device)
         row_map[:num_nodes] = perm.to(torch.int32)
-    return ReorderedHandle(pointer1, hspa_packed, hind, row_map, perm, num_nodes, int(indices.numel()), name,
-                           relabelled=bool(relabel) and not name.endswith("identity"))
+    handle = ReorderedHandle(pointer1, hspa_packed, hind, row_map, perm, num_nodes, int(indices.numel()), name,
+                             relabelled=bool(relabel) and not name.endswith("identity"))
+    if row_scale is not None:
+        assert row_scale.numel() == num_nodes
+        r = row_scale.to(indptr_d.device, torch.float32)
+        handle.row_scale = (r.index_select(0, perm) if handle.relabelled else r).contiguous()
+    if col_scale is not None:
+        assert col_scale.numel() == (num_nodes if num_cols is None else num_cols)
+        c = col_scale.to(indptr_d.device, torch.float32)
+        handle.col_scale = (c.index_select(0, perm) if handle.relabelled else c).contiguous()
+    return handle
 
 
 def permute_features(handle: ReorderedHandle, feat: torch.Tensor) -> torch.Tensor:
@@ -1074,6 +1094,15 @@ def spmm_reordered(handle: ReorderedHandle, feat: torch.Tensor, hash_tag: str = 
     assert isinstance(handle, ReorderedHandle)
     if hash_tag is not None and getattr(handle.hspa_packed, "hash_tag", None) is None:
         handle.hspa_packed.hash_tag = hash_tag
+    if handle.row_scale is not None or handle.col_scale is not None:      # separable edge values: two row scalings around the binary product
+        from .weighted import scale_rows_of
+
+        scaled = feat if handle.col_scale is None else scale_rows_of(feat, handle.col_scale)
+        binary = dataclasses.replace(handle, row_scale=None, col_scale=None)
+        out = spmm_reordered(binary, scaled, unpermute=False)
+        if handle.row_scale is not None:
+            out = scale_rows_of(out, handle.row_scale, in_place=True)
+        return unpermute_output(handle, out) if (unpermute and handle.relabelled) else out
     num_feats = feat.shape[1]
     from .spmm.spmm import spmm, two_level_of
 

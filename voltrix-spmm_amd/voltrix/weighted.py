@@ -396,6 +396,26 @@ def _spmm_separable(handle: WeightedHandle, feat: torch.Tensor, prescaled: bool 
     return out if padded == num_feats else out[:, :num_feats].contiguous()
 
 
+def scale_rows_of(feat: torch.Tensor, scale: torch.Tensor, in_place: bool = False) -> torch.Tensor:
+    """``feat[i, :] * scale[i]`` with the library's ``scale_rows`` pass (one HBM pass in ``feat``'s dtype; widths that are not a
+    16-byte multiple are padded for the pass and cut again).  ``in_place``: overwrite ``feat`` when its layout allows."""
+    from . import capi
+    from .jit_kernels.spmm import _raw_stream
+
+    assert feat.is_cuda and feat.dim() == 2 and scale.numel() == feat.shape[0] and scale.dtype == torch.float32
+    num_feats = feat.shape[1]
+    align = 4 if feat.dtype == torch.float32 else 8
+    padded = (num_feats + align - 1) // align * align
+    src = feat.contiguous()
+    if padded != num_feats:
+        src = torch.nn.functional.pad(src, (0, padded - num_feats))
+    if src.data_ptr() % 16:
+        src = src.clone()
+    dst = src if (in_place or src is not feat) else torch.empty_like(src)
+    capi.launch_scale_rows(src, scale.contiguous(), dst, _raw_stream(feat.device))
+    return dst if padded == num_feats else dst[:, :num_feats].contiguous()
+
+
 def transpose_order(indptr: torch.Tensor, indices: torch.Tensor, num_rows: int) -> torch.Tensor:
     """int64 [nnz]: entry k of the CSR of ``A^T`` (``transpose_weighted``) is entry ``order[k]`` of the CSR of ``A``."""
     deg = (indptr[1:] - indptr[:-1]).long()
