@@ -57,3 +57,41 @@ def test_rectangular_operator_and_exact_integers(cuda_device, monkeypatch):
     out.sum().backward()
     col_deg = np.bincount(indices, minlength=500).astype(np.float32)
     assert torch.equal(feat.grad.cpu(), torch.from_numpy(col_deg)[:, None].expand(500, 32))   # A^T @ 1 = in-degree, exact
+
+
+def test_two_layer_gcn_gradients_match_a_dense_reference(cuda_device, monkeypatch):
+    """examples/gcn_train.py end to end on a small graph: loss and every parameter gradient of the two-layer GCN (normalised
+    adjacency with self loops, separable values on the binary operator, both directions) against the same model on a dense fp64 Â."""
+    import importlib.util
+    import os
+
+    import synth_graphs
+
+    monkeypatch.setenv("VOLTRIX_TUNE_SPACE", "none")
+    spec = importlib.util.spec_from_file_location("gcn_train", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                             "examples", "gcn_train.py"))
+    gcn = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gcn)
+    indptr, indices, _ = synth_graphs.generate("com_amazon_like", device="cuda", scale=0.004)
+    n = indptr.numel() - 1
+    indptr, indices, values = gcn.normalised_adjacency(indptr, indices, n)
+    rows = torch.repeat_interleave(torch.arange(n, device="cuda"), (indptr[1:] - indptr[:-1]).long())
+    assert int((rows == indices.long()).sum()) == n                     # one self loop per node
+    op = SpMM(indptr, indices, n, values=values, hash_tag="gcn_example_test")
+    assert op.weighted.separable
+    dense = torch.zeros(n, n, dtype=torch.float64, device="cuda")
+    dense[rows, indices.long()] = values.double()
+    torch.manual_seed(1)
+    x = torch.randn(n, 24, device="cuda")
+    y = torch.randint(0, 8, (n,), device="cuda")
+    model = gcn.GCN(op, 24, 32, 8).cuda()
+    ref = gcn.GCN(lambda h: dense @ h, 24, 32, 8, dtype=torch.float64).cuda().double()
+    ref.load_state_dict({k: v.double() for k, v in model.state_dict().items()})
+    loss = torch.nn.functional.cross_entropy(model(x), y)
+    loss.backward()
+    ref_loss = torch.nn.functional.cross_entropy(ref(x.double()), y)
+    ref_loss.backward()
+    assert abs(float(loss) - float(ref_loss)) <= 2e-3 * abs(float(ref_loss))
+    for (name, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        err = float((p.grad.double() - q.grad).norm() / q.grad.norm())
+        assert err <= 1e-2, (name, err)              # four fp16 operand roundings along each gradient path
