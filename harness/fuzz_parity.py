@@ -53,12 +53,12 @@ def one_case(rng, case_no):
     num_feats = WIDTHS[int(rng.integers(0, len(WIDTHS)))]
     dtype = [torch.float16, torch.float16, torch.bfloat16, torch.float32][int(rng.integers(0, 4))]
     mode = ["plain", "plain", "full_space", "stream_space", "no_hybrid", "csr_on", "csr_off", "weighted_sep", "weighted_general",
-            "reordered", "backward", "exact32", "hybrid_on", "hybrid_on"][int(rng.integers(0, 14))]
+            "reordered", "backward", "exact32", "hybrid_on", "hybrid_on", "update_values", "reordered_scaled"][int(rng.integers(0, 16))]
     if mode == "hybrid_on":     # the two-level side-car whenever enough edges sit in shared columns (auto wants >= 110 k rows of degree >= 64)
         fam = ["reddit_like", "protein_like", "fraud_yelp_rsr_like", "ddi_like", "products_like"][int(rng.integers(0, 5))]
         scale = float(rng.uniform(0.05, 0.6)) if fam in ("reddit_like", "protein_like") else (float(rng.uniform(0.02, 0.2)) if fam == "products_like" else 1.0)
         dtype = torch.float16 if dtype == torch.float32 else dtype
-    if mode in ("weighted_sep", "weighted_general") and dtype == torch.float32:
+    if mode in ("weighted_sep", "weighted_general", "update_values", "reordered_scaled") and dtype == torch.float32:
         dtype = torch.float16
     if mode == "exact32":
         dtype = torch.float32
@@ -97,6 +97,29 @@ def one_case(rng, case_no):
         out = voltrix.spmm_weighted(h, feat, hash_tag=tag)
         ref, aabs = reference(indptr, indices, values, feat64, n, n)
         return desc, check(out, ref, aabs, deg, 2.0 * u + 2.0 ** -20, mode), "ran"      # values and operands both round to 16 bits
+    if mode == "update_values":      # general values, then new ones on the same pattern through the edge -> plane map (twice: the map is cached)
+        values = (0.25 + torch.rand(e, device="cuda", generator=gen)).float()
+        h = voltrix.csr_preprocess_weighted(indptr, indices, values, n, separable=False)
+        voltrix.spmm_weighted(h, feat, hash_tag=tag)
+        msg = None
+        for _ in range(2):
+            values = (torch.randn(e, device="cuda", generator=gen)).float()
+            voltrix.update_edge_values(h, values)
+            out = voltrix.spmm_weighted(h, feat)
+            ref, aabs = reference(indptr, indices, values, feat64, n, n)
+            msg = msg or check(out, ref, aabs, deg, 2.0 * u + 2.0 ** -20, mode)
+        return desc, msg, "ran"
+    if mode == "reordered_scaled":   # shuffled labels, the library's reorder, and the normalised adjacency's factors on the same handle
+        s_indptr, s_indices, _ = synth_graphs.shuffle_labels(indptr, indices, 77 + case_no)
+        sdeg = (s_indptr[1:] - s_indptr[:-1]).double()
+        r = sdeg.clamp(min=1.0).rsqrt().float()
+        c = torch.bincount(s_indices.long(), minlength=n).double().clamp(min=1.0).rsqrt().float()
+        h = voltrix.csr_preprocess_reordered(s_indptr, s_indices, n, method="auto", relabel=bool(case_no % 2), row_scale=r, col_scale=c)
+        h.hspa_packed.hash_tag = tag
+        out = voltrix.spmm_reordered(h, voltrix.permute_features(h, feat), unpermute=True)
+        rows = torch.repeat_interleave(torch.arange(n, device="cuda"), (s_indptr[1:] - s_indptr[:-1]).long())
+        ref, aabs = reference(s_indptr, s_indices, r[rows] * c[s_indices.long()], feat64, n, n)
+        return desc, check(out, ref, aabs, sdeg, 2.0 * u + 2.0 ** -20, mode), "ran"
     if mode == "reordered":
         s_indptr, s_indices, _ = synth_graphs.shuffle_labels(indptr, indices, 77 + case_no)
         h = voltrix.csr_preprocess_reordered(s_indptr, s_indices, n, method="auto", relabel=True)
