@@ -428,6 +428,20 @@ void voltrix_launch_cast_f32_f16_scaled(void* src, void* dst, int64_t count, voi
 void voltrix_launch_spmm_csr_rows(void* indptr, void* indices, int num_rows, int embedding_dim, void* input, int dtype, void* output,
                                   int xcd_ranges, void* stream, int* return_code);
 
+/* The same kernel with edge values: output = csr(values) * input, values = device float[nnz] in CSR order (duplicate entries ADD, as in
+ * torch.sparse.mm).  One fused multiply-add per element in fp32: with fp32 rows the weighted product is exact up to the rounding of
+ * the sum (deg * 2^-23 (|A| |B|)) -- the block format's value planes are 16-bit.  Values can change between calls at no cost (nothing is
+ * preprocessed).  voltrix/weighted.py takes it for general values on handles of short windows where it measured faster, and for
+ * VOLTRIX_FP32_MODE=exact.  No reference counterpart (the reference has no edge values: spmm_kernels.cuh:1632-1644). */
+void voltrix_launch_spmm_csr_rows_weighted(void* indptr, void* indices, void* values, int num_rows, int embedding_dim, void* input, int dtype,
+                                           void* output, int xcd_ranges, void* stream, int* return_code);
+
+/* New edge values on a fixed pattern: plane[slots[e]] = T(values[e]) for e < count; values device float[count], slots device int64[count]
+ * (the element of the flat value plane [T * 128] every CSR entry lands on: voltrix/weighted.py::edge_slots; the entries of a
+ * duplicate-free pattern own their elements), plane of dtype 0 fp32 / 1 fp16 / 2 bfloat16 (round to nearest even).  One pass instead
+ * of rebuilding the plane (sorts and searches over all edges).  No reference counterpart. */
+void voltrix_launch_scatter_values(void* values, void* slots, void* plane, int64_t count, int dtype, void* stream, int* return_code);
+
 /* Rows of a dense row-major matrix times a per-row factor: dst[i, :] = T(float(src[i, :]) * scale[i]); dst may be src.
  * dtype 0 fp32 / 1 fp16 / 2 bfloat16; a row (num_feats elements) must be a multiple of 16 bytes; scale: device float[rows].
  * What edge values of the form v_ij = r_i * c_j cost on top of the binary product (voltrix/weighted.py: B's rows times c before,

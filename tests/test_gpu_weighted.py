@@ -412,3 +412,92 @@ def test_normalised_adjacency_on_a_reordered_handle(cuda_device, relabel, method
         again = voltrix.spmm_reordered(h, fin, unpermute=True)
         assert torch.equal(again, out)
         assert torch.equal(fin, voltrix.permute_features(h, feat))        # the operand was not scaled in place
+
+
+# ---- round 6: the CSR row-gather kernel with edge values (no plane) and the value-plane scatter kernel -----------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("width", [8, 72, 256, 520])
+def test_csr_kernel_with_values_matches_the_oracle(cuda_device, dtype, width, monkeypatch):
+    """voltrix_launch_spmm_csr_rows_weighted through spmm_weighted (VOLTRIX_CSR_PATH=1): fp32 values x rows as they are, one fused
+    multiply-add per element -- only the operand's own rounding and the fp32 sum remain: (deg + 1) 2^-23 (|A| |B|) against the oracle on
+    the same operand; duplicate entries add."""
+    from voltrix import capi
+
+    monkeypatch.setenv("VOLTRIX_CSR_PATH", "1")
+    ip_np, ix_np = _random_csr(1100, 60, seed=31)
+    rows = [ix_np[ip_np[r]:ip_np[r + 1]] for r in range(1100)]
+    rows = [np.concatenate([r[:1], r]) if i % 7 == 0 else r for i, r in enumerate(rows)]          # some duplicates
+    ip_np = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    ix_np = np.concatenate(rows).astype(np.int32)
+    ip, ix = torch.from_numpy(ip_np), torch.from_numpy(ix_np)
+    n = 1100
+    torch.manual_seed(12)
+    values = torch.randn(len(ix_np))
+    feat = torch.randn(n, width, device=cuda_device).to(dtype)
+    h = voltrix.csr_preprocess_weighted(ip, ix, values, n, separable=False)
+    out = voltrix.spmm_weighted(h, feat, hash_tag="weighted_csr")
+    assert out.shape == (n, width) and out.dtype == torch.float32
+    ref = _oracle(ip_np, ix_np, values, feat.cpu().float(), n, n)
+    scale = _oracle(ip_np, ix_np, values.abs(), feat.cpu().float().abs(), n, n)
+    deg = torch.from_numpy(np.diff(ip_np).astype(np.float64))[:, None]
+    assert ((out.cpu().double() - ref).abs() <= (deg + 1) * 2.0 ** -23 * scale + 1e-30).all()
+    # the entry point itself, without the XCD ranges
+    raw = torch.empty(n, width, dtype=torch.float32, device=cuda_device)
+    capi.launch_spmm_csr_rows(h.csr[0], h.csr[1], n, feat, raw, torch.cuda.current_stream().cuda_stream, 0, values=h.csr[2])
+    assert ((raw.cpu().double() - ref).abs() <= (deg + 1) * 2.0 ** -23 * scale + 1e-30).all()
+
+
+def test_exact_fp32_weighted_product_and_the_measured_path(cuda_device, monkeypatch):
+    """VOLTRIX_FP32_MODE=exact on a weighted handle used to be refused (16-bit planes); it now runs the CSR kernel with values.  Without
+    the flag a handle of short windows times both paths once per (width, dtype) and remembers the choice; either is within the plane
+    path's bound."""
+    import synth_graphs
+
+    indptr, indices, _ = synth_graphs.generate("com_amazon_like", scale=0.2)
+    n = indptr.numel() - 1
+    torch.manual_seed(13)
+    values = torch.rand(indices.numel()) + 0.1
+    h = voltrix.csr_preprocess_weighted(indptr, indices, values, n, separable=False)
+    feat = torch.randn(n, 64, device=cuda_device)
+    ref = _oracle(indptr.numpy(), indices.numpy(), values, feat.cpu(), n, n)
+    scale = _oracle(indptr.numpy(), indices.numpy(), values.abs(), feat.cpu().abs(), n, n)
+    deg = (indptr[1:] - indptr[:-1]).double()[:, None]
+    monkeypatch.setenv("VOLTRIX_FP32_MODE", "exact")
+    exact = voltrix.spmm_weighted(h, feat, hash_tag="weighted_exact")
+    assert ((exact.cpu().double() - ref).abs() <= (deg + 1) * 2.0 ** -23 * scale + 1e-30).all()
+    monkeypatch.delenv("VOLTRIX_FP32_MODE")
+    for operand in (feat, feat.half()):
+        out = voltrix.spmm_weighted(h, operand)
+        key = (64, str(operand.dtype))
+        assert h.path_choice[key] in ("csr", "plane")
+        assert ((out.cpu().double() - ref).abs() <= (2.0 ** -9 + deg * 2.0 ** -23) * scale + 1e-6).all()
+        assert torch.equal(out, voltrix.spmm_weighted(h, operand))                      # the remembered choice: the same kernel again
+    monkeypatch.setenv("VOLTRIX_CSR_PATH", "0")
+    plane = voltrix.spmm_weighted(h, feat.half())
+    assert ((plane.cpu().double() - ref).abs() <= (2.0 ** -9 + deg * 2.0 ** -23) * scale + 1e-6).all()
+    # new values: nothing to rebuild for the CSR path, one scatter for the plane -- both see them
+    new = torch.rand(indices.numel()) + 0.5
+    voltrix.update_edge_values(h, new)
+    ref2 = _oracle(indptr.numpy(), indices.numpy(), new, feat.cpu(), n, n)
+    scale2 = _oracle(indptr.numpy(), indices.numpy(), new.abs(), feat.cpu().abs(), n, n)
+    assert ((voltrix.spmm_weighted(h, feat.half()).cpu().double() - ref2).abs() <= (2.0 ** -9 + deg * 2.0 ** -23) * scale2 + 1e-6).all()
+    monkeypatch.setenv("VOLTRIX_CSR_PATH", "1")
+    assert ((voltrix.spmm_weighted(h, feat.half()).cpu().double() - ref2).abs() <= (2.0 ** -10 + deg * 2.0 ** -23) * scale2 + 1e-6).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_scatter_values_kernel_matches_torch(cuda_device, dtype):
+    from voltrix import capi
+
+    torch.manual_seed(14)
+    total, count = 1 << 20, 300_001
+    slots = torch.randperm(total, device=cuda_device)[:count].contiguous()
+    values = torch.randn(count, device=cuda_device) * 1e3
+    values[:4] = torch.tensor([0.0, float("inf"), 3.4e38, 1e-40], device=cuda_device)      # zero, inf, near-overflow, subnormal
+    plane = torch.full((total,), 7.0, dtype=dtype, device=cuda_device)
+    want = plane.clone()
+    want[slots] = values.to(dtype)
+    capi.launch_scatter_values(values, slots, plane, torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(plane, want)
+    capi.launch_scatter_values(values[:0], slots[:0], plane, torch.cuda.current_stream().cuda_stream)           # empty: a no-op
+    assert torch.equal(plane, want)

@@ -69,6 +69,8 @@ SYMBOLS = (
     "voltrix_launch_cast_f32_f16_scaled",
     "voltrix_launch_scale_rows",
     "voltrix_launch_spmm_csr_rows",
+    "voltrix_launch_spmm_csr_rows_weighted",
+    "voltrix_launch_scatter_values",
     "voltrix_csr_preprocess_workspace_bytes",
     "voltrix_launch_csr_window_count",
     "voltrix_launch_csr_fill",
@@ -558,25 +560,59 @@ def launch_cast_f32_f16_scaled(src, dst, scale, stream) -> None:
 _spmm_csr_rows = None
 
 
-def launch_spmm_csr_rows(indptr, indices, num_rows: int, feat, output, stream, xcd_ranges: int = 0) -> None:
-    """``output = csr(ones) @ feat`` with the CSR row-gather kernel (device int32 CSR; fp32 / fp16 / bf16 ``feat`` whose rows are a
-    multiple of 16 bytes; fp32 ``output`` [num_rows, F]); see include/voltrix_capi.h."""
+def launch_spmm_csr_rows(indptr, indices, num_rows: int, feat, output, stream, xcd_ranges: int = 0, values=None) -> None:
+    """``output = csr(ones) @ feat`` -- or ``csr(values) @ feat`` with ``values`` (device float32 [nnz], CSR order) -- with the CSR
+    row-gather kernel (device int32 CSR; fp32 / fp16 / bf16 ``feat`` whose rows are a multiple of 16 bytes; fp32 ``output``
+    [num_rows, F]); see include/voltrix_capi.h."""
     import torch
 
-    global _spmm_csr_rows
+    global _spmm_csr_rows, _spmm_csr_rows_weighted
     if _spmm_csr_rows is None:
         fn = lib().voltrix_launch_spmm_csr_rows
         fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
         _spmm_csr_rows = fn
+        fn = lib().voltrix_launch_spmm_csr_rows_weighted
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                       ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        _spmm_csr_rows_weighted = fn
     assert indptr.dtype == torch.int32 and indices.dtype == torch.int32 and indptr.numel() == num_rows + 1
     assert feat.dim() == 2 and feat.is_contiguous() and output.is_contiguous() and output.dtype == torch.float32
     assert output.shape == (num_rows, feat.shape[1])
     dtype = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[feat.dtype]
     rc = ctypes.c_int(-1)
-    _spmm_csr_rows(indptr.data_ptr(), indices.data_ptr(), num_rows, feat.shape[1], feat.data_ptr(), dtype, output.data_ptr(),
-                   int(xcd_ranges), stream, rc)
-    check(rc.value, "voltrix_launch_spmm_csr_rows")
+    if values is None:
+        _spmm_csr_rows(indptr.data_ptr(), indices.data_ptr(), num_rows, feat.shape[1], feat.data_ptr(), dtype, output.data_ptr(),
+                       int(xcd_ranges), stream, rc)
+        check(rc.value, "voltrix_launch_spmm_csr_rows")
+        return
+    assert values.dtype == torch.float32 and values.is_contiguous() and values.numel() == indices.numel() and values.is_cuda
+    _spmm_csr_rows_weighted(indptr.data_ptr(), indices.data_ptr(), values.data_ptr(), num_rows, feat.shape[1], feat.data_ptr(), dtype,
+                            output.data_ptr(), int(xcd_ranges), stream, rc)
+    check(rc.value, "voltrix_launch_spmm_csr_rows_weighted")
+
+
+_spmm_csr_rows_weighted = None
+_scatter_values = None
+
+
+def launch_scatter_values(values, slots, plane, stream) -> None:
+    """``plane.view(-1)[slots[e]] = values[e]`` (device float32 values, int64 slots, fp32 / fp16 / bf16 plane); see
+    include/voltrix_capi.h."""
+    import torch
+
+    global _scatter_values
+    if _scatter_values is None:
+        fn = lib().voltrix_launch_scatter_values
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p,
+                       ctypes.POINTER(ctypes.c_int)]
+        _scatter_values = fn
+    assert values.dtype == torch.float32 and slots.dtype == torch.int64 and values.numel() == slots.numel()
+    assert values.is_contiguous() and slots.is_contiguous() and plane.is_contiguous() and values.is_cuda and plane.is_cuda
+    dtype = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[plane.dtype]
+    rc = ctypes.c_int(-1)
+    _scatter_values(values.data_ptr(), slots.data_ptr(), plane.data_ptr(), values.numel(), dtype, stream, rc)
+    check(rc.value, "voltrix_launch_scatter_values")
 
 
 _scale_rows = None

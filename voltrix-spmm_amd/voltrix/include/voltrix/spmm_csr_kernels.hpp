@@ -37,6 +37,7 @@ struct CsrArgs {
   const int* indices;   // [nnz] column ids = rows of `input`
   const T* input;       // [*, F] row-major, rows 16-byte aligned
   float* output;        // [num_rows, F]
+  const float* values;  // WEIGHTED kernels: [nnz] fp32 edge values in CSR order (duplicate entries add); else unused
   int num_rows;
   int F;
   int lanes_per_row;    // power of two <= 64
@@ -63,7 +64,27 @@ __device__ __forceinline__ void csr_accumulate(float (&acc)[16 / sizeof(T)], con
   }
 }
 
-template <typename T, int UNROLL>
+// acc += v * row piece (WEIGHTED kernels: one fused multiply-add per element, a single fp32 rounding)
+template <typename T>
+__device__ __forceinline__ void csr_accumulate_scaled(float (&acc)[16 / sizeof(T)], const uint4_t raw, const float v) {
+  if constexpr (std::is_same<T, float>::value) {
+    const float4_t x = __builtin_bit_cast(float4_t, raw);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_fmaf(v, x[i], acc[i]);
+  } else if constexpr (std::is_same<T, _Float16>::value) {
+    const half8_t x = __builtin_bit_cast(half8_t, raw);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_fmaf(v, (float)x[i], acc[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[2 * i] = __builtin_fmaf(v, __builtin_bit_cast(float, raw[i] << 16), acc[2 * i]);
+      acc[2 * i + 1] = __builtin_fmaf(v, __builtin_bit_cast(float, raw[i] & 0xffff0000u), acc[2 * i + 1]);
+    }
+  }
+}
+
+template <typename T, int UNROLL, bool WEIGHTED = false>
 static __global__ __launch_bounds__(256) void spmm_csr_rows_kernel(const CsrArgs<T> a) {
   constexpr int V = 16 / (int)sizeof(T);
   const int L = a.lanes_per_row;
@@ -89,21 +110,33 @@ static __global__ __launch_bounds__(256) void spmm_csr_rows_kernel(const CsrArgs
   // serialised them (ppi-like x 128: 0.150 ms against 0.091; profiles/r06/experiment_csr_mapping.log)
   for (; e + UNROLL <= end; e += UNROLL) {
     uint4_t raw[UNROLL];
+    float v[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) raw[u] = *reinterpret_cast<const uint4_t*>(base + (long long)a.indices[e + u] * F);
+    for (int u = 0; u < UNROLL; ++u) {
+      raw[u] = *reinterpret_cast<const uint4_t*>(base + (long long)a.indices[e + u] * F);
+      if constexpr (WEIGHTED) v[u] = a.values[e + u];
+    }
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) csr_accumulate<T>(acc, raw[u]);
+    for (int u = 0; u < UNROLL; ++u) {
+      if constexpr (WEIGHTED) csr_accumulate_scaled<T>(acc, raw[u], v[u]);
+      else csr_accumulate<T>(acc, raw[u]);
+    }
   }
   if (e < end) {
     uint4_t raw[UNROLL];
+    float v[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int ee = e + u < end ? e + u : end - 1;
       raw[u] = *reinterpret_cast<const uint4_t*>(base + (long long)a.indices[ee] * F);
+      if constexpr (WEIGHTED) v[u] = a.values[ee];
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u)
-      if (e + u < end) csr_accumulate<T>(acc, raw[u]);
+      if (e + u < end) {
+        if constexpr (WEIGHTED) csr_accumulate_scaled<T>(acc, raw[u], v[u]);
+        else csr_accumulate<T>(acc, raw[u]);
+      }
   }
   float4_t* out = reinterpret_cast<float4_t*>(a.output + row * F + col0);
 #pragma unroll
@@ -111,8 +144,10 @@ static __global__ __launch_bounds__(256) void spmm_csr_rows_kernel(const CsrArgs
 }
 
 // dtype: 0 fp32, 1 fp16, 2 bfloat16.  embedding_dim % (16 / sizeof(T)) == 0 (16-byte row pieces).  Every row of `output` is written.
+// values (optional): fp32 [nnz] edge values in CSR order -- C = csr(values) * B, the products v * b in fp32 (one fused multiply-add per
+// element: exact for fp32 rows up to the sum's rounding), duplicates add.
 inline int launch_spmm_csr_rows(const int* indptr, const int* indices, int num_rows, int embedding_dim, const void* input, int dtype,
-                                float* output, hipStream_t stream, int xcd_ranges = 0) {
+                                float* output, hipStream_t stream, int xcd_ranges = 0, const float* values = nullptr) {
   if (num_rows < 0 || embedding_dim < 0 || dtype < 0 || dtype > 2) return kErrBadShape;
   if (num_rows == 0 || embedding_dim == 0) return kOk;
   const int v = dtype == 0 ? 4 : 8;
@@ -131,12 +166,51 @@ inline int launch_spmm_csr_rows(const int* indptr, const int* indices, int num_r
   const dim3 grid((unsigned)(per_xcd * kNumXcd), (unsigned)slabs);
   auto go = [&](auto tag) {
     using T = decltype(tag);
-    CsrArgs<T> a{indptr, indices, static_cast<const T*>(input), output, num_rows, embedding_dim, lanes, (int)per_xcd, xcd_ranges ? 1 : 0};
-    hipLaunchKernelGGL((spmm_csr_rows_kernel<T, 4>), grid, dim3(256), 0, stream, a);
+    CsrArgs<T> a{indptr, indices, static_cast<const T*>(input), output, values, num_rows, embedding_dim, lanes, (int)per_xcd,
+                 xcd_ranges ? 1 : 0};
+    if (values != nullptr)
+      hipLaunchKernelGGL((spmm_csr_rows_kernel<T, 4, true>), grid, dim3(256), 0, stream, a);
+    else
+      hipLaunchKernelGGL((spmm_csr_rows_kernel<T, 4, false>), grid, dim3(256), 0, stream, a);
   };
   if (dtype == 0) go(float{});
   else if (dtype == 1) go(_Float16{});
   else go(bfloat16_bits{});
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+// ---- value planes: new edge values on a fixed pattern (voltrix/weighted.py::update_values) ------------------------------------------
+// plane[slot[e]] = T(values[e]): `slot` = the element of the flat value plane [T * 128] every CSR entry lands on (weighted.edge_slots;
+// duplicate-free patterns: every entry owns its element).  One pass: 12 bytes read + one 2- or 4-byte store per edge.
+template <typename T>
+static __global__ __launch_bounds__(256) void scatter_values_kernel(const float* __restrict__ values, const long long* __restrict__ slot,
+                                                                    T* __restrict__ plane, const long long count) {
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < count; e += (long long)gridDim.x * 256) {
+    const float v = values[e];
+    if constexpr (std::is_same<T, float>::value) plane[slot[e]] = v;
+    else if constexpr (std::is_same<T, _Float16>::value) plane[slot[e]] = (_Float16)v;
+    else {   // bfloat16 bits: round to nearest even, NaN kept quiet
+      const unsigned b = __builtin_bit_cast(unsigned, v);
+      plane[slot[e]] = (v != v) ? (bfloat16_bits)0x7fc0 : (bfloat16_bits)((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
+    }
+  }
+}
+
+// dtype of the plane: 0 fp32, 1 fp16, 2 bfloat16
+inline int scatter_values(const float* values, const long long* slot, void* plane, long long count, int dtype, hipStream_t stream) {
+  if (count < 0 || dtype < 0 || dtype > 2) return kErrBadShape;
+  if (count == 0) return kOk;
+  if (values == nullptr || slot == nullptr || plane == nullptr) return kErrBadShape;
+  const long long want = (count + 255) / 256;
+  const int blocks = (int)(want < 256 * 32 ? want : 256 * 32);
+  if (dtype == 0)
+    hipLaunchKernelGGL((scatter_values_kernel<float>), dim3(blocks), dim3(256), 0, stream, values, slot, static_cast<float*>(plane), count);
+  else if (dtype == 1)
+    hipLaunchKernelGGL((scatter_values_kernel<_Float16>), dim3(blocks), dim3(256), 0, stream, values, slot,
+                       static_cast<_Float16*>(plane), count);
+  else
+    hipLaunchKernelGGL((scatter_values_kernel<bfloat16_bits>), dim3(blocks), dim3(256), 0, stream, values, slot,
+                       static_cast<bfloat16_bits*>(plane), count);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

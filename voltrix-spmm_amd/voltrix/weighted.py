@@ -50,6 +50,7 @@ class WeightedHandle:
                                        # derives the edge -> plane map of a general handle from (kept up to KEEP_CSR_MAX_EDGES edges)
     edge_slot: torch.Tensor = None     # int64 [nnz]: ``edge_slots`` of this handle, built by the first ``update_values``
     slot_duplicates: bool = None       # some (row, col) pair occurs more than once: updates ADD per slot instead of storing
+    path_choice: dict = dataclasses.field(default_factory=dict)   # (width, dtype) -> "csr" | "plane": ``_weighted_path``'s measured choice
 
     @property
     def separable(self) -> bool:
@@ -224,7 +225,8 @@ def csr_preprocess_weighted(indptr: torch.Tensor, indices: torch.Tensor, values:
     pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(indptr_d, indices_d, num_nodes, num_cols)
     universe = max(num_cols, int(indices_d.max()) + 1) if indices_d.numel() else num_cols
     total = int(pointer1[-1])
-    csr = (indptr_d, indices_d, None, universe) if indices_d.numel() <= KEEP_CSR_MAX_EDGES else None   # for update_values
+    # kept for update_values and for the CSR row-gather kernel with values (``_weighted_path``): 8 bytes per edge
+    csr = (indptr_d, indices_d, values_d.float(), universe) if indices_d.numel() <= KEEP_CSR_MAX_EDGES else None
     if total * 512 > MASTER_PLANE_MAX_BYTES:
         dt = plane_dtype or torch.float16
         handle = WeightedHandle(pointer1, hspa_packed, hind, None, num_nodes, int(indices.numel()), csr=csr)
@@ -261,7 +263,7 @@ def update_values(handle: WeightedHandle, values: torch.Tensor) -> WeightedHandl
             return handle
         handle.row_scale = handle.col_scale = None    # a general handle from here on: the plane path of spmm_weighted
         handle.planes.clear()
-        handle.csr = (indptr, indices, None, num_cols)
+        handle.csr = (indptr, indices, values.float(), num_cols)
         total = int(handle.blk_offsets[-1])
         if total * 512 > MASTER_PLANE_MAX_BYTES:
             handle.planes[torch.float16] = value_plane(indptr, indices, values, handle.blk_offsets, handle.num_nodes, num_cols,
@@ -280,18 +282,24 @@ def update_values(handle: WeightedHandle, values: torch.Tensor) -> WeightedHandl
         flat.index_add_(0, slot, values.float())
         for dt in list(handle.planes):
             handle.planes[dt].copy_(handle.values32)
+        handle.csr = (indptr, indices, values.float(), num_cols)
         return handle
     # no duplicates: every edge owns its element and every other element of the plane is a structural zero that stays one.  One scatter
-    # per 16-bit plane the handle holds (reddit-like: 2.5 ms each for 114.6 M edges -- torch's scatter; a rebuild is 107 ms); the fp32
-    # master is only written when it is the ONLY plane -- otherwise it is dropped, and a plane of another 16-bit type is later made
-    # from the latest values through the same map (``_plane_for``)
-    handle.csr = (indptr, indices, values, num_cols)
+    # pass per 16-bit plane the handle holds (``scatter_values_kernel``; torch's own scatter took 2.5 ms for 114.6 M edges, a rebuild
+    # 107-144 ms); the fp32 master is only written when it is the ONLY plane -- otherwise it is dropped, and a plane of another 16-bit
+    # type is later made from the latest values through the same map (``_plane_for``)
+    from . import capi
+    from .jit_kernels.spmm import _raw_stream
+
+    values32 = values.float().contiguous()
+    handle.csr = (indptr, indices, values32, num_cols)
+    stream = _raw_stream(values32.device)
     if handle.planes:
         handle.values32 = None
         for dt in list(handle.planes):
-            handle.planes[dt].view(-1)[slot] = values.to(dt)
+            capi.launch_scatter_values(values32, slot, handle.planes[dt], stream)
     else:
-        handle.values32.view(-1)[slot] = values.float()
+        capi.launch_scatter_values(values32, slot, handle.values32, stream)
     return handle
 
 
@@ -306,8 +314,11 @@ def _plane_for(handle: WeightedHandle, dtype: torch.dtype) -> torch.Tensor:
             assert latest is not None and handle.edge_slot is not None and not handle.slot_duplicates, (
                 f"this handle was built without an fp32 master (too large) and holds only the {list(handle.planes)} plane(s): pass "
                 f"plane_dtype={dtype} to csr_preprocess_weighted")
+            from . import capi
+            from .jit_kernels.spmm import _raw_stream
+
             plane = torch.zeros(int(handle.blk_offsets[-1]) * 128, dtype=dtype, device=latest.device)
-            plane[handle.edge_slot] = latest.to(dtype)
+            capi.launch_scatter_values(latest, handle.edge_slot, plane, _raw_stream(latest.device))
             handle.planes[dtype] = plane.view(-1, 16, 8)
     return handle.planes[dtype]
 
@@ -331,8 +342,11 @@ def spmm_weighted(handle: WeightedHandle, feat: torch.Tensor, hash_tag: str = No
     if handle.separable:
         if prescaled or not postscale or separable_pays(handle, num_feats, feat.element_size()):
             return _spmm_separable(handle, feat, prescaled, postscale)
+    if not handle.separable and _weighted_path(handle, feat) == "csr":
+        return _spmm_weighted_csr(handle, feat)
     operand, out_scale, padded, exact = _operand(feat)
-    assert not exact, "the weighted kernel takes a 16-bit operand (unset VOLTRIX_FP32_MODE=exact)"
+    assert not exact, ("the value planes are 16-bit: VOLTRIX_FP32_MODE=exact needs the CSR kernel with values, i.e. a general handle that "
+                       "kept its CSR and values (csr_preprocess_weighted(..., separable=False), at most KEEP_CSR_MAX_EDGES edges)")
     if handle.separable:
         _materialise_plane(handle, operand.dtype)
     output = torch.empty((handle.num_nodes, padded), dtype=torch.float32, device=feat.device)
@@ -340,6 +354,76 @@ def spmm_weighted(handle: WeightedHandle, feat: torch.Tensor, hash_tag: str = No
                 num_edges=handle.num_edges, embedding_dim=padded, input=operand, output=output, out_scale=out_scale,
                 values=_plane_for(handle, operand.dtype))
     return output if padded == num_feats else output[:, :num_feats].contiguous()
+
+
+WEIGHTED_CSR_MAX_BLOCKS_PER_WINDOW = 48     # as for the binary operator's CSR side-car (spmm/spmm.py): short windows only
+WEIGHTED_CSR_MIN_GAIN = 0.03
+
+
+def _spmm_weighted_csr(handle: WeightedHandle, feat: torch.Tensor) -> torch.Tensor:
+    """``csr(values) @ feat`` straight from the handle's CSR with the row-gather kernel (``spmm_csr_rows_kernel<T, 4, true>``): fp32 /
+    fp16 / bf16 rows as they are, fp32 values, one fused multiply-add per element -- no plane, nothing to update when values change."""
+    from . import capi
+    from .jit_kernels.spmm import _raw_stream
+
+    indptr, indices, values, _ = handle.csr
+    feat = feat.contiguous()
+    num_feats = feat.shape[1]
+    align = 4 if feat.dtype == torch.float32 else 8
+    padded = (num_feats + align - 1) // align * align
+    if padded != num_feats:
+        feat = torch.nn.functional.pad(feat, (0, padded - num_feats))
+    output = torch.empty((handle.num_nodes, padded), dtype=torch.float32, device=feat.device)
+    capi.launch_spmm_csr_rows(indptr, indices, handle.num_nodes, feat, output, _raw_stream(feat.device), 1, values=values)
+    return output if padded == num_feats else output[:, :num_feats].contiguous()
+
+
+def _weighted_path(handle: WeightedHandle, feat: torch.Tensor) -> str:
+    """"csr" | "plane" for a general handle and this operand.  The CSR kernel with values needs the handle's CSR and latest values
+    (kept up to ``KEEP_CSR_MAX_EDGES`` edges).  ``VOLTRIX_FP32_MODE=exact`` on fp32 features: "csr" (the planes are 16-bit).
+    ``VOLTRIX_CSR_PATH=1 / 0``: forced / never.  Otherwise, on handles of short windows only, the first call per (width, dtype) times
+    both (three calls each, one host sync, not inside a stream capture) and the faster is remembered on the handle; pinned kernels
+    (``VOLTRIX_TUNE_SPACE=none / stream``) keep the plane."""
+    import os
+
+    from .jit_kernels.spmm import tune_space_mode
+    from .project.const import FP32_MODE_FLAG
+    from .spmm.spmm import csr_path_mode
+
+    have = (handle.csr is not None and handle.csr[2] is not None and feat.is_cuda and feat.dim() == 2
+            and feat.dtype in (torch.float32, torch.float16, torch.bfloat16) and feat.shape[0] >= handle.csr[3])
+    mode = csr_path_mode()
+    if not have or mode == "off":
+        return "plane"
+    if mode == "on" or (feat.dtype == torch.float32 and os.getenv(FP32_MODE_FLAG, "auto") == "exact"):
+        return "csr"
+    if tune_space_mode() in ("none", "stream") or (feat.dtype == torch.float32 and os.getenv(FP32_MODE_FLAG, "auto") == "fp16"):
+        return "plane"
+    windows = (handle.num_nodes + 15) // 16
+    if handle.hspa_packed.numel() // 4 > WEIGHTED_CSR_MAX_BLOCKS_PER_WINDOW * windows:
+        return "plane"
+    key = (int(feat.shape[1]), str(feat.dtype))
+    if key in handle.path_choice:
+        return handle.path_choice[key]
+    if torch.cuda.is_current_stream_capturing():
+        return "plane"
+    handle.path_choice[key] = "plane"          # what the timed calls below take
+    times = {}
+    for name, fn in (("plane", lambda: spmm_weighted(handle, feat)), ("csr", lambda: _spmm_weighted_csr(handle, feat))):
+        fn()
+        fn()
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        for _ in range(3):
+            fn()
+        end.record()
+        end.synchronize()
+        times[name] = start.elapsed_time(end) / 3
+    best = "csr" if times["csr"] < (1.0 - WEIGHTED_CSR_MIN_GAIN) * times["plane"] else "plane"
+    if os.getenv("VOLTRIX_PRINT_AUTO_TUNE") or os.getenv("VOLTRIX_JIT_DEBUG"):
+        print(f"voltrix.spmm_weighted path for width {key[0]} {key[1]}: {times} -> {best}")
+    handle.path_choice[key] = best
+    return best
 
 
 def separable_pays(handle: WeightedHandle, num_feats: int, elem_bytes: int) -> bool:
