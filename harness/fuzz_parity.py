@@ -58,8 +58,8 @@ def one_case(rng, case_no):
         fam = ["reddit_like", "protein_like", "fraud_yelp_rsr_like", "ddi_like", "products_like"][int(rng.integers(0, 5))]
         scale = float(rng.uniform(0.05, 0.6)) if fam in ("reddit_like", "protein_like") else (float(rng.uniform(0.02, 0.2)) if fam == "products_like" else 1.0)
         dtype = torch.float16 if dtype == torch.float32 else dtype
-    if mode in ("weighted_sep", "weighted_general", "update_values", "reordered_scaled") and dtype == torch.float32:
-        dtype = torch.float16
+    if mode in ("weighted_sep", "update_values", "reordered_scaled") and dtype == torch.float32:
+        dtype = torch.float16          # (weighted_general keeps fp32 features: the value plane after a scaled cast, or the CSR kernel with values)
     if mode == "exact32":
         dtype = torch.float32
     env = {"VOLTRIX_TUNE_SPACE": {"full_space": "full", "stream_space": "stream"}.get(mode, ""),
