@@ -501,3 +501,30 @@ def test_scatter_values_kernel_matches_torch(cuda_device, dtype):
     assert torch.equal(plane, want)
     capi.launch_scatter_values(values[:0], slots[:0], plane, torch.cuda.current_stream().cuda_stream)           # empty: a no-op
     assert torch.equal(plane, want)
+
+
+def test_the_handle_owns_its_edge_values(cuda_device, monkeypatch):
+    """The CSR kernel with values reads the handle's values at every call: a caller that writes into its own tensor afterwards must not
+    change the product (both paths keep computing the values of the last csr_preprocess_weighted / update_edge_values)."""
+    ip_np, ix_np = _random_csr(500, 12, seed=41)
+    ip, ix = torch.from_numpy(ip_np).cuda(), torch.from_numpy(ix_np).cuda()
+    torch.manual_seed(15)
+    mine = (torch.rand(len(ix_np), device=cuda_device) + 0.5).float()
+    h = voltrix.csr_preprocess_weighted(ip, ix, mine, 500, separable=False)
+    feat = torch.randn(500, 32, device=cuda_device).half()
+    outs = {}
+    for path in ("0", "1"):
+        monkeypatch.setenv("VOLTRIX_CSR_PATH", path)
+        outs[path] = voltrix.spmm_weighted(h, feat, hash_tag="owned_values")
+    mine.mul_(3.0)
+    for path in ("0", "1"):
+        monkeypatch.setenv("VOLTRIX_CSR_PATH", path)
+        assert torch.equal(voltrix.spmm_weighted(h, feat), outs[path])
+    voltrix.update_edge_values(h, mine)
+    tripled = mine.cpu().clone()
+    mine.zero_()
+    ref = _oracle(ip_np, ix_np, tripled, feat.cpu(), 500, 500)
+    scale = _oracle(ip_np, ix_np, tripled.abs(), feat.cpu().abs(), 500, 500)
+    for path in ("0", "1"):
+        monkeypatch.setenv("VOLTRIX_CSR_PATH", path)
+        assert ((voltrix.spmm_weighted(h, feat).cpu().double() - ref).abs() <= 2.0 ** -9 * scale + 1e-6).all()

@@ -57,6 +57,13 @@ class WeightedHandle:
         return self.row_scale is not None
 
 
+def _own_values(values: torch.Tensor) -> torch.Tensor:
+    """float32 contiguous copy of the edge values that the HANDLE owns: the CSR kernel with values reads them at every call, so a caller
+    that later writes into its own tensor must not change what the handle computes (the planes would still hold the old values)."""
+    v = values.float().contiguous()
+    return v.clone() if v.data_ptr() == values.data_ptr() else v
+
+
 def _chunk_slots(indptr, indices, blk_offsets, w0, w1, num_nodes, num_cols):
     """int64 [edges of windows w0 .. w1)]: where every edge of a range of windows sits in the range's part of the value plane
     (definition: ``value_plane``; offsets relative to the first TC block of window w0)."""
@@ -219,14 +226,14 @@ def csr_preprocess_weighted(indptr: torch.Tensor, indices: torch.Tensor, values:
         pointer1, hspa_packed, hind = csr_preprocess_device(indptr_d, indices_d, num_nodes, num_cols)   # side-car policy included
         return WeightedHandle(pointer1, hspa_packed, hind, None, num_nodes, int(indices.numel()), row_scale=scales[0],
                               col_scale=scales[1],
-                              csr=(indptr_d, indices_d, values.contiguous().cuda() if values is not None else None, num_cols))
+                              csr=(indptr_d, indices_d, _own_values(values.cuda()) if values is not None else None, num_cols))
     assert values.numel() == indices.numel() and values.is_floating_point()
     values_d = values.contiguous().cuda()
     pointer1, hspa_packed, hind, _ = csr_fused_preprocess_kernel(indptr_d, indices_d, num_nodes, num_cols)
     universe = max(num_cols, int(indices_d.max()) + 1) if indices_d.numel() else num_cols
     total = int(pointer1[-1])
     # kept for update_values and for the CSR row-gather kernel with values (``_weighted_path``): 8 bytes per edge
-    csr = (indptr_d, indices_d, values_d.float(), universe) if indices_d.numel() <= KEEP_CSR_MAX_EDGES else None
+    csr = (indptr_d, indices_d, _own_values(values_d), universe) if indices_d.numel() <= KEEP_CSR_MAX_EDGES else None
     if total * 512 > MASTER_PLANE_MAX_BYTES:
         dt = plane_dtype or torch.float16
         handle = WeightedHandle(pointer1, hspa_packed, hind, None, num_nodes, int(indices.numel()), csr=csr)
@@ -258,12 +265,12 @@ def update_values(handle: WeightedHandle, values: torch.Tensor) -> WeightedHandl
         scales = separable_scales(indptr, indices, values, handle.num_nodes, num_cols) if values.numel() <= SEPARABLE_MAX_EDGES else None
         if scales is not None:
             handle.row_scale, handle.col_scale = scales
-            handle.csr = (indptr, indices, values, num_cols)
+            handle.csr = (indptr, indices, _own_values(values), num_cols)
             handle.planes.clear()                     # lazily built planes of the old values (separable_pays)
             return handle
         handle.row_scale = handle.col_scale = None    # a general handle from here on: the plane path of spmm_weighted
         handle.planes.clear()
-        handle.csr = (indptr, indices, values.float(), num_cols)
+        handle.csr = (indptr, indices, _own_values(values), num_cols)
         total = int(handle.blk_offsets[-1])
         if total * 512 > MASTER_PLANE_MAX_BYTES:
             handle.planes[torch.float16] = value_plane(indptr, indices, values, handle.blk_offsets, handle.num_nodes, num_cols,
@@ -282,7 +289,7 @@ def update_values(handle: WeightedHandle, values: torch.Tensor) -> WeightedHandl
         flat.index_add_(0, slot, values.float())
         for dt in list(handle.planes):
             handle.planes[dt].copy_(handle.values32)
-        handle.csr = (indptr, indices, values.float(), num_cols)
+        handle.csr = (indptr, indices, _own_values(values), num_cols)
         return handle
     # no duplicates: every edge owns its element and every other element of the plane is a structural zero that stays one.  One scatter
     # pass per 16-bit plane the handle holds (``scatter_values_kernel``; torch's own scatter took 2.5 ms for 114.6 M edges, a rebuild
@@ -291,7 +298,7 @@ def update_values(handle: WeightedHandle, values: torch.Tensor) -> WeightedHandl
     from . import capi
     from .jit_kernels.spmm import _raw_stream
 
-    values32 = values.float().contiguous()
+    values32 = _own_values(values)
     handle.csr = (indptr, indices, values32, num_cols)
     stream = _raw_stream(values32.device)
     if handle.planes:
