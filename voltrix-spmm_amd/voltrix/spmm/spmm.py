@@ -86,7 +86,9 @@ def preprocess_mode():
 
 def csr_preprocess_device(indptr: torch.Tensor, indices: torch.Tensor, num_nodes: int, num_cols: int = None):
     """``csr_preprocess`` for a CSR that already lives on the GPU (extension: the reference takes CPU tensors only; graph
-    pipelines and the row-sharded operator build their shards on the device).  Same handle, same side-car policy."""
+    pipelines and the row-sharded operator build their shards on the device).  Same handle, same side-car policy.  Handles of
+    short windows keep ``indptr`` / ``indices`` THEMSELVES as their CSR side-car (no copy: 4 (nnz + N) bytes saved): do not write into
+    them while the handle is in use -- the CSR kernel would see the change, the block format would not."""
     assert indptr.is_cuda and indptr.dtype == torch.int32 and indices.is_cuda and indices.dtype == torch.int32
     assert indptr.numel() == num_nodes + 1
     indptr, indices = indptr.contiguous(), indices.contiguous()
