@@ -11,10 +11,13 @@ consumes).  Inputs are resident in HBM before the timed region; preprocessing (C
 side-car, the unit table, the JIT tile sweep of the first call) happens once, outside it, as in the reference's
 protocol (bench/bm_voltrix.py:17,36).  Rank 0 prints ONE JSON line.
 
-Workloads (synth_graphs.py; BASELINE.json's configurations): N = 1 defaults to ``reddit_like`` (configs[1], the
-configuration the metric is quoted on); N > 1 defaults to ``papers_like`` (configs[4]: 111 M rows, row-window shards over
-the N GPUs + all-gather(B), every rank generating ITS OWN shard) -- the same matrix for every N, i.e. strong scaling;
-its single-GPU time is `python bench.py --gpus 1 --workload papers_like`.  ``--workload`` overrides either default.
+Workloads (synth_graphs.py; BASELINE.json's configurations): every N defaults to ``reddit_like`` (configs[1], the
+configuration the metric is quoted on) -- the same matrix for every N, row-window shards over the N GPUs + all-gather(B),
+i.e. strong scaling of the headline: the per-N values the driver derives its curve from are ONE workload (round 6; the
+N > 1 default used to be papers-like, which made N = 1 and N > 1 different graphs).  BASELINE configs[4] -- ``papers_like``,
+111 M rows sharded over the N ranks, every rank generating ITS OWN shard -- is measured BESIDE the timed steps of every
+N > 1 run and reported as ``config.config5_papers_like`` (all-gather, product and dependent step, MAX over ranks;
+``--no-config5`` skips it); as the timed workload: ``--workload papers_like`` (1 GPU: 62 ms/step).
 """
 import argparse
 import json
@@ -44,7 +47,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=None, choices=sorted(synth_graphs.CONFIGS),
-                    help="default: reddit_like at N = 1, papers_like at N > 1")
+                    help="default: reddit_like at every N (round 6: the driver derives its scaling curve from the per-N values, so "
+                         "they must be ONE workload -- the headline graph, strong scaling; BASELINE configs[4], papers-like sharded over "
+                         "the N ranks, is measured beside it at N > 1: config.config5_papers_like)")
     ap.add_argument("--feat", type=int, default=None, help="feature width (default: the workload's)")
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the node count (debug only)")
@@ -57,6 +62,10 @@ def parse_args():
                     help="measure the first call OFF the shipped buckets: VOLTRIX_TUNED_DEFAULTS=0 and an empty store of "
                          "choices, so the bounded sweep (tuner.py) runs; its cost is first_call_ms / tuner.sweep_seconds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="N > 1: skip the BASELINE configs[4] leg (papers-like sharded over the N ranks, measured after the timed "
+                         "steps and reported as config.config5_papers_like)")
+    ap.add_argument("--config5-scale", type=float, default=1.0, help="node-count scale of that leg (debug only)")
     ap.add_argument("--no-reference-formats", action="store_true",
                     help="skip the untimed comparison runs (window format alone, cold-cache timing)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for debugging)")
@@ -68,12 +77,14 @@ def parse_args():
     ap.add_argument("--no-overlap", action="store_true", help="accepted for compatibility: the dependent step is the default")
     ap.add_argument("--one-device", action="store_true",
                     help="debug: every rank uses cuda:0 (exercises the sharded path on a 1-GPU box, with --backend gloo)")
-    ap.add_argument("--gather", default="auto", choices=["auto", "collective", "p2p", "rows"],
-                    help="N > 1: the exchange step -- one all_gather_into_tensor (what RCCL picks over xGMI), the direct "
+    ap.add_argument("--gather", default="collective", choices=["auto", "collective", "p2p", "rows"],
+                    help="N > 1: the exchange step -- one all_gather_into_tensor (what RCCL picks over xGMI; the DEFAULT), the direct "
                          "schedule written out as world-1 batched point-to-point copies per rank, or only the rows of B the "
-                         "shard references (one all-to-all with uneven splits; voltrix/dist.py).  auto (default): the warm-up "
+                         "shard references (one all-to-all with uneven splits; voltrix/dist.py).  auto: the warm-up "
                          "times collective against p2p (and the referenced-rows operator when the shards reference < 70 %% of "
-                         "the remote rows), MAX over ranks, and the timed steps run the fastest")
+                         "the remote rows), MAX over ranks, and the timed steps run the fastest -- opt-in since round 6: no "
+                         "multi-GPU node has ever run these schedules, and the batched point-to-point candidate has been seen to "
+                         "stall between two gloo ranks on one device; the line the driver records must not depend on it")
     ap.add_argument("--rows-below", type=float, default=0.7,
                     help="--gather auto builds and times the referenced-rows operator when the shards reference less than this "
                          "fraction of the remote rows")
@@ -282,6 +293,74 @@ def measured_counters(key, sources_hash):
     return entry, None
 
 
+def config5_leg(world, rank, device, scale=1.0, steps=3):
+    """BASELINE configs[4] beside the timed headline steps of an N > 1 run: the papers-like stand-in (111 M nodes, 1.6 G edges, F = 128
+    fp16) row-sharded over the N ranks -- every rank generates and preprocesses its own shard on its device, one RCCL all-gather of B
+    per step, then the local product (voltrix.dist.RowShardedSpMM, the collective schedule).  Returns the figures SURVEY 8(d) asks for
+    (all-gather and product separately and combined, MAX over ranks); any failure is reported as a string instead of ending the run."""
+    import voltrix  # noqa: F401
+    from voltrix import dist as vdist
+
+    workload, num_feats = "papers_like", 128
+    try:
+        deg = synth_graphs.target_degrees(workload, device=device, scale=scale)
+        num_nodes, nnz = deg.numel(), int(deg.sum())
+        full_indptr = torch.zeros(num_nodes + 1, dtype=torch.int64, device=device)
+        full_indptr[1:] = torch.cumsum(deg, 0)
+        parts = vdist.partition_rows(full_indptr, num_nodes, world)
+        del deg, full_indptr
+        r0, r1 = parts[rank]
+        t0 = time.perf_counter()
+        local_indptr, local_indices, _ = synth_graphs.generate(workload, device=device, scale=scale, rows=(r0, r1))
+        torch.cuda.synchronize()
+        generate_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        op = vdist.RowShardedSpMM.from_shard(local_indptr, local_indices, num_nodes, parts, mode="collective")
+        torch.cuda.synchronize()
+        preprocess_ms = (time.perf_counter() - t0) * 1e3
+        op.handle[1].hash_tag = f"bench/{workload}/config5/s{scale}/r{rank}of{world}"
+        gen = torch.Generator(device=device).manual_seed(4321 + rank)
+        feat_local = torch.randn(r1 - r0, num_feats, generator=gen, device=device, dtype=torch.float32).half()
+        buf = op._buffer("whole", num_feats, feat_local)
+
+        def timed(fn, reps):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            t = torch.tensor([(time.perf_counter() - t0) / reps * 1e3], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t)
+
+        out = [None]
+
+        def step():
+            out[0] = op.multiply(op.gather_into(buf, feat_local))
+
+        step()          # first call: tile choice, tables, RCCL channels
+        step()
+        allgather_ms = timed(lambda: op.gather_into(buf, feat_local), steps)
+        spmm_ms = timed(lambda: op.multiply(buf), steps)
+        step_ms = timed(step, steps)
+        # row sums: C 1 = A (B 1) on this rank's rows, against the degrees times the column means it implies (cheap sanity check)
+        ones = torch.ones(r1 - r0, 8, device=device, dtype=torch.float16)
+        deg_local = (local_indptr[1:] - local_indptr[:-1]).float()
+        got = op.multiply(op.gather_into(op._buffer("ones", 8, ones), ones))[:, 0]
+        rel = float(((got - deg_local).abs().max() / deg_local.max().clamp(min=1)))
+        return {"workload": f"{workload}: N={num_nodes} nnz={nnz} x F={num_feats} fp16, row-window shards x{world} (BASELINE.json configs[4])",
+                "allgather_ms": allgather_ms, "local_spmm_ms": spmm_ms, "step_ms": step_ms,
+                "gflops": synth_graphs.flops(nnz, num_feats) / (step_ms * 1e-3) / 1e9,
+                "allgather_bytes_received_per_rank": op.exchange_bytes_received(num_feats, 2),
+                "shard_rows_rank0": r1 - r0, "shard_nnz_rank0": int(local_indices.numel()), "generate_s_rank0": generate_s,
+                "preprocess_ms_rank0": preprocess_ms, "degree_check_max_rel_err_rank0": rel, "steps": steps,
+                "what": "dependent step = all-gather(B) then the product that consumes it, MAX over ranks; measured after the timed "
+                        "headline steps, not part of `value`"}
+    except Exception as exc:  # noqa: BLE001 -- a side measurement must never take the bench line down
+        return {"error": f"{type(exc).__name__}: {str(exc)[:400]}"}
+
+
 def spawn_ranks(args):
     """``python bench.py --gpus N`` (N > 1) outside torch.distributed.run: start the N ranks as FRESH child processes -- one
     ``python -m torch.distributed.run`` with this command line -- before this process has touched the GPU, relay their output
@@ -302,6 +381,10 @@ def spawn_ranks(args):
 
 def main():
     args = parse_args()
+    if os.getenv("VOLTRIX_BENCH_STACKS_AFTER"):      # debugging aid: every thread's Python stack on stderr after that many seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["VOLTRIX_BENCH_STACKS_AFTER"]), repeat=False, file=sys.stderr)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -346,7 +429,7 @@ def main():
     from voltrix.jit_kernels import jit_tuner
     from voltrix.jit_kernels.spmm import ORDER_CHUNKS, SCHED_PAIRS, SCHED_STREAM, SCHED_UNITS, slab_launches
 
-    workload = args.workload or ("reddit_like" if world == 1 else "papers_like")
+    workload = args.workload or "reddit_like"
     config_index = {"cora_like": 0, "reddit_like": 1, "reddit_uniform": 1, "reddit_shuffled": 1, "reddit_sbm": 1,
                     "reddit_sbm_shuffled": 1, "products_like": 2,
                     "products_shuffled": 2, "powerlaw_4m": 3, "papers_like": 4}.get(workload)
@@ -793,6 +876,8 @@ def main():
         extras["cold_cache_ms"] = sorted(cold)[len(cold) // 2]
         del flush
 
+    if world > 1 and not args.no_config5 and workload == "reddit_like":
+        extras["config5_papers_like"] = config5_leg(world, rank, device, scale=args.config5_scale)
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         flop = synth_graphs.flops(nnz, num_feats)

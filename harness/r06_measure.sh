@@ -34,7 +34,7 @@ lines)
     NAME=$(echo "$ARGS" | tr -d ' ' | tr -s '-' '_')
     timeout -k 10 400 python bench.py $ARGS --no-cpu-baseline --no-reference-formats > $O/bench_reddit_like_f128${NAME}_final.json 2> $O/bench_reddit$NAME.err
   done
-  timeout -k 10 300 python bench.py --gpus 2 --backend gloo --one-device --workload reddit_like --feat 128 --scale 0.25 --steps 10 --warmup 3 --no-cpu-baseline --no-reference-formats > $O/bench_gpus2_one_device_dependent_step.json 2> $O/bench_gpus2.err
+  timeout -k 10 300 python bench.py --gpus 2 --backend gloo --one-device --workload reddit_like --feat 128 --scale 0.25 --config5-scale 0.004 --steps 10 --warmup 3 --no-cpu-baseline --no-reference-formats > $O/bench_gpus2_one_device_dependent_step.json 2> $O/bench_gpus2.err
   timeout -k 10 300 python bench.py --gpus 1 --force-dist --workload reddit_like --feat 128 --steps 10 --warmup 3 --no-cpu-baseline --no-reference-formats > $O/bench_force_dist_1rank_rccl.json 2> $O/bench_force_dist.err
   ;;
 widths)

@@ -50,7 +50,7 @@ def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
     env["VOLTRIX_TUNE_SPACE"] = "none"
     run = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device",
                           "--scale", "0.01", "--workload", "reddit_like", "--steps", "3", "--warmup", "1", "--tune", "none",
-                          "--gather", "collective"], capture_output=True, text=True, env=env, timeout=900)
+                          "--gather", "collective", "--config5-scale", "0.002"], capture_output=True, text=True, env=env, timeout=900)
     assert run.returncode == 0, run.stderr[-3000:]
     lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -61,6 +61,11 @@ def test_bench_gpus_2_starts_its_own_ranks(tmp_path):
     for key in ("allgather_ms", "local_spmm_ms", "predicted_ms", "step_independent_ms", "timed_step"):
         assert key in cfg, key
     assert cfg["timed_step"].startswith("dependent") and cfg["rowsum_check_max_rel_err"] < 1e-4
+    # round 6: BASELINE configs[4] (papers-like sharded over the ranks) measured beside the headline steps of every N > 1 run
+    c5 = cfg["config5_papers_like"]
+    assert "error" not in c5, c5
+    assert c5["workload"].startswith("papers_like") and c5["degree_check_max_rel_err_rank0"] == 0.0
+    assert c5["step_ms"] >= 0.5 * max(c5["allgather_ms"], c5["local_spmm_ms"]) and c5["gflops"] > 0
     assert cfg["allgather_ms"] > 0 and cfg["local_spmm_ms"] > 0 and cfg["step_independent_ms"] > 0
     # the dependent step cannot be shorter than its two halves one after the other allow
     assert line["ms_per_step"] >= 0.5 * max(cfg["allgather_ms"], cfg["local_spmm_ms"])

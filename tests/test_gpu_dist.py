@@ -121,7 +121,7 @@ def test_row_sharded_world2_two_processes_hip_path(cuda_device, tmp_path, mode):
         assert all(r["shared_edges"] > 0 for r in results)
 
 
-@pytest.mark.parametrize("extra", [[], ["--gather", "collective"], ["--gather", "p2p"], ["--slabs", "2"]])
+@pytest.mark.parametrize("extra", [[], ["--gather", "auto"], ["--gather", "p2p"], ["--slabs", "2"]])
 def test_bench_n_gt_1_branch_with_a_one_rank_rccl_group(tmp_path, extra):
     """bench.py's N > 1 code path -- init_process_group("nccl", device_id=...), voltrix.dist.RowShardedSpMM.from_shard on a
     device-resident shard, the in-place all_gather_into_tensor (or the batched point-to-point form, or the feature-slab
@@ -141,14 +141,16 @@ def test_bench_n_gt_1_branch_with_a_one_rank_rccl_group(tmp_path, extra):
     assert cfg["allgather_ms"] > 0 and cfg["local_spmm_ms"] > 0 and cfg["rowsum_check_max_rel_err"] < 1e-4
     assert "exchange:" in cfg["parallelism"] and cfg["predicted_ms"]["step_direct_ms"] > 0
     assert cfg["first_call_ms"] > 0 and cfg["handle_bytes"]["reference_handle"] > 0
-    if not extra:   # default = --gather auto: both schedules were timed over RCCL and one of them was kept
+    if not extra:   # the default since round 6: the RCCL collective, no measured choice
+        assert "exchange_choice" not in cfg and "exchange: collective" in cfg["parallelism"]
+    if extra == ["--gather", "auto"]:   # both schedules were timed over RCCL and one of them was kept
         choice = cfg["exchange_choice"]
         assert set(choice["candidates_ms"]) == {"collective", "p2p"} and choice["picked"] in ("collective", "p2p")
         assert all(v > 0 for v in choice["candidates_ms"].values())
 
 
-@pytest.mark.parametrize("extra", [[], ["--gather", "collective"], ["--gather", "p2p"], ["--slabs", "2"], ["--gather", "rows"],
-                                   ["--workload", "papers_like", "--scale", "0.002", "--rows-below", "1.01"]])
+@pytest.mark.parametrize("extra", [[], ["--gather", "auto"], ["--gather", "p2p"], ["--slabs", "2"], ["--gather", "rows"],
+                                   ["--gather", "auto", "--workload", "papers_like", "--scale", "0.002", "--rows-below", "1.01"]])
 def test_bench_two_ranks_share_one_device_over_gloo(extra):
     """The N = 2 data path of bench.py end to end -- two ranks generate their own shards, ``RowShardedSpMM.from_shard``, the
     exchange (collective / point-to-point / slab pipeline), the product, and the row-sum check of every rank's result against
@@ -158,11 +160,14 @@ def test_bench_two_ranks_share_one_device_over_gloo(extra):
     run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2",
                           "--one-device", "--backend", "gloo", "--workload", "reddit_like", "--scale", "0.1", "--steps", "2",
-                          "--warmup", "1", "--tune", "none", *extra], capture_output=True, text=True, env=env, timeout=900)
+                          "--warmup", "1", "--tune", "none", "--config5-scale", "0.001", *extra], capture_output=True, text=True,
+                         env=env, timeout=900)
     assert run.returncode == 0, run.stderr[-3000:]
     line = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["rowsum_check_max_rel_err"] < 1e-4 and line["config"]["allgather_ms"] > 0
-    if not extra or "--workload" in extra:   # --gather auto: measured choice, the same on both ranks (rank 0 prints it)
+    if "--workload" not in extra:            # headline workload at N > 1: BASELINE configs[4] is measured beside it (round 6)
+        assert "error" not in line["config"]["config5_papers_like"], line["config"]["config5_papers_like"]
+    if "auto" in extra:   # --gather auto: measured choice, the same on both ranks (rank 0 prints it)
         choice = line["config"]["exchange_choice"]
         assert choice["picked"] in ("collective", "p2p", "rows") and set(choice["candidates_ms"]) == {"collective", "p2p"}
         if "--workload" in extra:            # the referenced-rows operator is built beside the all-gather one and both are
