@@ -29,3 +29,17 @@ def test_kernel_sources_hash_follows_the_sources(tmp_path, monkeypatch):
     """Twelve hex digits over every header under include/voltrix and every source under csrc; stable across calls."""
     h = get_kernel_sources_version()
     assert len(h) == 12 and int(h, 16) >= 0 and h == get_kernel_sources_version()
+
+
+def test_multi_gpu_defaults_are_one_workload_and_the_collective(monkeypatch):
+    """Round 6: the driver derives its scaling curve from the per-N values of `bench.py --gpus N --steps K --warmup W`, so every N must
+    time the SAME workload (the headline graph; papers-like is measured beside it at N > 1), and the default exchange is the RCCL
+    collective -- the measured choice with its point-to-point candidate is opt-in."""
+    import sys
+
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2"])
+    args = bench.parse_args()
+    assert args.workload is None and args.gather == "collective" and not args.no_config5 and args.config5_scale == 1.0
+    src = open(bench.__file__).read()
+    assert 'workload = args.workload or "reddit_like"' in src          # N = 1 and N > 1 alike
+    assert 'extras["config5_papers_like"] = config5_leg(' in src
